@@ -1,0 +1,345 @@
+"""Host-side mirror of the reference's `dg_nn` public surface over the C ABI (include/dgnn.h).
+
+Names, argument meaning and error behaviour follow the reference so that the parity tests read like
+its own tests:
+
+    reference (Rust)                                         here
+    ------------------------------------------------------   -----------------------------------------
+    dg_nn::Network::new() -> Option<Network>                  Network.new(exe_path=None) -> Network | None
+      (src/libdg_nn/network.rs:92-127)
+    loader::load(path)   (src/libdg_nn/loader.rs:102-116)     Network.load(path) / Network.from_json(text)
+    Network::get_workspace(batch) -> Result<WorkspaceGuard>   Network.get_workspace(batch, device=0) -> WorkspaceGuard
+      (network.rs:132-142)                                      (context manager; leaving it = Drop, network.rs:71-79)
+    dg_nn::forward(&mut ws, &[f16]) -> Result<OutputMap<f16>> forward(ws, features) -> OutputMap
+      (src/libdg_nn/graph.rs:123-158)
+    OutputMap::unwrap() -> (Vec<f16>, Vec<f16>)               OutputMap.unwrap() -> (value, policy) np.float16 arrays
+      (src/libdg_nn/output_map.rs:29-33)
+    Network::synchronize()   (network.rs:145-159)             Network.synchronize()
+    dg_nn::Error  (src/libdg_nn/error.rs:19-24)               Error(status) with .status in {MISSING_WEIGHTS, ...}
+    dg_cuda::Device::{len, all} (src/libdg_cuda/devices.rs)   Device.len() / Device.all()
+
+There is NO fallback: if libdgnn_hip.so is missing or does not load, importing this module raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdgnn_hip.so")
+
+OK = 0
+MISSING_WEIGHTS = -1
+MALFORMED_WEIGHTS = -2
+HIP_ERROR = -3
+BAD_ARGUMENT = -4
+OUT_OF_MEMORY = -5
+UNSUPPORTED = -6
+
+NUM_FEATURES = 32
+NUM_POINTS = 361
+FEATURE_SIZE = 11552
+NUM_MOVES = 362
+
+# every symbol include/dgnn.h declares: (name, restype, argtypes)
+_u16p = ctypes.POINTER(ctypes.c_uint16)
+_vp = ctypes.c_void_p
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+_ip = ctypes.POINTER(ctypes.c_int)
+_fp = ctypes.POINTER(ctypes.c_float)
+SYMBOLS = [
+    ("dgnn_status_string", ctypes.c_char_p, [ctypes.c_int]),
+    ("dgnn_last_hip_error", ctypes.c_int, []),
+    ("dgnn_version", ctypes.c_char_p, []),
+    ("dgnn_device_count", ctypes.c_int, [_ip]),
+    ("dgnn_network_load", ctypes.c_int, [ctypes.c_char_p, _vpp]),
+    ("dgnn_network_from_json", ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, _vpp]),
+    ("dgnn_network_load_default", ctypes.c_int, [ctypes.c_char_p, _vpp]),
+    ("dgnn_network_destroy", None, [_vp]),
+    ("dgnn_network_info", ctypes.c_int, [_vp, _ip, _ip, _ip]),
+    ("dgnn_network_set_softmax_temperature", ctypes.c_int, [_vp, ctypes.c_float]),
+    ("dgnn_network_get_workspace", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_workspace_release", None, [_vp]),
+    ("dgnn_network_synchronize", ctypes.c_int, [_vp]),
+    ("dgnn_forward", ctypes.c_int, [_vp, _u16p, ctypes.c_size_t, _u16p, _u16p]),
+    ("dgnn_forward_submit", ctypes.c_int, [_vp, _u16p, ctypes.c_size_t]),
+    ("dgnn_forward_wait", ctypes.c_int, [_vp, _u16p, _u16p]),
+    ("dgnn_workspace_batch_size", ctypes.c_int, [_vp, _ip, _ip]),
+    ("dgnn_workspace_device_buffers", ctypes.c_int, [_vp, _vpp, _vpp, _vpp]),
+    ("dgnn_workspace_host_buffers", ctypes.c_int, [_vp, ctypes.POINTER(_u16p), ctypes.POINTER(_u16p), ctypes.POINTER(_u16p)]),
+    ("dgnn_workspace_stream", ctypes.c_int, [_vp, _vpp]),
+    ("dgnn_workspace_upload", ctypes.c_int, [_vp, _u16p, ctypes.c_size_t]),
+    ("dgnn_workspace_download", ctypes.c_int, [_vp, _u16p, _u16p]),
+    ("dgnn_forward_resident", ctypes.c_int, [_vp]),
+    ("dgnn_workspace_sync", ctypes.c_int, [_vp]),
+    ("dgnn_forward_timed", ctypes.c_int, [_vp, ctypes.c_int, _fp, _fp, _ip]),
+    ("dgnn_layer_conv3x3", ctypes.c_int, [ctypes.c_int, _u16p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u16p, _u16p,
+                                          ctypes.c_int, ctypes.c_float, ctypes.c_float, _u16p, ctypes.c_int, _u16p]),
+    ("dgnn_network_weight_image", ctypes.c_int, [_vp, ctypes.c_int, _vpp, ctypes.POINTER(ctypes.c_size_t)]),
+    ("dgnn_network_weight_checksum", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_network_set_weight_image", ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int]),
+    ("dgnn_network_weight_checksum_device", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_network_weight_image_host", ctypes.c_int, [_vp, _vpp, ctypes.POINTER(ctypes.c_size_t)]),
+]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python dream-go_amd/build.py` (hipcc, gfx950). "
+                          "There is no CPU fallback for the product path.")
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7, same as /opt/rocm's).  Two HIP runtimes in
+    # one process do not work, and the dynamic linker only shares one copy if torch's is loaded FIRST (ours is
+    # then resolved by SONAME against it).  So when torch is installed, import it before loading the library;
+    # set DGNN_NO_TORCH=1 for a torch-free process (the library itself only needs the HIP runtime).
+    if os.environ.get("DGNN_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()
+
+
+class Error(Exception):
+    """dg_nn::Error (src/libdg_nn/error.rs:19-24) as a status code."""
+
+    def __init__(self, status, where=""):
+        self.status = status
+        self.hip_error = lib.dgnn_last_hip_error() if status == HIP_ERROR else 0
+        text = lib.dgnn_status_string(status).decode("ascii")
+        detail = f" (hipError_t {self.hip_error})" if self.hip_error else ""
+        super().__init__(f"{where}: {text}{detail}" if where else text + detail)
+
+
+def _check(status, where):
+    if status != OK:
+        raise Error(status, where)
+
+
+def _as_u16(array, name):
+    a = np.ascontiguousarray(array)
+    if a.dtype == np.float16:
+        a = a.view(np.uint16)
+    if a.dtype != np.uint16:
+        raise TypeError(f"{name} must be float16 (or its uint16 bit patterns), got {a.dtype}")
+    return a.reshape(-1)
+
+
+class Device:
+    """dg_cuda::Device (src/libdg_cuda/devices.rs:38-73)."""
+
+    def __init__(self, device_id):
+        self.device_id = int(device_id)
+
+    def id(self):
+        return self.device_id
+
+    @staticmethod
+    def len():
+        count = ctypes.c_int(0)
+        _check(lib.dgnn_device_count(ctypes.byref(count)), "Device::len")
+        return count.value
+
+    @staticmethod
+    def all():
+        return [Device(i) for i in range(Device.len())]
+
+
+class OutputMap:
+    """dg_nn::OutputMap<f16> (src/libdg_nn/output_map.rs:15-34)."""
+
+    def __init__(self, value, policy):
+        self.value = value
+        self.policy = policy
+
+    def unwrap(self):
+        return self.value, self.policy
+
+
+class WorkspaceGuard:
+    """dg_nn::WorkspaceGuard (src/libdg_nn/network.rs:54-79): returns the workspace to its pool when dropped."""
+
+    def __init__(self, network, handle, batch_size, device):
+        self._network = network      # keeps the network alive
+        self._handle = handle
+        self.batch_size = batch_size
+        self.device = device
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            raise ValueError("workspace already released")
+        return self._handle
+
+    def release(self):
+        if self._handle is not None:
+            lib.dgnn_workspace_release(self._handle)
+            self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    # ---- measurement harness (device-resident) ----
+    def upload(self, features):
+        f = _as_u16(features, "features")
+        _check(lib.dgnn_workspace_upload(self.handle, f.ctypes.data_as(_u16p), f.size), "upload")
+
+    def download(self):
+        value = np.empty(self.batch_size, dtype=np.uint16)
+        policy = np.empty(self.batch_size * NUM_MOVES, dtype=np.uint16)
+        _check(lib.dgnn_workspace_download(self.handle, value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "download")
+        return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+    def forward_resident(self):
+        _check(lib.dgnn_forward_resident(self.handle), "forward_resident")
+
+    def sync(self):
+        _check(lib.dgnn_workspace_sync(self.handle), "sync")
+
+    def forward_timed(self, steps):
+        """-> (total_ms, tower_ms, tower_launches) measured with HIP events on the workspace's stream."""
+        total, tower, launches = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int(0)
+        _check(lib.dgnn_forward_timed(self.handle, steps, ctypes.byref(total), ctypes.byref(tower), ctypes.byref(launches)),
+               "forward_timed")
+        return total.value, tower.value, launches.value
+
+    def device_buffers(self):
+        f, v, p = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _check(lib.dgnn_workspace_device_buffers(self.handle, ctypes.byref(f), ctypes.byref(v), ctypes.byref(p)), "device_buffers")
+        return f.value, v.value, p.value
+
+    def stream(self):
+        s = ctypes.c_void_p()
+        _check(lib.dgnn_workspace_stream(self.handle, ctypes.byref(s)), "stream")
+        return s.value
+
+
+class Network:
+    """dg_nn::Network (src/libdg_nn/network.rs:83-160)."""
+
+    def __init__(self, handle):
+        self._handle = handle
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            raise ValueError("network already destroyed")
+        return self._handle
+
+    # -- constructors
+    @classmethod
+    def new(cls, exe_path=None):
+        """Network::new(): search the default paths; None when no weights file is found (network.rs:92-127)."""
+        out = ctypes.c_void_p()
+        status = lib.dgnn_network_load_default(exe_path.encode() if exe_path else None, ctypes.byref(out))
+        if status == MISSING_WEIGHTS:
+            return None
+        _check(status, "Network::new")      # the reference panics here
+        return cls(out)
+
+    @classmethod
+    def load(cls, path):
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_network_load(os.fsencode(path), ctypes.byref(out)), f"load({path})")
+        return cls(out)
+
+    @classmethod
+    def from_json(cls, text):
+        raw = text.encode("ascii") if isinstance(text, str) else bytes(text)
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_network_from_json(raw, len(raw), ctypes.byref(out)), "from_json")
+        return cls(out)
+
+    # -- queries
+    def info(self):
+        b, c, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib.dgnn_network_info(self.handle, ctypes.byref(b), ctypes.byref(c), ctypes.byref(s)), "info")
+        return {"num_blocks": b.value, "num_channels": c.value, "num_samples": s.value}
+
+    def set_softmax_temperature(self, temperature):
+        _check(lib.dgnn_network_set_softmax_temperature(self.handle, float(temperature)), "set_softmax_temperature")
+
+    def weight_checksum(self):
+        c = ctypes.c_uint64()
+        _check(lib.dgnn_network_weight_checksum(self.handle, ctypes.byref(c)), "weight_checksum")
+        return c.value
+
+    def weight_image_host(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib.dgnn_network_weight_image_host(self.handle, ctypes.byref(p), ctypes.byref(n)), "weight_image_host")
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value,))
+
+    def weight_image(self, device=0):
+        """-> (device pointer, bytes) of the packed weight image on `device` (uploads it on first use)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib.dgnn_network_weight_image(self.handle, device, ctypes.byref(p), ctypes.byref(n)), "weight_image")
+        return p.value, n.value
+
+    def set_weight_image(self, device, src_ptr, num_bytes, src_on_device=True):
+        _check(lib.dgnn_network_set_weight_image(self.handle, device, ctypes.c_void_p(src_ptr), num_bytes, int(src_on_device)),
+               "set_weight_image")
+
+    def weight_checksum_device(self, device=0):
+        c = ctypes.c_uint64()
+        _check(lib.dgnn_network_weight_checksum_device(self.handle, device, ctypes.byref(c)), "weight_checksum_device")
+        return c.value
+
+    # -- workspaces
+    def get_workspace(self, batch_size, device=0):
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_network_get_workspace(self.handle, int(device), int(batch_size), ctypes.byref(out)), "get_workspace")
+        return WorkspaceGuard(self, out, int(batch_size), int(device))
+
+    def synchronize(self):
+        _check(lib.dgnn_network_synchronize(self.handle), "synchronize")
+
+    def destroy(self):
+        if self._handle is not None:
+            lib.dgnn_network_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def forward(workspace, features):
+    """dg_nn::forward (src/libdg_nn/graph.rs:123-158): features [batch * 11552] fp16 HWC -> OutputMap."""
+    f = _as_u16(features, "features")
+    value = np.empty(workspace.batch_size, dtype=np.uint16)
+    policy = np.empty(workspace.batch_size * NUM_MOVES, dtype=np.uint16)
+    _check(lib.dgnn_forward(workspace.handle, f.ctypes.data_as(_u16p), f.size,
+                            value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "forward")
+    return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+
+def layer_conv3x3(x, batch, board_size, cin, w_krsc, bias, cout, alpha1=1.0, alpha2=0.0, z=None, relu=True, device=0):
+    """One Conv2d::forward / forward_skip (src/libdg_nn/layers/conv2d.rs:171-220) through the HIP kernel."""
+    x = _as_u16(x, "x"); w = _as_u16(w_krsc, "w"); b = _as_u16(bias, "bias")
+    zp = None
+    if z is not None:
+        z = _as_u16(z, "z")
+        zp = z.ctypes.data_as(_u16p)
+    y = np.empty(batch * board_size * board_size * cout, dtype=np.uint16)
+    _check(lib.dgnn_layer_conv3x3(device, x.ctypes.data_as(_u16p), batch, board_size, cin, w.ctypes.data_as(_u16p),
+                                  b.ctypes.data_as(_u16p), cout, alpha1, alpha2, zp, int(relu), y.ctypes.data_as(_u16p)),
+           "layer_conv3x3")
+    return y

@@ -1,0 +1,58 @@
+"""Builds libdgnn_hip.so (the C-ABI library, include/dgnn.h) for gfx950 with hipcc, in-tree.
+
+    python dream-go_amd/build.py [--force]
+
+The library depends only on the HIP runtime (libamdhip64); it does not link torch.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdgnn_hip.so")
+
+SOURCES = ["loader.cpp", "network.cpp", "engine.cpp", "kernels.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+
+
+def hipcc():
+    for candidate in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if candidate and (os.path.isabs(candidate) and os.path.exists(candidate) or not os.path.isabs(candidate)):
+            return candidate
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for name in os.listdir(root):
+            if os.path.getmtime(os.path.join(root, name)) > built:
+                return True
+    return False
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objects = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objects.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objects]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,101 @@
+// Internal declarations shared by the host side of libdgnn_hip.so.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dgnn.h"
+
+namespace dgnn {
+
+// ----------------------------------------------------------------------------------------------
+// fp16 helpers (host).  Same rounding as llvm.convert.to.fp16 (src/libdg_utils/types/fp16.rs:53-70).
+// ----------------------------------------------------------------------------------------------
+float half_to_float(uint16_t h);
+uint16_t float_to_half(float f);
+
+// ----------------------------------------------------------------------------------------------
+// Weights file (src/libdg_nn/loader.rs, src/libdg_nn/tensor.rs)
+// ----------------------------------------------------------------------------------------------
+enum class DataType { Int8, Int32, Half, Float };
+
+struct HostTensor {
+    DataType dtype = DataType::Float;   // Tensor::default(), tensor.rs:50-60
+    std::vector<uint8_t> bytes;         // raw little-endian payload as stored
+    float scale = 1.0f;                 // parsed, never applied (tensor.rs:89-91)
+
+    size_t element_size() const;
+    size_t num_elements() const { return bytes.size() / element_size(); }
+    float as_f32() const;               // tensor.rs:106-112
+    int32_t as_i32() const;             // tensor.rs:114-120
+};
+
+using TensorMap = std::map<std::string, HostTensor>;
+
+// base85 (RFC 1924 alphabet), src/libdg_utils/b85.rs:101-132.  Returns false on an invalid character.
+bool b85_decode(const char* text, size_t len, std::vector<uint8_t>& out);
+
+// loader::load_aux, loader.rs:36-100.  Returns a DGNN_* status.
+int parse_weights(const char* text, size_t len, TensorMap& out);
+int load_weights_file(const char* path, TensorMap& out);
+
+// ----------------------------------------------------------------------------------------------
+// Topology + packed weight image
+// ----------------------------------------------------------------------------------------------
+struct ConvParams {
+    // one 3x3 convolution as the kernels consume it
+    size_t w_offset = 0;     // byte offset of the filter in the image, layout [9 * cin / 32][cout_pad][32] fp16
+    size_t b_offset = 0;     // byte offset of the bias, [cout_pad] fp16 (already scaled where the reference scales)
+    int cin = 0;
+    int cout = 0;
+    int cout_pad = 0;        // cout rounded up to a multiple of 16
+    float alpha1 = 1.0f;     // scale of the convolution result
+    float alpha2 = 0.0f;     // scale of the skip input (0: skip is not read)
+};
+
+struct Topology {
+    int num_blocks = 0;
+    int num_channels = 0;
+    int num_samples = 0;
+    float softmax_temperature = 0.709888f;
+
+    ConvParams up;
+    std::vector<ConvParams> res1, res2;
+    ConvParams policy_conv, value_conv;
+    size_t policy_w_offset = 0;  // [361 * S][362] fp16 as stored ([in][out])
+    size_t policy_b_offset = 0;  // [362] fp16, tau * b_l rounded to fp16
+    size_t value_w_offset = 0;   // [722] fp16
+    size_t value_b_offset = 0;   // [1] fp16
+};
+
+struct DeviceState;   // per-device weight copy + workspace pool (network.cpp)
+struct Workspace;     // workspace.hip
+
+struct Network {
+    TensorMap tensors;             // as loaded; kept so that the temperature can be re-baked
+    Topology topo;
+    std::vector<uint8_t> image;    // packed host weight image
+    bool frozen = false;           // set once the first workspace exists
+
+    std::mutex mutex;
+    std::map<int, std::unique_ptr<DeviceState>> devices;
+
+    ~Network();
+};
+
+// Filter [cout][3][3][cin] (KRSC, conv2d.rs:111-117) -> [9 * cin / 32][cout_pad][32] (zero padded rows):
+// k-step = tap * (cin / 32) + chunk; one k-step is one contiguous [cout_pad][32] slab.  dst must be zeroed.
+void pack_filter(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
+
+// Builds topo + image from tensors.  Returns a DGNN_* status.
+int build_network(Network& net);
+
+// thread-local HIP error detail
+void set_last_hip_error(int code);
+
+}  // namespace dgnn

@@ -1,0 +1,688 @@
+// Device-side resource model, the forward pass and the C ABI (include/dgnn.h).
+//
+// Resource model (replaces src/libdg_nn/network.rs:54-160, graph.rs:30-113 and the allocator stack of
+// src/libdg_cuda/allocator.rs:24-221):
+//   Network      immutable packed weight image on the host + one copy per device, uploaded on first use
+//   Workspace    (device, batch size) -> one HIP stream, a static activation arena in HBM (no per-layer malloc),
+//                pinned host staging for features / value / policy; pooled per (device, batch size)
+// Nothing here depends on a process-global current device: every entry point sets the device of the object it
+// was handed (hipSetDevice is per-thread).
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "dgnn_internal.h"
+#include "kernels.h"
+
+namespace dgnn {
+
+static thread_local int g_last_hip_error = 0;
+
+void set_last_hip_error(int code) { g_last_hip_error = code; }
+
+#define DGNN_HIP(expr)                                      \
+    do {                                                    \
+        const hipError_t hip_status__ = (expr);             \
+        if (hip_status__ != hipSuccess) {                   \
+            set_last_hip_error((int)hip_status__);          \
+            return DGNN_HIP_ERROR;                          \
+        }                                                   \
+    } while (0)
+
+struct Workspace {
+    Network* net = nullptr;
+    DeviceState* dev = nullptr;
+    int device = 0;
+    int batch = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> tower_events;   // pairs, grown on demand by dgnn_forward_timed
+
+    void* arena = nullptr;                  // one allocation, carved below
+    uint16_t* d_features = nullptr;         // [batch][361][32]
+    uint16_t* d_act[3] = {nullptr, nullptr, nullptr};   // [batch][361][C], rotating
+    uint16_t* d_policy_features = nullptr;  // [batch][361][S]
+    uint16_t* d_value_features = nullptr;   // [batch][361][2]
+    uint16_t* d_value = nullptr;            // [batch]
+    uint16_t* d_policy = nullptr;           // [batch][362]
+
+    void* pinned = nullptr;                 // host staging, one allocation
+    uint16_t* h_features = nullptr;
+    uint16_t* h_value = nullptr;
+    uint16_t* h_policy = nullptr;
+
+    bool pending = false;                   // a submit without its wait
+
+    ~Workspace();
+};
+
+struct DeviceState {
+    int device = 0;
+    uint8_t* d_image = nullptr;
+    std::map<int, std::vector<Workspace*>> idle;   // batch size -> pooled workspaces
+    std::vector<Workspace*> all;                   // ownership
+
+    ~DeviceState();
+};
+
+Workspace::~Workspace()
+{
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (hipEvent_t e : tower_events) (void)hipEventDestroy(e);
+    if (ev_begin) (void)hipEventDestroy(ev_begin);
+    if (ev_end) (void)hipEventDestroy(ev_end);
+    if (arena) (void)hipFree(arena);
+    if (pinned) (void)hipHostFree(pinned);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+DeviceState::~DeviceState()
+{
+    for (Workspace* ws : all) delete ws;
+    (void)hipSetDevice(device);
+    if (d_image) (void)hipFree(d_image);
+}
+
+Network::~Network() { devices.clear(); }
+
+namespace {
+
+size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
+
+// Lazily creates the per-device state: weight image upload (tensor.rs:123-141 done once per device).
+int get_device_state(Network* net, int device, DeviceState** out)
+{
+    auto it = net->devices.find(device);
+    if (it != net->devices.end()) { *out = it->second.get(); return DGNN_OK; }
+
+    int count = 0;
+    DGNN_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP(hipSetDevice(device));
+
+    std::unique_ptr<DeviceState> state(new (std::nothrow) DeviceState());
+    if (!state) return DGNN_OUT_OF_MEMORY;
+    state->device = device;
+    DGNN_HIP(hipMalloc((void**)&state->d_image, net->image.size()));
+    DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
+
+    *out = state.get();
+    net->devices[device] = std::move(state);
+    net->frozen = true;
+    return DGNN_OK;
+}
+
+int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
+{
+    std::unique_ptr<Workspace> ws(new (std::nothrow) Workspace());
+    if (!ws) return DGNN_OUT_OF_MEMORY;
+
+    const Topology& t = net->topo;
+    ws->net = net;
+    ws->dev = dev;
+    ws->device = dev->device;
+    ws->batch = batch;
+
+    DGNN_HIP(hipSetDevice(dev->device));
+    DGNN_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));   // stream.rs:55
+    DGNN_HIP(hipEventCreate(&ws->ev_begin));
+    DGNN_HIP(hipEventCreate(&ws->ev_end));
+
+    const size_t num_pos = (size_t)batch * DGNN_NUM_POINTS;
+    const size_t sz_features = align_up(num_pos * DGNN_NUM_FEATURES * 2, 256);
+    const size_t sz_act = align_up(num_pos * t.num_channels * 2, 256);
+    const size_t sz_pf = align_up(num_pos * t.num_samples * 2, 256);
+    const size_t sz_vf = align_up(num_pos * 2 * 2, 256);
+    const size_t sz_value = align_up((size_t)batch * 2, 256);
+    const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
+    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy;
+
+    DGNN_HIP(hipMalloc(&ws->arena, total));
+    uint8_t* p = (uint8_t*)ws->arena;
+    ws->d_features = (uint16_t*)p; p += sz_features;
+    for (int i = 0; i < 3; ++i) { ws->d_act[i] = (uint16_t*)p; p += sz_act; }
+    ws->d_policy_features = (uint16_t*)p; p += sz_pf;
+    ws->d_value_features = (uint16_t*)p; p += sz_vf;
+    ws->d_value = (uint16_t*)p; p += sz_value;
+    ws->d_policy = (uint16_t*)p;
+
+    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_value + sz_policy, hipHostMallocDefault));
+    uint8_t* h = (uint8_t*)ws->pinned;
+    ws->h_features = (uint16_t*)h; h += sz_features;
+    ws->h_value = (uint16_t*)h; h += sz_value;
+    ws->h_policy = (uint16_t*)h;
+
+    *out = ws.release();
+    return DGNN_OK;
+}
+
+// Enqueues graph.rs:134-152 on the workspace's stream.  `tower_pair` (may be -1) selects the event pair that
+// brackets the residual convolutions.
+int enqueue_forward(Workspace* ws, int tower_pair)
+{
+    const Topology& t = ws->net->topo;
+    const uint8_t* image = ws->dev->d_image;
+    const int num_pos = ws->batch * DGNN_NUM_POINTS;
+
+    auto conv = [&](const ConvParams& c, const uint16_t* x, const uint16_t* z, uint16_t* y) -> hipError_t {
+        ConvLaunch a;
+        a.x = x;
+        a.w = (const uint16_t*)(image + c.w_offset);
+        a.bias = (const uint16_t*)(image + c.b_offset);
+        a.z = c.alpha2 != 0.0f ? z : nullptr;
+        a.y = y;
+        a.num_pos = num_pos;
+        a.board = 19;   // conv2d.rs:50
+        a.cin = c.cin;
+        a.cout = c.cout;
+        a.cout_pad = c.cout_pad;
+        a.alpha1 = c.alpha1;
+        a.alpha2 = c.alpha2;
+        a.relu = 1;   // every 3x3 convolution of the network uses ReLU (conv2d.rs:119-125, value_head.rs:45)
+        return launch_conv3x3(a, ws->stream);
+    };
+
+    int cur = 0;
+    DGNN_HIP(conv(t.up, ws->d_features, nullptr, ws->d_act[cur]));                 // up_block.rs:56
+
+    if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair], ws->stream));
+    for (int i = 0; i < t.num_blocks; ++i) {                                        // graph.rs:139-143
+        const int tmp = (cur + 1) % 3, next = (cur + 2) % 3;
+        DGNN_HIP(conv(t.res1[i], ws->d_act[cur], nullptr, ws->d_act[tmp]));        // residual_block.rs:76
+        DGNN_HIP(conv(t.res2[i], ws->d_act[tmp], ws->d_act[cur], ws->d_act[next])); // residual_block.rs:77
+        cur = next;
+    }
+    if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
+
+    DGNN_HIP(conv(t.value_conv, ws->d_act[cur], nullptr, ws->d_value_features));   // value_head.rs:76
+    DGNN_HIP(conv(t.policy_conv, ws->d_act[cur], nullptr, ws->d_policy_features)); // policy_head.rs:92
+
+    HeadsLaunch h;
+    h.policy_features = ws->d_policy_features;
+    h.value_features = ws->d_value_features;
+    h.policy_w = (const uint16_t*)(image + t.policy_w_offset);
+    h.policy_b = (const uint16_t*)(image + t.policy_b_offset);
+    h.value_w = (const uint16_t*)(image + t.value_w_offset);
+    h.value_b = (const uint16_t*)(image + t.value_b_offset);
+    h.value_out = ws->d_value;
+    h.policy_out = ws->d_policy;
+    h.batch = ws->batch;
+    h.samples = t.num_samples;
+    h.tau = 1.0f / t.softmax_temperature;
+    DGNN_HIP(launch_heads(h, ws->stream));                                         // policy_head.rs:95-100, value_head.rs:80-81
+    return DGNN_OK;
+}
+
+float env_softmax_temperature()
+{
+    // config.rs:176-177: get_env("SOFTMAX_TEMPERATURE").unwrap_or(0.709888)
+    const char* s = std::getenv("SOFTMAX_TEMPERATURE");
+    if (s && *s) {
+        char* end = nullptr;
+        const float v = std::strtof(s, &end);
+        if (end != s && *end == '\0' && v > 0.0f) return v;
+    }
+    return 0.709888f;
+}
+
+int finish_network(std::unique_ptr<Network>& net, dgnn_network** out)
+{
+    net->topo.softmax_temperature = env_softmax_temperature();
+    const int status = build_network(*net);
+    if (status != DGNN_OK) return status;
+    *out = reinterpret_cast<dgnn_network*>(net.release());
+    return DGNN_OK;
+}
+
+}  // namespace
+}  // namespace dgnn
+
+using namespace dgnn;
+
+static Network* N(dgnn_network* p) { return reinterpret_cast<Network*>(p); }
+static const Network* N(const dgnn_network* p) { return reinterpret_cast<const Network*>(p); }
+static Workspace* W(dgnn_workspace* p) { return reinterpret_cast<Workspace*>(p); }
+static const Workspace* W(const dgnn_workspace* p) { return reinterpret_cast<const Workspace*>(p); }
+
+extern "C" {
+
+const char* dgnn_status_string(int status)
+{
+    switch (status) {
+        case DGNN_OK: return "success";
+        case DGNN_MISSING_WEIGHTS: return "missing weights";
+        case DGNN_MALFORMED_WEIGHTS: return "malformed weights";
+        case DGNN_HIP_ERROR: return "HIP runtime error";
+        case DGNN_BAD_ARGUMENT: return "bad argument";
+        case DGNN_OUT_OF_MEMORY: return "out of host memory";
+        case DGNN_UNSUPPORTED: return "unsupported network architecture";
+        default: return "unknown status";
+    }
+}
+
+int dgnn_last_hip_error(void) { return g_last_hip_error; }
+
+const char* dgnn_version(void) { return "dgnn-hip 0.1 (gfx950; conv3x3 mfma_f32_16x16x32_f16)"; }
+
+int dgnn_device_count(int* count)
+{
+    if (!count) return DGNN_BAD_ARGUMENT;
+    *count = 0;
+    DGNN_HIP(hipGetDeviceCount(count));
+    return DGNN_OK;
+}
+
+int dgnn_network_load(const char* json_path, dgnn_network** out)
+{
+    if (!json_path || !out) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<Network> net(new (std::nothrow) Network());
+    if (!net) return DGNN_OUT_OF_MEMORY;
+    const int status = load_weights_file(json_path, net->tensors);
+    if (status != DGNN_OK) return status;
+    return finish_network(net, out);
+}
+
+int dgnn_network_from_json(const char* json_text, size_t json_len, dgnn_network** out)
+{
+    if (!json_text || !out) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<Network> net(new (std::nothrow) Network());
+    if (!net) return DGNN_OUT_OF_MEMORY;
+    const int status = parse_weights(json_text, json_len, net->tensors);
+    if (status != DGNN_OK) return status;
+    return finish_network(net, out);
+}
+
+int dgnn_network_load_default(const char* exe_path, dgnn_network** out)
+{
+    if (!out) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+
+    std::vector<std::string> paths;
+    if (exe_path && *exe_path) {   // network.rs:96-101: the executable's path with extension "json"
+        std::string p(exe_path);
+        const size_t slash = p.find_last_of('/');
+        const size_t dot = p.find_last_of('.');
+        if (dot != std::string::npos && (slash == std::string::npos || dot > slash + 1)) p.erase(dot);
+        paths.push_back(p + ".json");
+    } else {
+        paths.push_back("dream_go.json");
+    }
+    paths.push_back("dream_go.json");
+    paths.push_back("models/dream_go.json");
+    paths.push_back("/usr/share/dreamgo/dream_go.json");
+    paths.push_back("/usr/share/dream_go/dream_go.json");
+
+    for (const std::string& path : paths) {
+        const int status = dgnn_network_load(path.c_str(), out);
+        if (status == DGNN_MISSING_WEIGHTS) continue;   // network.rs:112-113
+        return status;                                   // success, or the reference's panic! (:114-116)
+    }
+    return DGNN_MISSING_WEIGHTS;
+}
+
+void dgnn_network_destroy(dgnn_network* net) { delete N(net); }
+
+int dgnn_network_info(const dgnn_network* net, int* num_blocks, int* num_channels, int* num_samples)
+{
+    if (!net) return DGNN_BAD_ARGUMENT;
+    if (num_blocks) *num_blocks = N(net)->topo.num_blocks;
+    if (num_channels) *num_channels = N(net)->topo.num_channels;
+    if (num_samples) *num_samples = N(net)->topo.num_samples;
+    return DGNN_OK;
+}
+
+int dgnn_network_set_softmax_temperature(dgnn_network* net, float temperature)
+{
+    if (!net || !(temperature > 0.0f)) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+    if (n->frozen) return DGNN_BAD_ARGUMENT;   // tau * b_l is baked into the image that is already on a device
+    n->topo.softmax_temperature = temperature;
+    return build_network(*n);
+}
+
+int dgnn_network_get_workspace(dgnn_network* net, int device, int batch_size, dgnn_workspace** out)
+{
+    if (!net || !out || batch_size <= 0) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+
+    DeviceState* dev = nullptr;
+    int status = get_device_state(n, device, &dev);
+    if (status != DGNN_OK) return status;
+
+    std::vector<Workspace*>& idle = dev->idle[batch_size];
+    if (!idle.empty()) {   // network.rs:137-140: candidates.try_pop()
+        *out = reinterpret_cast<dgnn_workspace*>(idle.back());
+        idle.pop_back();
+        return DGNN_OK;
+    }
+
+    Workspace* ws = nullptr;
+    status = create_workspace(n, dev, batch_size, &ws);
+    if (status != DGNN_OK) { delete ws; return status; }
+    dev->all.push_back(ws);
+    *out = reinterpret_cast<dgnn_workspace*>(ws);
+    return DGNN_OK;
+}
+
+void dgnn_workspace_release(dgnn_workspace* handle)
+{
+    if (!handle) return;
+    Workspace* ws = W(handle);
+    if (ws->pending) {   // never hand back a workspace with work in flight
+        (void)hipSetDevice(ws->device);
+        (void)hipStreamSynchronize(ws->stream);
+        ws->pending = false;
+    }
+    std::lock_guard<std::mutex> lock(ws->net->mutex);
+    ws->dev->idle[ws->batch].push_back(ws);
+}
+
+int dgnn_network_synchronize(dgnn_network* net)
+{
+    if (!net) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+
+    int status = DGNN_OK;
+    for (auto& entry : n->devices) {
+        DeviceState* dev = entry.second.get();
+        if (hipSetDevice(dev->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            status = DGNN_HIP_ERROR;   // "this should be allowed to fail", network.rs:150-153: keep going
+
+        // self.workspaces.clear(): drop everything that is pooled; checked-out workspaces stay valid
+        for (auto& bucket : dev->idle) {
+            for (Workspace* ws : bucket.second) {
+                for (size_t i = 0; i < dev->all.size(); ++i)
+                    if (dev->all[i] == ws) { dev->all.erase(dev->all.begin() + i); break; }
+                delete ws;
+            }
+            bucket.second.clear();
+        }
+    }
+    return status;
+}
+
+// ---------------------------------------------------------------------------------------------- hot path
+
+int dgnn_forward_submit(dgnn_workspace* handle, const uint16_t* features, size_t num_features)
+{
+    if (!handle || !features) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    if (num_features != (size_t)ws->batch * DGNN_FEATURE_SIZE) return DGNN_BAD_ARGUMENT;   // graph.rs:124-125
+    if (ws->pending) return DGNN_BAD_ARGUMENT;
+
+    DGNN_HIP(hipSetDevice(ws->device));
+    const size_t in_bytes = num_features * sizeof(uint16_t);
+    if (features != ws->h_features) std::memcpy(ws->h_features, features, in_bytes);
+    DGNN_HIP(hipMemcpyAsync(ws->d_features, ws->h_features, in_bytes, hipMemcpyHostToDevice, ws->stream));   // graph.rs:130-131
+
+    const int status = enqueue_forward(ws, -1);
+    if (status != DGNN_OK) return status;
+
+    DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->batch * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->batch * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    ws->pending = true;
+    return DGNN_OK;
+}
+
+int dgnn_forward_wait(dgnn_workspace* handle, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!handle || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    if (!ws->pending) return DGNN_BAD_ARGUMENT;
+
+    DGNN_HIP(hipSetDevice(ws->device));
+    ws->pending = false;
+    DGNN_HIP(hipStreamSynchronize(ws->stream));   // graph.rs:155-156 (to_vec + synchronize)
+    if (value_out != ws->h_value) std::memcpy(value_out, ws->h_value, (size_t)ws->batch * 2);
+    if (policy_out != ws->h_policy) std::memcpy(policy_out, ws->h_policy, (size_t)ws->batch * DGNN_NUM_MOVES * 2);
+    return DGNN_OK;
+}
+
+int dgnn_forward(dgnn_workspace* ws, const uint16_t* features, size_t num_features,
+                 uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    const int status = dgnn_forward_submit(ws, features, num_features);
+    if (status != DGNN_OK) return status;
+    return dgnn_forward_wait(ws, value_out, policy_out);
+}
+
+// ---------------------------------------------------------------------------------------------- harness
+
+int dgnn_workspace_batch_size(const dgnn_workspace* ws, int* batch_size, int* device)
+{
+    if (!ws) return DGNN_BAD_ARGUMENT;
+    if (batch_size) *batch_size = W(ws)->batch;
+    if (device) *device = W(ws)->device;
+    return DGNN_OK;
+}
+
+int dgnn_workspace_device_buffers(dgnn_workspace* ws, void** d_features, void** d_value, void** d_policy)
+{
+    if (!ws) return DGNN_BAD_ARGUMENT;
+    if (d_features) *d_features = W(ws)->d_features;
+    if (d_value) *d_value = W(ws)->d_value;
+    if (d_policy) *d_policy = W(ws)->d_policy;
+    return DGNN_OK;
+}
+
+int dgnn_workspace_host_buffers(dgnn_workspace* ws, uint16_t** h_features, uint16_t** h_value, uint16_t** h_policy)
+{
+    if (!ws) return DGNN_BAD_ARGUMENT;
+    if (h_features) *h_features = W(ws)->h_features;
+    if (h_value) *h_value = W(ws)->h_value;
+    if (h_policy) *h_policy = W(ws)->h_policy;
+    return DGNN_OK;
+}
+
+int dgnn_workspace_stream(dgnn_workspace* ws, void** hip_stream)
+{
+    if (!ws || !hip_stream) return DGNN_BAD_ARGUMENT;
+    *hip_stream = (void*)W(ws)->stream;
+    return DGNN_OK;
+}
+
+int dgnn_workspace_upload(dgnn_workspace* handle, const uint16_t* features, size_t num_features)
+{
+    if (!handle || !features) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    if (num_features != (size_t)ws->batch * DGNN_FEATURE_SIZE) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(hipMemcpyAsync(ws->d_features, features, num_features * 2, hipMemcpyHostToDevice, ws->stream));
+    DGNN_HIP(hipStreamSynchronize(ws->stream));
+    return DGNN_OK;
+}
+
+int dgnn_workspace_download(dgnn_workspace* handle, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!handle || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(hipMemcpyAsync(value_out, ws->d_value, (size_t)ws->batch * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipMemcpyAsync(policy_out, ws->d_policy, (size_t)ws->batch * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipStreamSynchronize(ws->stream));
+    return DGNN_OK;
+}
+
+int dgnn_forward_resident(dgnn_workspace* handle)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    DGNN_HIP(hipSetDevice(ws->device));
+    return enqueue_forward(ws, -1);
+}
+
+int dgnn_workspace_sync(dgnn_workspace* handle)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(hipStreamSynchronize(ws->stream));
+    return DGNN_OK;
+}
+
+int dgnn_forward_timed(dgnn_workspace* handle, int steps, float* total_ms, float* tower_ms, int* tower_launches)
+{
+    if (!handle || steps <= 0) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    DGNN_HIP(hipSetDevice(ws->device));
+
+    while (ws->tower_events.size() < (size_t)2 * steps) {
+        hipEvent_t e = nullptr;
+        DGNN_HIP(hipEventCreate(&e));
+        ws->tower_events.push_back(e);
+    }
+
+    DGNN_HIP(hipEventRecord(ws->ev_begin, ws->stream));
+    for (int i = 0; i < steps; ++i) {
+        const int status = enqueue_forward(ws, i);
+        if (status != DGNN_OK) return status;
+    }
+    DGNN_HIP(hipEventRecord(ws->ev_end, ws->stream));
+    DGNN_HIP(hipStreamSynchronize(ws->stream));
+
+    float ms = 0.0f;
+    DGNN_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
+    if (total_ms) *total_ms = ms;
+
+    float tower = 0.0f;
+    for (int i = 0; i < steps; ++i) {
+        float t = 0.0f;
+        DGNN_HIP(hipEventElapsedTime(&t, ws->tower_events[2 * i], ws->tower_events[2 * i + 1]));
+        tower += t;
+    }
+    if (tower_ms) *tower_ms = tower;
+    if (tower_launches) *tower_launches = 2 * ws->net->topo.num_blocks * steps;
+    return DGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- layer level
+
+int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size, int cin,
+                       const uint16_t* w_krsc, const uint16_t* bias, int cout,
+                       float alpha1, float alpha2, const uint16_t* z, int relu, uint16_t* y)
+{
+    if (!x || !w_krsc || !bias || !y || batch <= 0 || board_size <= 0 || cout <= 0) return DGNN_BAD_ARGUMENT;
+    if (cin <= 0 || cin % 32 != 0) return DGNN_UNSUPPORTED;
+    if (alpha2 != 0.0f && !z) return DGNN_BAD_ARGUMENT;
+
+    int count = 0;
+    DGNN_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP(hipSetDevice(device));
+
+    const int cout_pad = (cout + 15) / 16 * 16;
+    const size_t num_pos = (size_t)batch * board_size * board_size;
+    const size_t sz_x = align_up(num_pos * cin * 2, 256);
+    const size_t sz_y = align_up(num_pos * cout * 2, 256);
+    const size_t sz_w = align_up((size_t)9 * cin * cout_pad * 2, 256);
+    const size_t sz_b = align_up((size_t)cout_pad * 2, 256);
+
+    std::vector<uint16_t> packed((size_t)9 * cin * cout_pad, 0), bias_pad(cout_pad, 0);
+    pack_filter(w_krsc, cout, cin, packed.data());
+    std::memcpy(bias_pad.data(), bias, (size_t)cout * 2);
+
+    uint8_t* d = nullptr;
+    DGNN_HIP(hipMalloc((void**)&d, sz_x + 2 * sz_y + sz_w + sz_b));
+    uint16_t* d_x = (uint16_t*)d;
+    uint16_t* d_y = (uint16_t*)(d + sz_x);
+    uint16_t* d_z = (uint16_t*)(d + sz_x + sz_y);
+    uint16_t* d_w = (uint16_t*)(d + sz_x + 2 * sz_y);
+    uint16_t* d_b = (uint16_t*)(d + sz_x + 2 * sz_y + sz_w);
+
+    int status = DGNN_OK;
+    hipError_t err = hipMemcpy(d_x, x, num_pos * cin * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_b, bias_pad.data(), bias_pad.size() * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess && alpha2 != 0.0f) err = hipMemcpy(d_z, z, num_pos * cout * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        ConvLaunch a;
+        a.x = d_x; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_z : nullptr; a.y = d_y;
+        a.num_pos = (int)num_pos; a.board = board_size; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad;
+        a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
+        err = launch_conv3x3(a, nullptr);
+    }
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(y, d_y, num_pos * cout * 2, hipMemcpyDeviceToHost);
+    if (err != hipSuccess) { set_last_hip_error((int)err); status = DGNN_HIP_ERROR; }
+    (void)hipFree(d);
+    return status;
+}
+
+// ---------------------------------------------------------------------------------------------- multi-GPU
+
+int dgnn_network_weight_image(dgnn_network* net, int device, void** d_image, size_t* num_bytes)
+{
+    if (!net) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+    DeviceState* dev = nullptr;
+    const int status = get_device_state(n, device, &dev);
+    if (status != DGNN_OK) return status;
+    if (d_image) *d_image = dev->d_image;
+    if (num_bytes) *num_bytes = n->image.size();
+    return DGNN_OK;
+}
+
+int dgnn_network_weight_checksum(const dgnn_network* net, uint64_t* checksum)
+{
+    if (!net || !checksum) return DGNN_BAD_ARGUMENT;
+    uint64_t h = 1469598103934665603ull;   // FNV-1a
+    for (uint8_t byte : N(net)->image) { h ^= byte; h *= 1099511628211ull; }
+    *checksum = h;
+    return DGNN_OK;
+}
+
+int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src, size_t num_bytes, int src_on_device)
+{
+    if (!net || !src) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+    if (num_bytes != n->image.size()) return DGNN_BAD_ARGUMENT;
+    DeviceState* dev = nullptr;
+    const int status = get_device_state(n, device, &dev);
+    if (status != DGNN_OK) return status;
+    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(hipDeviceSynchronize());   // no forward may be reading the old image
+    if ((const void*)dev->d_image != src)
+        DGNN_HIP(hipMemcpy(dev->d_image, src, num_bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return DGNN_OK;
+}
+
+int dgnn_network_weight_checksum_device(dgnn_network* net, int device, uint64_t* checksum)
+{
+    if (!net || !checksum) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+    DeviceState* dev = nullptr;
+    const int status = get_device_state(n, device, &dev);
+    if (status != DGNN_OK) return status;
+    std::vector<uint8_t> copy(n->image.size());
+    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(hipMemcpy(copy.data(), dev->d_image, copy.size(), hipMemcpyDeviceToHost));
+    uint64_t h = 1469598103934665603ull;
+    for (uint8_t byte : copy) { h ^= byte; h *= 1099511628211ull; }
+    *checksum = h;
+    return DGNN_OK;
+}
+
+int dgnn_network_weight_image_host(const dgnn_network* net, const void** image, size_t* num_bytes)
+{
+    if (!net) return DGNN_BAD_ARGUMENT;
+    if (image) *image = N(net)->image.data();
+    if (num_bytes) *num_bytes = N(net)->image.size();
+    return DGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Launch wrappers of the gfx950 kernels (kernels.hip).  Host-callable, plain C++.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace dgnn {
+
+struct ConvLaunch {
+    const uint16_t* x;     // input  [num_pos][cin]  fp16, NHWC with N*H*W flattened
+    const uint16_t* w;     // filter [9 * cin / 32][cout_pad][32] fp16 (network.cpp: pack_conv)
+    const uint16_t* bias;  // [cout_pad] fp16
+    const uint16_t* z;     // skip   [num_pos][cout] fp16, read only when alpha2 != 0
+    uint16_t* y;           // output [num_pos][cout] fp16
+    int num_pos;           // batch * board * board
+    int board;             // board edge length (19; the layer-level known-answer test uses 3)
+    int cin;
+    int cout;
+    int cout_pad;
+    float alpha1;
+    float alpha2;
+    int relu;
+};
+
+// y = act(alpha1 * conv3x3(x, w) + alpha2 * z + bias) on 19x19 boards; see kernels.hip.
+hipError_t launch_conv3x3(const ConvLaunch& args, hipStream_t stream);
+
+struct HeadsLaunch {
+    const uint16_t* policy_features;  // [batch][361 * samples] fp16  (policy conv output, NHWC flattened)
+    const uint16_t* value_features;   // [batch][722] fp16
+    const uint16_t* policy_w;         // [361 * samples][362] fp16, as stored ([in][out])
+    const uint16_t* policy_b;         // [362] fp16, already multiplied by tau
+    const uint16_t* value_w;          // [722] fp16
+    const uint16_t* value_b;          // [1] fp16
+    uint16_t* value_out;              // [batch] fp16
+    uint16_t* policy_out;             // [batch][362] fp16
+    int batch;
+    int samples;
+    float tau;
+};
+
+// policy = softmax(tau * (W_l . p) + b_l'), value = tanh(W_d . v + b_d); see kernels.hip.
+hipError_t launch_heads(const HeadsLaunch& args, hipStream_t stream);
+
+}  // namespace dgnn

@@ -1,0 +1,181 @@
+// Topology discovery and the packed, kernel-native weight image.
+//
+// Mirrors what graph::Builder::get_workspace and the layer constructors derive from the tensor map
+// (src/libdg_nn/graph.rs:50-96, layers/up_block.rs:37-47, layers/residual_block.rs:40-63,
+// layers/policy_head.rs:43-63, layers/value_head.rs:40-57, layers/common.rs:22-50) and performs on the
+// host, once, the preparation steps the reference performs on the device at first use:
+//   residual_block.rs:72-74   b2 <- fp16(alpha * b2)      (cudnnScaleTensor)
+//   policy_head.rs:87-89      b_l <- fp16(tau * b_l)      (cudnnScaleTensor)
+//   dense.rs:182-189          dense filter transpose      (not needed: the head kernel consumes [in][out])
+#include "dgnn_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace dgnn {
+
+namespace {
+
+constexpr size_t kAlign = 256;   // every tensor of the image starts on a 256-byte boundary
+
+size_t reserve(std::vector<uint8_t>& image, size_t bytes)
+{
+    const size_t offset = (image.size() + kAlign - 1) / kAlign * kAlign;
+    image.resize(offset + bytes, 0);
+    return offset;
+}
+
+const HostTensor* find_half(const TensorMap& tensors, const std::string& name, size_t min_elements)
+{
+    auto it = tensors.find(name);
+    if (it == tensors.end()) return nullptr;
+    if (it->second.dtype != DataType::Half) return nullptr;
+    if (it->second.num_elements() < min_elements) return nullptr;   // may carry base85 padding
+    return &it->second;
+}
+
+// Filter [cout][3][3][cin] (KRSC, conv2d.rs:111-117) -> [9 * cin / 32][cout_pad][32]:
+// k-step = tap * (cin / 32) + chunk; one k-step is one contiguous [cout_pad][32] slab.
+int pack_conv(const TensorMap& tensors, const std::string& name, int cout, int cin,
+              float alpha1, float alpha2, float bias_scale, std::vector<uint8_t>& image, ConvParams& out)
+{
+    const HostTensor* w = find_half(tensors, name + ":0", (size_t)cout * 9 * cin);
+    const HostTensor* b = find_half(tensors, name + "/offset:0", (size_t)cout);
+    if (!w || !b) return DGNN_MALFORMED_WEIGHTS;   // reference: expect("no filter available") panics
+
+    const int cout_pad = (cout + 15) / 16 * 16;
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(w->bytes.data());
+
+    out.cin = cin;
+    out.cout = cout;
+    out.cout_pad = cout_pad;
+    out.alpha1 = alpha1;
+    out.alpha2 = alpha2;
+    out.w_offset = reserve(image, (size_t)9 * cin * cout_pad * sizeof(uint16_t));
+    pack_filter(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_offset));
+
+    out.b_offset = reserve(image, (size_t)cout_pad * sizeof(uint16_t));
+    uint16_t* bias = reinterpret_cast<uint16_t*>(image.data() + out.b_offset);
+    const uint16_t* bsrc = reinterpret_cast<const uint16_t*>(b->bytes.data());
+    for (int co = 0; co < cout; ++co)
+        bias[co] = bias_scale == 1.0f ? bsrc[co] : float_to_half(bias_scale * half_to_float(bsrc[co]));
+
+    return DGNN_OK;
+}
+
+}  // namespace
+
+void pack_filter(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
+{
+    const int chunks = cin / 32;
+    const int cout_pad = (cout + 15) / 16 * 16;
+    for (int co = 0; co < cout; ++co)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < cin; ++ci) {
+                const size_t kstep = (size_t)tap * chunks + ci / 32;
+                dst[(kstep * cout_pad + co) * 32 + ci % 32] = krsc[((size_t)co * 9 + tap) * cin + ci];
+            }
+}
+
+namespace {
+
+std::string scope(int index, const char* suffix)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%02d%s", index, suffix);
+    return buf;
+}
+
+}  // namespace
+
+int build_network(Network& net)
+{
+    const TensorMap& t = net.tensors;
+    Topology& topo = net.topo;
+    std::vector<uint8_t> image;
+
+    // layers/common.rs:26-50
+    auto meta = [&](const char* name, int fallback) {
+        auto it = t.find(name);
+        return (it != t.end() && it->second.bytes.size() >= 4) ? (int)it->second.as_i32() : fallback;
+    };
+    const int c = meta("num_channels:0", 128);
+    const int s = meta("num_samples:0", 8);
+
+    if (c <= 0 || s <= 0) return DGNN_MALFORMED_WEIGHTS;
+    if (c % 32 != 0 || c > 1024 || s > 16) return DGNN_UNSUPPORTED;
+
+    topo.num_channels = c;
+    topo.num_samples = s;
+    topo.res1.clear();
+    topo.res2.clear();
+
+    int status = pack_conv(t, "01_upsample/conv_1", c, DGNN_NUM_FEATURES, 1.0f, 0.0f, 1.0f, image, topo.up);
+    if (status != DGNN_OK) return status;
+
+    // graph.rs:76-96: probe `{:02}_residual/conv_{1,2}:0` from 2 upwards until one is missing
+    for (int i = 2;; ++i) {
+        const std::string base = scope(i, "_residual");
+        if (t.find(base + "/conv_1:0") == t.end() || t.find(base + "/conv_2:0") == t.end()) break;
+
+        float alpha = 0.5f;   // residual_block.rs:50
+        auto it = t.find(base + "/alpha:0");
+        if (it != t.end()) {
+            if (it->second.bytes.size() < 4) return DGNN_MALFORMED_WEIGHTS;
+            alpha = it->second.as_f32();
+        }
+
+        ConvParams c1, c2;
+        status = pack_conv(t, base + "/conv_1", c, c, 1.0f, 0.0f, 1.0f, image, c1);
+        if (status != DGNN_OK) return status;
+        // conv_2: alpha = [gate, 1 - gate] (residual_block.rs:57) and offset scaled by gate (:72-74)
+        status = pack_conv(t, base + "/conv_2", c, c, alpha, 1.0f - alpha, alpha, image, c2);
+        if (status != DGNN_OK) return status;
+
+        topo.res1.push_back(c1);
+        topo.res2.push_back(c2);
+    }
+    topo.num_blocks = (int)topo.res1.size();
+
+    const int head = 2 + topo.num_blocks;   // graph.rs:54-55
+    const std::string policy = scope(head, "p_policy");
+    const std::string value = scope(head, "v_value");
+
+    status = pack_conv(t, policy + "/conv_1", s, c, 1.0f, 0.0f, 1.0f, image, topo.policy_conv);
+    if (status != DGNN_OK) return status;
+    status = pack_conv(t, value + "/conv_1", 2, c, 1.0f, 0.0f, 1.0f, image, topo.value_conv);
+    if (status != DGNN_OK) return status;
+
+    const float tau = 1.0f / topo.softmax_temperature;   // policy_head.rs:46
+    const size_t policy_in = (size_t)DGNN_NUM_POINTS * s;
+
+    const HostTensor* pw = find_half(t, policy + "/linear_1:0", policy_in * DGNN_NUM_MOVES);
+    const HostTensor* pb = find_half(t, policy + "/linear_1/offset:0", DGNN_NUM_MOVES);
+    const HostTensor* vw = find_half(t, value + "/linear_2:0", (size_t)DGNN_NUM_POINTS * 2);
+    const HostTensor* vb = find_half(t, value + "/linear_2/offset:0", 1);
+    if (!pw || !pb || !vw || !vb) return DGNN_MALFORMED_WEIGHTS;
+
+    topo.policy_w_offset = reserve(image, policy_in * DGNN_NUM_MOVES * sizeof(uint16_t));
+    std::memcpy(image.data() + topo.policy_w_offset, pw->bytes.data(), policy_in * DGNN_NUM_MOVES * sizeof(uint16_t));
+
+    topo.policy_b_offset = reserve(image, DGNN_NUM_MOVES * sizeof(uint16_t));
+    {
+        uint16_t* dst = reinterpret_cast<uint16_t*>(image.data() + topo.policy_b_offset);
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(pb->bytes.data());
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) dst[i] = float_to_half(tau * half_to_float(src[i]));
+    }
+
+    topo.value_w_offset = reserve(image, (size_t)DGNN_NUM_POINTS * 2 * sizeof(uint16_t));
+    std::memcpy(image.data() + topo.value_w_offset, vw->bytes.data(), (size_t)DGNN_NUM_POINTS * 2 * sizeof(uint16_t));
+
+    topo.value_b_offset = reserve(image, sizeof(uint16_t));
+    std::memcpy(image.data() + topo.value_b_offset, vb->bytes.data(), sizeof(uint16_t));
+
+    reserve(image, 0);
+    image.resize((image.size() + kAlign - 1) / kAlign * kAlign, 0);
+    net.image.swap(image);
+    return DGNN_OK;
+}
+
+}  // namespace dgnn

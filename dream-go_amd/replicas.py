@@ -1,0 +1,61 @@
+"""Multi-GPU plumbing of the leaf-evaluation path: independent replicas, one process per GPU.
+
+The reference treats GPUs as replicas fed whole batches round-robin and uploads the weights to each device from
+the host (src/libdg_mcts/predictors/nn.rs:87-89, src/libdg_nn/tensor.rs:123-141); no activation ever crosses
+devices.  Here every rank owns one engine; leaf batches (and, above them, games: game_id mod world) are sharded
+statically, nothing is exchanged per step, and the only collective is ONE broadcast of the packed weight image
+from the rank that loaded the file (RCCL over xGMI with backend "nccl"; gloo in the CPU tests).
+"""
+import numpy as np
+
+
+def shard(num_units, world, rank):
+    """Static contiguous sharding of independent units (games / leaf batches): -> range for this rank."""
+    base, extra = divmod(int(num_units), int(world))
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def owner_of_game(game_id, world):
+    """Games are pinned to a GPU so that a game's transposition cache and batches stay local."""
+    return int(game_id) % int(world)
+
+
+def rank_seed(base_seed, rank):
+    """Distinct synthetic inputs per rank (ranks must not evaluate identical batches)."""
+    return int(base_seed) + 7919 * int(rank)
+
+
+def broadcast_image(dist, image, src=0):
+    """In-place broadcast of the weight image (a torch uint8 tensor on the rank's device, or on CPU for gloo)."""
+    dist.broadcast(image, src=src)
+    return image
+
+
+def all_agree(dist, torch, value, device="cpu"):
+    """True iff every rank holds the same 63-bit integer (e.g. an image checksum)."""
+    mine = torch.tensor([int(value) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, mine)
+    return len({int(g.item()) for g in gathered}) == 1
+
+
+def max_over_ranks(dist, torch, seconds, device="cpu"):
+    """The job's wall time is the slowest rank's."""
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist, torch, count, device="cpu"):
+    t = torch.tensor([int(count)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def fnv1a(data):
+    """The checksum libdgnn_hip.so uses for weight images (dgnn_network_weight_checksum)."""
+    h = 1469598103934665603
+    for byte in np.asarray(data, dtype=np.uint8).tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h

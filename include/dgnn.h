@@ -1,0 +1,195 @@
+/*
+ * dgnn.h -- C ABI of libdgnn_hip.so, the MI355X-native replacement for dream-go's
+ * neural-network leaf evaluation (crate `dg_nn` + the parts of `dg_cuda` it uses).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference checkout, kblomdahl/dream-go).  The reference-side binding a maintainer would
+ * add (Rust `extern "C"` block + safe wrappers keeping `Network` / `WorkspaceGuard` /
+ * `forward` / `OutputMap` source-compatible) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; fp16 values travel as their IEEE binary16 bit patterns (uint16_t),
+ *     which is the in-memory representation of the reference's `f16` (repr(C) u16,
+ *     src/libdg_utils/types/fp16.rs:16-20);
+ *   - every function returns a status: 0 on success, negative on failure; nothing aborts or
+ *     panics (the reference's `Result<_, Error>`, src/libdg_nn/error.rs:19-24);
+ *   - no process-global "current device": the device is an argument, and a call may be made
+ *     from any thread (the reference relies on thread-local cudaSetDevice,
+ *     src/libdg_mcts/predictors/nn.rs:87-89);
+ *   - a workspace is used by one thread at a time (`&mut Workspace`, graph.rs:123); distinct
+ *     workspaces may run concurrently from distinct threads; the network is immutable and shared.
+ */
+#ifndef DGNN_H
+#define DGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: src/libdg_nn/error.rs:19-24 flattened to integers ---------------------- */
+#define DGNN_OK                  0
+#define DGNN_MISSING_WEIGHTS    -1  /* Error::MissingWeights: no file / empty document (non-fatal while searching paths, network.rs:110-118) */
+#define DGNN_MALFORMED_WEIGHTS  -2  /* Error::MalformedWeights: bad JSON / base85 / dtype tag, or a required tensor absent or too short */
+#define DGNN_HIP_ERROR          -3  /* Error::Cuda(..) / Error::CuDNN(..): a HIP runtime call failed; see dgnn_last_hip_error() */
+#define DGNN_BAD_ARGUMENT       -4  /* null pointer, batch <= 0, feature count != batch * 11552 (the debug_assert!s of graph.rs:124-125) */
+#define DGNN_OUT_OF_MEMORY      -5  /* host allocation failed */
+#define DGNN_UNSUPPORTED        -6  /* architecture outside what the kernels cover (num_channels not a multiple of 32, > 1024, ...) */
+
+#define DGNN_NUM_FEATURES   32      /* features::V1::num_features(), src/libdg_go/utils/features.rs:88-90 */
+#define DGNN_NUM_POINTS     361     /* 19 x 19, src/libdg_nn/layers/conv2d.rs:50 */
+#define DGNN_FEATURE_SIZE   11552   /* features::V1::size() = 32 * 361, features.rs:94-96 */
+#define DGNN_NUM_MOVES      362     /* 361 points + pass, src/libdg_nn/layers/policy_head.rs:54 */
+
+typedef struct dgnn_network dgnn_network;     /* replaces dg_nn::Network  (src/libdg_nn/network.rs:83-86)  */
+typedef struct dgnn_workspace dgnn_workspace; /* replaces dg_nn::Workspace (src/libdg_nn/graph.rs:99-113) */
+
+/* Human readable text for a status code.  Never NULL. */
+const char* dgnn_status_string(int status);
+
+/* The hipError_t of the most recent DGNN_HIP_ERROR on the calling thread (0 if none).
+ * Replaces the payload of Error::Cuda(cuda::Error), src/libdg_cuda/error.rs:27-41. */
+int dgnn_last_hip_error(void);
+
+/* ---- devices: dg_cuda::Device, src/libdg_cuda/devices.rs:55-73 ----------------------------- */
+
+/* Device::len() -- number of visible GPUs. */
+int dgnn_device_count(int* count);
+
+/* ---- network: dg_nn::Network + loader ------------------------------------------------------ */
+
+/* loader::load(path) + graph::Builder::new (src/libdg_nn/loader.rs:102-116, graph.rs:35-41).
+ * Parses the weights JSON ({name: {"s": b85 f32, "t": "i1|i4|f2|f4", "v": b85 bytes}}),
+ * discovers the topology by name probing (graph.rs:76-96) and prepares the packed weight image
+ * (alpha * b2, tau * b_l, kernel-native filter layout) on the host.  Touches no GPU.
+ * Returns DGNN_MISSING_WEIGHTS if the file does not exist or holds no tensor. */
+int dgnn_network_load(const char* json_path, dgnn_network** out);
+
+/* Same, from a document already in memory (the reference's loader::load_aux, loader.rs:36-100). */
+int dgnn_network_from_json(const char* json_text, size_t json_len, dgnn_network** out);
+
+/* Network::new() (network.rs:92-127): tries, in order, `<exe_path with extension .json>`
+ * (skipped when exe_path is NULL), "dream_go.json", "models/dream_go.json",
+ * "/usr/share/dreamgo/dream_go.json", "/usr/share/dream_go/dream_go.json"; the first file that
+ * loads wins; MISSING_WEIGHTS moves on to the next path, any other error is returned. */
+int dgnn_network_load_default(const char* exe_path, dgnn_network** out);
+
+/* Drop of the last Network clone.  Drains and frees every workspace and device copy. */
+void dgnn_network_destroy(dgnn_network* net);
+
+/* Topology as the reference derives it: residual block count (graph.rs:76-96),
+ * get_num_channels / get_num_samples (layers/common.rs:26-50).  Any out pointer may be NULL. */
+int dgnn_network_info(const dgnn_network* net, int* num_blocks, int* num_channels, int* num_samples);
+
+/* config::SOFTMAX_TEMPERATURE (src/libdg_utils/config.rs:176-177; read by policy_head.rs:46 when a
+ * workspace is built).  The loader initialises it from the SOFTMAX_TEMPERATURE environment variable
+ * exactly like the reference (default 0.709888).  Must be called before the first workspace is created. */
+int dgnn_network_set_softmax_temperature(dgnn_network* net, float temperature);
+
+/* Network::get_workspace(batch_size) (network.rs:132-142) with the device made explicit instead of
+ * thread-local: pops a pooled workspace for (device, batch_size) or builds one.  The first workspace
+ * on a device uploads the weight image to it (the lazy Tensor::copy_to_device of tensor.rs:123-141). */
+int dgnn_network_get_workspace(dgnn_network* net, int device, int batch_size, dgnn_workspace** out);
+
+/* Drop of the WorkspaceGuard (network.rs:71-79): returns the workspace to its pool. */
+void dgnn_workspace_release(dgnn_workspace* ws);
+
+/* Network::synchronize() (network.rs:145-159): waits for every device, then drops all pooled workspaces. */
+int dgnn_network_synchronize(dgnn_network* net);
+
+/* ---- the hot path: dg_nn::forward, src/libdg_nn/graph.rs:123-158 --------------------------- */
+
+/* forward(&mut Workspace, &[f16]) -> OutputMap<f16>.
+ *   features     batch * 11552 fp16, HWC per board (index 32 * (19 * y + x) + c), borrowed for the call
+ *   num_features must equal batch_size(ws) * 11552 (graph.rs:124-125), else DGNN_BAD_ARGUMENT
+ *   value_out    batch fp16          tanh output in [-1, 1]           (OutputMap::value)
+ *   policy_out   batch * 362 fp16    soft-maxed with temperature, index 361 = pass; NOT masked, NOT
+ *                renormalised (callers do that, src/libdg_mcts/pool/policy_helper.rs:87-134)
+ * Synchronous like the reference (to_vec + cudaStreamSynchronize, src/libdg_cuda/memory.rs:138-153):
+ * returns after both outputs are in the caller's host buffers. */
+int dgnn_forward(dgnn_workspace* ws, const uint16_t* features, size_t num_features,
+                 uint16_t* value_out, uint16_t* policy_out);
+
+/* Split form of the same call for callers that overlap tree work with the GPU (no reference
+ * counterpart; the reference blocks).  submit copies the features out before returning. */
+int dgnn_forward_submit(dgnn_workspace* ws, const uint16_t* features, size_t num_features);
+int dgnn_forward_wait(dgnn_workspace* ws, uint16_t* value_out, uint16_t* policy_out);
+
+/* ---- device-resident variants (measurement harness; inputs already in HBM) ----------------- */
+
+int dgnn_workspace_batch_size(const dgnn_workspace* ws, int* batch_size, int* device);
+
+/* The workspace's own HBM buffers: features [batch*11552] fp16, value [batch] fp16,
+ * policy [batch*362] fp16.  Valid until the workspace is destroyed. */
+int dgnn_workspace_device_buffers(dgnn_workspace* ws, void** d_features, void** d_value, void** d_policy);
+
+/* The workspace's pinned host staging buffers (same shapes).  A batcher may assemble features directly in
+ * h_features and pass that pointer to dgnn_forward / dgnn_forward_submit: the staging memcpy is then skipped
+ * (likewise for value_out == h_value, policy_out == h_policy). */
+int dgnn_workspace_host_buffers(dgnn_workspace* ws, uint16_t** h_features, uint16_t** h_value, uint16_t** h_policy);
+
+/* The HIP stream (hipStream_t) every kernel of this workspace is launched on. */
+int dgnn_workspace_stream(dgnn_workspace* ws, void** hip_stream);
+
+/* Host -> HBM copy of the features without running anything (blocking). */
+int dgnn_workspace_upload(dgnn_workspace* ws, const uint16_t* features, size_t num_features);
+/* HBM -> host copy of the outputs (blocking). */
+int dgnn_workspace_download(dgnn_workspace* ws, uint16_t* value_out, uint16_t* policy_out);
+
+/* Enqueue one pass of the hot path over the features resident in HBM; asynchronous. */
+int dgnn_forward_resident(dgnn_workspace* ws);
+/* Block until everything enqueued on the workspace's stream has finished. */
+int dgnn_workspace_sync(dgnn_workspace* ws);
+
+/* `steps` back-to-back resident passes bracketed by HIP events on the workspace's stream.
+ *   total_ms    elapsed time of all passes
+ *   tower_ms    summed elapsed time of the residual-tower launches only (event pairs recorded on the
+ *               same stream around the residual convolutions of every pass)
+ *   tower_launches  number of residual convolution launches those events bracket (2 * blocks * steps)
+ * Any out pointer may be NULL. */
+int dgnn_forward_timed(dgnn_workspace* ws, int steps, float* total_ms, float* tower_ms, int* tower_launches);
+
+/* ---- layer-level entry point (parity tests) --------------------------------------------------- */
+
+/* One Conv2d::forward / forward_skip (src/libdg_nn/layers/conv2d.rs:171-220) on host buffers, for the
+ * layer-level parity tests that mirror the reference's own (conv2d.rs:252-291):
+ *   y = act(alpha1 * conv3x3(x, w) + alpha2 * z + bias)
+ *   x [batch][board][board][cin] fp16 NHWC, w [cout][3][3][cin] fp16 KRSC, bias [cout], z/y [..][cout];
+ *   cin must be a multiple of 32 (pad with zero channels); z is read only when alpha2 != 0;
+ *   relu != 0 selects ReLU, 0 the identity.  Allocates, runs and frees on `device`; blocking. */
+int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size, int cin,
+                       const uint16_t* w_krsc, const uint16_t* bias, int cout,
+                       float alpha1, float alpha2, const uint16_t* z, int relu, uint16_t* y);
+
+/* ---- multi-GPU: weight image for an RCCL broadcast ------------------------------------------ */
+
+/* The packed, kernel-native weight image of `net` on `device` (uploaded on first use) and its size.
+ * One ncclBroadcast of this range from the rank that loaded the file is the only collective the
+ * path needs (replaces the per-device host upload of tensor.rs:123-141 on weight refresh). */
+int dgnn_network_weight_image(dgnn_network* net, int device, void** d_image, size_t* num_bytes);
+
+/* A 64-bit FNV-1a checksum of the host-side weight image, to verify a broadcast. */
+int dgnn_network_weight_checksum(const dgnn_network* net, uint64_t* checksum);
+
+/* Weight refresh: overwrite the image on `device` with `num_bytes` (== the image size) from `src`, which is a
+ * device pointer on the same device when src_on_device != 0 (e.g. the buffer an RCCL broadcast landed in; pass
+ * the pointer dgnn_network_weight_image returned to make it a no-op) or a host pointer otherwise.
+ * Waits for the device to go idle first. */
+int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src, size_t num_bytes, int src_on_device);
+
+/* FNV-1a checksum of the image as it currently sits in `device` memory (downloads it). */
+int dgnn_network_weight_checksum_device(dgnn_network* net, int device, uint64_t* checksum);
+
+/* The host-side weight image itself (read-only, owned by the network). */
+int dgnn_network_weight_image_host(const dgnn_network* net, const void** image, size_t* num_bytes);
+
+/* Library version / build info string (static). */
+const char* dgnn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* DGNN_H */

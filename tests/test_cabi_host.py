@@ -1,0 +1,186 @@
+"""CPU-side tests of the C-ABI library: it loads, exports every symbol include/dgnn.h declares, ingests the
+reference's weights format identically to the oracle's restatement of loader.rs, and fails with status codes
+(never a crash, never a silent fallback) when there is no GPU.  No compute is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dgnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dgnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(api):
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(api.LIB_PATH)
+    missing = [name for name in declared if not hasattr(raw, name)]
+    assert not missing, missing
+    bound = {name for name, _, _ in api.SYMBOLS}
+    assert set(declared) == bound, set(declared) ^ bound
+
+
+def test_status_strings(api):
+    for status in (0, -1, -2, -3, -4, -5, -6, -99):
+        assert api.lib.dgnn_status_string(status)
+    assert b"gfx950" in api.lib.dgnn_version()
+
+
+def test_loader_kats_through_the_c_abi(api):
+    # loader.rs:123-129 empty_json
+    with pytest.raises(api.Error) as e:
+        api.Network.from_json("")
+    assert e.value.status == api.MISSING_WEIGHTS
+    with pytest.raises(api.Error) as e:
+        api.Network.from_json("{}")
+    assert e.value.status == api.MISSING_WEIGHTS
+    # loader.rs:131-141 load_json parses, but a single offset tensor is not a network
+    with pytest.raises(api.Error) as e:
+        api.Network.from_json('{"11v_value/linear_2/offset:0": {"s": "(^d>V", "t": "f2", "v": "(^d>V"}}')
+    assert e.value.status == api.MALFORMED_WEIGHTS
+    for bad in ('{"a": {"t": "f8"}}', '{"a": {"q": "00000"}}', '{"a": {"v": "00 00"}}', '{"a": 5}', '[1]', '{"a": {"t": "f2"}'):
+        with pytest.raises(api.Error) as e:
+            api.Network.from_json(bad)
+        assert e.value.status == api.MALFORMED_WEIGHTS, bad
+
+
+def test_missing_file_and_default_search(api, tmp_path, monkeypatch):
+    with pytest.raises(api.Error) as e:
+        api.Network.load(str(tmp_path / "nope.json"))
+    assert e.value.status == api.MISSING_WEIGHTS
+    monkeypatch.chdir(tmp_path)
+    assert api.Network.new() is None                      # Network::new() -> None (network.rs:108-127)
+
+
+def test_default_search_order(api, synth, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    os.makedirs(tmp_path / "models")
+    synth.write_network(str(tmp_path / "models" / "dream_go.json"), 1, 32, num_samples=2, seed=2)
+    net = api.Network.new()
+    assert net is not None and net.info()["num_blocks"] == 1
+    synth.write_network(str(tmp_path / "dream_go.json"), 2, 32, num_samples=2, seed=2)
+    assert api.Network.new().info()["num_blocks"] == 2     # "dream_go.json" precedes "models/dream_go.json"
+    synth.write_network(str(tmp_path / "engine.json"), 3, 32, num_samples=2, seed=2)
+    assert api.Network.new(exe_path=str(tmp_path / "engine")).info()["num_blocks"] == 3   # <exe>.json first
+    (tmp_path / "engine.json").write_text('{"a": {"t": "zz"}}')
+    with pytest.raises(api.Error) as e:                    # a malformed file is fatal, not skipped (network.rs:114-116)
+        api.Network.new(exe_path=str(tmp_path / "engine"))
+    assert e.value.status == api.MALFORMED_WEIGHTS
+
+
+@pytest.mark.parametrize("blocks,channels,samples", [(0, 32, 8), (2, 64, 8), (3, 96, 4)])
+def test_topology_discovery(api, synth, blocks, channels, samples):
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(blocks, channels, num_samples=samples, seed=1)))
+    assert net.info() == {"num_blocks": blocks, "num_channels": channels, "num_samples": samples}
+
+
+def test_topology_defaults_and_probing_stops_at_gap(api, synth):
+    tensors = synth.make_tensors(3, 128, num_samples=8, seed=1)
+    for name in ("num_channels:0", "num_samples:0", "num_blocks:0"):
+        del tensors[name]                                  # layers/common.rs:22-50 defaults 128 / 8
+    assert api.Network.from_json(synth.to_json(tensors)).info() == {"num_blocks": 3, "num_channels": 128, "num_samples": 8}
+
+    del tensors["03_residual/conv_2:0"]                     # graph.rs:76-96 stops at the first missing block ...
+    # ... and the heads are then looked up as "{2 + 1}p_policy" (graph.rs:54-55), which this file does not hold:
+    # the reference panics ("no filter available", conv2d.rs:62-63); the C ABI reports malformed weights.
+    with pytest.raises(api.Error) as e:
+        api.Network.from_json(synth.to_json(tensors))
+    assert e.value.status == api.MALFORMED_WEIGHTS
+
+    # re-number the heads to follow the single remaining block and the same file loads as a 1-block network
+    renamed = {name.replace("05p_policy", "03p_policy").replace("05v_value", "03v_value"): t for name, t in tensors.items()}
+    assert api.Network.from_json(synth.to_json(renamed)).info()["num_blocks"] == 1
+
+
+def test_unsupported_channel_count(api, synth):
+    with pytest.raises(api.Error) as e:
+        api.Network.from_json(synth.to_json(synth.make_tensors(1, 48, seed=1)))
+    assert e.value.status == api.UNSUPPORTED
+
+
+def test_weight_image_layout_and_prescaling(api, synth, oracle):
+    blocks, c, s = 1, 32, 2
+    text = synth.to_json(synth.make_tensors(blocks, c, num_samples=s, seed=4, alpha=0.25))
+    net = api.Network.from_json(text)
+    image = net.weight_image_host().copy()
+    tensors, _ = oracle.load_weights(text)
+
+    # first tensor of the image: up-conv filter, [9 * cin / 32][cout_pad][32] from KRSC [cout][3][3][cin]
+    w = tensors["01_upsample/conv_1:0"].view(np.uint16)[: c * 9 * 32].reshape(c, 9, 32)
+    expect = np.transpose(w, (1, 0, 2)).reshape(-1)
+    got = image[: expect.size * 2].view(np.uint16)
+    assert np.array_equal(got, expect)
+
+    # alpha * b2 rounded to fp16 (residual_block.rs:72-74) and tau * b_l (policy_head.rs:87-89) appear in the image
+    b2 = tensors["02_residual/conv_2/offset:0"].astype(np.float32)[:c]
+    scaled = (np.float32(0.25) * b2).astype(np.float16).view(np.uint16)
+    words = image.view(np.uint16)
+    assert _find(words, scaled) >= 0
+    tau = np.float32(1.0) / np.float32(0.709888)
+    bl = (tau * tensors["03p_policy/linear_1/offset:0"].astype(np.float32)[:362]).astype(np.float16).view(np.uint16)
+    assert _find(words, bl) >= 0
+
+    # temperature is baked at build time and can be changed before the first workspace (policy_head.rs:46)
+    before = net.weight_checksum()
+    net.set_softmax_temperature(1.0)
+    assert net.weight_checksum() != before
+    bl1 = tensors["03p_policy/linear_1/offset:0"][:362].view(np.uint16)
+    assert _find(net.weight_image_host().view(np.uint16), bl1) >= 0
+
+
+def _find(haystack, needle):
+    first = np.flatnonzero(haystack == needle[0])
+    for i in first:
+        if i + needle.size <= haystack.size and np.array_equal(haystack[i:i + needle.size], needle):
+            return int(i)
+    return -1
+
+
+def test_softmax_temperature_env(api, synth, monkeypatch):
+    text = synth.to_json(synth.make_tensors(0, 32, num_samples=2, seed=4))
+    a = api.Network.from_json(text).weight_checksum()
+    monkeypatch.setenv("SOFTMAX_TEMPERATURE", "1.5")      # config.rs:176-177
+    b = api.Network.from_json(text).weight_checksum()
+    monkeypatch.setenv("SOFTMAX_TEMPERATURE", "0.709888")
+    c = api.Network.from_json(text).weight_checksum()
+    assert a != b and a == c
+
+
+def test_checksum_is_deterministic(api, synth):
+    t1 = synth.to_json(synth.make_tensors(1, 32, num_samples=2, seed=1))
+    t2 = synth.to_json(synth.make_tensors(1, 32, num_samples=2, seed=2))
+    assert api.Network.from_json(t1).weight_checksum() == api.Network.from_json(t1).weight_checksum()
+    assert api.Network.from_json(t1).weight_checksum() != api.Network.from_json(t2).weight_checksum()
+
+
+def test_no_gpu_is_an_error_not_a_fallback(api, synth):
+    try:
+        count = api.Device.len()
+    except api.Error as e:
+        assert e.status == api.HIP_ERROR and e.hip_error != 0
+        count = 0
+    if count > 0:
+        pytest.skip("a GPU is present; the no-device path is covered on the CPU box")
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(0, 32, num_samples=2, seed=1)))
+    with pytest.raises(api.Error) as e:
+        net.get_workspace(1)
+    assert e.value.status == api.HIP_ERROR                 # the product path fails loudly without its device
+    x = np.zeros(361 * 32, dtype=np.uint16)
+    with pytest.raises(api.Error):
+        api.layer_conv3x3(x, 1, 19, 32, np.zeros(16 * 9 * 32, np.uint16), np.zeros(16, np.uint16), 16)
+
+
+def test_bad_arguments(api):
+    assert api.lib.dgnn_network_info(None, None, None, None) == api.BAD_ARGUMENT
+    assert api.lib.dgnn_forward(None, None, 0, None, None) == api.BAD_ARGUMENT
+    assert api.lib.dgnn_device_count(None) == api.BAD_ARGUMENT
+    assert api.lib.dgnn_network_get_workspace(None, 0, 1, None) == api.BAD_ARGUMENT
+    api.lib.dgnn_workspace_release(None)
+    api.lib.dgnn_network_destroy(None)

@@ -1,0 +1,269 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle, on a real MI355X.
+
+Tolerances are the ones BASELINE.json's north_star states: value abs diff <= 1e-3, policy max-abs diff <= 1e-3
+(both on fp16 outputs promoted to fp32); policy KL(oracle || hip) is asserted small and reported.
+Layer level: the convolution output is compared after fp16 rounding; the oracle accumulates k in order in
+fp32, the MFMA kernel accumulates 32-wide k-groups in fp32, so results agree to a few fp16 ulps of the output.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, f16_to_f32, policy_kl
+
+pytestmark = pytest.mark.gpu
+
+VALUE_TOL = 1e-3
+POLICY_TOL = 1e-3
+
+
+def _close_fp16(got_bits, ref_bits, ulps=2.0, atol=2e-3):
+    """|got - ref| <= ulps * ulp_fp16(|ref|) + tiny; returns (ok, worst absolute difference)."""
+    got, ref = f16_to_f32(got_bits), f16_to_f32(ref_bits)
+    diff = np.abs(got - ref)
+    bound = ulps * np.maximum(np.abs(ref), 2.0 ** -14) * 2.0 ** -10 + atol * 0
+    return bool(np.all(diff <= bound + 1e-7)), float(diff.max()), float((diff / np.maximum(np.abs(ref), 1e-3)).max())
+
+
+# --------------------------------------------------------------------------------------------- layer level
+
+def test_conv2d_pick_middle_and_sum_through_hip(api):
+    """The reference's own layer test (conv2d.rs:252-291) through the HIP kernel; cin padded 1 -> 32 with zeros."""
+    k = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))["conv2d_pick_middle_and_sum"]
+    x = np.zeros((9, 32), dtype=np.float16); x[:, 0] = k["input"]
+    w = np.zeros((2, 9, 32), dtype=np.float16); w[:, :, 0] = np.asarray(k["filter_kcrs_as_listed"], dtype=np.float16).reshape(2, 9)
+    y = api.layer_conv3x3(x, 1, 3, 32, w, np.zeros(2, np.float16), 2, relu=True)
+    assert f16_to_f32(y).tolist() == [float(v) for v in k["expected_nhwc"]]
+
+
+def test_conv_asymmetric_taps_and_channels(api, oracle):
+    """A transpose-detecting case: every (tap, cin, cout) weight distinct, single hot input pixels."""
+    cin, cout = 32, 16
+    w = (np.arange(cout * 9 * cin, dtype=np.float32).reshape(cout, 9, cin) % 251) / 64.0
+    x = np.zeros((1, 19, 19, cin), dtype=np.float32)
+    x[0, 0, 0, 3] = 1.0; x[0, 7, 11, 17] = 2.0; x[0, 18, 18, 31] = -1.0; x[0, 18, 0, 0] = 0.5
+    b = np.linspace(-1, 1, cout).astype(np.float32)
+    args = (oracle.f16(x), 1, 19, cin, oracle.f16(w), oracle.f16(b), cout)
+    ref = oracle.conv3x3(*args, relu=False)
+    got = api.layer_conv3x3(*args, relu=False)
+    assert np.array_equal(got, ref)      # every output is one exact product (+ bias): bit-exact
+
+
+@pytest.mark.parametrize("batch,cin,cout,alpha,relu", [
+    (1, 32, 64, None, True),       # up-layer shape (K1)
+    (3, 32, 128, None, True),      # up-layer shape (K2), ragged tile (3 * 361 = 1083 positions)
+    (2, 64, 64, 0.5, True),        # residual conv_2 with gated skip (K1)
+    (2, 128, 128, 0.25, True),     # K2
+    (1, 256, 256, 0.5, True),      # K3
+    (2, 256, 256, None, False),    # identity activation
+    (2, 96, 96, 0.5, True),        # channel count that is not a power of two (partial N tile)
+    (2, 128, 8, None, True),       # policy-head conv (fp32 compute in the reference, policy_head.rs:51)
+    (2, 128, 2, None, True),       # value-head conv (value_head.rs:47), scalar epilogue
+    (5, 64, 2, None, True),
+])
+def test_conv_layer_against_oracle(api, oracle, batch, cin, cout, alpha, relu):
+    rng = np.random.default_rng([batch, cin, cout])
+    x = np.maximum(rng.normal(0, 1, (batch, 19, 19, cin)), 0).astype(np.float16)     # post-ReLU like activations
+    w = rng.normal(0, np.sqrt(2.0 / (9 * cin)), (cout, 3, 3, cin)).astype(np.float16)
+    b = rng.normal(0, 0.1, (cout,)).astype(np.float16)
+    z = np.maximum(rng.normal(0, 1, (batch, 19, 19, cout)), 0).astype(np.float16) if alpha is not None else None
+    a1, a2 = (alpha, 1.0 - alpha) if alpha is not None else (1.0, 0.0)
+    ref = oracle.conv3x3(x, batch, 19, cin, w, b, cout, alpha1=a1, alpha2=a2, z=z, relu=relu)
+    got = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=a1, alpha2=a2, z=z, relu=relu)
+    ok, worst_abs, worst_rel = _close_fp16(got, ref, ulps=2.0)
+    mismatched = int(np.count_nonzero(got != ref))
+    print(f"conv B={batch} {cin}->{cout}: {mismatched}/{got.size} outputs differ, max abs {worst_abs:.3e}, max rel {worst_rel:.3e}")
+    assert np.abs(f16_to_f32(got) - f16_to_f32(ref)).max() <= 4e-3 * max(1.0, float(np.abs(f16_to_f32(ref)).max()))
+    assert mismatched <= 0.02 * got.size            # different fp32 summation order flips few fp16 roundings
+
+
+def test_conv_does_not_read_skip_when_alpha2_is_zero(api, oracle):
+    """Conv2d::forward aliases z to the uninitialised output with alpha2 = 0 (conv2d.rs:188-190): z must be ignored."""
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 1, (1, 19, 19, 32)).astype(np.float16)
+    w = rng.normal(0, 0.1, (32, 3, 3, 32)).astype(np.float16)
+    b = np.zeros(32, np.float16)
+    nan = np.full((1, 19, 19, 32), np.nan, dtype=np.float16)
+    a = api.layer_conv3x3(x, 1, 19, 32, w, b, 32, alpha1=1.0, alpha2=0.0, z=nan)
+    c = api.layer_conv3x3(x, 1, 19, 32, w, b, 32, alpha1=1.0, alpha2=0.0, z=None)
+    assert np.array_equal(a, c) and not np.isnan(f16_to_f32(a)).any()
+
+
+def test_conv_linearity(api):
+    """Size-independent property: conv(x1 + x2) == conv(x1) + conv(x2) for exactly representable small integers."""
+    rng = np.random.default_rng(8)
+    cin, cout, batch = 64, 64, 4
+    x1 = rng.integers(0, 3, (batch, 19, 19, cin)).astype(np.float16)
+    x2 = rng.integers(0, 3, (batch, 19, 19, cin)).astype(np.float16)
+    w = (rng.integers(-2, 3, (cout, 3, 3, cin)) / 8.0).astype(np.float16)
+    b = np.zeros(cout, np.float16)
+    run = lambda x: f16_to_f32(api.layer_conv3x3(x, batch, 19, cin, w, b, cout, relu=False))
+    assert np.array_equal(run(x1 + x2), run(x1) + run(x2))     # all sums are exact in fp32 and fp16 here
+
+
+# --------------------------------------------------------------------------------------------- whole network
+
+def _compare(api, oracle, text, features, batch, label, oracle_boards=None):
+    net = api.Network.from_json(text) if text.lstrip().startswith("{") else api.Network.load(text)
+    with net.get_workspace(batch) as ws:
+        value, policy = api.forward(ws, features).unwrap()
+    tensors, _ = oracle.load_weights(text)
+    onet = oracle.OracleNetwork(tensors)
+    boards = list(range(batch)) if oracle_boards is None else oracle_boards
+    f = np.ascontiguousarray(features).view(np.uint16).reshape(batch, 11552)
+    rv, rp = onet.forward(f[boards].reshape(-1), len(boards))
+    rv, rp = f16_to_f32(rv), f16_to_f32(rp).reshape(len(boards), 362)
+    gv, gp = value.astype(np.float32)[boards], policy.astype(np.float32).reshape(batch, 362)[boards]
+    dv, dp = float(np.abs(gv - rv).max()), float(np.abs(gp - rp).max())
+    kl = policy_kl(rp, gp)
+    print(f"{label}: max|dvalue| {dv:.3e}  max|dpolicy| {dp:.3e}  max KL {kl.max():.3e}  (boards checked: {len(boards)})")
+    assert dv <= VALUE_TOL and dp <= POLICY_TOL, (dv, dp)
+    assert kl.max() <= 1e-4
+    sums = policy.astype(np.float32).reshape(batch, 362).sum(axis=1)
+    assert np.all(np.abs(sums - 1.0) < 5e-3)
+    assert np.all(np.abs(value.astype(np.float32)) <= 1.0)
+    net.destroy()
+    return value, policy
+
+
+@pytest.mark.parametrize("name", ["net_2x32_s2", "net_1x128_s2"])
+def test_golden_fixture(api, name):
+    """HIP path against the committed fixture (no oracle needed at run time)."""
+    case = np.load(os.path.join(GOLDEN, name + "_case.npz"))
+    batch = int(case["batch"])
+    net = api.Network.load(os.path.join(GOLDEN, name + ".json"))
+    with net.get_workspace(batch) as ws:
+        value, policy = api.forward(ws, case["features"]).unwrap()
+    dv = np.abs(value.astype(np.float32) - f16_to_f32(case["value"])).max()
+    dp = np.abs(policy.astype(np.float32) - f16_to_f32(case["policy"])).max()
+    print(f"{name}: max|dvalue| {dv:.3e} max|dpolicy| {dp:.3e}")
+    assert dv <= VALUE_TOL and dp <= POLICY_TOL
+
+
+@pytest.mark.parametrize("blocks,channels,batch", [
+    (6, 64, 8),      # BASELINE.json configs[0] shape (the "plumbing" net), batch 8
+    (6, 64, 16),
+    (9, 128, 32),    # configs[1]: 9-block / 128-filter, batch 32
+    (2, 256, 4),     # a slice of configs[2]
+    (0, 32, 1),      # no residual block at all, batch 1 (edge case: empty tower)
+    (1, 32, 7),      # ragged: 7 * 361 positions is not a multiple of any tile
+])
+def test_network_against_oracle(api, oracle, synth, blocks, channels, batch):
+    text = synth.to_json(synth.make_tensors(blocks, channels, seed=100 + blocks))
+    features = synth.make_features(batch, seed=blocks * 1000 + batch)
+    _compare(api, oracle, text, features, batch, f"{blocks}x{channels} B={batch}")
+
+
+def test_full_size_network_sampled_boards(api, oracle, synth):
+    """BASELINE.json configs[2] at full size (20 x 256, batch 256).  Leaf evaluations are independent, so the
+    oracle evaluates a sample of the boards (first, last, two in the middle) and every one must match."""
+    blocks, channels, batch = 20, 256, 256
+    text = synth.to_json(synth.make_tensors(blocks, channels, seed=2020))
+    features = synth.make_features(batch, seed=77)
+    value, policy = _compare(api, oracle, text, features, batch, "20x256 B=256", oracle_boards=[0, 101, 200, 255])
+    # size-independent property on ALL boards: a board's result does not depend on its batch neighbours
+    f = features.reshape(batch, 11552)
+    perm = np.random.default_rng(1).permutation(batch)
+    net = api.Network.from_json(text)
+    with net.get_workspace(batch) as ws:
+        v2, p2 = api.forward(ws, f[perm].reshape(-1)).unwrap()
+    assert np.array_equal(v2.view(np.uint16), value.view(np.uint16)[perm])
+    assert np.array_equal(p2.view(np.uint16).reshape(batch, 362), policy.view(np.uint16).reshape(batch, 362)[perm])
+
+
+def test_every_batch_size_up_to_sixteen_and_pooling(api, oracle, synth):
+    """The pool sees any batch size 1..max (worker_thread.rs:131-133, batch.rs:109-117): same board, any batch."""
+    text = synth.to_json(synth.make_tensors(2, 64, seed=31))
+    net = api.Network.from_json(text)
+    one = synth.make_features(1, seed=5)
+    with net.get_workspace(1) as ws:
+        v1, p1 = api.forward(ws, one).unwrap()
+    for batch in list(range(1, 17)) + [33]:
+        with net.get_workspace(batch) as ws:
+            v, p = api.forward(ws, np.tile(one, batch)).unwrap()
+            handle = ws.handle.value
+        assert np.all(v.view(np.uint16) == v1.view(np.uint16)[0])
+        assert np.all(p.view(np.uint16).reshape(batch, 362) == p1.view(np.uint16)[None, :])
+        with net.get_workspace(batch) as ws:          # a released workspace is reused (network.rs:137-140)
+            assert ws.handle.value == handle
+    net.synchronize()                                  # network.rs:145-159: drains the pool
+    with net.get_workspace(4) as ws:
+        api.forward(ws, np.tile(one, 4))
+    net.destroy()
+
+
+def test_forward_argument_checks(api, synth):
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(0, 32, seed=1)))
+    with net.get_workspace(2) as ws:
+        with pytest.raises(api.Error) as e:            # graph.rs:124-125 debug_assert
+            api.forward(ws, synth.make_features(3))
+        assert e.value.status == api.BAD_ARGUMENT
+        api.forward(ws, synth.make_features(2))
+    with pytest.raises(api.Error) as e:
+        net.get_workspace(1, device=api.Device.len())
+    assert e.value.status == api.BAD_ARGUMENT
+
+
+def test_softmax_temperature_changes_policy_only(api, oracle, synth):
+    text = synth.to_json(synth.make_tensors(1, 32, seed=9))
+    features = synth.make_features(2, seed=3)
+    tensors, _ = oracle.load_weights(text)
+    for temperature in (0.709888, 1.0, 2.5):
+        net = api.Network.from_json(text)
+        net.set_softmax_temperature(temperature)
+        with net.get_workspace(2) as ws:
+            value, policy = api.forward(ws, features).unwrap()
+        rv, rp = oracle.OracleNetwork(tensors, softmax_temperature=temperature).forward(features, 2)
+        assert np.abs(value.astype(np.float32) - f16_to_f32(rv)).max() <= VALUE_TOL
+        assert np.abs(policy.astype(np.float32) - f16_to_f32(rp)).max() <= POLICY_TOL
+        with pytest.raises(api.Error):                 # baked into the device image: too late to change
+            net.set_softmax_temperature(1.0)
+
+
+def test_concurrent_workspaces_from_threads(api, synth):
+    """predict() is called concurrently from pool workers and game threads (predictors/nn.rs:64-67, lib.rs:114)."""
+    import threading
+    text = synth.to_json(synth.make_tensors(2, 64, seed=13))
+    net = api.Network.from_json(text)
+    feats = {b: synth.make_features(b, seed=40 + b) for b in (1, 3, 8)}
+    with net.get_workspace(8) as ws:
+        expect = {b: None for b in feats}
+    for b in feats:
+        with net.get_workspace(b) as ws:
+            expect[b] = [a.view(np.uint16).copy() for a in api.forward(ws, feats[b]).unwrap()]
+    errors = []
+
+    def worker(b, rounds):
+        try:
+            for _ in range(rounds):
+                with net.get_workspace(b) as ws:
+                    v, p = api.forward(ws, feats[b]).unwrap()
+                if not (np.array_equal(v.view(np.uint16), expect[b][0]) and np.array_equal(p.view(np.uint16), expect[b][1])):
+                    errors.append(f"mismatch at batch {b}")
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(b, 20)) for b in (1, 3, 8, 1, 3, 8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[:3]
+    net.destroy()
+
+
+def test_resident_and_timed_paths_match_host_path(api, synth):
+    text = synth.to_json(synth.make_tensors(2, 64, seed=17))
+    net = api.Network.from_json(text)
+    features = synth.make_features(5, seed=1)
+    with net.get_workspace(5) as ws:
+        v0, p0 = api.forward(ws, features).unwrap()
+        ws.upload(features)
+        ws.forward_resident(); ws.sync()
+        out = ws.download()
+        assert np.array_equal(out.value.view(np.uint16), v0.view(np.uint16))
+        assert np.array_equal(out.policy.view(np.uint16), p0.view(np.uint16))
+        total, tower, launches = ws.forward_timed(3)
+        assert launches == 2 * 2 * 3 and 0 < tower <= total
+        out = ws.download()
+        assert np.array_equal(out.policy.view(np.uint16), p0.view(np.uint16))

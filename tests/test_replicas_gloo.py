@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: two processes, gloo backend.  Covers the sharding, the max-over-ranks clock, and the
+weight-image broadcast + checksum agreement that bench.py performs with RCCL on the GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.package()
+    from dream_go_amd import api, replicas, synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank starts from DIFFERENT weights of the same architecture; rank 0's must win
+        net = api.Network.from_json(synth.to_json(synth.make_tensors(1, 32, num_samples=2, seed=10 + rank)))
+        before = net.weight_checksum()
+        agree_before = replicas.all_agree(dist, torch, before)
+        image = torch.from_numpy(net.weight_image_host())          # view of the library's host image
+        replicas.broadcast_image(dist, image, src=0)
+        after = net.weight_checksum()
+        agree_after = replicas.all_agree(dist, torch, after)
+        assert replicas.fnv1a(net.weight_image_host()) == after    # python restatement of the checksum
+
+        units = list(replicas.shard(11, world, rank))
+        total = replicas.sum_over_ranks(dist, torch, len(units))
+        slowest = replicas.max_over_ranks(dist, torch, 1.0 + rank)
+        results[rank] = dict(before=before, after=after, agree_before=agree_before, agree_after=agree_after,
+                             units=units, total=total, slowest=slowest,
+                             seed=replicas.rank_seed(5, rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_replicas_over_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as manager:
+        results = manager.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, results)) for port in [_free_port()] for r in range(world)]
+        [p.start() for p in procs]
+        [p.join(180) for p in procs]
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        r0, r1 = results[0], results[1]
+    assert r0["before"] != r1["before"] and not r0["agree_before"]
+    assert r0["after"] == r0["before"] == r1["after"] and r0["agree_after"] and r1["agree_after"]
+    assert r0["units"] + r1["units"] == list(range(11)) and r0["total"] == 11
+    assert r0["slowest"] == r1["slowest"] == 2.0
+    assert r0["seed"] != r1["seed"]
+
+
+def test_shard_covers_everything_once():
+    from dream_go_amd import replicas
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 8, 512, 1000003 % 4096):
+            seen = [u for r in range(world) for u in replicas.shard(n, world, r)]
+            assert seen == list(range(n))
+            sizes = [len(replicas.shard(n, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert [replicas.owner_of_game(g, 8) for g in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
