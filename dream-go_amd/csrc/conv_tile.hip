@@ -1,0 +1,272 @@
+// conv3x3_tile_kernel -- the tuned residual-tower convolution for gfx950 (C_out a multiple of 256, C_in a multiple
+// of 64).  Same contract as conv3x3_kernel (kernels.hip):  y = act(alpha1 * conv3x3(x, w) + alpha2 * z + bias).
+//
+// Implicit GEMM, output tile = BM board positions x 256 output channels per 512-thread workgroup (8 waves, 4 along
+// the channels x 2 along the positions; wave tile 64 channels x BM/2 positions), K loop over (64-channel chunk, tap).
+//
+//   HBM/L2 -> LDS   __builtin_amdgcn_global_load_lds, 16 B per lane (no VGPR round trip, no ds_write pass).
+//                   Activations: every lane gathers its 16 B straight from the NHWC tensor at the tap-shifted board
+//                   position; taps that leave the board (and rows past the end) read a zero page instead, so the
+//                   kernel contains no masking arithmetic.  Filter: the host packs every k-step's [256][64] slab in
+//                   exactly the LDS image order, so its copy is a linear 32 KiB stream.
+//   LDS layout      row-major [rows][64 halfs] (128 B rows), 16-byte slots XOR-swizzled with (row >> 1) & 7 so that
+//                   the 16 rows x one k-slot pattern of an MFMA fragment read (ds_read_b128) touches 16 distinct
+//                   slots of the 256 B bank row: conflict-free.  The DMA destination is lane-linear, so the swizzle
+//                   is applied to the per-lane SOURCE address (activations) / baked into the packed filter.
+//   pipeline        two LDS buffers; ONE workgroup barrier per k-step, placed in the MIDDLE of the step's MFMA
+//                   stream: before it every read of the current buffer has completed, after it the current buffer is
+//                   refilled for step + 2 and the first fragments of step + 1 are read while the step's last MFMAs
+//                   (operands already in registers) keep the matrix pipe busy.  A tile's loads therefore have a full
+//                   k-step (~1500 cycles) to land.
+//   MFMA            v_mfma_f32_16x16x32_f16, A operand = filter rows (output channels), B operand = positions: a lane
+//                   ends up with 4 consecutive output channels of one position -> 8-byte NHWC epilogue accesses.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace dgnn {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBN = 256;                  // output channels per workgroup
+constexpr int kBK = 64;                   // channels per k-step
+constexpr int kRowBytes = kBK * 2;        // 128
+constexpr int kWTileBytes = kBN * kRowBytes;
+constexpr int kThreads = 512;
+
+template <int FM>   // 16-position fragments per wave along the positions; BM = 32 * FM
+__global__ __launch_bounds__(kThreads)
+void conv3x3_tile_kernel(ConvTileLaunch a)
+{
+    constexpr int BM = 32 * FM;
+    constexpr int XTileBytes = BM * kRowBytes;
+    constexpr int BufBytes = XTileBytes + kWTileBytes;
+    constexpr int XI = BM / 64;           // activation DMA instructions per wave per k-step (8 rows each)
+    constexpr int WI = kBN / 64;          // filter DMA instructions per wave per k-step
+    constexpr int FN = 4;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * BufBytes];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3;
+    const int wm = wave >> 2;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * kBN;
+    const int cin = a.cin;
+    const int board = a.board;
+    const int chunks = cin / kBK;
+    const int nsteps = 9 * chunks;
+
+    // ---- per-lane gather description of the activation tile (fixed over the K loop) ----
+    const uint16_t* x_ptr[XI];    // address of this lane's 16 bytes at the centre tap, chunk 0
+    unsigned x_taps[XI];          // bit t set <=> tap t stays on the board
+    const int slot = lane & 7;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave * XI + i) * 8 + (lane >> 3);
+        const int pos = m0 + row;
+        const int piece = slot ^ ((row >> 1) & 7);
+        unsigned taps = 0;
+        if (pos < a.num_pos) {
+            const int p = pos % (board * board);
+            const int yy = p / board;
+            const int xx = p % board;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int sy = yy + t / 3 - 1;
+                const int sx = xx + t % 3 - 1;
+                if (sy >= 0 && sy < board && sx >= 0 && sx < board) taps |= 1u << t;
+            }
+        }
+        x_taps[i] = taps;
+        x_ptr[i] = a.x + (long)pos * cin + piece * 8;
+    }
+    const uint16_t* const zero_src = a.zero_page + slot * 8;
+    const uint16_t* const w_src = a.w + (long)blockIdx.y * nsteps * (kWTileBytes / 2) + (wave * WI) * 512 + lane * 8;
+
+    // issue the DMA of k-step `step` (chunk-major, tap-minor) into LDS buffer `buf`
+    auto issue = [&](int step, int buf) {
+        const int chunk = step / 9;
+        const int tap = step - chunk * 9;
+        const long shift = (long)((tap / 3 - 1) * board + (tap % 3 - 1)) * cin + chunk * kBK;
+        char* const xb = lds + buf * BufBytes + (wave * XI) * 1024;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const uint16_t* src = ((x_taps[i] >> tap) & 1u) ? x_ptr[i] + shift : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, 0, 0);
+        }
+        char* const wb = lds + buf * BufBytes + XTileBytes + (wave * WI) * 1024;
+        const uint16_t* ws = w_src + (long)step * (kWTileBytes / 2);
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + i * 512),
+                                             (__attribute__((address_space(3))) void*)(wb + i * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read addresses: row = base + (lane & 15), k-slot = (kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7) ----
+    const int s0 = (lane >> 4) ^ ((lane >> 1) & 7);
+    const int x_frag = (wm * (BM / 2) + (lane & 15)) * kRowBytes;                 // + fm * 2048 + slot * 16
+    const int w_frag = XTileBytes + (wn * 64 + (lane & 15)) * kRowBytes;          // + fn * 2048 + slot * 16
+    const int k_off[2] = {s0 * 16, (s0 ^ 4) * 16};
+
+    auto read_w = [&](int buf, int kk, int fn) -> half8 {
+        return *reinterpret_cast<const half8*>(lds + buf * BufBytes + w_frag + fn * 2048 + k_off[kk]);
+    };
+    auto read_x = [&](int buf, int kk, int fm) -> half8 {
+        return *reinterpret_cast<const half8*>(lds + buf * BufBytes + x_frag + fm * 2048 + k_off[kk]);
+    };
+
+    floatx4 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- prologue: tile 0 landed and visible, tile 1 in flight, first fragments of tile 0 in registers ----
+    issue(0, 0);
+    __syncthreads();                       // vmcnt(0) + barrier: buffer 0 complete for every wave
+    if (nsteps > 1) issue(1, 1);
+
+    half8 wf[FN], xf[FM];                  // fragments of the (step, kk) being contracted
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) wf[fn] = read_w(0, 0, fn);
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) xf[fm] = read_x(0, 0, fm);
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+
+        // kk = 0 of this step (operands were read at the end of the previous iteration / in the prologue);
+        // the kk = 1 fragments are read underneath these MFMAs
+        half8 wg[FN], xg[FM];
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) wg[fn] = read_w(cur, 1, fn);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) xg[fm] = read_x(cur, 1, fm);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[fn], xf[fm], acc[fn][fm], 0, 0, 0);
+
+        // first half of kk = 1
+#pragma unroll
+        for (int fm = 0; fm < FM / 2; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[fn], xg[fm], acc[fn][fm], 0, 0, 0);
+
+        // ---- the step's only barrier: every read of buffer `cur` is complete (the MFMAs above consumed them or
+        // the waitcnt of __syncthreads covers them); the DMA of step + 1 (issued one step ago) has landed ----
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (step + 2 < nsteps) issue(step + 2, cur);        // buffer `cur` is free again
+        if (step + 1 < nsteps) {                            // first fragments of the next step, from the other buffer
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) wf[fn] = read_w(cur ^ 1, 0, fn);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) xf[fm] = read_x(cur ^ 1, 0, fm);
+        }
+
+        // second half of kk = 1: operands already in registers, covers the latency of the reads just issued
+#pragma unroll
+        for (int fm = FM / 2; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[fn], xg[fm], acc[fn][fm], 0, 0, 0);
+    }
+
+    // ---- epilogue: D[i = 4 * (lane >> 4) + r][j = lane & 15], i = output channel, j = position ----
+    // Loads are unconditional (positions clamped) and issued a whole fragment row ahead of their use so that
+    // they overlap; only the stores are predicated.
+    const int cout = a.cout;
+    const int co0 = n0 + wn * 64 + (lane >> 4) * 4;
+    const bool skip = a.alpha2 != 0.0f;        // wave-uniform
+    const bool relu = a.relu != 0;
+    half4 b4[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) b4[fn] = *reinterpret_cast<const half4*>(a.bias + co0 + fn * 16);
+
+    auto finish = [&](int fm, const half4 (&z4)[FN]) {
+        const int pos = m0 + wm * (BM / 2) + fm * 16 + (lane & 15);
+        const long out = (long)pos * cout + co0;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            half4 y4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = __builtin_fmaf(a.alpha1, acc[fn][fm][r], (float)b4[fn][r]);
+                if (skip) t = __builtin_fmaf(a.alpha2, (float)z4[fn][r], t);
+                if (relu && !(t > 0.0f)) t = 0.0f;
+                y4[r] = (_Float16)t;
+            }
+            if (pos < a.num_pos) *reinterpret_cast<half4*>(a.y + out + fn * 16) = y4;
+        }
+    };
+
+    if (skip) {
+        half4 z4[FM][FN];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            int pos = m0 + wm * (BM / 2) + fm * 16 + (lane & 15);
+            pos = pos < a.num_pos ? pos : a.num_pos - 1;
+            const uint16_t* zp = a.z + (long)pos * cout + co0;
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) z4[fm][fn] = *reinterpret_cast<const half4*>(zp + fn * 16);
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) finish(fm, z4[fm]);
+    } else {
+        const half4 none[FN] = {};
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) finish(fm, none);
+    }
+}
+
+}  // namespace
+
+bool conv_tile_supported(int cin, int cout)
+{
+    return cin >= 64 && cin % 64 == 0 && cout >= 256 && cout % 256 == 0;
+}
+
+// Picks the position-tile height that wastes the fewest CU-rounds (256 CUs, one workgroup per CU).
+int conv_tile_pick_fm(int num_pos, int cout)
+{
+    const int candidates[3] = {8, 6, 4};
+    int best = 8;
+    double best_cost = 1e30;
+    for (int fm : candidates) {
+        const long bm = 32 * fm;
+        const long tiles = ((num_pos + bm - 1) / bm) * (cout / 256);
+        const long rounds = (tiles + 255) / 256;
+        // time ~ rounds * tile work; smaller tiles pay a little more per FLOP for filter traffic
+        const double cost = (double)rounds * bm * (1.0 + 8.0 / bm);
+        if (cost < best_cost) { best_cost = cost; best = fm; }
+    }
+    return best;
+}
+
+hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, hipStream_t stream)
+{
+    if (args.num_pos <= 0) return hipSuccess;
+    const int bm = 32 * fm;
+    dim3 grid((args.num_pos + bm - 1) / bm, args.cout / 256);
+    switch (fm) {
+        case 8: hipLaunchKernelGGL((conv3x3_tile_kernel<8>), grid, dim3(kThreads), 0, stream, args); break;
+        case 6: hipLaunchKernelGGL((conv3x3_tile_kernel<6>), grid, dim3(kThreads), 0, stream, args); break;
+        case 4: hipLaunchKernelGGL((conv3x3_tile_kernel<4>), grid, dim3(kThreads), 0, stream, args); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dgnn

@@ -50,6 +50,7 @@ int load_weights_file(const char* path, TensorMap& out);
 struct ConvParams {
     // one 3x3 convolution as the kernels consume it
     size_t w_offset = 0;     // byte offset of the filter in the image, layout [9 * cin / 32][cout_pad][32] fp16
+    size_t w_tile_offset = 0; // byte offset of the filter in tile layout (pack_filter_tile), 0 = not available
     size_t b_offset = 0;     // byte offset of the bias, [cout_pad] fp16 (already scaled where the reference scales)
     int cin = 0;
     int cout = 0;
@@ -91,6 +92,13 @@ struct Network {
 // Filter [cout][3][3][cin] (KRSC, conv2d.rs:111-117) -> [9 * cin / 32][cout_pad][32] (zero padded rows):
 // k-step = tap * (cin / 32) + chunk; one k-step is one contiguous [cout_pad][32] slab.  dst must be zeroed.
 void pack_filter(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
+
+// Filter KRSC -> the LDS image order of conv3x3_tile_kernel (conv_tile.hip):
+// [cout / 256][9 * cin / 64][256 rows][8 slots][8 halfs], k-step = chunk * 9 + tap, and the 16-byte slot s of row r
+// holds channels chunk * 64 + (s ^ ((r >> 1) & 7)) * 8 .. + 8.  Requires cout % 256 == 0 and cin % 64 == 0.
+void pack_filter_tile(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
+
+constexpr size_t kZeroPageBytes = 256;   // the image starts with a page of zeros (source of off-board taps)
 
 // Builds topo + image from tensors.  Returns a DGNN_* status.
 int build_network(Network& net);

@@ -56,6 +56,8 @@ struct Workspace {
     uint16_t* h_policy = nullptr;
 
     bool pending = false;                   // a submit without its wait
+    bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
+    int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
 
     ~Workspace();
 };
@@ -117,6 +119,17 @@ int get_device_state(Network* net, int device, DeviceState** out)
     return DGNN_OK;
 }
 
+// Kernel selection: the tuned tile kernel by default; DGNN_CONV=v1 forces the generic kernel, DGNN_CONV_FM=4|6|8
+// overrides the position-tile height (both exist for A/B measurements and as a safety valve).
+void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm)
+{
+    const char* impl = std::getenv("DGNN_CONV");
+    *use_tile = !(impl && std::strcmp(impl, "v1") == 0);
+    *fm = conv_tile_pick_fm(num_pos, cout >= 256 ? cout : 256);
+    const char* f = std::getenv("DGNN_CONV_FM");
+    if (f && (std::atoi(f) == 4 || std::atoi(f) == 6 || std::atoi(f) == 8)) *fm = std::atoi(f);
+}
+
 int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
 {
     std::unique_ptr<Workspace> ws(new (std::nothrow) Workspace());
@@ -127,6 +140,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->dev = dev;
     ws->device = dev->device;
     ws->batch = batch;
+
+    conv_impl_from_env(batch * DGNN_NUM_POINTS, t.num_channels, &ws->use_tile, &ws->tile_fm);
 
     DGNN_HIP(hipSetDevice(dev->device));
     DGNN_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));   // stream.rs:55
@@ -170,6 +185,23 @@ int enqueue_forward(Workspace* ws, int tower_pair)
     const int num_pos = ws->batch * DGNN_NUM_POINTS;
 
     auto conv = [&](const ConvParams& c, const uint16_t* x, const uint16_t* z, uint16_t* y) -> hipError_t {
+        if (ws->use_tile && c.w_tile_offset != 0 && conv_tile_supported(c.cin, c.cout)) {
+            ConvTileLaunch a;
+            a.x = x;
+            a.w = (const uint16_t*)(image + c.w_tile_offset);
+            a.bias = (const uint16_t*)(image + c.b_offset);
+            a.z = c.alpha2 != 0.0f ? z : nullptr;
+            a.y = y;
+            a.zero_page = (const uint16_t*)image;
+            a.num_pos = num_pos;
+            a.board = 19;
+            a.cin = c.cin;
+            a.cout = c.cout;
+            a.alpha1 = c.alpha1;
+            a.alpha2 = c.alpha2;
+            a.relu = 1;
+            return launch_conv3x3_tile(a, ws->tile_fm, ws->stream);
+        }
         ConvLaunch a;
         a.x = x;
         a.w = (const uint16_t*)(image + c.w_offset);
@@ -584,29 +616,43 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
 
     const int cout_pad = (cout + 15) / 16 * 16;
     const size_t num_pos = (size_t)batch * board_size * board_size;
+    bool use_tile = true;
+    int fm = 8;
+    conv_impl_from_env((int)num_pos, cout, &use_tile, &fm);
+    use_tile = use_tile && conv_tile_supported(cin, cout);
+
     const size_t sz_x = align_up(num_pos * cin * 2, 256);
     const size_t sz_y = align_up(num_pos * cout * 2, 256);
     const size_t sz_w = align_up((size_t)9 * cin * cout_pad * 2, 256);
     const size_t sz_b = align_up((size_t)cout_pad * 2, 256);
 
     std::vector<uint16_t> packed((size_t)9 * cin * cout_pad, 0), bias_pad(cout_pad, 0);
-    pack_filter(w_krsc, cout, cin, packed.data());
+    if (use_tile) pack_filter_tile(w_krsc, cout, cin, packed.data());
+    else pack_filter(w_krsc, cout, cin, packed.data());
     std::memcpy(bias_pad.data(), bias, (size_t)cout * 2);
 
     uint8_t* d = nullptr;
-    DGNN_HIP(hipMalloc((void**)&d, sz_x + 2 * sz_y + sz_w + sz_b));
-    uint16_t* d_x = (uint16_t*)d;
-    uint16_t* d_y = (uint16_t*)(d + sz_x);
-    uint16_t* d_z = (uint16_t*)(d + sz_x + sz_y);
-    uint16_t* d_w = (uint16_t*)(d + sz_x + 2 * sz_y);
-    uint16_t* d_b = (uint16_t*)(d + sz_x + 2 * sz_y + sz_w);
+    DGNN_HIP(hipMalloc((void**)&d, kZeroPageBytes + sz_x + 2 * sz_y + sz_w + sz_b));
+    uint16_t* d_zero = (uint16_t*)d;
+    uint16_t* d_x = (uint16_t*)(d + kZeroPageBytes);
+    uint16_t* d_y = (uint16_t*)(d + kZeroPageBytes + sz_x);
+    uint16_t* d_z = (uint16_t*)(d + kZeroPageBytes + sz_x + sz_y);
+    uint16_t* d_w = (uint16_t*)(d + kZeroPageBytes + sz_x + 2 * sz_y);
+    uint16_t* d_b = (uint16_t*)(d + kZeroPageBytes + sz_x + 2 * sz_y + sz_w);
 
     int status = DGNN_OK;
-    hipError_t err = hipMemcpy(d_x, x, num_pos * cin * 2, hipMemcpyHostToDevice);
+    hipError_t err = hipMemset(d_zero, 0, kZeroPageBytes);
+    if (err == hipSuccess) err = hipMemcpy(d_x, x, num_pos * cin * 2, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(d_b, bias_pad.data(), bias_pad.size() * 2, hipMemcpyHostToDevice);
     if (err == hipSuccess && alpha2 != 0.0f) err = hipMemcpy(d_z, z, num_pos * cout * 2, hipMemcpyHostToDevice);
-    if (err == hipSuccess) {
+    if (err == hipSuccess && use_tile) {
+        ConvTileLaunch a;
+        a.x = d_x; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_z : nullptr; a.y = d_y; a.zero_page = d_zero;
+        a.num_pos = (int)num_pos; a.board = board_size; a.cin = cin; a.cout = cout;
+        a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
+        err = launch_conv3x3_tile(a, fm, nullptr);
+    } else if (err == hipSuccess) {
         ConvLaunch a;
         a.x = d_x; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_z : nullptr; a.y = d_y;
         a.num_pos = (int)num_pos; a.board = board_size; a.cin = cin; a.cout = cout; a.cout_pad = cout_pad;

@@ -26,6 +26,27 @@ struct ConvLaunch {
 // y = act(alpha1 * conv3x3(x, w) + alpha2 * z + bias) on 19x19 boards; see kernels.hip.
 hipError_t launch_conv3x3(const ConvLaunch& args, hipStream_t stream);
 
+struct ConvTileLaunch {
+    const uint16_t* x;          // input  [num_pos][cin] fp16
+    const uint16_t* w;          // filter [cout / 256][9 * cin / 64][256][8 slots][8] fp16, slots XOR-swizzled (pack_filter_tile)
+    const uint16_t* bias;       // [cout] fp16
+    const uint16_t* z;          // skip [num_pos][cout] fp16, read only when alpha2 != 0
+    uint16_t* y;                // output [num_pos][cout] fp16
+    const uint16_t* zero_page;  // >= 128 bytes of zeros in device memory (source of off-board taps)
+    int num_pos;
+    int board;
+    int cin;                    // multiple of 64
+    int cout;                   // multiple of 256
+    float alpha1;
+    float alpha2;
+    int relu;
+};
+
+// Tuned residual-tower convolution (conv_tile.hip).  fm selects the position tile (32 * fm positions per workgroup).
+bool conv_tile_supported(int cin, int cout);
+int conv_tile_pick_fm(int num_pos, int cout);
+hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, hipStream_t stream);
+
 struct HeadsLaunch {
     const uint16_t* policy_features;  // [batch][361 * samples] fp16  (policy conv output, NHWC flattened)
     const uint16_t* value_features;   // [batch][722] fp16

@@ -55,6 +55,11 @@ int pack_conv(const TensorMap& tensors, const std::string& name, int cout, int c
     out.w_offset = reserve(image, (size_t)9 * cin * cout_pad * sizeof(uint16_t));
     pack_filter(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_offset));
 
+    if (cout % 256 == 0 && cin % 64 == 0) {
+        out.w_tile_offset = reserve(image, (size_t)9 * cin * cout * sizeof(uint16_t));
+        pack_filter_tile(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_tile_offset));
+    }
+
     out.b_offset = reserve(image, (size_t)cout_pad * sizeof(uint16_t));
     uint16_t* bias = reinterpret_cast<uint16_t*>(image.data() + out.b_offset);
     const uint16_t* bsrc = reinterpret_cast<const uint16_t*>(b->bytes.data());
@@ -76,6 +81,25 @@ void pack_filter(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
                 const size_t kstep = (size_t)tap * chunks + ci / 32;
                 dst[(kstep * cout_pad + co) * 32 + ci % 32] = krsc[((size_t)co * 9 + tap) * cin + ci];
             }
+}
+
+void pack_filter_tile(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
+{
+    const int chunks = cin / 64;
+    const int nsteps = 9 * chunks;
+    for (int co = 0; co < cout; ++co) {
+        const int nb = co / 256, r = co % 256;
+        for (int chunk = 0; chunk < chunks; ++chunk)
+            for (int tap = 0; tap < 9; ++tap) {
+                const size_t step = (size_t)chunk * 9 + tap;
+                uint16_t* row = dst + (((size_t)nb * nsteps + step) * 256 + r) * 64;
+                const uint16_t* src = krsc + ((size_t)co * 9 + tap) * cin + chunk * 64;
+                for (int s = 0; s < 8; ++s) {
+                    const int piece = s ^ ((r >> 1) & 7);
+                    for (int e = 0; e < 8; ++e) row[s * 8 + e] = src[piece * 8 + e];
+                }
+            }
+    }
 }
 
 namespace {
@@ -105,6 +129,8 @@ int build_network(Network& net)
 
     if (c <= 0 || s <= 0) return DGNN_MALFORMED_WEIGHTS;
     if (c % 32 != 0 || c > 1024 || s > 16) return DGNN_UNSUPPORTED;
+
+    reserve(image, kZeroPageBytes);   // offset 0: the zero page
 
     topo.num_channels = c;
     topo.num_samples = s;

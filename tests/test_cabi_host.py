@@ -115,7 +115,8 @@ def test_weight_image_layout_and_prescaling(api, synth, oracle):
     # first tensor of the image: up-conv filter, [9 * cin / 32][cout_pad][32] from KRSC [cout][3][3][cin]
     w = tensors["01_upsample/conv_1:0"].view(np.uint16)[: c * 9 * 32].reshape(c, 9, 32)
     expect = np.transpose(w, (1, 0, 2)).reshape(-1)
-    got = image[: expect.size * 2].view(np.uint16)
+    assert not image[:256].any()                          # the image starts with the zero page (off-board taps)
+    got = image[256: 256 + expect.size * 2].view(np.uint16)
     assert np.array_equal(got, expect)
 
     # alpha * b2 rounded to fp16 (residual_block.rs:72-74) and tau * b_l (policy_head.rs:87-89) appear in the image
@@ -133,6 +134,24 @@ def test_weight_image_layout_and_prescaling(api, synth, oracle):
     assert net.weight_checksum() != before
     bl1 = tensors["03p_policy/linear_1/offset:0"][:362].view(np.uint16)
     assert _find(net.weight_image_host().view(np.uint16), bl1) >= 0
+
+
+def test_tile_filter_layout(api, synth, oracle):
+    """conv_tile.hip consumes [cout/256][chunk * 9 + tap][256 rows][8 slots][8] with slot ^= (row >> 1) & 7."""
+    c = 256
+    text = synth.to_json(synth.make_tensors(1, c, num_samples=2, seed=6))
+    net = api.Network.from_json(text)                      # keep alive: the image view borrows its memory
+    words = net.weight_image_host().view(np.uint16)
+    tensors, _ = oracle.load_weights(text)
+    w = tensors["02_residual/conv_1:0"].view(np.uint16)[: c * 9 * c].reshape(c, 9, c // 64, 8, 8)   # [co][tap][chunk][piece][e]
+    rows = np.arange(c)
+    expect = np.empty((c // 64, 9, c, 8, 8), dtype=np.uint16)                                        # [chunk][tap][row][slot][e]
+    for slot in range(8):
+        piece = slot ^ ((rows >> 1) & 7)
+        expect[:, :, rows, slot, :] = np.transpose(w[rows, :, :, piece, :], (2, 1, 0, 3))
+    at = _find(words, expect.reshape(-1)[:4096])
+    assert at >= 0
+    assert np.array_equal(words[at: at + expect.size], expect.reshape(-1))
 
 
 def _find(haystack, needle):
