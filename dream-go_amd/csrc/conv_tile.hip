@@ -37,6 +37,16 @@ constexpr int kRowBytes = kBK * 2;        // 128
 constexpr int kWTileBytes = kBN * kRowBytes;
 constexpr int kThreads = 512;
 
+// fp32 -> fp16 at exactly one place: the fp32 value is made opaque first so that the compiler cannot fuse the
+// producing fma with the conversion (v_fma_mixlo_f16 rounds once, v_fma_f32 + v_cvt_f16_f32 rounds twice; hipcc
+// picks one or the other per unrolled copy, which made results depend on the fragment index).  The reference
+// semantics -- and the oracle's -- are "compute in fp32, then convert": two roundings.
+__device__ __forceinline__ _Float16 round_to_half(float t)
+{
+    asm volatile("" : "+v"(t));
+    return (_Float16)t;
+}
+
 template <int FM>   // 16-position fragments per wave along the positions; BM = 32 * FM
 __global__ __launch_bounds__(kThreads)
 void conv3x3_tile_kernel(ConvTileLaunch a)
@@ -206,7 +216,7 @@ void conv3x3_tile_kernel(ConvTileLaunch a)
                 float t = __builtin_fmaf(a.alpha1, acc[fn][fm][r], (float)b4[fn][r]);
                 if (skip) t = __builtin_fmaf(a.alpha2, (float)z4[fn][r], t);
                 if (relu && !(t > 0.0f)) t = 0.0f;
-                y4[r] = (_Float16)t;
+                y4[r] = round_to_half(t);
             }
             if (pos < a.num_pos) *reinterpret_cast<half4*>(a.y + out + fn * 16) = y4;
         }

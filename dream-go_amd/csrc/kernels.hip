@@ -35,9 +35,20 @@ __device__ __forceinline__ float half_bits_to_float(uint16_t h)
     return (float)__builtin_bit_cast(_Float16, h);
 }
 
+
+// fp32 -> fp16 at exactly one place: the fp32 value is made opaque first so that the compiler cannot fuse the
+// producing fma with the conversion (v_fma_mixlo_f16 rounds once, v_fma_f32 + v_cvt_f16_f32 rounds twice; hipcc
+// picks one or the other per unrolled copy, which made results depend on the fragment index).  The reference
+// semantics -- and the oracle's -- are "compute in fp32, then convert": two roundings.
+__device__ __forceinline__ _Float16 round_to_half(float t)
+{
+    asm volatile("" : "+v"(t));
+    return (_Float16)t;
+}
+
 __device__ __forceinline__ uint16_t float_to_half_bits(float f)
 {
-    return __builtin_bit_cast(uint16_t, (_Float16)f);   // v_cvt_f16_f32, round to nearest even
+    return __builtin_bit_cast(uint16_t, round_to_half(f));   // v_cvt_f16_f32, round to nearest even
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -202,7 +213,7 @@ void conv3x3_kernel(ConvLaunch a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (a.relu && !(t[r] > 0.0f)) t[r] = 0.0f;
-                    y4[r] = (_Float16)t[r];
+                    y4[r] = round_to_half(t[r]);
                 }
                 *reinterpret_cast<half4*>(a.y + out) = y4;
             } else {
@@ -259,7 +270,7 @@ void heads_kernel(HeadsLaunch a)
         const uint16_t* w = a.policy_w + tid;
         float acc = 0.0f;
         for (int k = 0; k < num_in; ++k) acc = __builtin_fmaf(sx[k], half_bits_to_float(w[(long)k * kMoves]), acc);
-        logit = (float)(_Float16)__builtin_fmaf(a.tau, acc, half_bits_to_float(a.policy_b[tid]));
+        logit = (float)round_to_half(__builtin_fmaf(a.tau, acc, half_bits_to_float(a.policy_b[tid])));
     }
 
     // value_head.rs:80: fp16(w . v + b), partial sums per thread
@@ -290,7 +301,7 @@ void heads_kernel(HeadsLaunch a)
     if (tid < kMoves) a.policy_out[(long)b * kMoves + tid] = float_to_half_bits(e / sum);
 
     if (tid == 0) {
-        const float v = (float)(_Float16)(vsum + half_bits_to_float(a.value_b[0]));
+        const float v = (float)round_to_half(vsum + half_bits_to_float(a.value_b[0]));
         a.value_out[b] = float_to_half_bits(tanhf(v));   // activation.rs:60-82
     }
 }
