@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace dgnn {
 namespace {
 
@@ -241,6 +243,214 @@ void conv3x3_tile_kernel(ConvTileLaunch a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv3x3_tile2_kernel -- same tile, same LDS image, same MFMA mapping as conv3x3_tile_kernel, but the eight waves
+// run as TWO GROUPS STAGGERED BY ONE BARRIER (group g = wave >> 2 owns the position half g of the tile; waves w and
+// w + 4 share a SIMD).  Every k-step is split into a load phase L and a matrix phase M:
+//
+//     L(s)  issue this group's share of the DMA for later tiles, read ALL fragments of tile s into registers
+//     M(s)  48 MFMAs (FM = 6) out of registers, nothing else
+//
+//   interval      2s        2s+1      2s+2      2s+3
+//   group 0       L(s)      M(s)      L(s+1)    M(s+1)
+//   group 1       M(s-1)    L(s)      M(s)      L(s+1)
+//
+// so on every SIMD one wave feeds the matrix pipe while its partner pays the DMA issue cost and the LDS reads.
+// DMA duties are chosen so that every byte has at least one whole interval to land before its first reader:
+//     group 0 in L(s):  filter slab of tile s+1            -> buffer (s+1)&1   (read from interval 2s+2)
+//     group 1 in L(s):  positions half 0 of tile s+2       -> buffer  s   &1   (group 0 finished it in interval 2s,
+//                                                                               read again from interval 2s+4)
+//                       positions half 1 of tile s+1       -> buffer (s+1)&1   (read by group 1 in interval 2s+3)
+// Ordering rules used (MI355X guide, "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  a wave drains its own DMA (s_waitcnt vmcnt(0)) at the end of its M phase, i.e. one interval after issuing
+//        it, then passes a barrier; every reader of that data starts at a later barrier.
+//   WAR  a region is overwritten only in an interval that starts at a barrier which every reader of the previous
+//        contents passed after retiring its reads (s_waitcnt lgkmcnt(0) closes every L phase).
+template <int FM>
+__global__ __launch_bounds__(kThreads)
+void conv3x3_tile2_kernel(ConvTileLaunch a)
+{
+    static_assert(FM % 2 == 0, "position half must be a whole number of DMA instructions per wave");
+    constexpr int BM = 32 * FM;
+    constexpr int XTileBytes = BM * kRowBytes;
+    constexpr int BufBytes = XTileBytes + kWTileBytes;
+    constexpr int XH = FM / 2;            // DMA instructions per wave for one position half (16 * FM rows)
+    constexpr int FN = 4;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * BufBytes];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3;
+    const int g = wave >> 2;              // group = position half
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * kBN;
+    const int cin = a.cin;
+    const int board = a.board;
+    const int nsteps = 9 * (cin / kBK);
+
+    // ---- gather description: rows (wn * XH + i) * 8 + (lane >> 3) of position half h ----
+    const uint16_t* x_ptr[2][XH];
+    unsigned x_taps[2][XH];
+    const int slot = lane & 7;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < XH; ++i) {
+            const int row = h * (BM / 2) + (wn * XH + i) * 8 + (lane >> 3);
+            const int pos = m0 + row;
+            const int piece = slot ^ ((row >> 1) & 7);
+            unsigned taps = 0;
+            if (pos < a.num_pos) {
+                const int p = pos % (board * board);
+                const int yy = p / board;
+                const int xx = p % board;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int sy = yy + t / 3 - 1;
+                    const int sx = xx + t % 3 - 1;
+                    if (sy >= 0 && sy < board && sx >= 0 && sx < board) taps |= 1u << t;
+                }
+            }
+            x_taps[h][i] = taps;
+            x_ptr[h][i] = a.x + (long)pos * cin + piece * 8;
+        }
+    const uint16_t* const zero_src = a.zero_page + slot * 8;
+    const uint16_t* const w_base = a.w + (long)blockIdx.y * nsteps * (kWTileBytes / 2) + lane * 8;
+
+    auto issue_x = [&](int step, int h, int buf) {
+        const int chunk = step / 9;
+        const int tap = step - chunk * 9;
+        const long shift = (long)((tap / 3 - 1) * board + (tap % 3 - 1)) * cin + chunk * kBK;
+        char* const dst = lds + buf * BufBytes + (h * (BM / 16) + wn * XH) * 1024;
+#pragma unroll
+        for (int i = 0; i < XH; ++i) {
+            const uint16_t* src = ((x_taps[h][i] >> tap) & 1u) ? x_ptr[h][i] + shift : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+    // filter slab instructions [first, first + COUNT) of the 32 that make up one k-step
+    auto issue_w = [&](int step, int buf, int first, auto count) {
+        char* const dst = lds + buf * BufBytes + XTileBytes + first * 1024;
+        const uint16_t* src = w_base + (long)step * (kWTileBytes / 2) + first * 512;
+#pragma unroll
+        for (int i = 0; i < decltype(count)::value; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 512),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+
+    const int s0 = (lane >> 4) ^ ((lane >> 1) & 7);
+    const int x_frag = (g * (BM / 2) + (lane & 15)) * kRowBytes;
+    const int w_frag = XTileBytes + (wn * 64 + (lane & 15)) * kRowBytes;
+    const int k_off[2] = {s0 * 16, (s0 ^ 4) * 16};
+
+    floatx4 acc[FN][FM];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) acc[fn][fm] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- prologue (all waves together): tile 0 complete, positions half 0 of tile 1 ----
+    issue_w(0, 0, wave * 4, std::integral_constant<int, 4>());
+    issue_x(0, g, 0);
+    if (g == 0) issue_x(1, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (g == 1) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+
+        // ---------------- L(step) ----------------
+        if (g == 0) {
+            if (step + 1 < nsteps) issue_w(step + 1, cur ^ 1, wn * 8, std::integral_constant<int, 8>());
+        } else {
+            if (step + 2 < nsteps) issue_x(step + 2, 0, cur);
+            if (step + 1 < nsteps) issue_x(step + 1, 1, cur ^ 1);
+        }
+        half8 wf[2][FN], xf[2][FM];
+        const char* const base = lds + cur * BufBytes;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                wf[kk][fn] = *reinterpret_cast<const half8*>(base + w_frag + fn * 2048 + k_off[kk]);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+                xf[kk][fm] = *reinterpret_cast<const half8*>(base + x_frag + fm * 2048 + k_off[kk]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of this tile has retired
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- M(step) ----------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][fn], xf[kk][fm], acc[fn][fm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA of the previous L phase has landed
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(g == 1 && step == nsteps - 1)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (identical to conv3x3_tile_kernel) ----
+    const int cout = a.cout;
+    const int co0 = n0 + wn * 64 + (lane >> 4) * 4;
+    const bool skip = a.alpha2 != 0.0f;
+    const bool relu = a.relu != 0;
+    half4 b4[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) b4[fn] = *reinterpret_cast<const half4*>(a.bias + co0 + fn * 16);
+
+    auto finish = [&](int fm, const half4 (&z4)[FN]) {
+        const int pos = m0 + g * (BM / 2) + fm * 16 + (lane & 15);
+        const long out = (long)pos * cout + co0;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            half4 y4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = __builtin_fmaf(a.alpha1, acc[fn][fm][r], (float)b4[fn][r]);
+                if (skip) t = __builtin_fmaf(a.alpha2, (float)z4[fn][r], t);
+                if (relu && !(t > 0.0f)) t = 0.0f;
+                y4[r] = round_to_half(t);
+            }
+            if (pos < a.num_pos) *reinterpret_cast<half4*>(a.y + out + fn * 16) = y4;
+        }
+    };
+
+    if (skip) {
+        half4 z4[FM][FN];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            int pos = m0 + g * (BM / 2) + fm * 16 + (lane & 15);
+            pos = pos < a.num_pos ? pos : a.num_pos - 1;
+            const uint16_t* zp = a.z + (long)pos * cout + co0;
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) z4[fm][fn] = *reinterpret_cast<const half4*>(zp + fn * 16);
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) finish(fm, z4[fm]);
+    } else {
+        const half4 none[FN] = {};
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) finish(fm, none);
+    }
+}
+
 }  // namespace
 
 bool conv_tile_supported(int cin, int cout)
@@ -265,16 +475,25 @@ int conv_tile_pick_fm(int num_pos, int cout)
     return best;
 }
 
-hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, hipStream_t stream)
+hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, int variant, hipStream_t stream)
 {
     if (args.num_pos <= 0) return hipSuccess;
     const int bm = 32 * fm;
     dim3 grid((args.num_pos + bm - 1) / bm, args.cout / 256);
-    switch (fm) {
-        case 8: hipLaunchKernelGGL((conv3x3_tile_kernel<8>), grid, dim3(kThreads), 0, stream, args); break;
-        case 6: hipLaunchKernelGGL((conv3x3_tile_kernel<6>), grid, dim3(kThreads), 0, stream, args); break;
-        case 4: hipLaunchKernelGGL((conv3x3_tile_kernel<4>), grid, dim3(kThreads), 0, stream, args); break;
-        default: return hipErrorInvalidValue;
+    if (variant == 1) {
+        switch (fm) {
+            case 8: hipLaunchKernelGGL((conv3x3_tile_kernel<8>), grid, dim3(kThreads), 0, stream, args); break;
+            case 6: hipLaunchKernelGGL((conv3x3_tile_kernel<6>), grid, dim3(kThreads), 0, stream, args); break;
+            case 4: hipLaunchKernelGGL((conv3x3_tile_kernel<4>), grid, dim3(kThreads), 0, stream, args); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (fm) {
+            case 8: hipLaunchKernelGGL((conv3x3_tile2_kernel<8>), grid, dim3(kThreads), 0, stream, args); break;
+            case 6: hipLaunchKernelGGL((conv3x3_tile2_kernel<6>), grid, dim3(kThreads), 0, stream, args); break;
+            case 4: hipLaunchKernelGGL((conv3x3_tile2_kernel<4>), grid, dim3(kThreads), 0, stream, args); break;
+            default: return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }

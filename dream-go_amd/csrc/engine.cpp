@@ -58,6 +58,7 @@ struct Workspace {
     bool pending = false;                   // a submit without its wait
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
     int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
+    int tile_variant = 2;                   // 1 = lock-step pipeline, 2 = staggered wave groups (DGNN_CONV=tile1 selects 1)
 
     ~Workspace();
 };
@@ -119,12 +120,14 @@ int get_device_state(Network* net, int device, DeviceState** out)
     return DGNN_OK;
 }
 
-// Kernel selection: the tuned tile kernel by default; DGNN_CONV=v1 forces the generic kernel, DGNN_CONV_FM=4|6|8
+// Kernel selection: the staggered tile kernel by default; DGNN_CONV=tile1 selects the lock-step tile kernel,
+// DGNN_CONV=v1 forces the generic kernel, DGNN_CONV_FM=4|6|8
 // overrides the position-tile height (both exist for A/B measurements and as a safety valve).
-void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm)
+void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm, int* variant)
 {
     const char* impl = std::getenv("DGNN_CONV");
     *use_tile = !(impl && std::strcmp(impl, "v1") == 0);
+    *variant = (impl && std::strcmp(impl, "tile1") == 0) ? 1 : 2;
     *fm = conv_tile_pick_fm(num_pos, cout >= 256 ? cout : 256);
     const char* f = std::getenv("DGNN_CONV_FM");
     if (f && (std::atoi(f) == 4 || std::atoi(f) == 6 || std::atoi(f) == 8)) *fm = std::atoi(f);
@@ -141,7 +144,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->device = dev->device;
     ws->batch = batch;
 
-    conv_impl_from_env(batch * DGNN_NUM_POINTS, t.num_channels, &ws->use_tile, &ws->tile_fm);
+    conv_impl_from_env(batch * DGNN_NUM_POINTS, t.num_channels, &ws->use_tile, &ws->tile_fm, &ws->tile_variant);
 
     DGNN_HIP(hipSetDevice(dev->device));
     DGNN_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));   // stream.rs:55
@@ -200,7 +203,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
             a.alpha1 = c.alpha1;
             a.alpha2 = c.alpha2;
             a.relu = 1;
-            return launch_conv3x3_tile(a, ws->tile_fm, ws->stream);
+            return launch_conv3x3_tile(a, ws->tile_fm, ws->tile_variant, ws->stream);
         }
         ConvLaunch a;
         a.x = x;
@@ -617,8 +620,8 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
     const int cout_pad = (cout + 15) / 16 * 16;
     const size_t num_pos = (size_t)batch * board_size * board_size;
     bool use_tile = true;
-    int fm = 8;
-    conv_impl_from_env((int)num_pos, cout, &use_tile, &fm);
+    int fm = 8, variant = 2;
+    conv_impl_from_env((int)num_pos, cout, &use_tile, &fm, &variant);
     use_tile = use_tile && conv_tile_supported(cin, cout);
 
     const size_t sz_x = align_up(num_pos * cin * 2, 256);
@@ -651,7 +654,7 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
         a.x = d_x; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_z : nullptr; a.y = d_y; a.zero_page = d_zero;
         a.num_pos = (int)num_pos; a.board = board_size; a.cin = cin; a.cout = cout;
         a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
-        err = launch_conv3x3_tile(a, fm, nullptr);
+        err = launch_conv3x3_tile(a, fm, variant, nullptr);
     } else if (err == hipSuccess) {
         ConvLaunch a;
         a.x = d_x; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_z : nullptr; a.y = d_y;

@@ -45,7 +45,8 @@ struct ConvTileLaunch {
 // Tuned residual-tower convolution (conv_tile.hip).  fm selects the position tile (32 * fm positions per workgroup).
 bool conv_tile_supported(int cin, int cout);
 int conv_tile_pick_fm(int num_pos, int cout);
-hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, hipStream_t stream);
+// variant 1: lock-step pipeline (conv3x3_tile_kernel); variant 2: two staggered wave groups (conv3x3_tile2_kernel).
+hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, int variant, hipStream_t stream);
 
 struct HeadsLaunch {
     const uint16_t* policy_features;  // [batch][361 * samples] fp16  (policy conv output, NHWC flattened)
