@@ -24,6 +24,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace dgnn {
@@ -267,7 +268,18 @@ void conv3x3_tile_kernel(ConvTileLaunch a)
 //        it, then passes a barrier; every reader of that data starts at a later barrier.
 //   WAR  a region is overwritten only in an interval that starts at a barrier which every reader of the previous
 //        contents passed after retiring its reads (s_waitcnt lgkmcnt(0) closes every L phase).
-template <int FM>
+// ABL (measurement only, results are garbage when != 0): bit 0 drops the MFMAs, bit 1 the in-loop DMA, bit 2 the
+// in-loop fragment reads.  Used by tools/ablate.sh to price each pipeline component on its own.
+//
+// SCHED = 3 rebalances the two intervals of a k-step so that each carries HALF of the step's MFMAs:
+//     b(s)  read all fragments of tile s, 24 MFMAs (kk = 0) as the reads return, drain this wave's DMA
+//     a(s)  issue this group's DMA, 24 MFMAs (kk = 1) out of registers
+//   group 0:  b(s) in interval 2s, a(s) in 2s+1;   group 1 one interval later.
+//   DMA duties (every byte still has one whole interval to land, same RAW / WAR argument as above):
+//     group 0 in a(s):  positions half 0 of tile s+2 -> buffer s&1     (group 0 read it in interval 2s)
+//                       positions half 1 of tile s+1 -> buffer (s+1)&1 (group 1 read it in interval 2s-1)
+//     group 1 in a(s):  filter slab of tile s+2      -> buffer s&1     (last read by group 1 in interval 2s+1)
+template <int FM, int SCHED = 2, int ABL = 0>
 __global__ __launch_bounds__(kThreads)
 void conv3x3_tile2_kernel(ConvTileLaunch a)
 {
@@ -355,6 +367,7 @@ void conv3x3_tile2_kernel(ConvTileLaunch a)
 
     // ---- prologue (all waves together): tile 0 complete, positions half 0 of tile 1 ----
     issue_w(0, 0, wave * 4, std::integral_constant<int, 4>());
+    if constexpr (SCHED == 3) issue_w(1, 1, wave * 4, std::integral_constant<int, 4>());
     issue_x(0, g, 0);
     if (g == 0) issue_x(1, 0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -364,46 +377,115 @@ void conv3x3_tile2_kernel(ConvTileLaunch a)
     if (g == 1) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
+    unsigned long long t_seg[4] = {0, 0, 0, 0};       // ABL & 8: cycles in phase 1, barrier 1, phase 2, barrier 2
+    unsigned long long t_mark = 0;
+    auto stamp = [&](int seg) {
+        if constexpr (ABL & 8) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (seg >= 0) t_seg[seg] += now - t_mark;
+            t_mark = now;
+        }
+    };
+    stamp(-1);
+
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-
-        // ---------------- L(step) ----------------
-        if (g == 0) {
-            if (step + 1 < nsteps) issue_w(step + 1, cur ^ 1, wn * 8, std::integral_constant<int, 8>());
-        } else {
-            if (step + 2 < nsteps) issue_x(step + 2, 0, cur);
-            if (step + 1 < nsteps) issue_x(step + 1, 1, cur ^ 1);
-        }
         half8 wf[2][FN], xf[2][FM];
         const char* const base = lds + cur * BufBytes;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn)
-                wf[kk][fn] = *reinterpret_cast<const half8*>(base + w_frag + fn * 2048 + k_off[kk]);
-#pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
-                xf[kk][fm] = *reinterpret_cast<const half8*>(base + x_frag + fm * 2048 + k_off[kk]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of this tile has retired
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
 
-        // ---------------- M(step) ----------------
-        __builtin_amdgcn_s_setprio(1);
+        auto read_fragments = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
                 for (int fn = 0; fn < FN; ++fn)
-                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][fn], xf[kk][fm], acc[fn][fm], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA of the previous L phase has landed
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(g == 1 && step == nsteps - 1)) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+                    wf[kk][fn] = *reinterpret_cast<const half8*>(base + w_frag + fn * 2048 + k_off[kk]);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    xf[kk][fm] = *reinterpret_cast<const half8*>(base + x_frag + fm * 2048 + k_off[kk]);
+            }
+        };
+        auto contract = [&](int kk) {
+            if constexpr (ABL & 1) {
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) asm volatile("" ::"v"(wf[kk][fn]));
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) asm volatile("" ::"v"(xf[kk][fm]));
+            } else {
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                    for (int fn = 0; fn < FN; ++fn)
+                        acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][fn], xf[kk][fm], acc[fn][fm], 0, 0, 0);
+            }
+        };
+
+        if constexpr (SCHED == 2) {
+            // ---------------- L(step) ----------------
+            if constexpr (!(ABL & 2)) {
+                if (g == 0) {
+                    if (step + 1 < nsteps) issue_w(step + 1, cur ^ 1, wn * 8, std::integral_constant<int, 8>());
+                } else {
+                    if (step + 2 < nsteps) issue_x(step + 2, 0, cur);
+                    if (step + 1 < nsteps) issue_x(step + 1, 1, cur ^ 1);
+                }
+            }
+            read_fragments();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of this tile has retired
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(0);
+            __builtin_amdgcn_s_barrier();
+            stamp(1);
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---------------- M(step) ----------------
+            __builtin_amdgcn_s_setprio(1);
+            contract(0);
+            contract(1);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA of the previous L phase has landed
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
+            if (!(g == 1 && step == nsteps - 1)) __builtin_amdgcn_s_barrier();
+            stamp(3);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // ---------------- b(step): reads + first half of the MFMAs ----------------
+            read_fragments();
+            contract(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // DMA of the previous a phase landed; reads retired
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(0);
+            __builtin_amdgcn_s_barrier();
+            stamp(1);
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---------------- a(step): DMA issue + second half of the MFMAs ----------------
+            if constexpr (!(ABL & 2)) {
+                if (g == 0) {
+                    if (step + 2 < nsteps) issue_x(step + 2, 0, cur);
+                    if (step + 1 < nsteps) issue_x(step + 1, 1, cur ^ 1);
+                } else {
+                    if (step + 2 < nsteps) issue_w(step + 2, cur, wn * 8, std::integral_constant<int, 8>());
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            contract(1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
+            if (!(g == 1 && step == nsteps - 1)) __builtin_amdgcn_s_barrier();
+            stamp(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (ABL & 8) {
+        if (a.timing != nullptr && lane == 0) {
+            unsigned long long* out = a.timing + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[i] = t_seg[i];
+        }
     }
 
     // ---- epilogue (identical to conv3x3_tile_kernel) ----
@@ -489,9 +571,37 @@ hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, int variant, 
         }
     } else {
         switch (fm) {
-            case 8: hipLaunchKernelGGL((conv3x3_tile2_kernel<8>), grid, dim3(kThreads), 0, stream, args); break;
-            case 6: hipLaunchKernelGGL((conv3x3_tile2_kernel<6>), grid, dim3(kThreads), 0, stream, args); break;
-            case 4: hipLaunchKernelGGL((conv3x3_tile2_kernel<4>), grid, dim3(kThreads), 0, stream, args); break;
+            case 8:
+                if (variant == 3) hipLaunchKernelGGL((conv3x3_tile2_kernel<8, 3>), grid, dim3(kThreads), 0, stream, args);
+                else hipLaunchKernelGGL((conv3x3_tile2_kernel<8, 2>), grid, dim3(kThreads), 0, stream, args);
+                break;
+            case 6: {
+                static const int ablate = std::getenv("DGNN_CONV_ABLATE") ? std::atoi(std::getenv("DGNN_CONV_ABLATE")) : 0;
+                if (ablate == 8 && variant == 3) {
+                    hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 3, 8>), grid, dim3(kThreads), 0, stream, args);
+                } else if (ablate == 8) {
+                    hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 2, 8>), grid, dim3(kThreads), 0, stream, args);
+                } else if (variant == 3) {
+                    switch (ablate) {
+                        case 1: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 3, 1>), grid, dim3(kThreads), 0, stream, args); break;
+                        case 2: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 3, 2>), grid, dim3(kThreads), 0, stream, args); break;
+                        case 3: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 3, 3>), grid, dim3(kThreads), 0, stream, args); break;
+                        default: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 3, 0>), grid, dim3(kThreads), 0, stream, args); break;
+                    }
+                } else {
+                    switch (ablate) {
+                        case 1: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 2, 1>), grid, dim3(kThreads), 0, stream, args); break;
+                        case 2: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 2, 2>), grid, dim3(kThreads), 0, stream, args); break;
+                        case 3: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 2, 3>), grid, dim3(kThreads), 0, stream, args); break;
+                        default: hipLaunchKernelGGL((conv3x3_tile2_kernel<6, 2, 0>), grid, dim3(kThreads), 0, stream, args); break;
+                    }
+                }
+                break;
+            }
+            case 4:
+                if (variant == 3) hipLaunchKernelGGL((conv3x3_tile2_kernel<4, 3>), grid, dim3(kThreads), 0, stream, args);
+                else hipLaunchKernelGGL((conv3x3_tile2_kernel<4, 2>), grid, dim3(kThreads), 0, stream, args);
+                break;
             default: return hipErrorInvalidValue;
         }
     }

@@ -58,7 +58,7 @@ struct Workspace {
     bool pending = false;                   // a submit without its wait
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
     int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
-    int tile_variant = 2;                   // 1 = lock-step pipeline, 2 = staggered wave groups (DGNN_CONV=tile1 selects 1)
+    int tile_variant = 2;                   // 1 = lock-step, 2 = staggered load|matrix phases, 3 = staggered balanced half-steps
 
     ~Workspace();
 };
@@ -127,7 +127,9 @@ void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm, int* var
 {
     const char* impl = std::getenv("DGNN_CONV");
     *use_tile = !(impl && std::strcmp(impl, "v1") == 0);
-    *variant = (impl && std::strcmp(impl, "tile1") == 0) ? 1 : 2;
+    *variant = 2;
+    if (impl && std::strcmp(impl, "tile1") == 0) *variant = 1;
+    if (impl && std::strcmp(impl, "tile3") == 0) *variant = 3;
     *fm = conv_tile_pick_fm(num_pos, cout >= 256 ? cout : 256);
     const char* f = std::getenv("DGNN_CONV_FM");
     if (f && (std::atoi(f) == 4 || std::atoi(f) == 6 || std::atoi(f) == 8)) *fm = std::atoi(f);
@@ -196,6 +198,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
             a.z = c.alpha2 != 0.0f ? z : nullptr;
             a.y = y;
             a.zero_page = (const uint16_t*)image;
+            a.timing = nullptr;
             a.num_pos = num_pos;
             a.board = 19;
             a.cin = c.cin;
@@ -654,7 +657,33 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
         a.x = d_x; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_z : nullptr; a.y = d_y; a.zero_page = d_zero;
         a.num_pos = (int)num_pos; a.board = board_size; a.cin = cin; a.cout = cout;
         a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
+        a.timing = nullptr;
+        // instrumentation: DGNN_CONV_ABLATE=8 makes the staggered kernel accumulate s_memtime per pipeline segment
+        const char* ab = std::getenv("DGNN_CONV_ABLATE");
+        const bool timing = ab && std::atoi(ab) == 8 && fm == 6 && variant >= 2;
+        const size_t num_wg = ((num_pos + 32 * fm - 1) / (32 * fm)) * (cout / 256);
+        unsigned long long* d_timing = nullptr;
+        if (timing && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemset(d_timing, 0, num_wg * 8 * 4 * sizeof(unsigned long long));
+            a.timing = d_timing;
+        }
         err = launch_conv3x3_tile(a, fm, variant, nullptr);
+        if (err == hipSuccess && d_timing) {
+            std::vector<unsigned long long> t(num_wg * 8 * 4);
+            if (hipDeviceSynchronize() == hipSuccess &&
+                hipMemcpy(t.data(), d_timing, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                double sum[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                for (size_t wg = 0; wg < num_wg; ++wg)
+                    for (int w = 0; w < 8; ++w)
+                        for (int i = 0; i < 4; ++i) sum[w >> 2][i] += (double)t[(wg * 8 + w) * 4 + i];
+                const double n = (double)num_wg * 4 * (9.0 * cin / 64);
+                std::fprintf(stderr, "[dgnn timing] variant %d: cycles per k-step per wave  group0: phase1 %.0f barrier1 %.0f phase2 %.0f barrier2 %.0f | "
+                             "group1: phase1 %.0f barrier1 %.0f phase2 %.0f barrier2 %.0f\n", variant,
+                             sum[0][0] / n, sum[0][1] / n, sum[0][2] / n, sum[0][3] / n,
+                             sum[1][0] / n, sum[1][1] / n, sum[1][2] / n, sum[1][3] / n);
+            }
+        }
+        if (d_timing) (void)hipFree(d_timing);
     } else if (err == hipSuccess) {
         ConvLaunch a;
         a.x = d_x; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_z : nullptr; a.y = d_y;

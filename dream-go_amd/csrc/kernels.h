@@ -33,6 +33,7 @@ struct ConvTileLaunch {
     const uint16_t* z;          // skip [num_pos][cout] fp16, read only when alpha2 != 0
     uint16_t* y;                // output [num_pos][cout] fp16
     const uint16_t* zero_page;  // >= 128 bytes of zeros in device memory (source of off-board taps)
+    unsigned long long* timing; // instrumentation (DGNN_CONV_ABLATE=8): [workgroup][wave][4] cycle sums, or nullptr
     int num_pos;
     int board;
     int cin;                    // multiple of 64
@@ -45,7 +46,8 @@ struct ConvTileLaunch {
 // Tuned residual-tower convolution (conv_tile.hip).  fm selects the position tile (32 * fm positions per workgroup).
 bool conv_tile_supported(int cin, int cout);
 int conv_tile_pick_fm(int num_pos, int cout);
-// variant 1: lock-step pipeline (conv3x3_tile_kernel); variant 2: two staggered wave groups (conv3x3_tile2_kernel).
+// variant 1: lock-step pipeline (conv3x3_tile_kernel); variants 2 / 3: two staggered wave groups
+// (conv3x3_tile2_kernel with SCHED = 2: load phase | matrix phase, SCHED = 3: balanced half-steps).
 hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, int variant, hipStream_t stream);
 
 struct HeadsLaunch {

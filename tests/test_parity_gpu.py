@@ -79,7 +79,7 @@ def test_conv_layer_against_oracle(api, oracle, batch, cin, cout, alpha, relu):
     assert mismatched <= 0.02 * got.size            # different fp32 summation order flips few fp16 roundings
 
 
-@pytest.mark.parametrize("variant", ["tile1", "tile2"])
+@pytest.mark.parametrize("variant", ["tile1", "tile2", "tile3"])
 @pytest.mark.parametrize("fm", [4, 6, 8])
 @pytest.mark.parametrize("batch,cin,cout,alpha", [
     (1, 256, 256, 0.5),      # one board: 361 positions, ragged in every tile height
@@ -121,7 +121,7 @@ def test_tile_kernel_exact_on_integers(api, monkeypatch):
     z = rng.integers(0, 4, (batch, 19, 19, cout)).astype(np.float16)
     monkeypatch.setenv("DGNN_CONV", "v1")
     want = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=0.5, alpha2=0.5, z=z, relu=False)
-    for variant in ("tile1", "tile2"):
+    for variant in ("tile1", "tile2", "tile3"):
         monkeypatch.setenv("DGNN_CONV", variant)
         for fm in (4, 6, 8):
             monkeypatch.setenv("DGNN_CONV_FM", str(fm))
@@ -129,7 +129,7 @@ def test_tile_kernel_exact_on_integers(api, monkeypatch):
             assert np.array_equal(got, want), (variant, fm)
 
 
-@pytest.mark.parametrize("variant", ["tile1", "tile2"])
+@pytest.mark.parametrize("variant", ["tile1", "tile2", "tile3"])
 def test_tile_kernel_exact_under_full_load(api, monkeypatch, variant):
     """BASELINE.json configs[2] layer shape at full size (256 boards, 256 -> 256 channels, every CU busy, two rounds
     of workgroups): integer-valued data make the generic kernel a bit-exact reference; three runs must be identical
