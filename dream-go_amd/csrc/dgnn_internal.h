@@ -51,6 +51,7 @@ struct ConvParams {
     // one 3x3 convolution as the kernels consume it
     size_t w_offset = 0;     // byte offset of the filter in the image, layout [9 * cin / 32][cout_pad][32] fp16
     size_t w_tile_offset = 0; // byte offset of the filter in tile layout (pack_filter_tile), 0 = not available
+    size_t w_board_offset = 0; // byte offset of the filter in board layout (pack_filter_board), 0 = not available
     size_t b_offset = 0;     // byte offset of the bias, [cout_pad] fp16 (already scaled where the reference scales)
     int cin = 0;
     int cout = 0;
@@ -97,6 +98,14 @@ void pack_filter(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
 // [cout / 256][9 * cin / 64][256 rows][8 slots][8 halfs], k-step = chunk * 9 + tap, and the 16-byte slot s of row r
 // holds channels chunk * 64 + (s ^ ((r >> 1) & 7)) * 8 .. + 8.  Requires cout % 256 == 0 and cin % 64 == 0.
 void pack_filter_tile(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
+
+// Filter KRSC -> the per-wave MFMA fragment stream of conv3x3_board_kernel (conv_board.hip):
+// [cout / 256][9 * cin / 32 k-steps][4 channel slices][4 fragments][64 lanes][8 halfs], k-step = chunk * 9 + tap,
+// fragment f = k16 * 2 + channel tile, lane l holds w[co = slice * 64 + tile * 32 + (l & 31)][tap]
+// [ci = chunk * 32 + k16 * 16 + (l >> 5) * 8 .. + 8].  Requires cout % 256 == 0 and cin % 32 == 0.
+// dst holds board_filter_elements(cout, cin) halfs: the kernel reads (never uses) up to 3 k-steps past the end.
+void pack_filter_board(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
+size_t board_filter_elements(int cout, int cin);
 
 constexpr size_t kZeroPageBytes = 256;   // the image starts with a page of zeros (source of off-board taps)
 

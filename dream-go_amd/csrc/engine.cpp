@@ -44,7 +44,9 @@ struct Workspace {
 
     void* arena = nullptr;                  // one allocation, carved below
     uint16_t* d_features = nullptr;         // [batch][361][32]
-    uint16_t* d_act[3] = {nullptr, nullptr, nullptr};   // [batch][361][C], rotating
+    uint16_t* d_act[3] = {nullptr, nullptr, nullptr};   // rotating; [batch][361][C] NHWC, or [batch][C/8][400][8] on the board path
+    uint16_t* d_features_board = nullptr;   // board path: features in padded slot-major layout [batch][4][400][8]
+    uint16_t* d_tower_nhwc = nullptr;       // board path: tower output converted back to NHWC for the head kernels
     uint16_t* d_policy_features = nullptr;  // [batch][361][S]
     uint16_t* d_value_features = nullptr;   // [batch][361][2]
     uint16_t* d_value = nullptr;            // [batch]
@@ -56,6 +58,7 @@ struct Workspace {
     uint16_t* h_policy = nullptr;
 
     bool pending = false;                   // a submit without its wait
+    bool use_board = false;                 // padded slot-major layout + one-board-per-workgroup kernel (conv_board.hip)
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
     int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
     int tile_variant = 2;                   // 1 = lock-step, 2 = staggered load|matrix phases, 3 = staggered balanced half-steps
@@ -123,6 +126,16 @@ int get_device_state(Network* net, int device, DeviceState** out)
 // Kernel selection: the staggered tile kernel by default; DGNN_CONV=tile1 selects the lock-step tile kernel,
 // DGNN_CONV=v1 forces the generic kernel, DGNN_CONV_FM=4|6|8
 // overrides the position-tile height (both exist for A/B measurements and as a safety valve).
+// DGNN_CONV=board forces the board kernel, DGNN_CONV=tile1|tile2|tile3|v1 rule it out; by default it is used when the
+// batch fills at least half of the chip's 256 CUs (one board per workgroup).
+bool board_impl_from_env(int batch, int channels)
+{
+    if (!conv_board_supported(channels, channels)) return false;
+    const char* impl = std::getenv("DGNN_CONV");
+    if (impl && *impl) return std::strcmp(impl, "board") == 0;
+    return batch >= 128;
+}
+
 void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm, int* variant)
 {
     const char* impl = std::getenv("DGNN_CONV");
@@ -147,6 +160,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->batch = batch;
 
     conv_impl_from_env(batch * DGNN_NUM_POINTS, t.num_channels, &ws->use_tile, &ws->tile_fm, &ws->tile_variant);
+    ws->use_board = board_impl_from_env(batch, t.num_channels) && t.up.w_board_offset != 0;
 
     DGNN_HIP(hipSetDevice(dev->device));
     DGNN_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));   // stream.rs:55
@@ -155,21 +169,32 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
 
     const size_t num_pos = (size_t)batch * DGNN_NUM_POINTS;
     const size_t sz_features = align_up(num_pos * DGNN_NUM_FEATURES * 2, 256);
-    const size_t sz_act = align_up(num_pos * t.num_channels * 2, 256);
+    // board path: 400 padded rows per board, + 1 KiB of slack (the last DMA piece of a k-slot reads rows 384..447)
+    const size_t board_pos = (size_t)batch * kBoardRows;
+    const size_t sz_act = ws->use_board ? align_up(board_pos * t.num_channels * 2 + 1024, 256)
+                                        : align_up(num_pos * t.num_channels * 2, 256);
+    const size_t sz_fboard = ws->use_board ? align_up(board_pos * DGNN_NUM_FEATURES * 2 + 1024, 256) : 0;
+    const size_t sz_nhwc = ws->use_board ? align_up(num_pos * t.num_channels * 2, 256) : 0;
     const size_t sz_pf = align_up(num_pos * t.num_samples * 2, 256);
     const size_t sz_vf = align_up(num_pos * 2 * 2, 256);
     const size_t sz_value = align_up((size_t)batch * 2, 256);
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
-    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy;
+    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc;
 
     DGNN_HIP(hipMalloc(&ws->arena, total));
+    // board path: pad rows 384..399 of every k-slot are never written by the kernels and must read as zero
+    if (ws->use_board) DGNN_HIP(hipMemset(ws->arena, 0, total));
     uint8_t* p = (uint8_t*)ws->arena;
     ws->d_features = (uint16_t*)p; p += sz_features;
     for (int i = 0; i < 3; ++i) { ws->d_act[i] = (uint16_t*)p; p += sz_act; }
     ws->d_policy_features = (uint16_t*)p; p += sz_pf;
     ws->d_value_features = (uint16_t*)p; p += sz_vf;
     ws->d_value = (uint16_t*)p; p += sz_value;
-    ws->d_policy = (uint16_t*)p;
+    ws->d_policy = (uint16_t*)p; p += sz_policy;
+    if (ws->use_board) {
+        ws->d_features_board = (uint16_t*)p; p += sz_fboard;
+        ws->d_tower_nhwc = (uint16_t*)p;
+    }
 
     DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_value + sz_policy, hipHostMallocDefault));
     uint8_t* h = (uint8_t*)ws->pinned;
@@ -225,7 +250,39 @@ int enqueue_forward(Workspace* ws, int tower_pair)
         return launch_conv3x3(a, ws->stream);
     };
 
+    auto conv_board = [&](const ConvParams& c, const uint16_t* x, const uint16_t* z, uint16_t* y) -> hipError_t {
+        ConvBoardLaunch a;
+        a.x = x;
+        a.w = (const uint16_t*)(image + c.w_board_offset);
+        a.bias = (const uint16_t*)(image + c.b_offset);
+        a.z = c.alpha2 != 0.0f ? z : nullptr;
+        a.y = y;
+        a.timing = nullptr;
+        a.batch = ws->batch;
+        a.cin = c.cin;
+        a.cout = c.cout;
+        a.alpha1 = c.alpha1;
+        a.alpha2 = c.alpha2;
+        a.relu = 1;
+        return launch_conv3x3_board(a, ws->stream);
+    };
+
     int cur = 0;
+    const uint16_t* tower = nullptr;   // NHWC tower output for the heads
+    if (ws->use_board) {
+        DGNN_HIP(launch_nhwc_to_board(ws->d_features, ws->d_features_board, ws->batch, DGNN_NUM_FEATURES, ws->stream));
+        DGNN_HIP(conv_board(t.up, ws->d_features_board, nullptr, ws->d_act[cur]));
+        if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair], ws->stream));
+        for (int i = 0; i < t.num_blocks; ++i) {
+            const int tmp = (cur + 1) % 3, next = (cur + 2) % 3;
+            DGNN_HIP(conv_board(t.res1[i], ws->d_act[cur], nullptr, ws->d_act[tmp]));
+            DGNN_HIP(conv_board(t.res2[i], ws->d_act[tmp], ws->d_act[cur], ws->d_act[next]));
+            cur = next;
+        }
+        if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
+        DGNN_HIP(launch_board_to_nhwc(ws->d_act[cur], ws->d_tower_nhwc, ws->batch, t.num_channels, ws->stream));
+        tower = ws->d_tower_nhwc;
+    } else {
     DGNN_HIP(conv(t.up, ws->d_features, nullptr, ws->d_act[cur]));                 // up_block.rs:56
 
     if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair], ws->stream));
@@ -236,9 +293,11 @@ int enqueue_forward(Workspace* ws, int tower_pair)
         cur = next;
     }
     if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
+    tower = ws->d_act[cur];
+    }
 
-    DGNN_HIP(conv(t.value_conv, ws->d_act[cur], nullptr, ws->d_value_features));   // value_head.rs:76
-    DGNN_HIP(conv(t.policy_conv, ws->d_act[cur], nullptr, ws->d_policy_features)); // policy_head.rs:92
+    DGNN_HIP(conv(t.value_conv, tower, nullptr, ws->d_value_features));            // value_head.rs:76
+    DGNN_HIP(conv(t.policy_conv, tower, nullptr, ws->d_policy_features));          // policy_head.rs:92
 
     HeadsLaunch h;
     h.policy_features = ws->d_policy_features;
@@ -281,6 +340,84 @@ int finish_network(std::unique_ptr<Network>& net, dgnn_network** out)
 }  // namespace dgnn
 
 using namespace dgnn;
+
+// dgnn_layer_conv3x3 on the board path: NHWC host buffers -> device -> padded slot-major layout -> board kernel ->
+// NHWC -> host.  Exercises the layout kernels too.
+static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint16_t* w_krsc, const uint16_t* bias, int cout,
+                               float alpha1, float alpha2, const uint16_t* z, int relu, uint16_t* y)
+{
+    const size_t num_pos = (size_t)batch * DGNN_NUM_POINTS;
+    const size_t board_pos = (size_t)batch * kBoardRows;
+    const size_t sz_xn = align_up(num_pos * cin * 2, 256), sz_yn = align_up(num_pos * cout * 2, 256);
+    const size_t sz_xb = align_up(board_pos * cin * 2 + 1024, 256), sz_yb = align_up(board_pos * cout * 2 + 1024, 256);
+    const size_t sz_w = align_up(board_filter_elements(cout, cin) * 2, 256), sz_b = align_up((size_t)cout * 2, 256);
+
+    std::vector<uint16_t> packed(board_filter_elements(cout, cin), 0);
+    pack_filter_board(w_krsc, cout, cin, packed.data());
+
+    uint8_t* d = nullptr;
+    const size_t total = sz_xn + sz_yn + sz_xb + 2 * sz_yb + sz_w + sz_b;
+    DGNN_HIP(hipMalloc((void**)&d, total));
+    uint16_t* d_xn = (uint16_t*)d;
+    uint16_t* d_yn = (uint16_t*)(d + sz_xn);
+    uint16_t* d_xb = (uint16_t*)(d + sz_xn + sz_yn);
+    uint16_t* d_yb = (uint16_t*)(d + sz_xn + sz_yn + sz_xb);
+    uint16_t* d_zb = (uint16_t*)(d + sz_xn + sz_yn + sz_xb + sz_yb);
+    uint16_t* d_w = (uint16_t*)(d + sz_xn + sz_yn + sz_xb + 2 * sz_yb);
+    uint16_t* d_b = (uint16_t*)(d + sz_xn + sz_yn + sz_xb + 2 * sz_yb + sz_w);
+
+    int status = DGNN_OK;
+    hipError_t err = hipMemset(d, 0, total);
+    if (err == hipSuccess) err = hipMemcpy(d_xn, x, num_pos * cin * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = launch_nhwc_to_board(d_xn, d_xb, batch, cin, nullptr);
+    if (err == hipSuccess && alpha2 != 0.0f) {
+        err = hipMemcpy(d_yn, z, num_pos * cout * 2, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = launch_nhwc_to_board(d_yn, d_zb, batch, cout, nullptr);
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+    }
+    if (err == hipSuccess) err = hipMemcpy(d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d_b, bias, (size_t)cout * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        ConvBoardLaunch a;
+        a.x = d_xb; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_zb : nullptr; a.y = d_yb;
+        a.batch = batch; a.cin = cin; a.cout = cout; a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
+        a.timing = nullptr;
+        // instrumentation: DGNN_CONV_ABLATE=8 prints where the workgroups spend their cycles (s_memtime stamps)
+        const char* ab = std::getenv("DGNN_CONV_ABLATE");
+        const size_t num_wg = (size_t)batch * (cout / 256);
+        unsigned long long* d_timing = nullptr;
+        if (ab && std::atoi(ab) == 8 && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess)
+            a.timing = d_timing;
+        const int reps = a.timing ? 3 : 1;   // the last repetition is reported (caches warm)
+        for (int r = 0; r < reps && err == hipSuccess; ++r) err = launch_conv3x3_board(a, nullptr);
+        if (err == hipSuccess && d_timing && hipDeviceSynchronize() == hipSuccess) {
+            std::vector<unsigned long long> t(num_wg * 8 * 4);
+            if (hipMemcpy(t.data(), d_timing, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                double pro = 0, loop = 0, epi = 0;
+                unsigned long long first = ~0ull, last = 0, first_end = ~0ull;
+                for (size_t i = 0; i < num_wg * 8; ++i) {
+                    pro += (double)(t[i * 4 + 1] - t[i * 4 + 0]);
+                    loop += (double)(t[i * 4 + 2] - t[i * 4 + 1]);
+                    epi += (double)(t[i * 4 + 3] - t[i * 4 + 2]);
+                    if (t[i * 4] < first) first = t[i * 4];
+                    if (t[i * 4 + 3] > last) last = t[i * 4 + 3];
+                    if (t[i * 4 + 3] < first_end) first_end = t[i * 4 + 3];
+                }
+                const double n = (double)num_wg * 8;
+                std::fprintf(stderr, "[dgnn timing] board kernel, %zu workgroups: mean cycles per wave  prologue %.0f  k-loop %.0f (%.0f per k-step)  "
+                             "epilogue %.0f | first start -> last end %llu, first end at %llu (s_memtime ticks)\n",
+                             num_wg, pro / n, loop / n, loop / n / (9.0 * cin / 32), epi / n, last - first, first_end - first);
+            }
+        }
+        if (d_timing) (void)hipFree(d_timing);
+    }
+    if (err == hipSuccess) err = launch_board_to_nhwc(d_yb, d_yn, batch, cout, nullptr);
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(y, d_yn, num_pos * cout * 2, hipMemcpyDeviceToHost);
+    if (err != hipSuccess) { set_last_hip_error((int)err); status = DGNN_HIP_ERROR; }
+    (void)hipFree(d);
+    return status;
+}
 
 static Network* N(dgnn_network* p) { return reinterpret_cast<Network*>(p); }
 static const Network* N(const dgnn_network* p) { return reinterpret_cast<const Network*>(p); }
@@ -626,6 +763,11 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
     int fm = 8, variant = 2;
     conv_impl_from_env((int)num_pos, cout, &use_tile, &fm, &variant);
     use_tile = use_tile && conv_tile_supported(cin, cout);
+    {
+        const char* impl = std::getenv("DGNN_CONV");
+        if (impl && std::strcmp(impl, "board") == 0 && board_size == 19 && conv_board_supported(cin, cout))
+            return layer_conv3x3_board(x, batch, cin, w_krsc, bias, cout, alpha1, alpha2, z, relu, y);
+    }
 
     const size_t sz_x = align_up(num_pos * cin * 2, 256);
     const size_t sz_y = align_up(num_pos * cout * 2, 256);

@@ -50,6 +50,32 @@ int conv_tile_pick_fm(int num_pos, int cout);
 // (conv3x3_tile2_kernel with SCHED = 2: load phase | matrix phase, SCHED = 3: balanced half-steps).
 hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, int variant, hipStream_t stream);
 
+constexpr int kBoardRows = 400;   // padded slot-major layout: 20 rows x 20 columns per board, row 19 / column 19 zero
+
+struct ConvBoardLaunch {
+    const uint16_t* x;     // input  [batch][cin / 8][400][8] fp16 (padded slot-major, pads zero)
+    const uint16_t* w;     // filter [cout / 256][9 * cin / 32][4 waves][4 fragments][64 lanes][8] fp16 (pack_filter_board)
+                           //        + 3 slabs (48 KiB) of readable padding behind the last one
+    const uint16_t* bias;  // [cout] fp16
+    const uint16_t* z;     // skip, same layout as y, read only when alpha2 != 0
+    uint16_t* y;           // output [batch][cout / 8][400][8] fp16; pad rows < 384 are written as zero, rows 384..399
+                           //        are never written (must be zero from initialisation)
+    unsigned long long* timing;   // instrumentation: [workgroup][wave][4] s_memtime stamps (start, loop, epilogue, end) or nullptr
+    int batch;
+    int cin;               // multiple of 32
+    int cout;              // multiple of 256
+    float alpha1;
+    float alpha2;
+    int relu;
+};
+
+// Residual-tower convolution on the padded slot-major layout, one board per workgroup (conv_board.hip).
+bool conv_board_supported(int cin, int cout);
+hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream);
+// Layout changes at the two ends of the tower: [B][361][C] NHWC <-> [B][C / 8][400][8].  C a multiple of 8.
+hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
+hipError_t launch_board_to_nhwc(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
+
 struct HeadsLaunch {
     const uint16_t* policy_features;  // [batch][361 * samples] fp16  (policy conv output, NHWC flattened)
     const uint16_t* value_features;   // [batch][722] fp16

@@ -149,6 +149,81 @@ def test_tile_kernel_exact_under_full_load(api, monkeypatch, variant):
         assert np.array_equal(got, want), (variant, run, int(np.count_nonzero(got != want)))
 
 
+# ---- board kernel (conv_board.hip): padded slot-major layout, one board per workgroup
+
+def test_board_kernel_asymmetric_taps(api, oracle, monkeypatch):
+    """Transpose- and shift-detecting: distinct weight per (tap, cin, cout), hot pixels in corners, on edges and in
+    the interior; every output is one exact product (+ bias), so the board path must be bit-exact."""
+    cin, cout = 32, 256
+    w = ((np.arange(cout * 9 * cin, dtype=np.float32).reshape(cout, 9, cin) * 7) % 251) / 64.0
+    x = np.zeros((2, 19, 19, cin), dtype=np.float32)
+    x[0, 0, 0, 3] = 1.0; x[0, 7, 11, 17] = 2.0; x[0, 18, 18, 31] = -1.0; x[0, 18, 0, 0] = 0.5; x[0, 0, 18, 9] = 4.0
+    x[1, 9, 0, 1] = 1.0; x[1, 9, 18, 30] = 2.0; x[1, 3, 4, 15] = -2.0
+    b = np.linspace(-1, 1, cout).astype(np.float32)
+    args = (oracle.f16(x), 2, 19, cin, oracle.f16(w), oracle.f16(b), cout)
+    ref = oracle.conv3x3(*args, relu=False)
+    monkeypatch.setenv("DGNN_CONV", "board")
+    got = api.layer_conv3x3(*args, relu=False)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("batch,cin,cout,alpha,relu", [
+    (1, 32, 256, None, True),      # up-layer shape of configs[2]: one chunk
+    (3, 256, 256, 0.5, True),      # residual conv_2 with gated skip
+    (2, 256, 256, None, False),    # identity activation, negative outputs
+    (2, 64, 512, 0.25, True),      # two 256-channel blocks (grid.y = 2), two chunks
+])
+@pytest.mark.parametrize("skip_mode", ["0", "1"])     # skip folded into the K loop (default) / added in the epilogue
+def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode):
+    monkeypatch.setenv("DGNN_BOARD_SKIP", skip_mode)
+    rng = np.random.default_rng([7, batch, cin, cout])
+    x = np.maximum(rng.normal(0, 1, (batch, 19, 19, cin)), 0).astype(np.float16)
+    w = rng.normal(0, np.sqrt(2.0 / (9 * cin)), (cout, 3, 3, cin)).astype(np.float16)
+    b = rng.normal(0, 0.1, (cout,)).astype(np.float16)
+    z = np.maximum(rng.normal(0, 1, (batch, 19, 19, cout)), 0).astype(np.float16) if alpha is not None else None
+    a1, a2 = (alpha, 1.0 - alpha) if alpha is not None else (1.0, 0.0)
+    ref = oracle.conv3x3(x, batch, 19, cin, w, b, cout, alpha1=a1, alpha2=a2, z=z, relu=relu)
+    monkeypatch.setenv("DGNN_CONV", "board")
+    got = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=a1, alpha2=a2, z=z, relu=relu)
+    mismatched = int(np.count_nonzero(got != ref))
+    print(f"board conv B={batch} {cin}->{cout}: {mismatched}/{got.size} outputs differ")
+    assert np.abs(f16_to_f32(got) - f16_to_f32(ref)).max() <= 4e-3 * max(1.0, float(np.abs(f16_to_f32(ref)).max()))
+    assert mismatched <= 0.02 * got.size
+
+
+def test_board_kernel_exact_under_full_load(api, monkeypatch):
+    """configs[2] layer shape at full size (256 boards = 256 workgroups, every CU busy): integer-valued data make the
+    generic kernel a bit-exact reference; three runs must be identical (a DMA / ring race shows up as run-to-run
+    differences under load)."""
+    rng = np.random.default_rng(29)
+    batch, cin, cout = 256, 256, 256
+    x = rng.integers(0, 4, (batch, 19, 19, cin)).astype(np.float16)
+    w = (rng.integers(-3, 4, (cout, 3, 3, cin)) / 16.0).astype(np.float16)
+    b = (rng.integers(-8, 9, (cout,)) / 8.0).astype(np.float16)
+    z = rng.integers(0, 4, (batch, 19, 19, cout)).astype(np.float16)
+    monkeypatch.setenv("DGNN_CONV", "v1")
+    want = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=0.5, alpha2=0.5, z=z, relu=False)
+    monkeypatch.setenv("DGNN_CONV", "board")
+    for run in range(3):
+        got = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=0.5, alpha2=0.5, z=z, relu=False)
+        assert np.array_equal(got, want), (run, int(np.count_nonzero(got != want)))
+
+
+def test_board_path_whole_network(api, oracle, synth, monkeypatch):
+    """Whole forward pass on the board path (layout conversion, up layer, tower, heads) at a small batch."""
+    monkeypatch.setenv("DGNN_CONV", "board")
+    text = synth.to_json(synth.make_tensors(3, 256, seed=303))
+    features = synth.make_features(5, seed=3030)
+    v1, p1 = _compare(api, oracle, text, features, 5, "board path 3x256 B=5")
+    monkeypatch.setenv("DGNN_CONV", "tile2")
+    net = api.Network.from_json(text)
+    with net.get_workspace(5) as ws:
+        v2, p2 = api.forward(ws, features).unwrap()
+    # two different kernels, same fp32-accumulate contract: fp16 outputs agree to the tolerance
+    assert np.abs(v1.astype(np.float32) - v2.astype(np.float32)).max() <= VALUE_TOL
+    assert np.abs(p1.astype(np.float32) - p2.astype(np.float32)).max() <= POLICY_TOL
+
+
 def test_conv_does_not_read_skip_when_alpha2_is_zero(api, oracle):
     """Conv2d::forward aliases z to the uninitialised output with alpha2 = 0 (conv2d.rs:188-190): z must be ignored."""
     rng = np.random.default_rng(5)
