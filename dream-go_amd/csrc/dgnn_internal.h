@@ -73,6 +73,10 @@ struct Topology {
     size_t policy_b_offset = 0;  // [362] fp16, tau * b_l rounded to fp16
     size_t value_w_offset = 0;   // [722] fp16
     size_t value_b_offset = 0;   // [1] fp16
+    size_t policy_wt_offset = 0; // [384][policy_k_pad] fp16: linear_1 transposed to [out][in] (dense.rs:182-189), zero padded
+    int policy_k_pad = 0;        // 361 * S rounded up to a multiple of 64
+    size_t head_w_board_offset = 0; // both head convolutions as one 32-row filter in board fragment order, 0 = not available
+    size_t head_b_offset = 0;       // [32] fp16: policy conv offsets, then the two value conv offsets, then zeros
 };
 
 struct DeviceState;   // per-device weight copy + workspace pool (network.cpp)

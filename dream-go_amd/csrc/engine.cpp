@@ -49,6 +49,7 @@ struct Workspace {
     uint16_t* d_tower_nhwc = nullptr;       // board path: tower output converted back to NHWC for the head kernels
     uint16_t* d_policy_features = nullptr;  // [batch][361][S]
     uint16_t* d_value_features = nullptr;   // [batch][361][2]
+    uint16_t* d_logits = nullptr;           // [batch][384] fp16 policy logits
     uint16_t* d_value = nullptr;            // [batch]
     uint16_t* d_policy = nullptr;           // [batch][362]
 
@@ -133,7 +134,12 @@ bool board_impl_from_env(int batch, int channels)
     if (!conv_board_supported(channels, channels)) return false;
     const char* impl = std::getenv("DGNN_CONV");
     if (impl && *impl) return std::strcmp(impl, "board") == 0;
-    return batch >= 128;
+    // One board per workgroup: ceil(batch / 256) rounds of ~92 us on 256 CUs (measured, C = 256), against the NHWC tile
+    // kernel's ceil(tiles / 256) rounds of ~54 us with 192-position tiles.  Scale-free comparison of the two counts.
+    const long rounds_board = (batch + 255) / 256;
+    const long tiles = ((long)batch * DGNN_NUM_POINTS + 191) / 192;
+    const long rounds_tile = (tiles + 255) / 256;
+    return rounds_board * 92 <= rounds_tile * 54;
 }
 
 void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm, int* variant)
@@ -179,7 +185,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_vf = align_up(num_pos * 2 * 2, 256);
     const size_t sz_value = align_up((size_t)batch * 2, 256);
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
-    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc;
+    const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
+    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits;
 
     DGNN_HIP(hipMalloc(&ws->arena, total));
     // board path: pad rows 384..399 of every k-slot are never written by the kernels and must read as zero
@@ -191,6 +198,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_value_features = (uint16_t*)p; p += sz_vf;
     ws->d_value = (uint16_t*)p; p += sz_value;
     ws->d_policy = (uint16_t*)p; p += sz_policy;
+    ws->d_logits = (uint16_t*)p; p += sz_logits;
     if (ws->use_board) {
         ws->d_features_board = (uint16_t*)p; p += sz_fboard;
         ws->d_tower_nhwc = (uint16_t*)p;
@@ -280,8 +288,21 @@ int enqueue_forward(Workspace* ws, int tower_pair)
             cur = next;
         }
         if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
-        DGNN_HIP(launch_board_to_nhwc(ws->d_act[cur], ws->d_tower_nhwc, ws->batch, t.num_channels, ws->stream));
-        tower = ws->d_tower_nhwc;
+        if (t.head_w_board_offset != 0) {
+            HeadConvLaunch hc;                                                      // value_head.rs:76 + policy_head.rs:92
+            hc.x = ws->d_act[cur];
+            hc.w = (const uint16_t*)(image + t.head_w_board_offset);
+            hc.bias = (const uint16_t*)(image + t.head_b_offset);
+            hc.policy_features = ws->d_policy_features;
+            hc.value_features = ws->d_value_features;
+            hc.batch = ws->batch;
+            hc.cin = t.num_channels;
+            hc.samples = t.num_samples;
+            DGNN_HIP(launch_head_conv_board(hc, ws->stream));
+        } else {
+            DGNN_HIP(launch_board_to_nhwc(ws->d_act[cur], ws->d_tower_nhwc, ws->batch, t.num_channels, ws->stream));
+            tower = ws->d_tower_nhwc;
+        }
     } else {
     DGNN_HIP(conv(t.up, ws->d_features, nullptr, ws->d_act[cur]));                 // up_block.rs:56
 
@@ -296,22 +317,31 @@ int enqueue_forward(Workspace* ws, int tower_pair)
     tower = ws->d_act[cur];
     }
 
-    DGNN_HIP(conv(t.value_conv, tower, nullptr, ws->d_value_features));            // value_head.rs:76
-    DGNN_HIP(conv(t.policy_conv, tower, nullptr, ws->d_policy_features));          // policy_head.rs:92
+    if (tower != nullptr) {
+        DGNN_HIP(conv(t.value_conv, tower, nullptr, ws->d_value_features));        // value_head.rs:76
+        DGNN_HIP(conv(t.policy_conv, tower, nullptr, ws->d_policy_features));      // policy_head.rs:92
+    }
 
-    HeadsLaunch h;
-    h.policy_features = ws->d_policy_features;
-    h.value_features = ws->d_value_features;
-    h.policy_w = (const uint16_t*)(image + t.policy_w_offset);
-    h.policy_b = (const uint16_t*)(image + t.policy_b_offset);
-    h.value_w = (const uint16_t*)(image + t.value_w_offset);
-    h.value_b = (const uint16_t*)(image + t.value_b_offset);
-    h.value_out = ws->d_value;
-    h.policy_out = ws->d_policy;
-    h.batch = ws->batch;
-    h.samples = t.num_samples;
-    h.tau = 1.0f / t.softmax_temperature;
-    DGNN_HIP(launch_heads(h, ws->stream));                                         // policy_head.rs:95-100, value_head.rs:80-81
+    PolicyGemmLaunch pg;                                                           // policy_head.rs:95
+    pg.features = ws->d_policy_features;
+    pg.wt = (const uint16_t*)(image + t.policy_wt_offset);
+    pg.bias = (const uint16_t*)(image + t.policy_b_offset);
+    pg.logits = ws->d_logits;
+    pg.batch = ws->batch;
+    pg.k_in = DGNN_NUM_POINTS * t.num_samples;
+    pg.k_pad = t.policy_k_pad;
+    pg.tau = 1.0f / t.softmax_temperature;
+    DGNN_HIP(launch_policy_gemm(pg, ws->stream));
+
+    SoftmaxValueLaunch sv;                                                         // policy_head.rs:98-100, value_head.rs:80-81
+    sv.logits = ws->d_logits;
+    sv.value_features = ws->d_value_features;
+    sv.value_w = (const uint16_t*)(image + t.value_w_offset);
+    sv.value_b = (const uint16_t*)(image + t.value_b_offset);
+    sv.policy_out = ws->d_policy;
+    sv.value_out = ws->d_value;
+    sv.batch = ws->batch;
+    DGNN_HIP(launch_softmax_value(sv, ws->stream));
     return DGNN_OK;
 }
 

@@ -1,0 +1,303 @@
+// The two heads of the network (policy_head.rs:43-103, value_head.rs:40-84 of the reference) after the tower.
+//
+//   head_conv_board_kernel   both 3x3 head convolutions (C -> S policy planes, C -> 2 value planes) as ONE convolution
+//                            with S + 2 <= 32 output channels on the padded slot-major layout of conv_board.hip, one
+//                            board per workgroup.  HBM/L2-bound: the tower output is read once (the generic path read
+//                            it twice, once per head, and ran two launches of 100 us each).
+//   policy_gemm_kernel       dense 361 * S -> 362 for the whole batch as an MFMA GEMM [B x K] x [K x 384] against the
+//                            TRANSPOSED weight matrix (the reference transposes it on the device at first use,
+//                            dense.rs:182-189; here the host does it once).  logits = fp16(tau * (w . x) + fp16(tau * b)).
+//   softmax_value_kernel     soft-max over the 362 logits (cudnnSoftmaxForward ACCURATE: max-subtracted, softmax.rs:58-79),
+//                            dense 722 -> 1 + tanh (value_head.rs:80-81, activation.rs:60-82); one wave per board,
+//                            wave-shuffle reductions.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace dgnn {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPoints = 361;
+constexpr int kMoves = 362;
+constexpr int kMovesPad = 384;                         // 12 MFMA tiles of 32
+
+// ---- geometry shared with conv_board.hip ----
+constexpr int kRows = kBoardRows;
+constexpr int kHalo = 21;
+constexpr int kPieces = 7;
+constexpr int kSlotRows = kHalo + kPieces * 64;        // 469
+constexpr int kSlotBytes = kSlotRows * 16;             // 7504
+constexpr int kXBufBytes = 4 * kSlotBytes;             // 30016: one 32-channel chunk of activations
+constexpr int kWBufBytes = 9 * 2 * 1024;               // 18432: one 32-channel chunk of the 32-row filter, all taps
+constexpr int kBufBytes = kXBufBytes + kWBufBytes;
+constexpr int kHeadThreads = 256;
+
+__device__ __forceinline__ _Float16 round_to_half(float t)
+{
+    asm volatile("" : "+v"(t));          // fma and cvt stay separate instructions (two roundings, like the oracle)
+    return (_Float16)t;
+}
+
+__device__ __forceinline__ float half_bits_to_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t float_to_half_bits(float f) { return __builtin_bit_cast(uint16_t, round_to_half(f)); }
+
+// 4 waves; wave w owns row tiles 3w .. 3w + 2 (rows 96w .. 96w + 95) of the board and all 32 (padded) output channels.
+// Per 32-channel chunk the activations (28 DMA pieces) and the chunk's filter rows for all 9 taps (18 pieces) are
+// brought into one of two LDS buffers; one barrier per chunk.
+__global__ __launch_bounds__(kHeadThreads)
+void head_conv_board_kernel(HeadConvLaunch a)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * kBufBytes];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int nchunks = a.cin / 32;
+
+    if (tid < 2 * 4 * kHalo) {           // halo rows of both activation buffers
+        const int buf = tid / (4 * kHalo);
+        const int rem = tid - buf * (4 * kHalo);
+        const int slot = rem / kHalo;
+        const int row = rem - slot * kHalo;
+        *reinterpret_cast<uint4*>(lds + buf * kBufBytes + slot * kSlotBytes + row * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    const uint16_t* const x_board = a.x + (long)b * a.cin * kRows + lane * 8;
+    const uint16_t* const w_lane = a.w + lane * 8;
+
+    auto issue = [&](int chunk, int buf) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int p = wave + 4 * j;          // 0..45: 28 activation pieces, then 18 filter pieces
+            if (p < 4 * kPieces) {
+                const int s = p / kPieces;
+                const int i = p - s * kPieces;
+                const uint16_t* src = x_board + ((long)(chunk * 4 + s) * kRows + i * 64) * 8;
+                char* const dst = lds + buf * kBufBytes + s * kSlotBytes + (kHalo + i * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            } else if (p < 4 * kPieces + 18) {
+                const int f = p - 4 * kPieces;   // tap * 2 + k16
+                const uint16_t* src = w_lane + ((long)chunk * 18 + f) * 512;
+                char* const dst = lds + buf * kBufBytes + kXBufBytes + f * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    floatx16 acc[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int x_lane = (lane >> 5) * kSlotBytes + (wave * 96 + (lane & 31)) * 16;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) issue(chunk + 1, buf ^ 1);
+        const char* const xb = lds + buf * kBufBytes + x_lane;
+        const char* const wb = lds + buf * kBufBytes + kXBufBytes + lane * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int shift = (tap / 3 - 1) * 20 + (tap % 3 - 1);
+#pragma unroll
+            for (int k16 = 0; k16 < 2; ++k16) {
+                const half8 af = *reinterpret_cast<const half8*>(wb + (tap * 2 + k16) * 1024);
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) {
+                    const half8 bf = *reinterpret_cast<const half8*>(xb + k16 * 2 * kSlotBytes + rt * 512 + (kHalo + shift) * 16);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next chunk landed; this chunk's reads retired
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // D[i][j]: j = lane & 31 = row within the tile, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output channel.
+    // Channels 0 .. S-1 are the policy planes, S and S + 1 the value planes; both outputs are compact NHWC.
+    const int samples = a.samples;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+        const int row = wave * 96 + rt * 32 + (lane & 31);
+        const int y = row / 20, x = row - y * 20;
+        if (x == 19 || y >= 19) continue;
+        const long pos = (long)b * kPoints + y * 19 + x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (c >= samples + 2) continue;
+            float t = acc[rt][r] + half_bits_to_float(a.bias[c]);
+            t = __builtin_fmaxf(t, 0.0f);                             // conv2d.rs:119-125: ReLU on both head convolutions
+            const uint16_t bits = float_to_half_bits(t);
+            if (c < samples) a.policy_features[pos * samples + c] = bits;
+            else a.value_features[pos * 2 + (c - samples)] = bits;
+        }
+    }
+}
+
+// C[b][m] = sum_k P[b][k] * Wt[m][k];  one 32 x 32 tile per workgroup, the 4 waves split K (k16 step s goes to wave s & 3).
+__global__ __launch_bounds__(256)
+void policy_gemm_kernel(PolicyGemmLaunch a)
+{
+    __shared__ float partial[4][16][64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * 32;
+    const int k_in = a.k_in;            // 361 * S
+    const int kp = a.k_pad;             // k_in rounded up to a multiple of 64; Wt rows are zero beyond k_in
+
+    // rows past the batch read board 0 instead (their results are never stored)
+    const int brow = b0 + (lane & 31);
+    const uint16_t* const prow = a.features + (long)(brow < a.batch ? brow : 0) * k_in;
+    const uint16_t* const wrow = a.wt + (long)(m0 + (lane & 31)) * kp;
+    const int kl = (lane >> 5) * 8;
+
+    floatx16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+
+    const int nmain = k_in / 16;        // k16 steps that lie completely inside the input row
+    const int nsteps = kp / 16;
+    int s = wave;
+    for (; s + 12 < nmain; s += 16) {   // four steps of this wave per trip: eight loads in flight, two MFMA chains
+        half8 af[4], bf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = (s + 4 * u) * 16 + kl;
+            af[u] = *reinterpret_cast<const half8*>(prow + k);
+            bf[u] = *reinterpret_cast<const half8*>(wrow + k);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2], bf[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[3], bf[3], acc2, 0, 0, 0);
+    }
+    for (; s < nmain; s += 4) {
+        const int k = s * 16 + kl;
+        const half8 af = *reinterpret_cast<const half8*>(prow + k);
+        const half8 bf = *reinterpret_cast<const half8*>(wrow + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    }
+    for (; s < nsteps; s += 4) {        // the ragged end of the row: element-wise, zero beyond k_in
+        const int k = s * 16 + kl;
+        half8 af;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[e] = (k + e < k_in) ? __builtin_bit_cast(_Float16, prow[k + e]) : (_Float16)0.0f;
+        const half8 bf = *reinterpret_cast<const half8*>(wrow + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) partial[wave][r][lane] = acc[r] + acc2[r];
+    __syncthreads();
+
+    // D[i][j]: i = board row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = move = lane & 31.  256 threads x 4 elements.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
+        const float sum = partial[0][r][lane] + partial[1][r][lane] + partial[2][r][lane] + partial[3][r][lane];
+        const int bi = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + (lane & 31);
+        if (bi < a.batch && m < kMoves) {
+            // dense.rs:197-220 with alpha1 = tau (policy_head.rs:54): fp16(tau * (w . x) + fp16(tau * b))
+            const float logit = __builtin_fmaf(a.tau, sum, half_bits_to_float(a.bias[m]));
+            a.logits[(long)bi * kMovesPad + m] = float_to_half_bits(logit);
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// one wave per board, 4 boards per workgroup
+__global__ __launch_bounds__(256)
+void softmax_value_kernel(SoftmaxValueLaunch a)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.batch) return;
+
+    float logit[6];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int mv = lane + 64 * j;
+        logit[j] = mv < kMoves ? half_bits_to_float(a.logits[(long)b * kMovesPad + mv]) : -INFINITY;
+        m = fmaxf(m, logit[j]);
+    }
+    m = wave_max(m);
+    float e[6];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        e[j] = (lane + 64 * j) < kMoves ? expf(logit[j] - m) : 0.0f;
+        sum += e[j];
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int mv = lane + 64 * j;
+        if (mv < kMoves) a.policy_out[(long)b * kMoves + mv] = float_to_half_bits(e[j] / sum);
+    }
+
+    // value_head.rs:80-81: tanh(fp16(w . v + b))
+    const uint16_t* vf = a.value_features + (long)b * (kPoints * 2);
+    float part = 0.0f;
+    for (int k = lane; k < kPoints * 2; k += 64)
+        part = __builtin_fmaf(half_bits_to_float(vf[k]), half_bits_to_float(a.value_w[k]), part);
+    part = wave_sum(part);
+    if (lane == 0) {
+        const float v = (float)round_to_half(part + half_bits_to_float(a.value_b[0]));
+        a.value_out[b] = float_to_half_bits(tanhf(v));
+    }
+}
+
+}  // namespace
+
+hipError_t launch_head_conv_board(const HeadConvLaunch& args, hipStream_t stream)
+{
+    if (args.batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(head_conv_board_kernel, dim3(args.batch), dim3(kHeadThreads), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_gemm(const PolicyGemmLaunch& args, hipStream_t stream)
+{
+    if (args.batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(policy_gemm_kernel, dim3((args.batch + 31) / 32, kMovesPad / 32), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_softmax_value(const SoftmaxValueLaunch& args, hipStream_t stream)
+{
+    if (args.batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(softmax_value_kernel, dim3((args.batch + 3) / 4), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace dgnn

@@ -76,6 +76,42 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)
 hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
 hipError_t launch_board_to_nhwc(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
 
+struct HeadConvLaunch {
+    const uint16_t* x;          // tower output [batch][cin / 8][400][8] fp16 (padded slot-major)
+    const uint16_t* w;          // [cin / 32][9 taps][2 k16][64 lanes][8] fp16: rows 0..S-1 policy conv, S..S+1 value conv, rest 0
+    const uint16_t* bias;       // [32] fp16, same row order
+    uint16_t* policy_features;  // [batch][361][S] fp16
+    uint16_t* value_features;   // [batch][361][2] fp16
+    int batch;
+    int cin;                    // multiple of 32
+    int samples;                // S, S + 2 <= 32
+};
+// Both head convolutions in one pass over the tower output (heads.hip).
+hipError_t launch_head_conv_board(const HeadConvLaunch& args, hipStream_t stream);
+
+struct PolicyGemmLaunch {
+    const uint16_t* features;   // [batch][k_in] fp16 (policy conv output, NHWC flattened: index S * pos + s)
+    const uint16_t* wt;         // [384][k_pad] fp16: the dense matrix TRANSPOSED ([out][in]), zero padded
+    const uint16_t* bias;       // [362] fp16, already multiplied by tau
+    uint16_t* logits;           // [batch][384] fp16
+    int batch;
+    int k_in;                   // 361 * S
+    int k_pad;                  // k_in rounded up to a multiple of 64
+    float tau;
+};
+hipError_t launch_policy_gemm(const PolicyGemmLaunch& args, hipStream_t stream);
+
+struct SoftmaxValueLaunch {
+    const uint16_t* logits;         // [batch][384] fp16
+    const uint16_t* value_features; // [batch][722] fp16
+    const uint16_t* value_w;        // [722] fp16
+    const uint16_t* value_b;        // [1] fp16
+    uint16_t* policy_out;           // [batch][362] fp16
+    uint16_t* value_out;            // [batch] fp16
+    int batch;
+};
+hipError_t launch_softmax_value(const SoftmaxValueLaunch& args, hipStream_t stream);
+
 struct HeadsLaunch {
     const uint16_t* policy_features;  // [batch][361 * samples] fp16  (policy conv output, NHWC flattened)
     const uint16_t* value_features;   // [batch][722] fp16

@@ -226,6 +226,47 @@ int build_network(Network& net)
     topo.value_b_offset = reserve(image, sizeof(uint16_t));
     std::memcpy(image.data() + topo.value_b_offset, vb->bytes.data(), sizeof(uint16_t));
 
+    // dense.rs:182-189: the policy matrix transposed to [out][in] for the MFMA GEMM (heads.hip), rows and columns zero padded
+    topo.policy_k_pad = (int)((policy_in + 63) / 64 * 64);
+    topo.policy_wt_offset = reserve(image, (size_t)384 * topo.policy_k_pad * sizeof(uint16_t));
+    {
+        uint16_t* dst = reinterpret_cast<uint16_t*>(image.data() + topo.policy_wt_offset);
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(pw->bytes.data());
+        for (size_t k = 0; k < policy_in; ++k)
+            for (int m = 0; m < DGNN_NUM_MOVES; ++m) dst[(size_t)m * topo.policy_k_pad + k] = src[k * DGNN_NUM_MOVES + m];
+    }
+
+    // both head convolutions as one filter with 32 (zero padded) output rows, in the fragment order of
+    // head_conv_board_kernel: [chunk][tap][k16][lane][8], lane l = row (l & 31), channels chunk*32 + k16*16 + (l>>5)*8 ..
+    topo.head_w_board_offset = 0;
+    if (c % 32 == 0 && s + 2 <= 32) {
+        const HostTensor* pcw = find_half(t, policy + "/conv_1:0", (size_t)s * 9 * c);
+        const HostTensor* pcb = find_half(t, policy + "/conv_1/offset:0", (size_t)s);
+        const HostTensor* vcw = find_half(t, value + "/conv_1:0", (size_t)2 * 9 * c);
+        const HostTensor* vcb = find_half(t, value + "/conv_1/offset:0", 2);
+        if (!pcw || !pcb || !vcw || !vcb) return DGNN_MALFORMED_WEIGHTS;
+        topo.head_w_board_offset = reserve(image, (size_t)(c / 32) * 18 * 512 * sizeof(uint16_t));
+        uint16_t* dst = reinterpret_cast<uint16_t*>(image.data() + topo.head_w_board_offset);
+        const uint16_t* pwsrc = reinterpret_cast<const uint16_t*>(pcw->bytes.data());
+        const uint16_t* vwsrc = reinterpret_cast<const uint16_t*>(vcw->bytes.data());
+        for (int chunk = 0; chunk < c / 32; ++chunk)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int k16 = 0; k16 < 2; ++k16)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = lane & 31;
+                        const int ci = chunk * 32 + k16 * 16 + (lane >> 5) * 8;
+                        uint16_t* out = dst + ((((size_t)chunk * 9 + tap) * 2 + k16) * 64 + lane) * 8;
+                        const uint16_t* src = nullptr;
+                        if (row < s) src = pwsrc + ((size_t)row * 9 + tap) * c + ci;
+                        else if (row < s + 2) src = vwsrc + ((size_t)(row - s) * 9 + tap) * c + ci;
+                        for (int e = 0; e < 8; ++e) out[e] = src ? src[e] : 0;
+                    }
+        topo.head_b_offset = reserve(image, 32 * sizeof(uint16_t));
+        uint16_t* hb = reinterpret_cast<uint16_t*>(image.data() + topo.head_b_offset);
+        for (int i = 0; i < s; ++i) hb[i] = reinterpret_cast<const uint16_t*>(pcb->bytes.data())[i];
+        for (int i = 0; i < 2; ++i) hb[s + i] = reinterpret_cast<const uint16_t*>(vcb->bytes.data())[i];
+    }
+
     reserve(image, 0);
     image.resize((image.size() + kAlign - 1) / kAlign * kAlign, 0);
     net.image.swap(image);
