@@ -37,8 +37,9 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--cpu-sample", type=int, default=16, help="boards the CPU oracle evaluates for cpu_baseline (0 = skip)")
-    ap.add_argument("--check", action="store_true", help="also verify two boards of the batch against the oracle")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="boards the CPU oracle evaluates for cpu_baseline (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
     return ap.parse_args()
 
 
@@ -101,7 +102,10 @@ def main():
     from dream_go_amd import api, replicas, synth
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -152,14 +156,16 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
-        "kernel": "conv3x3_kernel (residual C->C)", "launch_us": conv_ms * 1e3, "launches_timed": tower_launches,
-        "flops_per_launch": conv_flops,
+        "kernel": f"residual 3x3 convolution C->C ({ws.conv_kernel()})", "launch_us": conv_ms * 1e3,
+        "launches_timed": tower_launches, "flops_per_launch": conv_flops,
     }
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/profile.sh +
+    # tools/pmc_summary.py); only quoted when the profile was taken on this workload and this kernel
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
             t = json.load(open(traffic_file))
-            if t.get("batch") == args.batch and t.get("channels") == c:
+            if t.get("batch") == args.batch and t.get("channels") == c and t.get("kernel", "") in roofline["kernel"]:
                 roofline["traffic"] = t["hbm_bytes_per_launch"]
         except Exception:   # noqa: BLE001
             pass

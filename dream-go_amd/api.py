@@ -68,6 +68,7 @@ SYMBOLS = [
     ("dgnn_workspace_device_buffers", ctypes.c_int, [_vp, _vpp, _vpp, _vpp]),
     ("dgnn_workspace_host_buffers", ctypes.c_int, [_vp, ctypes.POINTER(_u16p), ctypes.POINTER(_u16p), ctypes.POINTER(_u16p)]),
     ("dgnn_workspace_stream", ctypes.c_int, [_vp, _vpp]),
+    ("dgnn_workspace_conv_kernel", ctypes.c_char_p, [_vp]),
     ("dgnn_workspace_upload", ctypes.c_int, [_vp, _u16p, ctypes.c_size_t]),
     ("dgnn_workspace_download", ctypes.c_int, [_vp, _u16p, _u16p]),
     ("dgnn_forward_resident", ctypes.c_int, [_vp]),
@@ -223,6 +224,10 @@ class WorkspaceGuard:
         f, v, p = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         _check(lib.dgnn_workspace_device_buffers(self.handle, ctypes.byref(f), ctypes.byref(v), ctypes.byref(p)), "device_buffers")
         return f.value, v.value, p.value
+
+    def conv_kernel(self):
+        """Name of the residual-convolution kernel this workspace launches."""
+        return lib.dgnn_workspace_conv_kernel(self.handle).decode("ascii")
 
     def stream(self):
         s = ctypes.c_void_p()

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -77,7 +78,7 @@ __device__ __forceinline__ half8 lds_read(unsigned addr)
 {
     static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
     half8 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
 
@@ -112,7 +113,7 @@ __host__ __device__ constexpr int b_offset(int i) { return (i / kRowTiles) * 2 *
 // the row tiles of z are fetched one at a time while the memory system is otherwise idle and added to the fp32
 // accumulators as (alpha2 / alpha1) * z, so that the epilogue is store-only.  (With the skip read in the epilogue all
 // 256 workgroups fetch their 205 KiB of z at the same moment: 52 MB at HBM speed, 8 us of a 90 us kernel.)
-template <int SKIP, bool RELU>
+template <int SKIP, bool RELU, int SPREAD>     // SPREAD: 1 = DMA issue interleaved with the step's MFMAs, 0 = at its end
 __global__ __launch_bounds__(kThreads)
 void conv3x3_board_kernel(ConvBoardLaunch a)
 {
@@ -145,13 +146,15 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
     const uint16_t* const w_wave = a.w + ((long)nb * nsteps * 4 + wn) * 2048 + lane * 8;
 
     // k-step `st` of this wave's filter slice -> ring slot `slot`
-    auto issue_w = [&](int st, int slot) {
+    auto issue_w_piece = [&](int st, int slot, int f) {
         const uint16_t* src = w_wave + (long)st * 8192;
         char* const dst = lds + kWBase + wave * kWRingBytes + slot * kSlabBytes;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 512),
+                                         (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&](int st, int slot) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 512),
-                                             (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+        for (int f = 0; f < 4; ++f) issue_w_piece(st, slot, f);
     };
     // j-th (0..3) activation piece of this wave for `chunk` -> buffer `buf`.  28 pieces, 8 waves: waves 4..7 have
     // only three and repeat their third one (same bytes to the same place), so that every wave issues the same
@@ -269,6 +272,21 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
                 else wait_lgkm<YOUNGER>(bf[I % 3]);
                 acc[0][RT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[K16][0], bf[I % 3], acc[0][RT], 0, 0, 0);
                 acc[1][RT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[K16][1], bf[I % 3], acc[1][RT], 0, 0, 0);
+                if constexpr (SPREAD == 1) {
+                    // The A fragments of this step are in registers since the first wait (I == 0): the slab may be
+                    // refilled from now on.  One DMA instruction behind every second MFMA pair keeps the wave from
+                    // having a separate, MFMA-free "issue phase" at the end of the step.
+                    if constexpr (I == 1 || I == 3 || I == 5 || I == 7) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_w_piece(st0 + TAP + kRing, TAP % kRing, I / 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (I == 9 && TAP < 4) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_x(next_chunk, buf ^ 1, TAP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             });
             // every MFMA of this step has been issued => its operand reads retired => the slab may be overwritten
             __builtin_amdgcn_sched_barrier(0);
@@ -276,12 +294,15 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
             // at the end of tap t and added at the end of tap t + 1
             if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6) {
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations
-                wait_vmcnt<0>();
+                // but for the DMA instructions this step has already issued (SPREAD)
+                wait_vmcnt<SPREAD == 1 ? 4 + (TAP < 4) : 0>();
                 __builtin_amdgcn_sched_barrier(0);
                 add_z_half(std::integral_constant<int, TAP - 1>(), std::integral_constant<int, ZC>());
             }
-            issue_w(st0 + TAP + kRing, TAP % kRing);
-            if constexpr (TAP < 4) issue_x(next_chunk, buf ^ 1, TAP);
+            if constexpr (SPREAD == 0) {
+                issue_w(st0 + TAP + kRing, TAP % kRing);
+                if constexpr (TAP < 4) issue_x(next_chunk, buf ^ 1, TAP);
+            }
             // extra memory operations only make the counted waits above more conservative (they require that many
             // more of the OLDER operations to have completed), never unsafe
             if constexpr (ZC >= 0 && TAP <= 5) load_z_half(TAP, ZC);
@@ -443,12 +464,20 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)
     const char* const mode = std::getenv("DGNN_BOARD_SKIP");        // =1: keep the skip in the epilogue (A/B, tests)
     const bool epilogue_skip = mode && std::atoi(mode) == 1;
     const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !epilogue_skip) ? 2 : 1;
-    if (skip == 2 && relu) hipLaunchKernelGGL((conv3x3_board_kernel<2, true>), grid, dim3(kThreads), 0, stream, args);
-    else if (skip == 2) hipLaunchKernelGGL((conv3x3_board_kernel<2, false>), grid, dim3(kThreads), 0, stream, args);
-    else if (skip == 1 && relu) hipLaunchKernelGGL((conv3x3_board_kernel<1, true>), grid, dim3(kThreads), 0, stream, args);
-    else if (skip == 1) hipLaunchKernelGGL((conv3x3_board_kernel<1, false>), grid, dim3(kThreads), 0, stream, args);
-    else if (relu) hipLaunchKernelGGL((conv3x3_board_kernel<0, true>), grid, dim3(kThreads), 0, stream, args);
-    else hipLaunchKernelGGL((conv3x3_board_kernel<0, false>), grid, dim3(kThreads), 0, stream, args);
+    const char* const dma = std::getenv("DGNN_BOARD_DMA");                // =end: DMA issue at the end of each k-step (A/B)
+    const bool spread = !(dma && std::strcmp(dma, "end") == 0);
+#define DGNN_LAUNCH_BOARD(S, R)                                                                                       \
+    do {                                                                                                              \
+        if (spread) hipLaunchKernelGGL((conv3x3_board_kernel<S, R, 1>), grid, dim3(kThreads), 0, stream, args);      \
+        else hipLaunchKernelGGL((conv3x3_board_kernel<S, R, 0>), grid, dim3(kThreads), 0, stream, args);             \
+    } while (0)
+    if (skip == 2 && relu) DGNN_LAUNCH_BOARD(2, true);
+    else if (skip == 2) DGNN_LAUNCH_BOARD(2, false);
+    else if (skip == 1 && relu) DGNN_LAUNCH_BOARD(1, true);
+    else if (skip == 1) DGNN_LAUNCH_BOARD(1, false);
+    else if (relu) DGNN_LAUNCH_BOARD(0, true);
+    else DGNN_LAUNCH_BOARD(0, false);
+#undef DGNN_LAUNCH_BOARD
     return hipGetLastError();
 }
 

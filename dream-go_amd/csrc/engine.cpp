@@ -691,6 +691,22 @@ int dgnn_workspace_host_buffers(dgnn_workspace* ws, uint16_t** h_features, uint1
     return DGNN_OK;
 }
 
+const char* dgnn_workspace_conv_kernel(const dgnn_workspace* handle)
+{
+    if (!handle) return "";
+    const Workspace* ws = W(handle);
+    const Topology& t = ws->net->topo;
+    if (ws->use_board) return "conv3x3_board_kernel";
+    if (ws->use_tile && conv_tile_supported(t.num_channels, t.num_channels)) {
+        static const char* const names[3][3] = {
+            {"conv3x3_tile_kernel fm=4", "conv3x3_tile_kernel fm=6", "conv3x3_tile_kernel fm=8"},
+            {"conv3x3_tile2_kernel fm=4", "conv3x3_tile2_kernel fm=6", "conv3x3_tile2_kernel fm=8"},
+            {"conv3x3_tile2_kernel(balanced) fm=4", "conv3x3_tile2_kernel(balanced) fm=6", "conv3x3_tile2_kernel(balanced) fm=8"}};
+        return names[ws->tile_variant - 1][(ws->tile_fm - 4) / 2];
+    }
+    return "conv3x3_kernel";
+}
+
 int dgnn_workspace_stream(dgnn_workspace* ws, void** hip_stream)
 {
     if (!ws || !hip_stream) return DGNN_BAD_ARGUMENT;

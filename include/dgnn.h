@@ -130,6 +130,10 @@ int dgnn_workspace_device_buffers(dgnn_workspace* ws, void** d_features, void** 
  * (likewise for value_out == h_value, policy_out == h_policy). */
 int dgnn_workspace_host_buffers(dgnn_workspace* ws, uint16_t** h_features, uint16_t** h_value, uint16_t** h_policy);
 
+/* Name of the residual-convolution kernel this workspace launches ("conv3x3_board_kernel", "conv3x3_tile2_kernel fm=6",
+ * "conv3x3_kernel"): the harness quotes it next to the roofline numbers.  Static string, never NULL. */
+const char* dgnn_workspace_conv_kernel(const dgnn_workspace* ws);
+
 /* The HIP stream (hipStream_t) every kernel of this workspace is launched on. */
 int dgnn_workspace_stream(dgnn_workspace* ws, void** hip_stream);
 
