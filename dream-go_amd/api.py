@@ -81,6 +81,32 @@ SYMBOLS = [
     ("dgnn_network_set_weight_image", ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int]),
     ("dgnn_network_weight_checksum_device", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     ("dgnn_network_weight_image_host", ctypes.c_int, [_vp, _vpp, ctypes.POINTER(ctypes.c_size_t)]),
+    ("dgnn_forward_n", ctypes.c_int, [_vp, _u16p, ctypes.c_int, _u16p, _u16p]),
+    ("dgnn_forward_submit_n", ctypes.c_int, [_vp, _u16p, ctypes.c_int]),
+    # host side of the boundary (scope row f-1)
+    ("dgnn_symmetry_inverse", ctypes.c_int, [ctypes.c_int]),
+    ("dgnn_symmetry_apply", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    ("dgnn_policy_with_transform", ctypes.c_int, [_u16p, ctypes.c_int, _u16p]),
+    ("dgnn_cache_create", ctypes.c_int, [ctypes.c_size_t, ctypes.c_int, _vpp]),
+    ("dgnn_cache_destroy", None, [_vp]),
+    ("dgnn_cache_fetch", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u16p, _u16p]),
+    ("dgnn_cache_insert", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint16, _u16p]),
+    ("dgnn_cache_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_batcher_create", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_batcher_destroy", None, [_vp]),
+    ("dgnn_batcher_push", ctypes.c_int, [_vp, _u16p, ctypes.c_uint64]),
+    ("dgnn_batcher_get_batch", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
+    ("dgnn_batcher_push_and_get_batch", ctypes.c_int, [_vp, _u16p, ctypes.c_uint64, _vpp]),
+    ("dgnn_batcher_pending", ctypes.c_int, [_vp, _ip, _ip]),
+    ("dgnn_batcher_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_batch_size", ctypes.c_int, [_vp]),
+    ("dgnn_batch_tags", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_batch_features", _u16p, [_vp]),
+    ("dgnn_batch_forward", ctypes.c_int, [_vp, _u16p, _u16p]),
+    ("dgnn_batch_destroy", None, [_vp]),
+    ("dgnn_pool_create", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
+    ("dgnn_pool_destroy", None, [_vp]),
+    ("dgnn_pool_predict", ctypes.c_int, [_vp, _u16p, ctypes.c_int, _u16p, _u16p]),
 ]
 
 
@@ -348,3 +374,216 @@ def layer_conv3x3(x, batch, board_size, cin, w_krsc, bias, cout, alpha1=1.0, alp
                                   b.ctypes.data_as(_u16p), cout, alpha1, alpha2, zp, int(relu), y.ctypes.data_as(_u16p)),
            "layer_conv3x3")
     return y
+
+
+def forward_n(workspace, features, count):
+    """forward on the first `count` boards' worth of a workspace of larger capacity (include/dgnn.h: dgnn_forward_n)."""
+    f = _as_u16(features, "features")
+    if f.size != count * FEATURE_SIZE:
+        raise Error(BAD_ARGUMENT, "forward_n")
+    value = np.empty(count, dtype=np.uint16)
+    policy = np.empty(count * NUM_MOVES, dtype=np.uint16)
+    _check(lib.dgnn_forward_n(workspace.handle, f.ctypes.data_as(_u16p), int(count),
+                              value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "forward_n")
+    return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Host side of the boundary (scope row f-1): the reference's libdg_mcts names over batcher.cpp
+# ------------------------------------------------------------------------------------------------------------------
+
+class Transform:
+    """dg_go::utils::symmetry::Transform (src/libdg_go/utils/symmetry.rs:65-128), in the order of symmetry::ALL."""
+    Identity, FlipLR, FlipUD, Transpose, TransposeAnti, Rot90, Rot180, Rot270 = range(8)
+    ALL = tuple(range(8))
+
+    @staticmethod
+    def inverse(t):
+        return lib.dgnn_symmetry_inverse(int(t))
+
+    @staticmethod
+    def apply(t, packed_index):
+        return lib.dgnn_symmetry_apply(int(t), int(packed_index))
+
+
+class Prediction:
+    """dg_mcts::Prediction (src/libdg_mcts/predictor.rs:19-57): value fp16, policy 362 x fp16."""
+
+    def __init__(self, value, policy):
+        self._value = np.float16(value)
+        self._policy = np.ascontiguousarray(policy, dtype=np.float16).reshape(NUM_MOVES)
+
+    @staticmethod
+    def with_transform(other, transform):
+        out = np.empty(NUM_MOVES, dtype=np.uint16)
+        src = other._policy.view(np.uint16)
+        _check(lib.dgnn_policy_with_transform(src.ctypes.data_as(_u16p), int(transform), out.ctypes.data_as(_u16p)), "with_transform")
+        return Prediction(other._value, out.view(np.float16))
+
+    def value(self):
+        return float(self._value)
+
+    def winrate(self):
+        return 0.5 * self.value() + 0.5
+
+    def policy(self):
+        return self._policy.astype(np.float32)
+
+
+class LruCache:
+    """The transposition table of NnPredictor (src/libdg_mcts/predictors/nn.rs:29-82 over lru_cache.rs:56-150)."""
+
+    def __init__(self, capacity=200_001, num_shards=1):
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_cache_create(int(capacity), int(num_shards), ctypes.byref(out)), "LruCache")
+        self._handle = out
+
+    def fetch(self, board_hash, to_move, symmetry):
+        value = ctypes.c_uint16()
+        policy = np.empty(NUM_MOVES, dtype=np.uint16)
+        hit = lib.dgnn_cache_fetch(self._handle, int(board_hash), int(to_move), int(symmetry), ctypes.byref(value),
+                                   policy.ctypes.data_as(_u16p))
+        if hit < 0:
+            raise Error(hit, "LruCache.fetch")
+        if hit == 0:
+            return None
+        return Prediction(np.uint16(value.value).view(np.float16), policy.view(np.float16))
+
+    def cache(self, board_hash, to_move, symmetry, response):
+        bits = np.asarray(response._value).view(np.uint16)
+        _check(lib.dgnn_cache_insert(self._handle, int(board_hash), int(to_move), int(symmetry), int(bits),
+                                     response._policy.view(np.uint16).ctypes.data_as(_u16p)), "LruCache.cache")
+
+    def stats(self):
+        e, h, m = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib.dgnn_cache_stats(self._handle, ctypes.byref(e), ctypes.byref(h), ctypes.byref(m)), "LruCache.stats")
+        return {"entries": e.value, "hits": h.value, "misses": m.value}
+
+    def __len__(self):
+        return self.stats()["entries"]
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                lib.dgnn_cache_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+class Batch:
+    """dg_mcts::pool::Batch (src/libdg_mcts/pool/batch.rs:24-41)."""
+
+    def __init__(self, handle):
+        self._handle = handle
+
+    def __len__(self):
+        return lib.dgnn_batch_size(self._handle)
+
+    def tags(self):
+        out = np.empty(len(self), dtype=np.uint64)
+        _check(lib.dgnn_batch_tags(self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))), "Batch.tags")
+        return out
+
+    def features(self):
+        p = lib.dgnn_batch_features(self._handle)
+        return np.ctypeslib.as_array(p, shape=(len(self) * FEATURE_SIZE,)).copy().view(np.float16)
+
+    def forward(self):
+        """-> (tags, OutputMap); the batch stops counting as alive (batch.rs:35-40)."""
+        n = len(self)
+        value = np.empty(n, dtype=np.uint16)
+        policy = np.empty(n * NUM_MOVES, dtype=np.uint16)
+        _check(lib.dgnn_batch_forward(self._handle, value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "Batch.forward")
+        return self.tags(), OutputMap(value.view(np.float16), policy.view(np.float16))
+
+    def destroy(self):
+        if self._handle is not None:
+            lib.dgnn_batch_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Batcher:
+    """dg_mcts::pool::Batcher (src/libdg_mcts/pool/batch.rs:58-123), one per (network, device)."""
+
+    def __init__(self, network, max_batch_size, max_batches, device=0):
+        self._network = network
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_batcher_create(network.handle if network is not None else None, int(device), int(max_batch_size),
+                                       int(max_batches), ctypes.byref(out)), "Batcher")
+        self._handle = out
+        self.max_batch_size = int(max_batch_size)
+
+    def push(self, tag, features):
+        f = _as_u16(features, "features")
+        if f.size != FEATURE_SIZE:
+            raise Error(BAD_ARGUMENT, "Batcher.push")
+        _check(lib.dgnn_batcher_push(self._handle, f.ctypes.data_as(_u16p), int(tag)), "Batcher.push")
+
+    def get_batch(self, min_batch_size):
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_batcher_get_batch(self._handle, int(min_batch_size), ctypes.byref(out)), "Batcher.get_batch")
+        return Batch(out) if out.value else None
+
+    def push_and_get_batch(self, tag, features):
+        f = _as_u16(features, "features")
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_batcher_push_and_get_batch(self._handle, f.ctypes.data_as(_u16p), int(tag), ctypes.byref(out)),
+               "Batcher.push_and_get_batch")
+        return Batch(out) if out.value else None
+
+    def pending(self):
+        q, a = ctypes.c_int(), ctypes.c_int()
+        _check(lib.dgnn_batcher_pending(self._handle, ctypes.byref(q), ctypes.byref(a)), "Batcher.pending")
+        return q.value, a.value
+
+    def stats(self):
+        b, n = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib.dgnn_batcher_stats(self._handle, ctypes.byref(b), ctypes.byref(n)), "Batcher.stats")
+        return {"boards": b.value, "batches": n.value}
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                lib.dgnn_batcher_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+class LeafPool:
+    """A Predictor (src/libdg_mcts/predictor.rs:59-92) whose predict() coalesces across every calling thread."""
+
+    def __init__(self, batcher, num_workers=2):
+        self._batcher = batcher
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_pool_create(batcher._handle, int(num_workers), ctypes.byref(out)), "LeafPool")
+        self._handle = out
+
+    def predict(self, features, batch_size):
+        f = _as_u16(features, "features")
+        if f.size != batch_size * FEATURE_SIZE:
+            raise Error(BAD_ARGUMENT, "LeafPool.predict")
+        value = np.empty(batch_size, dtype=np.uint16)
+        policy = np.empty(batch_size * NUM_MOVES, dtype=np.uint16)
+        _check(lib.dgnn_pool_predict(self._handle, f.ctypes.data_as(_u16p), int(batch_size), value.ctypes.data_as(_u16p),
+                                     policy.ctypes.data_as(_u16p)), "LeafPool.predict")
+        v, p = value.view(np.float16), policy.view(np.float16).reshape(batch_size, NUM_MOVES)
+        return [Prediction(v[i], p[i]) for i in range(batch_size)]
+
+    def close(self):
+        if self._handle is not None:
+            lib.dgnn_pool_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

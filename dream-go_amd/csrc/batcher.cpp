@@ -1,0 +1,488 @@
+// Host side of the boundary, row f-1 of the scope table: the many-game leaf batcher, the transposition cache and the
+// policy symmetry remap of dream-go's libdg_mcts, as a C++ library behind the C ABI (include/dgnn.h).
+//
+//   symmetry   src/libdg_go/utils/symmetry.rs:19-128 (the 8 board symmetries and their inverses),
+//              Prediction::with_transform, src/libdg_mcts/predictor.rs:30-44
+//   cache      src/libdg_mcts/lru_cache.rs:56-150 (doubly linked hash map, insert of a present key is a no-op,
+//              the tail is dropped when len > capacity) keyed like NnPredictor's BoardTuple
+//              (src/libdg_mcts/predictors/nn.rs:29-45,69-82): entries are stored in the canonical orientation
+//              (cache() applies symmetry.inverse(), fetch() applies symmetry)
+//   batcher    src/libdg_mcts/pool/batch.rs:24-123: push appends, get_batch(min) hands out the NEWEST max_batch_size
+//              entries once at least `min` are queued and fewer than max_batches batches are alive
+//
+// Differences by design: the reference has ONE global mutex around the LRU (nn.rs:48) and one around the batcher list
+// (batch.rs:60-73); here the cache is sharded by key (shards = 1 reproduces the reference's eviction order exactly) and
+// a batcher is per (network, device) so that games sharded over the GPUs of a node never share a lock; every batch size
+// 1..max is served from workspaces of capacity max (dgnn_forward_n) instead of one workspace per size.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <thread>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+#include "dgnn_internal.h"
+
+namespace dgnn {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ symmetry
+
+struct SymmetryTables {
+    uint16_t map[8][DGNN_NUM_MOVES];   // map[t][i] = packed index of transform t applied to point i; pass maps to pass
+
+    SymmetryTables()
+    {
+        for (int t = 0; t < 8; ++t) {
+            for (int i = 0; i < DGNN_NUM_POINTS; ++i) {
+                const int x = i % 19 - 9, y = i / 19 - 9;
+                int tx = x, ty = y;
+                switch (t) {                       // symmetry.rs:39-62, same order as symmetry::ALL (:119-128)
+                    case 0: tx = x; ty = y; break;         // Identity
+                    case 1: tx = -x; ty = y; break;        // FlipLR
+                    case 2: tx = x; ty = -y; break;        // FlipUD
+                    case 3: tx = y; ty = x; break;         // Transpose (main diagonal)
+                    case 4: tx = -y; ty = -x; break;       // TransposeAnti
+                    case 5: tx = y; ty = -x; break;        // Rot90
+                    case 6: tx = -x; ty = -y; break;       // Rot180
+                    case 7: tx = -y; ty = x; break;        // Rot270
+                }
+                map[t][i] = (uint16_t)((ty + 9) * 19 + (tx + 9));
+            }
+            map[t][DGNN_NUM_POINTS] = DGNN_NUM_POINTS;
+        }
+    }
+};
+
+const SymmetryTables& tables()
+{
+    static const SymmetryTables t;
+    return t;
+}
+
+const int kInverse[8] = {0, 1, 2, 3, 4, 7, 6, 5};   // symmetry.rs:79-90
+
+void with_transform(const uint16_t* policy, int transform, uint16_t* out)
+{
+    const uint16_t* map = tables().map[transform];
+    for (int i = 0; i < DGNN_NUM_MOVES; ++i) out[map[i]] = policy[i];   // predictor.rs:34-38
+}
+
+// ------------------------------------------------------------------------------------------------ LRU cache
+
+struct CacheKey {
+    uint64_t hash;
+    int to_move;
+    bool operator==(const CacheKey& o) const { return hash == o.hash && to_move == o.to_move; }
+};
+
+struct CacheKeyHash {
+    size_t operator()(const CacheKey& k) const
+    {
+        uint64_t h = k.hash ^ (0x9e3779b97f4a7c15ull * (uint64_t)(k.to_move + 1));
+        h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33;
+        return (size_t)h;
+    }
+};
+
+struct CacheEntry {
+    CacheKey key;
+    uint16_t value;
+    uint16_t policy[DGNN_NUM_MOVES];
+};
+
+struct CacheShard {
+    std::mutex mutex;
+    std::list<CacheEntry> order;   // front = most recently used
+    std::unordered_map<CacheKey, std::list<CacheEntry>::iterator, CacheKeyHash> index;
+    size_t capacity = 0;
+};
+
+}  // namespace
+
+struct Cache {
+    std::vector<std::unique_ptr<CacheShard>> shards;
+    std::atomic<uint64_t> hits{0}, misses{0};
+
+    CacheShard& shard(const CacheKey& k) { return *shards[CacheKeyHash()(k) % shards.size()]; }
+};
+
+// ------------------------------------------------------------------------------------------------ batcher
+
+struct Batch {
+    struct Batcher* owner = nullptr;
+    std::vector<uint16_t> features;
+    std::vector<uint64_t> tags;
+    bool alive = true;              // still counted in owner->num_batches
+};
+
+struct Batcher {
+    dgnn_network* net = nullptr;
+    int device = 0;
+    int max_batch_size = 0;
+    int max_batches = 0;
+
+    std::mutex mutex;               // batch.rs:60-73: the list lock
+    std::vector<uint16_t> features;
+    std::vector<uint64_t> tags;
+    std::atomic<int> num_batches{0};
+    std::atomic<uint64_t> boards_evaluated{0}, batches_evaluated{0};
+};
+
+// ------------------------------------------------------------------------------------------------ leaf pool
+//
+// The reference coalesces leaf evaluations only inside ONE search (pool/worker_thread.rs:88-99); the <= 8-board
+// full_forward calls of its game threads go to the GPU one by one (lib.rs:114, self_play.rs:370-405), which makes
+// policy-play (BASELINE.json configs[4]) a small-batch latency path.  LeafPool gives every caller the blocking
+// Predictor::predict signature (predictor.rs:92) and coalesces ACROSS callers: requests are pushed into the batcher,
+// worker threads turn whatever has accumulated into device batches whenever fewer than max_batches are in flight.
+struct LeafSlot {
+    struct LeafRequest* request;
+    int index;
+};
+
+struct LeafRequest {
+    uint16_t* value_out;
+    uint16_t* policy_out;
+    int remaining;
+    int status;
+    std::mutex mutex;
+    std::condition_variable done;
+};
+
+struct LeafPool {
+    Batcher* batcher = nullptr;
+    std::vector<std::thread> workers;
+    std::mutex mutex;
+    std::condition_variable work;
+    bool stopping = false;
+    std::atomic<uint64_t> calls{0};
+
+    void run()
+    {
+        std::vector<uint16_t> value((size_t)batcher->max_batch_size), policy((size_t)batcher->max_batch_size * DGNN_NUM_MOVES);
+        std::vector<uint64_t> tags((size_t)batcher->max_batch_size);
+        for (;;) {
+            dgnn_batch* batch = nullptr;
+            // take whatever is queued as soon as a batch slot is free: with max_batches batches in flight the queue
+            // fills up behind them, which is what makes the batches large under load and keeps latency low when idle
+            (void)dgnn_batcher_get_batch(reinterpret_cast<dgnn_batcher*>(batcher), 1, &batch);
+            if (!batch) {
+                std::unique_lock<std::mutex> lock(mutex);
+                if (stopping) return;
+                work.wait_for(lock, std::chrono::microseconds(200));
+                continue;
+            }
+            const int n = dgnn_batch_size(batch);
+            (void)dgnn_batch_tags(batch, tags.data());
+            const int status = dgnn_batch_forward(batch, value.data(), policy.data());
+            dgnn_batch_destroy(batch);
+            work.notify_one();                      // a batch slot is free again
+            for (int i = 0; i < n; ++i) {
+                LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
+                LeafRequest* r = slot->request;
+                if (status == DGNN_OK) {
+                    r->value_out[slot->index] = value[i];
+                    std::memcpy(r->policy_out + (size_t)slot->index * DGNN_NUM_MOVES, policy.data() + (size_t)i * DGNN_NUM_MOVES,
+                                DGNN_NUM_MOVES * sizeof(uint16_t));
+                }
+                std::lock_guard<std::mutex> lock(r->mutex);
+                if (status != DGNN_OK) r->status = status;
+                if (--r->remaining == 0) r->done.notify_one();
+            }
+        }
+    }
+};
+
+}  // namespace dgnn
+
+using namespace dgnn;
+
+extern "C" {
+
+// ---- symmetry
+
+int dgnn_symmetry_inverse(int transform) { return (transform >= 0 && transform < 8) ? kInverse[transform] : -1; }
+
+int dgnn_symmetry_apply(int transform, int packed_index)
+{
+    if (transform < 0 || transform >= 8 || packed_index < 0 || packed_index >= DGNN_NUM_MOVES) return -1;
+    return tables().map[transform][packed_index];
+}
+
+int dgnn_policy_with_transform(const uint16_t* policy, int transform, uint16_t* out)
+{
+    if (!policy || !out || policy == out || transform < 0 || transform >= 8) return DGNN_BAD_ARGUMENT;
+    with_transform(policy, transform, out);
+    return DGNN_OK;
+}
+
+// ---- cache
+
+int dgnn_cache_create(size_t capacity, int num_shards, dgnn_cache** out)
+{
+    if (!out || capacity == 0 || num_shards <= 0) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<Cache> c(new (std::nothrow) Cache());
+    if (!c) return DGNN_OUT_OF_MEMORY;
+    for (int i = 0; i < num_shards; ++i) {
+        std::unique_ptr<CacheShard> s(new (std::nothrow) CacheShard());
+        if (!s) return DGNN_OUT_OF_MEMORY;
+        s->capacity = (capacity + num_shards - 1) / num_shards;
+        c->shards.push_back(std::move(s));
+    }
+    *out = reinterpret_cast<dgnn_cache*>(c.release());
+    return DGNN_OK;
+}
+
+void dgnn_cache_destroy(dgnn_cache* cache) { delete reinterpret_cast<Cache*>(cache); }
+
+int dgnn_cache_fetch(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!cache || !value_out || !policy_out || symmetry < 0 || symmetry >= 8) return DGNN_BAD_ARGUMENT;
+    Cache* c = reinterpret_cast<Cache*>(cache);
+    const CacheKey key{board_hash, to_move};
+    CacheShard& s = c->shard(key);
+    std::lock_guard<std::mutex> lock(s.mutex);
+    auto it = s.index.find(key);
+    if (it == s.index.end()) { c->misses.fetch_add(1, std::memory_order_relaxed); return 0; }
+    s.order.splice(s.order.begin(), s.order, it->second);                      // lru_cache.rs:106-109: detach + attach
+    *value_out = it->second->value;
+    with_transform(it->second->policy, symmetry, policy_out);                   // nn.rs:72-74
+    c->hits.fetch_add(1, std::memory_order_relaxed);
+    return 1;
+}
+
+int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy)
+{
+    if (!cache || !policy || symmetry < 0 || symmetry >= 8) return DGNN_BAD_ARGUMENT;
+    Cache* c = reinterpret_cast<Cache*>(cache);
+    const CacheKey key{board_hash, to_move};
+    CacheShard& s = c->shard(key);
+    std::lock_guard<std::mutex> lock(s.mutex);
+    if (s.index.find(key) != s.index.end()) return DGNN_OK;                    // lru_cache.rs:121: present keys are left alone
+    s.order.emplace_front();
+    CacheEntry& e = s.order.front();
+    e.key = key;
+    e.value = value;
+    with_transform(policy, kInverse[symmetry], e.policy);                       // nn.rs:78-81: symmetry.inverse()
+    s.index.emplace(key, s.order.begin());
+    if (s.index.size() > s.capacity) {                                          // lru_cache.rs:136-147: drop the tail
+        s.index.erase(s.order.back().key);
+        s.order.pop_back();
+    }
+    return DGNN_OK;
+}
+
+int dgnn_cache_stats(dgnn_cache* cache, uint64_t* entries, uint64_t* hits, uint64_t* misses)
+{
+    if (!cache) return DGNN_BAD_ARGUMENT;
+    Cache* c = reinterpret_cast<Cache*>(cache);
+    if (entries) {
+        uint64_t n = 0;
+        for (auto& s : c->shards) { std::lock_guard<std::mutex> lock(s->mutex); n += s->index.size(); }
+        *entries = n;
+    }
+    if (hits) *hits = c->hits.load();
+    if (misses) *misses = c->misses.load();
+    return DGNN_OK;
+}
+
+// ---- batcher
+
+int dgnn_batcher_create(dgnn_network* net, int device, int max_batch_size, int max_batches, dgnn_batcher** out)
+{
+    if (!out || max_batch_size <= 0 || max_batches <= 0) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<Batcher> b(new (std::nothrow) Batcher());
+    if (!b) return DGNN_OUT_OF_MEMORY;
+    b->net = net;            // may be NULL: a batcher without a predictor (queueing logic only; forward is then refused)
+    b->device = device;
+    b->max_batch_size = max_batch_size;
+    b->max_batches = max_batches;
+    b->features.reserve((size_t)2 * max_batch_size * DGNN_FEATURE_SIZE);        // batch.rs:51-56
+    b->tags.reserve((size_t)2 * max_batch_size);
+    *out = reinterpret_cast<dgnn_batcher*>(b.release());
+    return DGNN_OK;
+}
+
+void dgnn_batcher_destroy(dgnn_batcher* batcher) { delete reinterpret_cast<Batcher*>(batcher); }
+
+int dgnn_batcher_push(dgnn_batcher* batcher, const uint16_t* features, uint64_t tag)
+{
+    if (!batcher || !features) return DGNN_BAD_ARGUMENT;
+    Batcher* b = reinterpret_cast<Batcher*>(batcher);
+    std::lock_guard<std::mutex> lock(b->mutex);                                 // batch.rs:80-84
+    b->features.insert(b->features.end(), features, features + DGNN_FEATURE_SIZE);
+    b->tags.push_back(tag);
+    return DGNN_OK;
+}
+
+int dgnn_batcher_pending(dgnn_batcher* batcher, int* queued, int* batches_alive)
+{
+    if (!batcher) return DGNN_BAD_ARGUMENT;
+    Batcher* b = reinterpret_cast<Batcher*>(batcher);
+    if (queued) { std::lock_guard<std::mutex> lock(b->mutex); *queued = (int)b->tags.size(); }
+    if (batches_alive) *batches_alive = b->num_batches.load(std::memory_order_acquire);
+    return DGNN_OK;
+}
+
+int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch** out)
+{
+    if (!batcher || !out) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    Batcher* b = reinterpret_cast<Batcher*>(batcher);
+
+    int current = b->num_batches.load(std::memory_order_acquire);               // batch.rs:93-99
+    if (current >= b->max_batches) return DGNN_OK;
+
+    std::lock_guard<std::mutex> lock(b->mutex);
+    const size_t size = b->tags.size();
+    if (size == 0 || size < (size_t)(min_batch_size > 0 ? min_batch_size : 0)) return DGNN_OK;   // an empty batch is never useful
+    if (!b->num_batches.compare_exchange_strong(current, current + 1, std::memory_order_acquire, std::memory_order_relaxed))
+        return DGNN_OK;                                                         // batch.rs:105: lost the race, try again later
+
+    std::unique_ptr<Batch> batch(new (std::nothrow) Batch());
+    if (!batch) { b->num_batches.fetch_sub(1); return DGNN_OUT_OF_MEMORY; }
+    const size_t split = size >= (size_t)b->max_batch_size ? size - b->max_batch_size : 0;     // batch.rs:106
+    batch->owner = b;
+    batch->features.assign(b->features.begin() + split * DGNN_FEATURE_SIZE, b->features.end());   // split_off: the NEWEST entries
+    batch->tags.assign(b->tags.begin() + split, b->tags.end());
+    b->features.resize(split * DGNN_FEATURE_SIZE);
+    b->tags.resize(split);
+    *out = reinterpret_cast<dgnn_batch*>(batch.release());
+    return DGNN_OK;
+}
+
+int dgnn_batcher_push_and_get_batch(dgnn_batcher* batcher, const uint16_t* features, uint64_t tag, dgnn_batch** out)
+{
+    const int status = dgnn_batcher_push(batcher, features, tag);               // batch.rs:86-89
+    if (status != DGNN_OK) return status;
+    return dgnn_batcher_get_batch(batcher, reinterpret_cast<Batcher*>(batcher)->max_batch_size, out);
+}
+
+int dgnn_batch_size(const dgnn_batch* batch) { return batch ? (int)reinterpret_cast<const Batch*>(batch)->tags.size() : 0; }
+
+int dgnn_batch_tags(const dgnn_batch* batch, uint64_t* tags_out)
+{
+    if (!batch || !tags_out) return DGNN_BAD_ARGUMENT;
+    const Batch* bt = reinterpret_cast<const Batch*>(batch);
+    std::memcpy(tags_out, bt->tags.data(), bt->tags.size() * sizeof(uint64_t));
+    return DGNN_OK;
+}
+
+const uint16_t* dgnn_batch_features(const dgnn_batch* batch) { return batch ? reinterpret_cast<const Batch*>(batch)->features.data() : nullptr; }
+
+static void retire(Batch* bt)
+{
+    if (bt->alive) {
+        bt->alive = false;
+        bt->owner->num_batches.fetch_sub(1, std::memory_order_acq_rel);         // batch.rs:37
+    }
+}
+
+int dgnn_batch_forward(dgnn_batch* batch, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!batch || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    Batch* bt = reinterpret_cast<Batch*>(batch);
+    Batcher* b = bt->owner;
+    if (!b->net) return DGNN_BAD_ARGUMENT;
+    const int n = (int)bt->tags.size();
+
+    dgnn_workspace* ws = nullptr;
+    int status = dgnn_network_get_workspace(b->net, b->device, b->max_batch_size, &ws);
+    if (status == DGNN_OK) {
+        status = dgnn_forward_n(ws, bt->features.data(), n, value_out, policy_out);   // batch.rs:36 -> nn.rs:84-108
+        dgnn_workspace_release(ws);
+    }
+    retire(bt);
+    if (status == DGNN_OK) {
+        b->boards_evaluated.fetch_add((uint64_t)n, std::memory_order_relaxed);
+        b->batches_evaluated.fetch_add(1, std::memory_order_relaxed);
+    }
+    return status;
+}
+
+void dgnn_batch_destroy(dgnn_batch* batch)
+{
+    if (!batch) return;
+    Batch* bt = reinterpret_cast<Batch*>(batch);
+    retire(bt);
+    delete bt;
+}
+
+// ---- leaf pool
+
+int dgnn_pool_create(dgnn_batcher* batcher, int num_workers, dgnn_pool** out)
+{
+    if (!batcher || !out || num_workers <= 0) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    Batcher* b = reinterpret_cast<Batcher*>(batcher);
+    if (!b->net) return DGNN_BAD_ARGUMENT;
+    std::unique_ptr<LeafPool> pool(new (std::nothrow) LeafPool());
+    if (!pool) return DGNN_OUT_OF_MEMORY;
+    pool->batcher = b;
+    LeafPool* raw = pool.get();
+    for (int i = 0; i < num_workers; ++i) pool->workers.emplace_back([raw] { raw->run(); });
+    *out = reinterpret_cast<dgnn_pool*>(pool.release());
+    return DGNN_OK;
+}
+
+void dgnn_pool_destroy(dgnn_pool* handle)
+{
+    if (!handle) return;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    {
+        std::lock_guard<std::mutex> lock(pool->mutex);
+        pool->stopping = true;
+    }
+    pool->work.notify_all();
+    for (std::thread& t : pool->workers) t.join();
+    delete pool;
+}
+
+int dgnn_pool_predict(dgnn_pool* handle, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!handle || !features || !value_out || !policy_out || batch_size <= 0) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    LeafRequest request;
+    request.value_out = value_out;
+    request.policy_out = policy_out;
+    request.remaining = batch_size;
+    request.status = DGNN_OK;
+    std::vector<LeafSlot> slots((size_t)batch_size);
+    for (int i = 0; i < batch_size; ++i) {
+        slots[i].request = &request;
+        slots[i].index = i;
+        const int status = dgnn_batcher_push(reinterpret_cast<dgnn_batcher*>(pool->batcher), features + (size_t)i * DGNN_FEATURE_SIZE,
+                                             (uint64_t)(uintptr_t)&slots[i]);
+        if (status != DGNN_OK) {       // cannot happen after the argument checks above; the pushed part still completes
+            std::unique_lock<std::mutex> lock(request.mutex);
+            request.remaining -= batch_size - i;
+            request.status = status;
+            if (i == 0) return status;
+            break;
+        }
+    }
+    pool->calls.fetch_add(1, std::memory_order_relaxed);
+    pool->work.notify_one();
+    std::unique_lock<std::mutex> lock(request.mutex);
+    request.done.wait(lock, [&] { return request.remaining == 0; });
+    return request.status;
+}
+
+int dgnn_batcher_stats(dgnn_batcher* batcher, uint64_t* boards, uint64_t* batches)
+{
+    if (!batcher) return DGNN_BAD_ARGUMENT;
+    Batcher* b = reinterpret_cast<Batcher*>(batcher);
+    if (boards) *boards = b->boards_evaluated.load();
+    if (batches) *batches = b->batches_evaluated.load();
+    return DGNN_OK;
+}
+
+}  // extern "C"

@@ -58,6 +58,7 @@ struct Workspace {
     uint16_t* h_value = nullptr;
     uint16_t* h_policy = nullptr;
 
+    int active = 0;                         // boards of the submission in flight / being enqueued (<= batch, the capacity)
     bool pending = false;                   // a submit without its wait
     bool use_board = false;                 // padded slot-major layout + one-board-per-workgroup kernel (conv_board.hip)
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
@@ -164,6 +165,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->dev = dev;
     ws->device = dev->device;
     ws->batch = batch;
+    ws->active = batch;
 
     conv_impl_from_env(batch * DGNN_NUM_POINTS, t.num_channels, &ws->use_tile, &ws->tile_fm, &ws->tile_variant);
     ws->use_board = board_impl_from_env(batch, t.num_channels) && t.up.w_board_offset != 0;
@@ -220,7 +222,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
 {
     const Topology& t = ws->net->topo;
     const uint8_t* image = ws->dev->d_image;
-    const int num_pos = ws->batch * DGNN_NUM_POINTS;
+    const int num_pos = ws->active * DGNN_NUM_POINTS;
 
     auto conv = [&](const ConvParams& c, const uint16_t* x, const uint16_t* z, uint16_t* y) -> hipError_t {
         if (ws->use_tile && c.w_tile_offset != 0 && conv_tile_supported(c.cin, c.cout)) {
@@ -266,7 +268,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
         a.z = c.alpha2 != 0.0f ? z : nullptr;
         a.y = y;
         a.timing = nullptr;
-        a.batch = ws->batch;
+        a.batch = ws->active;
         a.cin = c.cin;
         a.cout = c.cout;
         a.alpha1 = c.alpha1;
@@ -278,7 +280,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
     int cur = 0;
     const uint16_t* tower = nullptr;   // NHWC tower output for the heads
     if (ws->use_board) {
-        DGNN_HIP(launch_nhwc_to_board(ws->d_features, ws->d_features_board, ws->batch, DGNN_NUM_FEATURES, ws->stream));
+        DGNN_HIP(launch_nhwc_to_board(ws->d_features, ws->d_features_board, ws->active, DGNN_NUM_FEATURES, ws->stream));
         DGNN_HIP(conv_board(t.up, ws->d_features_board, nullptr, ws->d_act[cur]));
         if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair], ws->stream));
         for (int i = 0; i < t.num_blocks; ++i) {
@@ -295,12 +297,12 @@ int enqueue_forward(Workspace* ws, int tower_pair)
             hc.bias = (const uint16_t*)(image + t.head_b_offset);
             hc.policy_features = ws->d_policy_features;
             hc.value_features = ws->d_value_features;
-            hc.batch = ws->batch;
+            hc.batch = ws->active;
             hc.cin = t.num_channels;
             hc.samples = t.num_samples;
             DGNN_HIP(launch_head_conv_board(hc, ws->stream));
         } else {
-            DGNN_HIP(launch_board_to_nhwc(ws->d_act[cur], ws->d_tower_nhwc, ws->batch, t.num_channels, ws->stream));
+            DGNN_HIP(launch_board_to_nhwc(ws->d_act[cur], ws->d_tower_nhwc, ws->active, t.num_channels, ws->stream));
             tower = ws->d_tower_nhwc;
         }
     } else {
@@ -327,7 +329,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
     pg.wt = (const uint16_t*)(image + t.policy_wt_offset);
     pg.bias = (const uint16_t*)(image + t.policy_b_offset);
     pg.logits = ws->d_logits;
-    pg.batch = ws->batch;
+    pg.batch = ws->active;
     pg.k_in = DGNN_NUM_POINTS * t.num_samples;
     pg.k_pad = t.policy_k_pad;
     pg.tau = 1.0f / t.softmax_temperature;
@@ -340,7 +342,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
     sv.value_b = (const uint16_t*)(image + t.value_b_offset);
     sv.policy_out = ws->d_policy;
     sv.value_out = ws->d_value;
-    sv.batch = ws->batch;
+    sv.batch = ws->active;
     DGNN_HIP(launch_softmax_value(sv, ws->stream));
     return DGNN_OK;
 }
@@ -624,7 +626,17 @@ int dgnn_forward_submit(dgnn_workspace* handle, const uint16_t* features, size_t
     if (!handle || !features) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
     if (num_features != (size_t)ws->batch * DGNN_FEATURE_SIZE) return DGNN_BAD_ARGUMENT;   // graph.rs:124-125
+    return dgnn_forward_submit_n(handle, features, ws->batch);
+}
+
+int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int count)
+{
+    if (!handle || !features) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
     if (ws->pending) return DGNN_BAD_ARGUMENT;
+    ws->active = count;
+    const size_t num_features = (size_t)count * DGNN_FEATURE_SIZE;
 
     DGNN_HIP(hipSetDevice(ws->device));
     const size_t in_bytes = num_features * sizeof(uint16_t);
@@ -634,8 +646,8 @@ int dgnn_forward_submit(dgnn_workspace* handle, const uint16_t* features, size_t
     const int status = enqueue_forward(ws, -1);
     if (status != DGNN_OK) return status;
 
-    DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->batch * 2, hipMemcpyDeviceToHost, ws->stream));
-    DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->batch * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
     ws->pending = true;
     return DGNN_OK;
 }
@@ -649,9 +661,18 @@ int dgnn_forward_wait(dgnn_workspace* handle, uint16_t* value_out, uint16_t* pol
     DGNN_HIP(hipSetDevice(ws->device));
     ws->pending = false;
     DGNN_HIP(hipStreamSynchronize(ws->stream));   // graph.rs:155-156 (to_vec + synchronize)
-    if (value_out != ws->h_value) std::memcpy(value_out, ws->h_value, (size_t)ws->batch * 2);
-    if (policy_out != ws->h_policy) std::memcpy(policy_out, ws->h_policy, (size_t)ws->batch * DGNN_NUM_MOVES * 2);
+    if (value_out != ws->h_value) std::memcpy(value_out, ws->h_value, (size_t)ws->active * 2);
+    if (policy_out != ws->h_policy) std::memcpy(policy_out, ws->h_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2);
+    ws->active = ws->batch;
     return DGNN_OK;
+}
+
+int dgnn_forward_n(dgnn_workspace* ws, const uint16_t* features, int count, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    const int status = dgnn_forward_submit_n(ws, features, count);
+    if (status != DGNN_OK) return status;
+    return dgnn_forward_wait(ws, value_out, policy_out);
 }
 
 int dgnn_forward(dgnn_workspace* ws, const uint16_t* features, size_t num_features,

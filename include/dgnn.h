@@ -117,6 +117,14 @@ int dgnn_forward(dgnn_workspace* ws, const uint16_t* features, size_t num_featur
 int dgnn_forward_submit(dgnn_workspace* ws, const uint16_t* features, size_t num_features);
 int dgnn_forward_wait(dgnn_workspace* ws, uint16_t* value_out, uint16_t* policy_out);
 
+/* The same calls for a batch SMALLER than the workspace's batch size: `count` boards (1 <= count <= batch size)
+ * are evaluated, count * 11552 features are read and count values / count * 362 policy entries are written.  The
+ * reference keeps one workspace per distinct batch size (network.rs:132-142) because cuDNN descriptors are per
+ * shape; the HIP kernels take the board count at launch, so a batcher can serve every batch 1..max from ONE
+ * workspace (and one arena) of capacity max. */
+int dgnn_forward_n(dgnn_workspace* ws, const uint16_t* features, int count, uint16_t* value_out, uint16_t* policy_out);
+int dgnn_forward_submit_n(dgnn_workspace* ws, const uint16_t* features, int count);
+
 /* ---- device-resident variants (measurement harness; inputs already in HBM) ----------------- */
 
 int dgnn_workspace_batch_size(const dgnn_workspace* ws, int* batch_size, int* device);
@@ -188,6 +196,71 @@ int dgnn_network_weight_checksum_device(dgnn_network* net, int device, uint64_t*
 
 /* The host-side weight image itself (read-only, owned by the network). */
 int dgnn_network_weight_image_host(const dgnn_network* net, const void** image, size_t* num_bytes);
+
+/* ============================================================================================================
+ * Host side of the boundary (scope row f-1): policy symmetries, transposition cache, many-game leaf batcher.
+ * Pure host code (batcher.cpp); only dgnn_batch_forward touches a GPU.
+ * ============================================================================================================ */
+
+/* The eight board symmetries in the order of symmetry::ALL (src/libdg_go/utils/symmetry.rs:119-128). */
+#define DGNN_SYM_IDENTITY        0
+#define DGNN_SYM_FLIP_LR         1
+#define DGNN_SYM_FLIP_UD         2
+#define DGNN_SYM_TRANSPOSE       3
+#define DGNN_SYM_TRANSPOSE_ANTI  4
+#define DGNN_SYM_ROT90           5
+#define DGNN_SYM_ROT180          6
+#define DGNN_SYM_ROT270          7
+
+/* Transform::inverse (symmetry.rs:78-90); -1 for an invalid transform. */
+int dgnn_symmetry_inverse(int transform);
+/* Transform::apply on a packed index 0..361 (361 = pass maps to itself); -1 for invalid arguments. */
+int dgnn_symmetry_apply(int transform, int packed_index);
+/* Prediction::with_transform (src/libdg_mcts/predictor.rs:30-44): out[apply(t, i)] = policy[i]; out != policy. */
+int dgnn_policy_with_transform(const uint16_t* policy, int transform, uint16_t* out);
+
+/* LruCache + NnPredictor::{fetch, cache} (src/libdg_mcts/lru_cache.rs:56-150, predictors/nn.rs:29-82).  Keyed by
+ * (zobrist hash, colour to move); entries are stored in the canonical orientation.  `num_shards` = 1 reproduces the
+ * reference's single list (and its eviction order) exactly; more shards remove the global lock.  Thread safe. */
+typedef struct dgnn_cache dgnn_cache;
+int dgnn_cache_create(size_t capacity, int num_shards, dgnn_cache** out);        /* reference: 200 000 + 1, nn.rs:29,57 */
+void dgnn_cache_destroy(dgnn_cache* cache);
+/* fetch: returns 1 on a hit (value_out / policy_out[362] filled, remapped by `symmetry`), 0 on a miss, < 0 on error. */
+int dgnn_cache_fetch(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t* value_out, uint16_t* policy_out);
+/* cache: stores the prediction remapped by symmetry.inverse(); a key that is already present is left untouched. */
+int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy);
+int dgnn_cache_stats(dgnn_cache* cache, uint64_t* entries, uint64_t* hits, uint64_t* misses);
+
+/* Batcher / Batch (src/libdg_mcts/pool/batch.rs:24-123).  Leaf positions from any number of games and threads are
+ * pushed with a caller-chosen 64-bit tag; get_batch hands out the NEWEST max_batch_size of them once at least
+ * `min_batch_size` are queued and fewer than `max_batches` batches are alive (the reference: 2 x devices,
+ * nn.rs:64-67).  `net` may be NULL for a batcher that only queues (dgnn_batch_forward is then refused). */
+typedef struct dgnn_batcher dgnn_batcher;
+typedef struct dgnn_batch dgnn_batch;
+int dgnn_batcher_create(dgnn_network* net, int device, int max_batch_size, int max_batches, dgnn_batcher** out);
+void dgnn_batcher_destroy(dgnn_batcher* batcher);
+int dgnn_batcher_push(dgnn_batcher* batcher, const uint16_t* features /* 11552 fp16 */, uint64_t tag);       /* batch.rs:80-84 */
+int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch** out /* NULL: none */);    /* batch.rs:91-121 */
+int dgnn_batcher_push_and_get_batch(dgnn_batcher* batcher, const uint16_t* features, uint64_t tag, dgnn_batch** out);  /* :86-89 */
+int dgnn_batcher_pending(dgnn_batcher* batcher, int* queued, int* batches_alive);
+int dgnn_batcher_stats(dgnn_batcher* batcher, uint64_t* boards_evaluated, uint64_t* batches_evaluated);
+int dgnn_batch_size(const dgnn_batch* batch);
+int dgnn_batch_tags(const dgnn_batch* batch, uint64_t* tags_out /* dgnn_batch_size entries, in push order */);
+const uint16_t* dgnn_batch_features(const dgnn_batch* batch);
+/* Batch::forward (batch.rs:35-40): evaluates the batch on the batcher's device through a pooled workspace of
+ * capacity max_batch_size; value_out[n], policy_out[n * 362] in tag order; the batch stops counting as alive. */
+int dgnn_batch_forward(dgnn_batch* batch, uint16_t* value_out, uint16_t* policy_out);
+void dgnn_batch_destroy(dgnn_batch* batch);
+
+/* Cross-caller coalescing (no reference counterpart: the reference sends the <= 8-board full_forward calls of its
+ * game threads to the GPU one by one, src/libdg_mcts/lib.rs:114).  dgnn_pool_predict has the blocking
+ * Predictor::predict signature (src/libdg_mcts/predictor.rs:92) and may be called from any number of threads; worker
+ * threads of the pool turn everything that has been pushed meanwhile into device batches (<= max_batch_size boards,
+ * <= max_batches in flight). */
+typedef struct dgnn_pool dgnn_pool;
+int dgnn_pool_create(dgnn_batcher* batcher, int num_workers, dgnn_pool** out);
+void dgnn_pool_destroy(dgnn_pool* pool);   /* every dgnn_pool_predict call must have returned */
+int dgnn_pool_predict(dgnn_pool* pool, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out);
 
 /* Library version / build info string (static). */
 const char* dgnn_version(void);

@@ -1,0 +1,194 @@
+"""Host side of the boundary (scope row f-1) through the C ABI, no GPU needed: policy symmetries, the transposition
+cache and the leaf batcher's queueing rules, pinned to the reference's own tests and arithmetic:
+
+    src/libdg_mcts/predictor.rs:98-108     Prediction::with_transform identities
+    src/libdg_go/utils/symmetry.rs:19-128  the eight tables and their inverses
+    src/libdg_mcts/lru_cache.rs:152-183    insert_only_20000, mixed_insert
+    src/libdg_mcts/pool/batch.rs:91-121    get_batch: newest max_batch_size entries, max_batches cap
+"""
+import threading
+
+import numpy as np
+import pytest
+
+
+def _reference_table(ax, ay):
+    """get_transformation of symmetry.rs:19-37 restated on packed indices."""
+    out = np.empty(362, dtype=np.int64)
+    for i in range(361):
+        x, y = i % 19 - 9, i // 19 - 9
+        out[i] = (ay(x, y) + 9) * 19 + (ax(x, y) + 9)
+    out[361] = 361
+    return out
+
+
+REFERENCE_TABLES = [                                   # symmetry.rs:39-62, order of symmetry::ALL (:119-128)
+    _reference_table(lambda x, y: x, lambda x, y: y),      # Identity
+    _reference_table(lambda x, y: -x, lambda x, y: y),     # FlipLR
+    _reference_table(lambda x, y: x, lambda x, y: -y),     # FlipUD
+    _reference_table(lambda x, y: y, lambda x, y: x),      # Transpose
+    _reference_table(lambda x, y: -y, lambda x, y: -x),    # TransposeAnti
+    _reference_table(lambda x, y: y, lambda x, y: -x),     # Rot90
+    _reference_table(lambda x, y: -x, lambda x, y: -y),    # Rot180
+    _reference_table(lambda x, y: -y, lambda x, y: x),     # Rot270
+]
+
+
+def test_symmetry_tables_and_inverses(api):
+    T = api.Transform
+    for t in T.ALL:
+        got = np.array([T.apply(t, i) for i in range(362)])
+        assert np.array_equal(got, REFERENCE_TABLES[t])
+        inv = T.inverse(t)
+        assert all(T.apply(inv, T.apply(t, i)) == i for i in range(362))
+    assert [T.inverse(t) for t in T.ALL] == [0, 1, 2, 3, 4, 7, 6, 5]          # symmetry.rs:78-90
+    assert T.apply(8, 0) == -1 and T.apply(0, 362) == -1 and T.inverse(-1) == -1
+
+
+def test_check_with_transform(api):
+    """predictor.rs:98-108, verbatim."""
+    original = api.Prediction(0.0, np.arange(362, dtype=np.float32))
+    T = api.Transform
+    assert original.policy()[0] == api.Prediction.with_transform(original, T.Identity).policy()[0]
+    assert original.policy()[0] == api.Prediction.with_transform(original, T.Rot180).policy()[360]
+    assert original.policy()[361] == api.Prediction.with_transform(original, T.Rot180).policy()[361]
+    # every transform is a permutation of the 361 points that fixes the pass move
+    for t in T.ALL:
+        p = api.Prediction.with_transform(original, t).policy()
+        assert sorted(p[:361].tolist()) == list(range(361)) and p[361] == 361
+        assert np.array_equal(p[REFERENCE_TABLES[t]], original.policy())        # out[t(i)] = in[i]
+
+
+def test_lru_insert_only_20000(api):
+    """lru_cache.rs:157-165."""
+    lru = api.LruCache(capacity=1000, num_shards=1)
+    p = api.Prediction(0.5, np.zeros(362))
+    for i in range(20000):
+        lru.cache(i, 0, 0, p)
+    assert len(lru) == 1000
+
+
+def test_lru_mixed_insert(api):
+    """lru_cache.rs:167-182: a get refreshes an entry, the least recently used ones are dropped."""
+    lru = api.LruCache(capacity=10, num_shards=1)
+    p = api.Prediction(0.25, np.zeros(362))
+    for i in range(10):
+        lru.cache(i, 0, 0, p)
+    for i in range(2):
+        assert lru.fetch(i, 0, 0) is not None
+    for i in range(6):
+        lru.cache(i + 20, 0, 0, p)
+    for i in (0, 1, 8, 9):
+        assert lru.fetch(i, 0, 0) is not None, i
+    for i in range(2, 8):
+        assert lru.fetch(i, 0, 0) is None, i
+
+
+def test_cache_is_keyed_by_colour_and_canonicalises_the_symmetry(api):
+    """nn.rs:69-82: cache() stores with_transform(response, symmetry.inverse()), fetch() returns with_transform(entry, symmetry)."""
+    T = api.Transform
+    lru = api.LruCache(capacity=100)
+    rng = np.random.default_rng(3)
+    response = api.Prediction(-0.75, rng.random(362).astype(np.float16))
+    lru.cache(0xDEADBEEFCAFEF00D, 1, T.Rot90, response)
+    assert lru.fetch(0xDEADBEEFCAFEF00D, 2, T.Rot90) is None                    # other colour to move
+    same = lru.fetch(0xDEADBEEFCAFEF00D, 1, T.Rot90)
+    assert same.value() == -0.75 and np.array_equal(same.policy(), response.policy())
+    for s in T.ALL:
+        got = lru.fetch(0xDEADBEEFCAFEF00D, 1, s)
+        canonical = api.Prediction.with_transform(response, T.inverse(T.Rot90))
+        assert np.array_equal(got.policy(), api.Prediction.with_transform(canonical, s).policy())
+    # a present key is left untouched (lru_cache.rs:121)
+    lru.cache(0xDEADBEEFCAFEF00D, 1, T.Identity, api.Prediction(0.1, np.zeros(362)))
+    assert lru.fetch(0xDEADBEEFCAFEF00D, 1, T.Rot90).value() == -0.75
+    assert lru.stats()["hits"] >= 9 and lru.stats()["misses"] == 1
+
+
+def test_sharded_cache_keeps_its_capacity_under_threads(api):
+    lru = api.LruCache(capacity=4096, num_shards=16)
+    p = api.Prediction(0.0, np.zeros(362))
+
+    def worker(base):
+        for i in range(3000):
+            lru.cache(base * 1_000_003 + i * 7919, i & 1, i & 7, p)
+            lru.fetch(base * 1_000_003 + (i // 2) * 7919, (i // 2) & 1, 0)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert 0 < len(lru) <= 4096
+
+
+def _board(tag):
+    f = np.zeros(11552, dtype=np.float16)
+    f[:8] = np.frombuffer(np.uint64(tag).tobytes(), dtype=np.uint8).astype(np.float16)
+    return f
+
+
+def test_batcher_hands_out_the_newest_entries(api):
+    """batch.rs:91-121 with max_batch_size 4: the split index is size - max when size >= max, else 0."""
+    b = api.Batcher(None, max_batch_size=4, max_batches=2)
+    assert b.get_batch(1) is None                                               # nothing queued
+    for tag in range(10):
+        b.push(tag, _board(tag))
+    assert b.get_batch(11) is None                                              # fewer than min_batch_size queued
+    first = b.get_batch(4)
+    assert first.tags().tolist() == [6, 7, 8, 9]                                # split_off(size - max): the NEWEST four
+    assert np.array_equal(first.features().reshape(4, 11552)[:, :8], np.stack([_board(t)[:8] for t in (6, 7, 8, 9)]))
+    assert b.pending() == (6, 1)
+    second = b.get_batch(1)
+    assert second.tags().tolist() == [2, 3, 4, 5]
+    assert b.pending() == (2, 2)
+    assert b.get_batch(1) is None                                               # max_batches alive (batch.rs:96-98)
+    first.destroy()                                                             # Batch::forward decrements (batch.rs:37); so does a drop here
+    third = b.get_batch(1)
+    assert third.tags().tolist() == [0, 1]                                      # size < max: split index 0, everything
+    assert b.pending() == (0, 2)
+    with pytest.raises(api.Error):                                              # no predictor behind this batcher
+        third.forward()
+
+
+def test_push_and_get_batch_triggers_at_max_batch_size(api):
+    """batch.rs:86-89: push_and_get_batch(event) == push + get_batch(max_batch_size)."""
+    b = api.Batcher(None, max_batch_size=3, max_batches=4)
+    assert b.push_and_get_batch(100, _board(100)) is None
+    assert b.push_and_get_batch(101, _board(101)) is None
+    batch = b.push_and_get_batch(102, _board(102))
+    assert batch is not None and batch.tags().tolist() == [100, 101, 102]
+    assert b.pending() == (0, 1)
+
+
+def test_batcher_conserves_every_event_under_threads(api):
+    """Many game threads push, several workers drain: every tag comes out exactly once, no batch exceeds the maximum."""
+    b = api.Batcher(None, max_batch_size=16, max_batches=3)
+    produced = 8 * 250
+    seen, lock, done = [], threading.Lock(), threading.Event()
+
+    def game(g):
+        for i in range(250):
+            b.push(g * 1000 + i, _board(g * 1000 + i))
+
+    def drain():
+        while True:
+            batch = b.get_batch(1)
+            if batch is None:
+                if done.is_set() and b.pending()[0] == 0:
+                    return
+                continue
+            assert 1 <= len(batch) <= 16
+            tags = batch.tags().tolist()
+            feats = batch.features().reshape(len(tags), 11552)
+            for t, f in zip(tags, feats):
+                assert np.array_equal(f[:8], _board(t)[:8])                     # features travel with their tag
+            with lock:
+                seen.extend(tags)
+            batch.destroy()
+
+    workers = [threading.Thread(target=drain) for _ in range(3)]
+    games = [threading.Thread(target=game, args=(g,)) for g in range(8)]
+    [t.start() for t in workers + games]
+    [t.join() for t in games]
+    done.set()
+    [t.join() for t in workers]
+    assert sorted(seen) == sorted(g * 1000 + i for g in range(8) for i in range(250))
+    assert len(seen) == produced and b.pending() == (0, 0)

@@ -412,3 +412,86 @@ def test_resident_and_timed_paths_match_host_path(api, synth):
         assert launches == 2 * 2 * 3 and 0 < tower <= total
         out = ws.download()
         assert np.array_equal(out.policy.view(np.uint16), p0.view(np.uint16))
+
+
+# --------------------------------------------------------------------------------------------- host side (f-1) on the GPU
+
+def test_partial_batches_from_one_workspace(api, synth):
+    """dgnn_forward_n: every count 1..capacity from ONE workspace gives the results of a dedicated workspace."""
+    text = synth.to_json(synth.make_tensors(2, 64, seed=41))
+    net = api.Network.from_json(text)
+    feats = synth.make_features(9, seed=410).reshape(9, 11552)
+    with net.get_workspace(9) as ws:
+        full_v, full_p = api.forward(ws, feats.reshape(-1)).unwrap()
+        for count in (1, 2, 5, 8, 9):
+            v, p = api.forward_n(ws, feats[:count].reshape(-1), count).unwrap()
+            assert np.array_equal(v.view(np.uint16), full_v.view(np.uint16)[:count])
+            assert np.array_equal(p.view(np.uint16), full_p.view(np.uint16)[:count * 362])
+        with pytest.raises(api.Error):
+            api.forward_n(ws, feats.reshape(-1)[:0], 0)
+        again_v, again_p = api.forward(ws, feats.reshape(-1)).unwrap()          # the full size still works afterwards
+        assert np.array_equal(again_p.view(np.uint16), full_p.view(np.uint16))
+    net.destroy()
+
+
+def test_batcher_forward_matches_direct_forward(api, synth):
+    """Batch::forward (batch.rs:35-40): boards evaluated through the batcher, in batches of whatever size the queue
+    had, give bit-identical results to evaluating each board alone."""
+    text = synth.to_json(synth.make_tensors(2, 64, seed=43))
+    net = api.Network.from_json(text)
+    feats = synth.make_features(23, seed=430).reshape(23, 11552)
+    with net.get_workspace(1) as ws:
+        alone = [api.forward(ws, feats[i]).unwrap() for i in range(23)]
+    b = api.Batcher(net, max_batch_size=8, max_batches=2)
+    for i in range(23):
+        b.push(1000 + i, feats[i])
+    got = {}
+    while True:
+        batch = b.get_batch(1)
+        if batch is None:
+            break
+        tags, out = batch.forward()
+        v, p = out.unwrap()
+        for j, tag in enumerate(tags.tolist()):
+            got[tag] = (v[j], p[j * 362:(j + 1) * 362])
+    assert sorted(got) == list(range(1000, 1023))
+    for i in range(23):
+        assert got[1000 + i][0].view(np.uint16) == alone[i][0].view(np.uint16)[0]
+        assert np.array_equal(got[1000 + i][1].view(np.uint16), alone[i][1].view(np.uint16))
+    assert b.stats() == {"boards": 23, "batches": 3} and b.pending() == (0, 0)
+
+
+def test_leaf_pool_coalesces_callers(api, synth):
+    """Many threads call predict() with <= 8 boards each (the shape of full_forward, lib.rs:83-130): everyone gets the
+    result of evaluating its boards alone, and the device saw fewer, larger batches than there were calls."""
+    import threading
+    text = synth.to_json(synth.make_tensors(2, 64, seed=47))
+    net = api.Network.from_json(text)
+    feats = synth.make_features(8, seed=470).reshape(8, 11552)
+    with net.get_workspace(8) as ws:
+        ref_v, ref_p = api.forward(ws, feats.reshape(-1)).unwrap()
+    batcher = api.Batcher(net, max_batch_size=64, max_batches=2)
+    pool = api.LeafPool(batcher, num_workers=2)
+    errors, calls = [], 24 * 10
+
+    def game(g):
+        try:
+            for i in range(10):
+                n = 1 + (g + i) % 8
+                preds = pool.predict(feats[:n].reshape(-1), n)
+                for j, pr in enumerate(preds):
+                    if not (np.float16(pr.value()).view(np.uint16) == ref_v.view(np.uint16)[j]
+                            and np.array_equal(pr.policy().astype(np.float16).view(np.uint16), ref_p.view(np.uint16)[j * 362:(j + 1) * 362])):
+                        errors.append((g, i, j))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=game, args=(g,)) for g in range(24)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    stats = batcher.stats()
+    pool.close()
+    assert not errors, errors[:3]
+    assert stats["boards"] == sum(1 + (g + i) % 8 for g in range(24) for i in range(10))
+    print(f"leaf pool: {calls} calls, {stats['boards']} boards in {stats['batches']} device batches")
+    assert stats["batches"] < calls
