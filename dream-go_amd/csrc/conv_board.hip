@@ -49,15 +49,9 @@ constexpr int kPieces = 7;                             // DMA instructions per k
 constexpr int kSlotRows = kHalo + kPieces * 64;        // 469
 constexpr int kSlotBytes = kSlotRows * 16;             // 7504
 constexpr int kXBufBytes = 4 * kSlotBytes;             // 30016: one 32-channel chunk
-constexpr int kRing = 3;
-constexpr int kSlabBytes = 4096;                       // one k-step of one wave: 64 channels x 32 k
-constexpr int kWRingBytes = kRing * kSlabBytes;
+constexpr int kRing = 3;                               // filter slabs per wave in flight / in use
 constexpr int kWBase = 2 * kXBufBytes;
-constexpr int kLdsBytes = kWBase + 8 * kWRingBytes;    // 158336 of 163840
 constexpr int kThreads = 512;
-constexpr int kRowTiles = 6;                           // 32-row MFMA tiles per wave
-
-static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ _Float16 round_to_half(float t)
 {
@@ -70,7 +64,6 @@ __device__ __forceinline__ void wait_vmcnt()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-
 
 // ds_read_b128 at a VGPR byte address + immediate; completion is the caller's business (wait_lgkm)
 template <int OFF>
@@ -90,6 +83,11 @@ __device__ __forceinline__ void wait_lgkm(half8& f0)
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f0) : "n"(N));
 }
 template <int N>
+__device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2)
+{
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f0), "+v"(f1), "+v"(f2) : "n"(N));
+}
+template <int N>
 __device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2, half8& f3, half8& f4)
 {
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4) : "n"(N));
@@ -106,24 +104,57 @@ __device__ __forceinline__ void static_for(F&& f)
     static_for_impl(f, std::make_integer_sequence<int, N>());
 }
 
-// byte offset of the B fragment of pair i = k16 * 6 + row tile relative to the lane's base row
-__host__ __device__ constexpr int b_offset(int i) { return (i / kRowTiles) * 2 * kSlotBytes + (i % kRowTiles) * 512; }
+// Work split of the 8 waves, template parameter NWN = waves along the 256 output channels:
+//   NWN = 4   4 channel slices of 64 (2 MFMA channel tiles) x 2 row halves of 192 (6 row tiles): every filter slab is
+//             fetched by the two waves that share a slice (2 x 4 DMA instructions per k-step and slice)
+//   NWN = 8   8 channel slices of 32 (1 channel tile) x all 384 rows (12 row tiles): every filter byte is fetched ONCE
+//             (2 DMA instructions per k-step and wave, half the filter traffic) at the price of one B-fragment read per
+//             MFMA instead of one per two.  Ablation on the NWN = 4 kernel (tools/ablate.sh): dropping the in-loop DMA
+//             saves 22 us of 91, dropping the B-fragment reads 2 us -- the DMA issue is what is worth halving.
+// A third split (2 slices of 128 channels x 4 row groups, the k-step's whole slab in a ring shared by all waves: 7 reads
+// per 12 MFMAs and no duplicate fetch, but a workgroup barrier every third k-step) was built and measured 1 % SLOWER
+// than NWN = 8.  tools/clock_probe.sh explains why the differences are small: the kernel runs at the POWER-LIMITED shader
+// clock (1.62 GHz at NWN = 8 with the MFMA pipe busy 76 % of the cycles; 1.94 GHz with the DMA ablated, 1.92 GHz with the
+// B-fragment reads ablated) -- saved cycles come back as a lower clock unless bytes moved per MFMA go down with them.
+// Both have 12 accumulator tiles (192 registers) per wave and read the same host packing of the filter:
+//   [256-block][k-step][slice of 64][channel tile][k16][64 lanes][8 halfs]  =  [256-block][k-step][slice of 32][k16][lane][8]
+template <int NWN>
+struct Split {
+    static constexpr int CT = 8 / NWN;                 // 32-channel MFMA tiles per wave
+    static constexpr int RT = 12 / (8 / NWN);          // 32-row MFMA tiles per wave
+    static constexpr int W = 2 * CT;                   // DMA instructions (1 KiB fragments) per filter slab
+    static constexpr int SlabBytes = W * 1024;
+    static constexpr int RingBytes = kRing * SlabBytes;
+    static constexpr int LdsBytes = kWBase + 8 * RingBytes;
+    static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step
+    static constexpr int BD = NWN == 8 ? 5 : 3;        // B-fragment registers in rotation: BD - 1 pairs of read-ahead
+    // byte offset of the B fragment of pair i = k16 * RT + row tile relative to the lane's base row
+    static constexpr int b_offset(int i) { return (i / RT) * 2 * kSlotBytes + (i % RT) * 512; }
+    // pair index behind which the j-th filter piece / the activation piece of the step is issued
+    static constexpr int w_pair(int j) { return NWN == 4 ? 1 + 2 * j : 5 + 10 * j; }
+    static constexpr int x_pair() { return NWN == 4 ? 9 : 20; }
+};
+static_assert(Split<4>::LdsBytes <= 160 * 1024 && Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
 
 // SKIP: 0 = no skip input, 1 = skip added in the epilogue (general), 2 = skip accumulated DURING the K loop (alpha1 != 0):
 // the row tiles of z are fetched one at a time while the memory system is otherwise idle and added to the fp32
 // accumulators as (alpha2 / alpha1) * z, so that the epilogue is store-only.  (With the skip read in the epilogue all
 // 256 workgroups fetch their 205 KiB of z at the same moment: 52 MB at HBM speed, 8 us of a 90 us kernel.)
-template <int SKIP, bool RELU, int SPREAD>     // SPREAD: 1 = DMA issue interleaved with the step's MFMAs, 0 = at its end
+// ABL = ablation bits for measurements only (results are garbage): 1 drops the MFMAs, 2 the in-loop DMA, 4 the in-loop
+// B-fragment reads, 8 the counted vmcnt waits of the k-steps (DMA still issued).
+template <int NWN, int SKIP, bool RELU, int ABL>
 __global__ __launch_bounds__(kThreads)
 void conv3x3_board_kernel(ConvBoardLaunch a)
 {
-    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    using S = Split<NWN>;
+    constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD;
+    __shared__ __attribute__((aligned(16))) char lds[S::LdsBytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3;                // 64-channel slice
-    const int g = wave >> 2;                // row half
+    const int wn = NWN == 4 ? (wave & 3) : wave;     // channel slice
+    const int g = NWN == 4 ? (wave >> 2) : 0;        // row group
     const int b = blockIdx.x;
     const int nb = blockIdx.y;
     const int cin = a.cin;
@@ -143,18 +174,19 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
     }
 
     const uint16_t* const x_board = a.x + (long)b * cin * kRows + lane * 8;
-    const uint16_t* const w_wave = a.w + ((long)nb * nsteps * 4 + wn) * 2048 + lane * 8;
+    // one k-step of one 256-channel block is 8192 halfs; this wave's slab starts wn * W fragments of 512 halfs into it
+    const uint16_t* const w_wave = a.w + (long)nb * nsteps * 8192 + wn * (W * 512) + lane * 8;
 
-    // k-step `st` of this wave's filter slice -> ring slot `slot`
+    // fragment f of k-step `st` of this wave's filter slice -> ring slot `slot`
     auto issue_w_piece = [&](int st, int slot, int f) {
         const uint16_t* src = w_wave + (long)st * 8192;
-        char* const dst = lds + kWBase + wave * kWRingBytes + slot * kSlabBytes;
+        char* const dst = lds + kWBase + wave * S::RingBytes + slot * S::SlabBytes;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 512),
                                          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
     };
     auto issue_w = [&](int st, int slot) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) issue_w_piece(st, slot, f);
+        for (int f = 0; f < W; ++f) issue_w_piece(st, slot, f);
     };
     // j-th (0..3) activation piece of this wave for `chunk` -> buffer `buf`.  28 pieces, 8 waves: waves 4..7 have
     // only three and repeat their third one (same bytes to the same place), so that every wave issues the same
@@ -172,40 +204,40 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
 
     // ---- fragment read addresses ----
     // B (rows): lane l reads row tile * 32 + (l & 31), k-slot k16 * 2 + (l >> 5); tap shift is an immediate.
-    const int x_lane = (lane >> 5) * kSlotBytes + (g * (kRowTiles * 32) + (lane & 31)) * 16;
-    // A (filter): fragment f = k16 * 2 + channel tile, lane-linear.
-    const int w_lane = kWBase + wave * kWRingBytes + lane * 16;
+    const int x_lane = (lane >> 5) * kSlotBytes + (g * (RT * 32) + (lane & 31)) * 16;
+    // A (filter): fragment ct * 2 + k16, lane-linear.
+    const int w_lane = kWBase + wave * S::RingBytes + lane * 16;
     const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)lds;
     const unsigned w_addr = lds_base + w_lane;
 
-    floatx16 acc[2][kRowTiles];
+    floatx16 acc[CT][RT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int rt = 0; rt < kRowTiles; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][rt][r] = 0.0f;
 
     // ---- skip input, 16-byte accesses: lanes 0..31 read the whole 16-byte row of k-slot k, lanes 32..63 that of
     // k-slot k + 1; one v_permlane32_swap per dword then gives every lane its 4 channels of both k-slots ----
     const int hi = lane >> 5;
-    const int co_base = nb * 256 + wn * 64;
+    const int co_base = nb * 256 + wn * (32 * CT);
     // element offset of (this wave's k-slot 0 (+1 for the upper half-wave), row 0); k-slot stride = 400 rows * 8
     const long ep_base = (((long)b * (cout / 8) + co_base / 8 + hi) * kRows) * 8;
-    auto row_of = [&](int rt) { return g * (kRowTiles * 32) + rt * 32 + (lane & 31); };
-    uint4 zl[2];                                      // half a row tile of z in flight: one channel tile, two k-slot pairs
+    auto row_of = [&](int rt) { return g * (RT * 32) + rt * 32 + (lane & 31); };
+    uint4 zl[2];                                      // one (row tile, channel tile) unit of z in flight: two k-slot pairs
     const uint16_t* const z_lane = a.z + ep_base + row_of(0) * 8;
-    auto load_z_half = [&](int rt, int ct) {          // rt compile-time after unrolling, ct wave-uniform
-        const uint16_t* p = z_lane + (long)ct * (4 * kRows * 8);
+    auto load_z_unit = [&](int rt, int ct) {
+        const uint16_t* p = z_lane;
         asm volatile("" : "+v"(p));                   // opaque per use: keeps the 24 addresses from being hoisted out of
                                                       // the K loop (they would be spilled), one 64-bit add per load instead
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair)          // k-slot ct * 4 + pair * 2 (+ hi), row tile rt
-            zl[pair] = *reinterpret_cast<const uint4*>(p + ((pair * 2) * kRows + rt * 32) * 8);
+            zl[pair] = *reinterpret_cast<const uint4*>(p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
     };
     const float zscale = SKIP == 2 ? a.alpha2 / a.alpha1 : 0.0f;
-    auto add_z_half = [&](auto rt_c, auto ct_c) {
-        constexpr int RT = decltype(rt_c)::value, CT = decltype(ct_c)::value;
+    auto add_z_unit = [&](auto rt_c, auto ct_c) {
+        constexpr int RTI = decltype(rt_c)::value, CTI = decltype(ct_c)::value;
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {
             const auto sx = __builtin_amdgcn_permlane32_swap(zl[pair].x, zl[pair].z, false, false);
@@ -214,8 +246,8 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
             const half4 z1 = __builtin_bit_cast(half4, make_uint2(sx[1], sy[1]));   // k-slot pair * 2 + 1
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                acc[CT][RT][pair * 8 + jj] = __builtin_fmaf(zscale, (float)z0[jj], acc[CT][RT][pair * 8 + jj]);
-                acc[CT][RT][pair * 8 + 4 + jj] = __builtin_fmaf(zscale, (float)z1[jj], acc[CT][RT][pair * 8 + 4 + jj]);
+                acc[CTI][RTI][pair * 8 + jj] = __builtin_fmaf(zscale, (float)z0[jj], acc[CTI][RTI][pair * 8 + jj]);
+                acc[CTI][RTI][pair * 8 + 4 + jj] = __builtin_fmaf(zscale, (float)z1[jj], acc[CTI][RTI][pair * 8 + 4 + jj]);
             }
         }
     };
@@ -230,8 +262,8 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
 
     const unsigned long long t_loop = a.timing ? __builtin_amdgcn_s_memtime() : 0;
 
-    // zc_c >= 0: this chunk also folds channel tile zc_c of the skip input into the accumulators (SKIP == 2; chunks 0
-    // and 1 are peeled off the loop so that those VALU updates are unconditional straight-line code -- inside a
+    // zc_c >= 0: this chunk also folds units 6 * zc_c .. 6 * zc_c + 5 of the skip input into the accumulators (SKIP == 2;
+    // chunks 0 and 1 are peeled off the loop so that those VALU updates are unconditional straight-line code -- inside a
     // branch the register allocator copies whole 16-register accumulator tuples and spills)
     auto run_chunk = [&](int chunk, auto zc_c) {
         constexpr int ZC = decltype(zc_c)::value;
@@ -244,68 +276,80 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
         auto step = [&](auto tap_c) {
             constexpr int TAP = decltype(tap_c)::value;
             constexpr int SHIFT = (TAP / 3 - 1) * 20 + (TAP % 3 - 1);
-            // DMA instructions issued after this step's slab (slab st is issued at the end of step st - 3, activation
-            // pieces at the end of taps 0..3):  8 + |{TAP-3, TAP-2, TAP-1} mod 9  intersected with  {0,1,2,3}|
-            constexpr int N = 8 + ((TAP + 6) % 9 < 4) + ((TAP + 7) % 9 < 4) + ((TAP + 8) % 9 < 4);
-            wait_vmcnt<N>();
+            // DMA instructions issued after this step's slab: slab st is issued during step st - 3, the activation piece
+            // of a step (taps 0..3 only) after its filter pieces:
+            //     2 * W + |{TAP-3, TAP-2, TAP-1} mod 9  intersected with  {0,1,2,3}|
+            constexpr int N = 2 * W + ((TAP + 6) % 9 < 4) + ((TAP + 7) % 9 < 4) + ((TAP + 8) % 9 < 4);
+            if constexpr (!(ABL & 8)) wait_vmcnt<N>();
 
             // Hand-placed LDS reads (inline asm, waits counted here: hipcc would otherwise serialise
-            // "read, s_waitcnt lgkmcnt(0), 2 MFMAs" to save registers).  Issue order A00 A01 A10 A11 B0 B1, then
-            // before the two MFMAs of pair i = k16 * 6 + row tile the B fragment of pair i + 2 is requested and the
+            // "read, s_waitcnt lgkmcnt(0), MFMAs" to save registers).  Issue order: the A fragments, B0 .. B(BD-2), then
+            // before the MFMAs of pair i = k16 * RT + row tile the B fragment of pair i + BD - 1 is requested and the
             // wait leaves exactly the reads younger than B[i] outstanding.
-            constexpr int WOFF = (TAP % kRing) * kSlabBytes;
+            constexpr int WOFF = (TAP % kRing) * S::SlabBytes;
             constexpr int XOFF = (kHalo + SHIFT) * 16;
-            half8 af[2][2];
-            half8 bf[3];
-            af[0][0] = lds_read<WOFF + 0 * 1024>(w_addr);
-            af[0][1] = lds_read<WOFF + 1 * 1024>(w_addr);
-            af[1][0] = lds_read<WOFF + 2 * 1024>(w_addr);
-            af[1][1] = lds_read<WOFF + 3 * 1024>(w_addr);
-            bf[0] = lds_read<XOFF + b_offset(0)>(x_addr);
-            bf[1] = lds_read<XOFF + b_offset(1)>(x_addr);
-            static_for<2 * kRowTiles>([&](auto ic) {
+            half8 af[CT][2];                          // [channel tile][k16]
+            half8 bf[BD];
+            static_for<CT * 2>([&](auto fc) {
+                constexpr int F = decltype(fc)::value;
+                af[F / 2][F % 2] = lds_read<WOFF + F * 1024>(w_addr);
+            });
+            static_for<BD - 1>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
-                constexpr int K16 = I / kRowTiles, RT = I % kRowTiles;
-                if constexpr (I + 2 < 2 * kRowTiles) bf[(I + 2) % 3] = lds_read<XOFF + b_offset(I + 2)>(x_addr);
-                constexpr int YOUNGER = I + 2 < 2 * kRowTiles ? 2 : 2 * kRowTiles - 1 - I;
-                if constexpr (I == 0) wait_lgkm<YOUNGER>(bf[I % 3], af[0][0], af[0][1], af[1][0], af[1][1]);
-                else wait_lgkm<YOUNGER>(bf[I % 3]);
-                acc[0][RT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[K16][0], bf[I % 3], acc[0][RT], 0, 0, 0);
-                acc[1][RT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[K16][1], bf[I % 3], acc[1][RT], 0, 0, 0);
-                if constexpr (SPREAD == 1) {
+                bf[I] = lds_read<XOFF + S::b_offset(I)>(x_addr);
+            });
+            static_for<NP>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                constexpr int K16 = I / RT, RTI = I % RT;
+                constexpr bool MORE = I + BD - 1 < NP && !(ABL & 4);
+                if constexpr (MORE) bf[(I + BD - 1) % BD] = lds_read<XOFF + S::b_offset(I + BD - 1)>(x_addr);
+                constexpr int YOUNGER = (ABL & 4) ? 0 : I + BD - 1 < NP ? BD - 1 : NP - 1 - I;
+                if constexpr (I == 0) {
+                    wait_lgkm<YOUNGER>(bf[0], af[0][0], af[0][1]);
+                    if constexpr (CT == 2) wait_lgkm<YOUNGER>(af[1][0], af[1][1], af[0][0]);
+                } else {
+                    wait_lgkm<YOUNGER>(bf[I % BD]);
+                }
+                if constexpr (ABL & 1) {
+                    asm volatile("" ::"v"(af[0][K16]), "v"(bf[I % BD]));
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct][RTI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ct][K16], bf[I % BD], acc[ct][RTI], 0, 0, 0);
+                }
+                if constexpr (!(ABL & 2)) {
                     // The A fragments of this step are in registers since the first wait (I == 0): the slab may be
-                    // refilled from now on.  One DMA instruction behind every second MFMA pair keeps the wave from
-                    // having a separate, MFMA-free "issue phase" at the end of the step.
-                    if constexpr (I == 1 || I == 3 || I == 5 || I == 7) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue_w_piece(st0 + TAP + kRing, TAP % kRing, I / 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if constexpr (I == 9 && TAP < 4) {
+                    // refilled from now on.  The step's DMA instructions are spread over its MFMAs so that the wave has
+                    // no separate, MFMA-free "issue phase".
+                    static_for<W>([&](auto jc) {
+                        constexpr int J = decltype(jc)::value;
+                        if constexpr (I == S::w_pair(J)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_w_piece(st0 + TAP + kRing, TAP % kRing, J);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                    if constexpr (I == S::x_pair() && TAP < 4) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue_x(next_chunk, buf ^ 1, TAP);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             });
-            // every MFMA of this step has been issued => its operand reads retired => the slab may be overwritten
             __builtin_amdgcn_sched_barrier(0);
-            // skip input folded into the accumulators: chunk c (0, 1) handles channel tile c; row tile t is requested
-            // at the end of tap t and added at the end of tap t + 1
+            // skip input folded into the accumulators: unit u = 6 * ZC + t (NWN = 4: row tile u % 6, channel tile u / 6;
+            // NWN = 8: row tile u) is requested at the end of tap t and added at the end of tap t + 1
             if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6) {
-                // the z rows requested at the end of the previous step are this wave's youngest memory operations
-                // but for the DMA instructions this step has already issued (SPREAD)
-                wait_vmcnt<SPREAD == 1 ? 4 + (TAP < 4) : 0>();
+                // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
+                // the DMA instructions this step has issued
+                wait_vmcnt<W + (TAP < 4)>();
                 __builtin_amdgcn_sched_barrier(0);
-                add_z_half(std::integral_constant<int, TAP - 1>(), std::integral_constant<int, ZC>());
-            }
-            if constexpr (SPREAD == 0) {
-                issue_w(st0 + TAP + kRing, TAP % kRing);
-                if constexpr (TAP < 4) issue_x(next_chunk, buf ^ 1, TAP);
+                constexpr int U = ZC * 6 + TAP - 1;
+                add_z_unit(std::integral_constant<int, U % RT>(), std::integral_constant<int, U / RT>());
             }
             // extra memory operations only make the counted waits above more conservative (they require that many
             // more of the OLDER operations to have completed), never unsafe
-            if constexpr (ZC >= 0 && TAP <= 5) load_z_half(TAP, ZC);
+            if constexpr (ZC >= 0 && TAP <= 5) load_z_unit((ZC * 6 + TAP) % RT, (ZC * 6 + TAP) / RT);
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>());
@@ -338,9 +382,9 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
     // D[i][j]: j = lane & 31 = row within the tile, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = channel within the
     // 32-channel tile.  For k = r >> 2 the lane owns 4 consecutive channels 8k + 4 * (lane >> 5) .. + 3 of k-slot k:
     // one 8-byte access; the two half-waves together cover 32 rows x 16 bytes = 512 contiguous bytes.
-    float bias[2][4][4];
+    float bias[CT][4][4];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const half4 b4 = *reinterpret_cast<const half4*>(a.bias + co_base + ct * 32 + k * 8 + hi * 4);
@@ -352,26 +396,25 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
     // row of a k-slot.  For a pair of k-slots (k, k + 1) one v_permlane32_swap per dword turns that into
     // "lanes 0..31 own the whole row of k-slot k, lanes 32..63 the whole row of k-slot k + 1": half as many memory
     // instructions, each covering two contiguous 512-byte runs.
-    // element offset of (this wave's k-slot 0 (+1 for the upper half-wave), row 0); k-slot stride = 400 rows * 8
     const uint16_t* const zb = a.z + ep_base;
     uint16_t* const yb = a.y + ep_base;
 
-    uint4 zq[2][4];                                   // skip rows of two tiles in flight: [tile parity][ct * 2 + pair]
+    uint4 zq[2][CT * 2];                              // skip rows of two tiles in flight: [tile parity][ct * 2 + pair]
     auto load_z = [&](int rt) {
         if constexpr (SKIP == 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)               // q = ct * 2 + pair -> k-slot ct * 4 + pair * 2 (+ hi)
+            for (int q = 0; q < CT * 2; ++q)          // q = ct * 2 + pair -> k-slot ct * 4 + pair * 2 (+ hi)
                 zq[rt & 1][q] = *reinterpret_cast<const uint4*>(zb + (((q >> 1) * 4 + (q & 1) * 2) * kRows + row_of(rt)) * 8);
         }
     };
     load_z(0);
     load_z(1);
 #pragma unroll
-    for (int rt = 0; rt < kRowTiles; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         const int row = row_of(rt);
         const unsigned live = ((row % 20 != 19) && row < 380) ? 0xffffffffu : 0u;   // pad column / pad row -> zero
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < CT * 2; ++q) {
             const int ct = q >> 1, k0 = (q & 1) * 2;
             // skip values for k-slots k0 (za) and k0 + 1 (zb2), 4 channels each, after the half exchange
             uint2 za = make_uint2(0, 0), zb2 = make_uint2(0, 0);
@@ -403,7 +446,7 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
             const auto sy = __builtin_amdgcn_permlane32_swap(out[0].y, out[1].y, false, false);
             *reinterpret_cast<uint4*>(yb + ((ct * 4 + k0) * kRows + row) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
-        if (rt + 2 < kRowTiles) load_z(rt + 2);
+        if (rt + 2 < RT) load_z(rt + 2);
     }
     if (a.timing) {
         wait_vmcnt<0>();
@@ -455,29 +498,45 @@ bool conv_board_supported(int cin, int cout)
     return cin >= 32 && cin % 32 == 0 && cout >= 256 && cout % 256 == 0;
 }
 
+template <int NWN>
+static void launch_board_variant(const ConvBoardLaunch& args, dim3 grid, int skip, bool relu, int ablate, hipStream_t stream)
+{
+#define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NWN, S, R, A>), grid, dim3(kThreads), 0, stream, args)
+    if (ablate != 0 && relu && skip != 1) {      // measurement only (tools/ablate.sh), residual shapes
+        if (skip == 2) {
+            switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 2: DGNN_BOARD(2, true, 2); break;
+                              case 3: DGNN_BOARD(2, true, 3); break; case 4: DGNN_BOARD(2, true, 4); break;
+                              default: DGNN_BOARD(2, true, 8); break; }
+        } else {
+            switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 2: DGNN_BOARD(0, true, 2); break;
+                              case 3: DGNN_BOARD(0, true, 3); break; case 4: DGNN_BOARD(0, true, 4); break;
+                              default: DGNN_BOARD(0, true, 8); break; }
+        }
+        return;
+    }
+    if (skip == 2 && relu) DGNN_BOARD(2, true, 0);
+    else if (skip == 2) DGNN_BOARD(2, false, 0);
+    else if (skip == 1 && relu) DGNN_BOARD(1, true, 0);
+    else if (skip == 1) DGNN_BOARD(1, false, 0);
+    else if (relu) DGNN_BOARD(0, true, 0);
+    else DGNN_BOARD(0, false, 0);
+#undef DGNN_BOARD
+}
+
 hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)
 {
     if (args.batch <= 0) return hipSuccess;
     dim3 grid(args.batch, args.cout / 256);
     const bool relu = args.relu != 0;
-    // skip folded into the K loop needs two chunks to spread its six row tiles over and a usable alpha2 / alpha1
+    // skip folded into the K loop needs two chunks to spread its twelve units over and a usable alpha2 / alpha1
     const char* const mode = std::getenv("DGNN_BOARD_SKIP");        // =1: keep the skip in the epilogue (A/B, tests)
     const bool epilogue_skip = mode && std::atoi(mode) == 1;
     const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !epilogue_skip) ? 2 : 1;
-    const char* const dma = std::getenv("DGNN_BOARD_DMA");                // =end: DMA issue at the end of each k-step (A/B)
-    const bool spread = !(dma && std::strcmp(dma, "end") == 0);
-#define DGNN_LAUNCH_BOARD(S, R)                                                                                       \
-    do {                                                                                                              \
-        if (spread) hipLaunchKernelGGL((conv3x3_board_kernel<S, R, 1>), grid, dim3(kThreads), 0, stream, args);      \
-        else hipLaunchKernelGGL((conv3x3_board_kernel<S, R, 0>), grid, dim3(kThreads), 0, stream, args);             \
-    } while (0)
-    if (skip == 2 && relu) DGNN_LAUNCH_BOARD(2, true);
-    else if (skip == 2) DGNN_LAUNCH_BOARD(2, false);
-    else if (skip == 1 && relu) DGNN_LAUNCH_BOARD(1, true);
-    else if (skip == 1) DGNN_LAUNCH_BOARD(1, false);
-    else if (relu) DGNN_LAUNCH_BOARD(0, true);
-    else DGNN_LAUNCH_BOARD(0, false);
-#undef DGNN_LAUNCH_BOARD
+    const char* const abl = std::getenv("DGNN_CONV_ABLATE");
+    const int ablate = abl ? std::atoi(abl) : 0;
+    const char* const split = std::getenv("DGNN_BOARD_SPLIT");      // =4: two waves per 64-channel slice (A/B, tests)
+    if (split && std::atoi(split) == 4) launch_board_variant<4>(args, grid, skip, relu, ablate >= 1 && ablate <= 8 ? ablate : 0, stream);
+    else launch_board_variant<8>(args, grid, skip, relu, ablate >= 1 && ablate <= 8 ? ablate : 0, stream);
     return hipGetLastError();
 }
 

@@ -414,11 +414,11 @@ static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint
         a.x = d_xb; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_zb : nullptr; a.y = d_yb;
         a.batch = batch; a.cin = cin; a.cout = cout; a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
         a.timing = nullptr;
-        // instrumentation: DGNN_CONV_ABLATE=8 prints where the workgroups spend their cycles (s_memtime stamps)
-        const char* ab = std::getenv("DGNN_CONV_ABLATE");
+        // instrumentation: DGNN_CONV_TIMING=1 prints where the workgroups spend their cycles (s_memtime stamps)
+        const char* ab = std::getenv("DGNN_CONV_TIMING");
         const size_t num_wg = (size_t)batch * (cout / 256);
         unsigned long long* d_timing = nullptr;
-        if (ab && std::atoi(ab) == 8 && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess)
+        if (ab && std::atoi(ab) == 1 && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess)
             a.timing = d_timing;
         const int reps = a.timing ? 3 : 1;   // the last repetition is reported (caches warm)
         for (int r = 0; r < reps && err == hipSuccess; ++r) err = launch_conv3x3_board(a, nullptr);

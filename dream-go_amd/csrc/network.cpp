@@ -121,7 +121,7 @@ void pack_filter_board(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
                 for (int wn = 0; wn < 4; ++wn)
                     for (int f = 0; f < 4; ++f)
                         for (int lane = 0; lane < 64; ++lane) {
-                            const int k16 = f >> 1, tile = f & 1;
+                            const int tile = f >> 1, k16 = f & 1;   // fragment order [channel tile][k16]
                             const int co = nb * 256 + wn * 64 + tile * 32 + (lane & 31);
                             const int ci = chunk * 32 + k16 * 16 + (lane >> 5) * 8;
                             uint16_t* out = dst + (((((size_t)nb * nsteps + chunk * 9 + tap) * 4 + wn) * 4 + f) * 64 + lane) * 8;

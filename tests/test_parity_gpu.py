@@ -174,8 +174,10 @@ def test_board_kernel_asymmetric_taps(api, oracle, monkeypatch):
     (2, 64, 512, 0.25, True),      # two 256-channel blocks (grid.y = 2), two chunks
 ])
 @pytest.mark.parametrize("skip_mode", ["0", "1"])     # skip folded into the K loop (default) / added in the epilogue
-def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode):
+@pytest.mark.parametrize("split", ["8", "4"])         # one wave per 32-channel slice (default) / two per 64-channel slice
+def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode, split):
     monkeypatch.setenv("DGNN_BOARD_SKIP", skip_mode)
+    monkeypatch.setenv("DGNN_BOARD_SPLIT", split)
     rng = np.random.default_rng([7, batch, cin, cout])
     x = np.maximum(rng.normal(0, 1, (batch, 19, 19, cin)), 0).astype(np.float16)
     w = rng.normal(0, np.sqrt(2.0 / (9 * cin)), (cout, 3, 3, cin)).astype(np.float16)
@@ -191,7 +193,8 @@ def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout,
     assert mismatched <= 0.02 * got.size
 
 
-def test_board_kernel_exact_under_full_load(api, monkeypatch):
+@pytest.mark.parametrize("split", ["8", "4"])
+def test_board_kernel_exact_under_full_load(api, monkeypatch, split):
     """configs[2] layer shape at full size (256 boards = 256 workgroups, every CU busy): integer-valued data make the
     generic kernel a bit-exact reference; three runs must be identical (a DMA / ring race shows up as run-to-run
     differences under load)."""
@@ -204,6 +207,7 @@ def test_board_kernel_exact_under_full_load(api, monkeypatch):
     monkeypatch.setenv("DGNN_CONV", "v1")
     want = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=0.5, alpha2=0.5, z=z, relu=False)
     monkeypatch.setenv("DGNN_CONV", "board")
+    monkeypatch.setenv("DGNN_BOARD_SPLIT", split)
     for run in range(3):
         got = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=0.5, alpha2=0.5, z=z, relu=False)
         assert np.array_equal(got, want), (run, int(np.count_nonzero(got != want)))

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Component pricing of the staggered tile kernel (results of ablated runs are garbage; only the timing matters).
-#   1 = no MFMA, 2 = no in-loop DMA, 3 = neither (fragment reads + barriers only)
+# Component pricing of the residual convolution (results of ablated runs are garbage; only the timing matters).
+#   1 = no MFMA, 2 = no in-loop DMA, 4 = no in-loop B-fragment reads, 3 = neither MFMA nor DMA, 8 = DMA issued but never waited for
 out=${1:-gpurun_out/ablate.jsonl}
 : > "$out"
-for ab in 0 1 2 3; do
+for ab in 0 1 2 4 3 8; do
   echo "# ablate=$ab" >> "$out"
-  DGNN_CONV=${VARIANT:-tile3} DGNN_CONV_FM=6 DGNN_CONV_ABLATE=$ab python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | tail -1 >> "$out"
+  DGNN_CONV=${VARIANT:-board} DGNN_CONV_ABLATE=$ab python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | tail -1 >> "$out"
 done
 python - "$out" <<'PY'
 import json, sys

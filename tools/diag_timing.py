@@ -1,6 +1,6 @@
-"""Prints where the workgroups of the residual convolution spend their cycles (DGNN_CONV_ABLATE=8 instrumentation).
+"""Prints where the workgroups of the residual convolution spend their cycles (DGNN_CONV_TIMING=1 instrumentation; board kernel).
 
-    DGNN_CONV=board|tile2|tile3 python tools/diag_timing.py [batch]
+    [DGNN_CONV_ABLATE=1|2|3|4|8] [DGNN_BOARD_SPLIT=4] python tools/diag_timing.py [batch]
 """
 import os
 import sys
@@ -9,7 +9,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["DGNN_CONV_ABLATE"] = "8"
+os.environ["DGNN_CONV_TIMING"] = "1"
+os.environ.setdefault("DGNN_CONV", "board")
 os.environ.setdefault("DGNN_CONV_FM", "6")
 import __graft_entry__ as graft  # noqa: E402
 
