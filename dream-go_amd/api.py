@@ -104,6 +104,11 @@ SYMBOLS = [
     ("dgnn_batch_features", _u16p, [_vp]),
     ("dgnn_batch_forward", ctypes.c_int, [_vp, _u16p, _u16p]),
     ("dgnn_batch_destroy", None, [_vp]),
+    ("dgnn_b85_encode_f16", ctypes.c_size_t, [_fp, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
+    ("dgnn_b85_decode", ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
+                                       ctypes.POINTER(ctypes.c_size_t)]),
+    ("dgnn_sgf_played", ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                          ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_char_p]),
     ("dgnn_pool_create", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
     ("dgnn_pool_destroy", None, [_vp]),
     ("dgnn_pool_predict", ctypes.c_int, [_vp, _u16p, ctypes.c_int, _u16p, _u16p]),
@@ -587,3 +592,42 @@ class LeafPool:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Formats either side of the path (scope row f-4)
+# ------------------------------------------------------------------------------------------------------------------
+
+def b85_encode(values):
+    """dg_utils::b85::encode (src/libdg_utils/b85.rs:141-165): fp32 values -> fp16 -> RFC 1924 base85 text."""
+    v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+    need = lib.dgnn_b85_encode_f16(v.ctypes.data_as(_fp), v.size, None, 0)
+    if need == 0:
+        raise Error(BAD_ARGUMENT, "b85_encode")
+    buf = ctypes.create_string_buffer(need)
+    lib.dgnn_b85_encode_f16(v.ctypes.data_as(_fp), v.size, buf, need)
+    return buf.value.decode("ascii")
+
+
+def b85_decode(text, dtype=np.float16):
+    """dg_utils::b85::decode (b85.rs:101-132) -> array of `dtype` (float16 or float32), or None for an invalid character."""
+    raw = text.encode("ascii") if isinstance(text, str) else bytes(text)
+    n = ctypes.c_size_t()
+    if lib.dgnn_b85_decode(raw, len(raw), None, 0, ctypes.byref(n)) != OK:
+        return None
+    out = np.empty(n.value, dtype=np.uint8)
+    _check(lib.dgnn_b85_decode(raw, len(raw), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), out.size, ctypes.byref(n)), "b85_decode")
+    return out.view(dtype)
+
+
+def sgf_played(color, packed_index, value=None, num_rollout=1, softmax=None, prior_index=-1, explain=""):
+    """Display of dg_mcts::self_play::Played (src/libdg_mcts/self_play.rs:187-213)."""
+    sm = None
+    if softmax is not None:
+        sm = np.ascontiguousarray(softmax, dtype=np.float32).reshape(NUM_MOVES)
+    args = (int(color), int(packed_index), int(num_rollout), sm.ctypes.data_as(_fp) if sm is not None else None,
+            int(value is not None), float(value if value is not None else 0.0), int(prior_index), explain.encode("utf-8"))
+    need = lib.dgnn_sgf_played(None, 0, *args)
+    buf = ctypes.create_string_buffer(need)
+    lib.dgnn_sgf_played(buf, need, *args)
+    return buf.value.decode("utf-8")

@@ -262,6 +262,24 @@ int dgnn_pool_create(dgnn_batcher* batcher, int num_workers, dgnn_pool** out);
 void dgnn_pool_destroy(dgnn_pool* pool);   /* every dgnn_pool_predict call must have returned */
 int dgnn_pool_predict(dgnn_pool* pool, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out);
 
+/* ============================================================================================================
+ * Formats either side of the path (scope row f-4), formats.cpp.
+ * ============================================================================================================ */
+
+/* b85::encode (src/libdg_utils/b85.rs:141-165): `count` (even) fp32 values -> fp16 -> 5 characters per pair, NUL
+ * terminated.  Returns the number of bytes needed including the NUL (also when out is NULL or too small: size query);
+ * 0 for invalid arguments. */
+size_t dgnn_b85_encode_f16(const float* values, size_t count, char* out, size_t capacity);
+/* b85::decode (b85.rs:101-132): raw little-endian bytes, 4 per 5 characters (a trailing partial group is dropped).
+ * out may be NULL to query *num_bytes.  DGNN_MALFORMED_WEIGHTS for a character outside the alphabet. */
+int dgnn_b85_decode(const char* text, size_t len, uint8_t* out, size_t capacity, size_t* num_bytes);
+/* Played::fmt (src/libdg_mcts/self_play.rs:187-213): one move of a self-play record,
+ * ";B[dd]" [C[explain]] [TR[prior]] [TV[rollouts]P[b85 of the 362 search probabilities]] [V[win rate, black's side]].
+ * color 0 = black, 1 = white; packed_index 361 (or any value outside 0..360) = pass; prior_index < 0 = none;
+ * value = win rate of the side to move in [0, 1].  Returns the bytes needed including the NUL; writes when it fits. */
+size_t dgnn_sgf_played(char* out, size_t capacity, int color, int packed_index, int num_rollout, const float* softmax,
+                       int has_value, float value, int prior_index, const char* explain);
+
 /* Library version / build info string (static). */
 const char* dgnn_version(void);
 
