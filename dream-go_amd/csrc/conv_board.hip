@@ -104,37 +104,38 @@ __device__ __forceinline__ void static_for(F&& f)
     static_for_impl(f, std::make_integer_sequence<int, N>());
 }
 
-// Work split of the 8 waves, template parameter NWN = waves along the 256 output channels:
-//   NWN = 4   4 channel slices of 64 (2 MFMA channel tiles) x 2 row halves of 192 (6 row tiles): every filter slab is
-//             fetched by the two waves that share a slice (2 x 4 DMA instructions per k-step and slice)
-//   NWN = 8   8 channel slices of 32 (1 channel tile) x all 384 rows (12 row tiles): every filter byte is fetched ONCE
-//             (2 DMA instructions per k-step and wave, half the filter traffic) at the price of one B-fragment read per
-//             MFMA instead of one per two.  Ablation on the NWN = 4 kernel (tools/ablate.sh): dropping the in-loop DMA
-//             saves 22 us of 91, dropping the B-fragment reads 2 us -- the DMA issue is what is worth halving.
-// A third split (2 slices of 128 channels x 4 row groups, the k-step's whole slab in a ring shared by all waves: 7 reads
-// per 12 MFMAs and no duplicate fetch, but a workgroup barrier every third k-step) was built and measured 1 % SLOWER
-// than NWN = 8.  tools/clock_probe.sh explains why the differences are small: the kernel runs at the POWER-LIMITED shader
-// clock (1.62 GHz at NWN = 8 with the MFMA pipe busy 76 % of the cycles; 1.94 GHz with the DMA ablated, 1.92 GHz with the
-// B-fragment reads ablated) -- saved cycles come back as a lower clock unless bytes moved per MFMA go down with them.
-// Both have 12 accumulator tiles (192 registers) per wave and read the same host packing of the filter:
-//   [256-block][k-step][slice of 64][channel tile][k16][64 lanes][8 halfs]  =  [256-block][k-step][slice of 32][k16][lane][8]
-template <int NWN>
+// Work split of the 8 waves, template parameter NS = 32-channel slices per workgroup (a workgroup covers 32 * NS output
+// channels of one board; grid.y = C_out / (32 * NS)):
+//   NS = 8   8 slices x 1 row group of 384 rows (12 row tiles per wave)      C_out % 256 == 0, one workgroup per board
+//   NS = 4   4 slices x 2 row groups of 192 rows (6 row tiles per wave)      C_out % 128 == 0
+//   NS = 2   2 slices x 4 row groups of 96 rows  (3 row tiles per wave)      C_out % 64 == 0
+// A wave owns ONE 32-channel MFMA tile column, so every filter byte is fetched by 8 / NS waves (once at NS = 8).  Smaller NS
+// = more, smaller workgroups per board: used for narrow networks and to fill the chip at small batch sizes.
+// History: a layout with two channel tiles per wave and two waves per 64-channel slice fetched every
+// filter slab twice and was 2 % slower; one with the k-step's whole slab in a ring shared by all waves (barrier every
+// third k-step) was 1 % slower still.  tools/clock_probe.sh shows why such differences are small: the kernel runs at the
+// POWER-LIMITED shader clock (1.62 GHz with the MFMA pipe busy 76 % of the cycles; 1.94 GHz with the DMA ablated, 1.92 GHz
+// with the B-fragment reads ablated) -- saved cycles come back as a lower clock unless bytes moved per MFMA go down too.
+// Filter packing (host, pack_filter_board): [k-step][C_out / 32 slices][k16][64 lanes][8 halfs], k-step = chunk * 9 + tap,
+// lane l holds w[co = slice * 32 + (l & 31)][tap][ci = chunk * 32 + k16 * 16 + (l >> 5) * 8 .. + 8].
+template <int NS>
 struct Split {
-    static constexpr int CT = 8 / NWN;                 // 32-channel MFMA tiles per wave
-    static constexpr int RT = 12 / (8 / NWN);          // 32-row MFMA tiles per wave
-    static constexpr int W = 2 * CT;                   // DMA instructions (1 KiB fragments) per filter slab
+    static constexpr int CT = 1;                       // 32-channel MFMA tiles per wave
+    static constexpr int RG = 8 / NS;                  // row groups
+    static constexpr int RT = 12 / RG;                 // 32-row MFMA tiles per wave
+    static constexpr int W = 2;                        // DMA instructions (1 KiB fragments) per filter slab: k16 = 0, 1
     static constexpr int SlabBytes = W * 1024;
     static constexpr int RingBytes = kRing * SlabBytes;
     static constexpr int LdsBytes = kWBase + 8 * RingBytes;
     static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step
-    static constexpr int BD = NWN == 8 ? 5 : 3;        // B-fragment registers in rotation: BD - 1 pairs of read-ahead
+    static constexpr int BD = NS == 8 ? 5 : NS == 4 ? 4 : 3;   // B-fragment registers in rotation: BD - 1 pairs of read-ahead
     // byte offset of the B fragment of pair i = k16 * RT + row tile relative to the lane's base row
     static constexpr int b_offset(int i) { return (i / RT) * 2 * kSlotBytes + (i % RT) * 512; }
     // pair index behind which the j-th filter piece / the activation piece of the step is issued
-    static constexpr int w_pair(int j) { return NWN == 4 ? 1 + 2 * j : 5 + 10 * j; }
-    static constexpr int x_pair() { return NWN == 4 ? 9 : 20; }
+    static constexpr int w_pair(int j) { return NS == 8 ? 5 + 10 * j : NS == 4 ? 2 + 5 * j : 1 + 2 * j; }
+    static constexpr int x_pair() { return NS == 8 ? 20 : NS == 4 ? 10 : 5; }
 };
-static_assert(Split<4>::LdsBytes <= 160 * 1024 && Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
+static_assert(Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
 
 // SKIP: 0 = no skip input, 1 = skip added in the epilogue (general), 2 = skip accumulated DURING the K loop (alpha1 != 0):
 // the row tiles of z are fetched one at a time while the memory system is otherwise idle and added to the fp32
@@ -142,25 +143,24 @@ static_assert(Split<4>::LdsBytes <= 160 * 1024 && Split<8>::LdsBytes <= 160 * 10
 // 256 workgroups fetch their 205 KiB of z at the same moment: 52 MB at HBM speed, 8 us of a 90 us kernel.)
 // ABL = ablation bits for measurements only (results are garbage): 1 drops the MFMAs, 2 the in-loop DMA, 4 the in-loop
 // B-fragment reads, 8 the counted vmcnt waits of the k-steps (DMA still issued).
-template <int NWN, int SKIP, bool RELU, int ABL>
+template <int NS, int SKIP, bool RELU, int ABL>
 __global__ __launch_bounds__(kThreads)
 void conv3x3_board_kernel(ConvBoardLaunch a)
 {
-    using S = Split<NWN>;
+    using S = Split<NS>;
     constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD;
     __shared__ __attribute__((aligned(16))) char lds[S::LdsBytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = NWN == 4 ? (wave & 3) : wave;     // channel slice
-    const int g = NWN == 4 ? (wave >> 2) : 0;        // row group
+    const int wn = wave % NS;                        // channel slice
+    const int g = wave / NS;                         // row group
     const int b = blockIdx.x;
     const int nb = blockIdx.y;
     const int cin = a.cin;
     const int cout = a.cout;
     const int nchunks = cin / 32;
-    const int nsteps = nchunks * 9;
 
     const unsigned long long t_start = a.timing ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -175,11 +175,12 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
 
     const uint16_t* const x_board = a.x + (long)b * cin * kRows + lane * 8;
     // one k-step of one 256-channel block is 8192 halfs; this wave's slab starts wn * W fragments of 512 halfs into it
-    const uint16_t* const w_wave = a.w + (long)nb * nsteps * 8192 + wn * (W * 512) + lane * 8;
+    const int step_halfs = (cout / 32) * 1024;       // one k-step of the packed filter
+    const uint16_t* const w_wave = a.w + (long)(nb * NS + wn) * 1024 + lane * 8;
 
     // fragment f of k-step `st` of this wave's filter slice -> ring slot `slot`
     auto issue_w_piece = [&](int st, int slot, int f) {
-        const uint16_t* src = w_wave + (long)st * 8192;
+        const uint16_t* src = w_wave + (long)st * step_halfs;
         char* const dst = lds + kWBase + wave * S::RingBytes + slot * S::SlabBytes;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 512),
                                          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
@@ -221,7 +222,7 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
     // ---- skip input, 16-byte accesses: lanes 0..31 read the whole 16-byte row of k-slot k, lanes 32..63 that of
     // k-slot k + 1; one v_permlane32_swap per dword then gives every lane its 4 channels of both k-slots ----
     const int hi = lane >> 5;
-    const int co_base = nb * 256 + wn * (32 * CT);
+    const int co_base = (nb * NS + wn) * 32;
     // element offset of (this wave's k-slot 0 (+1 for the upper half-wave), row 0); k-slot stride = 400 rows * 8
     const long ep_base = (((long)b * (cout / 8) + co_base / 8 + hi) * kRows) * 8;
     auto row_of = [&](int rt) { return g * (RT * 32) + rt * 32 + (lane & 31); };
@@ -306,7 +307,6 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
                 constexpr int YOUNGER = (ABL & 4) ? 0 : I + BD - 1 < NP ? BD - 1 : NP - 1 - I;
                 if constexpr (I == 0) {
                     wait_lgkm<YOUNGER>(bf[0], af[0][0], af[0][1]);
-                    if constexpr (CT == 2) wait_lgkm<YOUNGER>(af[1][0], af[1][1], af[0][0]);
                 } else {
                     wait_lgkm<YOUNGER>(bf[I % BD]);
                 }
@@ -337,19 +337,18 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
-            // skip input folded into the accumulators: unit u = 6 * ZC + t (NWN = 4: row tile u % 6, channel tile u / 6;
-            // NWN = 8: row tile u) is requested at the end of tap t and added at the end of tap t + 1
-            if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6) {
+            // skip input folded into the accumulators: row tile 6 * ZC + t is requested at the end of tap t of chunk ZC and
+            // added at the end of tap t + 1
+            if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6 && ZC * 6 + TAP - 1 < RT) {
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
                 wait_vmcnt<W + (TAP < 4)>();
                 __builtin_amdgcn_sched_barrier(0);
-                constexpr int U = ZC * 6 + TAP - 1;
-                add_z_unit(std::integral_constant<int, U % RT>(), std::integral_constant<int, U / RT>());
+                add_z_unit(std::integral_constant<int, ZC * 6 + TAP - 1>(), std::integral_constant<int, 0>());
             }
             // extra memory operations only make the counted waits above more conservative (they require that many
             // more of the OLDER operations to have completed), never unsafe
-            if constexpr (ZC >= 0 && TAP <= 5) load_z_unit((ZC * 6 + TAP) % RT, (ZC * 6 + TAP) / RT);
+            if constexpr (ZC >= 0 && TAP <= 5 && ZC * 6 + TAP < RT) load_z_unit(ZC * 6 + TAP, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>());
@@ -495,24 +494,27 @@ void board_to_nhwc_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict_
 
 bool conv_board_supported(int cin, int cout)
 {
-    return cin >= 32 && cin % 32 == 0 && cout >= 256 && cout % 256 == 0;
+    return cin >= 32 && cin % 32 == 0 && cout >= 64 && cout % 64 == 0;
 }
 
-template <int NWN>
-static void launch_board_variant(const ConvBoardLaunch& args, dim3 grid, int skip, bool relu, int ablate, hipStream_t stream)
+template <int NS>
+static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool relu, int ablate, hipStream_t stream)
 {
-#define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NWN, S, R, A>), grid, dim3(kThreads), 0, stream, args)
-    if (ablate != 0 && relu && skip != 1) {      // measurement only (tools/ablate.sh), residual shapes
-        if (skip == 2) {
-            switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 2: DGNN_BOARD(2, true, 2); break;
-                              case 3: DGNN_BOARD(2, true, 3); break; case 4: DGNN_BOARD(2, true, 4); break;
-                              default: DGNN_BOARD(2, true, 8); break; }
-        } else {
-            switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 2: DGNN_BOARD(0, true, 2); break;
-                              case 3: DGNN_BOARD(0, true, 3); break; case 4: DGNN_BOARD(0, true, 4); break;
-                              default: DGNN_BOARD(0, true, 8); break; }
+    const dim3 grid(args.batch, args.cout / (32 * NS));
+#define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(kThreads), 0, stream, args)
+    if constexpr (NS == 8) {
+        if (ablate != 0 && relu && skip != 1) {      // measurement only (tools/ablate.sh), residual shapes
+            if (skip == 2) {
+                switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 2: DGNN_BOARD(2, true, 2); break;
+                                  case 3: DGNN_BOARD(2, true, 3); break; case 4: DGNN_BOARD(2, true, 4); break;
+                                  default: DGNN_BOARD(2, true, 8); break; }
+            } else {
+                switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 2: DGNN_BOARD(0, true, 2); break;
+                                  case 3: DGNN_BOARD(0, true, 3); break; case 4: DGNN_BOARD(0, true, 4); break;
+                                  default: DGNN_BOARD(0, true, 8); break; }
+            }
+            return;
         }
-        return;
     }
     if (skip == 2 && relu) DGNN_BOARD(2, true, 0);
     else if (skip == 2) DGNN_BOARD(2, false, 0);
@@ -523,20 +525,37 @@ static void launch_board_variant(const ConvBoardLaunch& args, dim3 grid, int ski
 #undef DGNN_BOARD
 }
 
+// Slices per workgroup: the largest that divides C_out / 32, unless a smaller one is needed to put a workgroup on most
+// of the 256 CUs (a launch has batch * C_out / (32 * NS) workgroups).  DGNN_BOARD_NS=2|4|8 overrides.
+int conv_board_pick_ns(int batch, int cout)
+{
+    const int slices = cout / 32;
+    int best = slices % 8 == 0 ? 8 : slices % 4 == 0 ? 4 : 2;
+    while (best > 2 && (long)batch * (slices / best) < 192) best /= 2;
+    const char* const force = std::getenv("DGNN_BOARD_NS");
+    if (force) {
+        const int ns = std::atoi(force);
+        if ((ns == 2 || ns == 4 || ns == 8) && slices % ns == 0) best = ns;
+    }
+    return best;
+}
+
 hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)
 {
     if (args.batch <= 0) return hipSuccess;
-    dim3 grid(args.batch, args.cout / 256);
+    if (!conv_board_supported(args.cin, args.cout)) return hipErrorInvalidValue;
     const bool relu = args.relu != 0;
-    // skip folded into the K loop needs two chunks to spread its twelve units over and a usable alpha2 / alpha1
+    // skip folded into the K loop needs two chunks to spread its row tiles over and a usable alpha2 / alpha1
     const char* const mode = std::getenv("DGNN_BOARD_SKIP");        // =1: keep the skip in the epilogue (A/B, tests)
     const bool epilogue_skip = mode && std::atoi(mode) == 1;
     const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !epilogue_skip) ? 2 : 1;
     const char* const abl = std::getenv("DGNN_CONV_ABLATE");
     const int ablate = abl ? std::atoi(abl) : 0;
-    const char* const split = std::getenv("DGNN_BOARD_SPLIT");      // =4: two waves per 64-channel slice (A/B, tests)
-    if (split && std::atoi(split) == 4) launch_board_variant<4>(args, grid, skip, relu, ablate >= 1 && ablate <= 8 ? ablate : 0, stream);
-    else launch_board_variant<8>(args, grid, skip, relu, ablate >= 1 && ablate <= 8 ? ablate : 0, stream);
+    switch (conv_board_pick_ns(args.batch, args.cout)) {
+        case 8: launch_board_variant<8>(args, skip, relu, ablate >= 1 && ablate <= 8 ? ablate : 0, stream); break;
+        case 4: launch_board_variant<4>(args, skip, relu, 0, stream); break;
+        default: launch_board_variant<2>(args, skip, relu, 0, stream); break;
+    }
     return hipGetLastError();
 }
 

@@ -128,19 +128,18 @@ int get_device_state(Network* net, int device, DeviceState** out)
 // Kernel selection: the staggered tile kernel by default; DGNN_CONV=tile1 selects the lock-step tile kernel,
 // DGNN_CONV=v1 forces the generic kernel, DGNN_CONV_FM=4|6|8
 // overrides the position-tile height (both exist for A/B measurements and as a safety valve).
-// DGNN_CONV=board forces the board kernel, DGNN_CONV=tile1|tile2|tile3|v1 rule it out; by default it is used when the
-// batch fills at least half of the chip's 256 CUs (one board per workgroup).
+// DGNN_CONV=board forces the board kernel, DGNN_CONV=tile1|tile2|tile3|v1 rule it out; by default it is used whenever the
+// channel count allows (a multiple of 64).
 bool board_impl_from_env(int batch, int channels)
 {
     if (!conv_board_supported(channels, channels)) return false;
     const char* impl = std::getenv("DGNN_CONV");
     if (impl && *impl) return std::strcmp(impl, "board") == 0;
-    // One board per workgroup: ceil(batch / 256) rounds of ~92 us on 256 CUs (measured, C = 256), against the NHWC tile
-    // kernel's ceil(tiles / 256) rounds of ~54 us with 192-position tiles.  Scale-free comparison of the two counts.
-    const long rounds_board = (batch + 255) / 256;
-    const long tiles = ((long)batch * DGNN_NUM_POINTS + 191) / 192;
-    const long rounds_tile = (tiles + 255) / 256;
-    return rounds_board * 92 <= rounds_tile * 54;
+    // Measured on MI355X (C = 256): the board kernel with 2 / 4 / 8 slices per workgroup beats the NHWC tile kernel at
+    // every batch size (B = 8: 21 vs 37 us per residual convolution, B = 64: 28 vs 40, B = 128: 47 vs 56, B = 256: 84 vs 107)
+    // and is the only tuned kernel for C that is not a multiple of 256.
+    (void)batch;
+    return true;
 }
 
 void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm, int* variant)

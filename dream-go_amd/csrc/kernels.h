@@ -54,8 +54,8 @@ constexpr int kBoardRows = 400;   // padded slot-major layout: 20 rows x 20 colu
 
 struct ConvBoardLaunch {
     const uint16_t* x;     // input  [batch][cin / 8][400][8] fp16 (padded slot-major, pads zero)
-    const uint16_t* w;     // filter [cout / 256][9 * cin / 32][4 waves][4 fragments][64 lanes][8] fp16 (pack_filter_board)
-                           //        + 3 slabs (48 KiB) of readable padding behind the last one
+    const uint16_t* w;     // filter [9 * cin / 32 k-steps][cout / 32 slices][2 k16][64 lanes][8] fp16 (pack_filter_board)
+                           //        + 3 k-steps of readable padding behind the last one
     const uint16_t* bias;  // [cout] fp16
     const uint16_t* z;     // skip, same layout as y, read only when alpha2 != 0
     uint16_t* y;           // output [batch][cout / 8][400][8] fp16; pad rows < 384 are written as zero, rows 384..399
@@ -63,7 +63,7 @@ struct ConvBoardLaunch {
     unsigned long long* timing;   // instrumentation: [workgroup][wave][4] s_memtime stamps (start, loop, epilogue, end) or nullptr
     int batch;
     int cin;               // multiple of 32
-    int cout;              // multiple of 256
+    int cout;              // multiple of 64
     float alpha1;
     float alpha2;
     int relu;
@@ -71,6 +71,7 @@ struct ConvBoardLaunch {
 
 // Residual-tower convolution on the padded slot-major layout, one board per workgroup (conv_board.hip).
 bool conv_board_supported(int cin, int cout);
+int conv_board_pick_ns(int batch, int cout);   // 32-channel slices per workgroup the launcher will use
 hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream);
 // Layout changes at the two ends of the tower: [B][361][C] NHWC <-> [B][C / 8][400][8].  C a multiple of 8.
 hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);

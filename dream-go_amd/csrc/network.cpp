@@ -60,7 +60,7 @@ int pack_conv(const TensorMap& tensors, const std::string& name, int cout, int c
         pack_filter_tile(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_tile_offset));
     }
 
-    if (cout % 256 == 0 && cin % 32 == 0) {
+    if (cout % 64 == 0 && cin % 32 == 0) {
         out.w_board_offset = reserve(image, board_filter_elements(cout, cin) * sizeof(uint16_t));
         pack_filter_board(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_board_offset));
     }
@@ -109,25 +109,23 @@ void pack_filter_tile(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
 
 size_t board_filter_elements(int cout, int cin)
 {
-    return (size_t)9 * cin * cout + (size_t)3 * 8192;   // + 3 k-steps of one 256-channel block (read ahead, never used)
+    return (size_t)9 * cin * cout + (size_t)3 * (cout / 32) * 1024;   // + 3 k-steps (read ahead by the kernel, never used)
 }
 
 void pack_filter_board(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
 {
-    const int nsteps = 9 * (cin / 32);
-    for (int nb = 0; nb < cout / 256; ++nb)
-        for (int chunk = 0; chunk < cin / 32; ++chunk)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int wn = 0; wn < 4; ++wn)
-                    for (int f = 0; f < 4; ++f)
-                        for (int lane = 0; lane < 64; ++lane) {
-                            const int tile = f >> 1, k16 = f & 1;   // fragment order [channel tile][k16]
-                            const int co = nb * 256 + wn * 64 + tile * 32 + (lane & 31);
-                            const int ci = chunk * 32 + k16 * 16 + (lane >> 5) * 8;
-                            uint16_t* out = dst + (((((size_t)nb * nsteps + chunk * 9 + tap) * 4 + wn) * 4 + f) * 64 + lane) * 8;
-                            const uint16_t* src = krsc + ((size_t)co * 9 + tap) * cin + ci;
-                            for (int e = 0; e < 8; ++e) out[e] = src[e];
-                        }
+    const int slices = cout / 32;
+    for (int chunk = 0; chunk < cin / 32; ++chunk)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int slice = 0; slice < slices; ++slice)
+                for (int k16 = 0; k16 < 2; ++k16)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = slice * 32 + (lane & 31);
+                        const int ci = chunk * 32 + k16 * 16 + (lane >> 5) * 8;
+                        uint16_t* out = dst + (((((size_t)chunk * 9 + tap) * slices + slice) * 2 + k16) * 64 + lane) * 8;
+                        const uint16_t* src = krsc + ((size_t)co * 9 + tap) * cin + ci;
+                        for (int e = 0; e < 8; ++e) out[e] = src[e];
+                    }
 }
 
 namespace {

@@ -172,12 +172,16 @@ def test_board_kernel_asymmetric_taps(api, oracle, monkeypatch):
     (3, 256, 256, 0.5, True),      # residual conv_2 with gated skip
     (2, 256, 256, None, False),    # identity activation, negative outputs
     (2, 64, 512, 0.25, True),      # two 256-channel blocks (grid.y = 2), two chunks
+    (2, 128, 128, 0.5, True),      # configs[1] residual shape (9 x 128)
+    (3, 64, 192, 0.375, True),     # 6 slices: only 2 slices per workgroup divide it
+    (1, 32, 64, None, True),       # configs[0] up-layer shape (6 x 64)
+    (2, 64, 64, 0.5, False),
 ])
 @pytest.mark.parametrize("skip_mode", ["0", "1"])     # skip folded into the K loop (default) / added in the epilogue
-@pytest.mark.parametrize("split", ["8", "4"])         # one wave per 32-channel slice (default) / two per 64-channel slice
-def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode, split):
+@pytest.mark.parametrize("ns", ["8", "4", "2"])       # 32-channel slices per workgroup (ignored when it does not divide C_out / 32)
+def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode, ns):
     monkeypatch.setenv("DGNN_BOARD_SKIP", skip_mode)
-    monkeypatch.setenv("DGNN_BOARD_SPLIT", split)
+    monkeypatch.setenv("DGNN_BOARD_NS", ns)
     rng = np.random.default_rng([7, batch, cin, cout])
     x = np.maximum(rng.normal(0, 1, (batch, 19, 19, cin)), 0).astype(np.float16)
     w = rng.normal(0, np.sqrt(2.0 / (9 * cin)), (cout, 3, 3, cin)).astype(np.float16)
@@ -193,8 +197,8 @@ def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout,
     assert mismatched <= 0.02 * got.size
 
 
-@pytest.mark.parametrize("split", ["8", "4"])
-def test_board_kernel_exact_under_full_load(api, monkeypatch, split):
+@pytest.mark.parametrize("ns", ["8", "4", "2"])
+def test_board_kernel_exact_under_full_load(api, monkeypatch, ns):
     """configs[2] layer shape at full size (256 boards = 256 workgroups, every CU busy): integer-valued data make the
     generic kernel a bit-exact reference; three runs must be identical (a DMA / ring race shows up as run-to-run
     differences under load)."""
@@ -207,7 +211,7 @@ def test_board_kernel_exact_under_full_load(api, monkeypatch, split):
     monkeypatch.setenv("DGNN_CONV", "v1")
     want = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=0.5, alpha2=0.5, z=z, relu=False)
     monkeypatch.setenv("DGNN_CONV", "board")
-    monkeypatch.setenv("DGNN_BOARD_SPLIT", split)
+    monkeypatch.setenv("DGNN_BOARD_NS", ns)
     for run in range(3):
         got = api.layer_conv3x3(x, batch, 19, cin, w, b, cout, alpha1=0.5, alpha2=0.5, z=z, relu=False)
         assert np.array_equal(got, want), (run, int(np.count_nonzero(got != want)))
