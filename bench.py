@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--cpu-sample", type=int, default=64, help="boards the CPU oracle evaluates for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="boards the CPU oracle evaluates for cpu_baseline (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
     return ap.parse_args()
@@ -197,6 +197,19 @@ def main():
                               "SURVEY.md 8f-1/8f-2)",
             },
         }
+        # the reference's own harness style (`dream_go --bench`, src/dg/bench/forward.rs:28-47): one thread, one workspace,
+        # synchronous forward() calls on host buffers -- PCIe-inclusive, reported beside `value`, never as `value`
+        if world == 1:
+            reps = max(3, min(args.steps, 10))
+            api.forward(ws, features)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                api.forward(ws, features)
+            dt1 = time.perf_counter() - t1
+            out["reference_style"] = {
+                "boards_per_sec": args.batch * reps / dt1, "calls": reps, "batch": args.batch,
+                "what": "synchronous dgnn_forward on host buffers (H2D + pass + D2H per call), single thread",
+            }
         if bcast is not None:
             out["weight_broadcast"] = {"mode": bcast[0], "bytes": bcast[1], "backend": "rccl"}
         if world == 1 and args.cpu_sample > 0:

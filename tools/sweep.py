@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Batch-size sweep of the hot path, the counterpart of src/dg_tests/benches/batch_sizes.rs:41-68 (batch 1 ... 256,
+Bernoulli(0.2) features).  One JSON line per batch size: evals/s with inputs resident in HBM, and the synchronous
+host-buffer rate (PCIe-inclusive).
+
+    python tools/sweep.py [--blocks 20 --channels 256] > profiles/<round>/batch_sweep.jsonl
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+graft.package()
+from dream_go_amd import api, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=20)
+    args = ap.parse_args()
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
+    for batch in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        features = synth.make_features(batch, seed=batch)
+        with net.get_workspace(batch) as ws:
+            ws.upload(features)
+            for _ in range(3):
+                ws.forward_resident()
+            ws.sync()
+            total_ms, tower_ms, launches = ws.forward_timed(args.steps)
+            api.forward(ws, features)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                api.forward(ws, features)
+            dt = time.perf_counter() - t0
+            print(json.dumps({
+                "net": f"{args.blocks}x{args.channels}", "batch": batch, "kernel": ws.conv_kernel(),
+                "evals_per_sec_resident": batch * args.steps / (total_ms * 1e-3), "ms_per_pass": total_ms / args.steps,
+                "residual_conv_us": tower_ms / max(launches, 1) * 1e3,
+                "evals_per_sec_host_buffers": batch * 5 / dt,
+            }), flush=True)
+
+
+if __name__ == "__main__":
+    main()
