@@ -473,7 +473,7 @@ const char* dgnn_status_string(int status)
 
 int dgnn_last_hip_error(void) { return g_last_hip_error; }
 
-const char* dgnn_version(void) { return "dgnn-hip 0.1 (gfx950; conv3x3 mfma_f32_16x16x32_f16)"; }
+const char* dgnn_version(void) { return "dgnn-hip 0.2 (gfx950; board kernel mfma_f32_32x32x16_f16)"; }
 
 int dgnn_device_count(int* count)
 {

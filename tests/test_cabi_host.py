@@ -203,3 +203,17 @@ def test_bad_arguments(api):
     assert api.lib.dgnn_network_get_workspace(None, 0, 1, None) == api.BAD_ARGUMENT
     api.lib.dgnn_workspace_release(None)
     api.lib.dgnn_network_destroy(None)
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/dgnn.h must be usable from C (the boundary is a C ABI): the example host compiles as strict C99 and links
+    against the library with nothing but the header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "forward_example"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "forward.c"), "-L" + os.path.join(root, "dream-go_amd", "lib"),
+                    "-ldgnn_hip", "-Wl,-rpath," + os.path.join(root, "dream-go_amd", "lib"), "-o", str(exe)], check=True)
+    # without a weights file it reports the reference's MissingWeights and exits non-zero (no GPU needed for that)
+    run = subprocess.run([str(exe), str(tmp_path / "nothing.json")], capture_output=True, text=True)
+    assert run.returncode == 1 and "missing weights" in run.stderr

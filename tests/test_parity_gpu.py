@@ -309,6 +309,19 @@ def test_network_against_oracle(api, oracle, synth, blocks, channels, batch):
     _compare(api, oracle, text, features, batch, f"{blocks}x{channels} B={batch}")
 
 
+@pytest.mark.parametrize("blocks,channels,samples,batch", [
+    (2, 192, 8, 6),      # 6 slices of 32 channels: only 2 slices per workgroup divide it
+    (1, 64, 16, 3),      # the widest policy head the loader accepts (S = 16: 18 of the 32 head-conv rows in use)
+    (1, 64, 4, 2),       # S = 4: dense input 1444, not a multiple of the GEMM's k-step
+    (3, 128, 8, 300),    # more boards than CUs, not a multiple of anything
+])
+def test_network_shapes_on_the_board_path(api, oracle, synth, blocks, channels, samples, batch):
+    text = synth.to_json(synth.make_tensors(blocks, channels, num_samples=samples, seed=500 + channels + samples))
+    features = synth.make_features(batch, seed=channels * 7 + batch)
+    boards = None if batch <= 8 else [0, 1, batch // 2, batch - 1]
+    _compare(api, oracle, text, features, batch, f"{blocks}x{channels} S={samples} B={batch}", oracle_boards=boards)
+
+
 def test_full_size_network_sampled_boards(api, oracle, synth):
     """BASELINE.json configs[2] at full size (20 x 256, batch 256).  Leaf evaluations are independent, so the
     oracle evaluates a sample of the boards (first, last, two in the middle) and every one must match."""
