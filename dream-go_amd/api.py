@@ -109,6 +109,36 @@ SYMBOLS = [
                                        ctypes.POINTER(ctypes.c_size_t)]),
     ("dgnn_sgf_played", ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                           ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_char_p]),
+    ("dgnn_config_uct_exp", ctypes.c_float, [ctypes.c_int]),
+    ("dgnn_config_fpu_reduce", ctypes.c_float, [ctypes.c_int]),
+    ("dgnn_config_lcb_critical_value", ctypes.c_float, [ctypes.c_int]),
+    ("dgnn_config_vloss_cnt", ctypes.c_int, []),
+    ("dgnn_intp_value", ctypes.c_float, [_ip, _fp, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_argmax_f32", ctypes.c_int, [_fp, ctypes.c_int]),
+    ("dgnn_tree_node_new", _vp, [ctypes.c_int, ctypes.c_float, _fp]),
+    ("dgnn_tree_node_free", None, [_vp]),
+    ("dgnn_tree_probe", ctypes.c_int, [_vp, _vp, _vp, _vpp]),
+    ("dgnn_trace_len", ctypes.c_int, [_vp]),
+    ("dgnn_trace_get", ctypes.c_int, [_vp, ctypes.c_int, _vpp, _ip, _ip]),
+    ("dgnn_trace_free", None, [_vp]),
+    ("dgnn_tree_undo", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("dgnn_tree_insert", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_float, _fp]),
+    ("dgnn_tree_node_child", ctypes.c_int, [_vp, ctypes.c_int, _ip, _ip, _fp, _fp, _ip]),
+    ("dgnn_tree_node_info", ctypes.c_int, [_vp, _ip, _ip, _ip, _ip, _fp]),
+    ("dgnn_tree_node_prior", ctypes.c_int, [_vp, _fp]),
+    ("dgnn_tree_node_disqualify", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("dgnn_tree_node_softmax", ctypes.c_int, [_vp, _fp]),
+    ("dgnn_tree_node_best", ctypes.c_int, [_vp, ctypes.c_float, ctypes.c_double, _fp, _ip]),
+    ("dgnn_choose", ctypes.c_int, [_ip, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, _ip,
+                                   ctypes.POINTER(ctypes.c_double)]),
+    ("dgnn_pool_predictor", _vp, []),
+    ("dgnn_hash_predictor", _vp, []),
+    ("dgnn_search_run", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_synthetic_game_ops", _vp, []),
+    ("dgnn_synthetic_board_new", _vp, [ctypes.c_uint64]),
+    ("dgnn_synthetic_board_free", None, [_vp]),
+    ("dgnn_selfplay_synthetic", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vp]),
     ("dgnn_pool_create", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
     ("dgnn_pool_destroy", None, [_vp]),
     ("dgnn_pool_predict", ctypes.c_int, [_vp, _u16p, ctypes.c_int, _u16p, _u16p]),
@@ -631,3 +661,224 @@ def sgf_played(color, packed_index, value=None, num_rollout=1, softmax=None, pri
     buf = ctypes.create_string_buffer(need)
     lib.dgnn_sgf_played(buf, need, *args)
     return buf.value.decode("utf-8")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Search tree (scope row f-2, first part): dg_mcts::tree over tree.cpp
+# ------------------------------------------------------------------------------------------------------------------
+
+BLACK, WHITE = 0, 1
+PROBE_FOUND, PROBE_NO_RESULT, PROBE_CONFLICT = 1, 0, -7
+
+
+class config:
+    """dg_utils::config accessors used by the tree (src/libdg_utils/config.rs:181-195, 289-330)."""
+    VLOSS_CNT = lib.dgnn_config_vloss_cnt()
+    get_uct_exp = staticmethod(lambda visits: lib.dgnn_config_uct_exp(int(visits)))
+    get_fpu_reduce = staticmethod(lambda visits: lib.dgnn_config_fpu_reduce(int(visits)))
+    get_lcb_critical_value = staticmethod(lambda visits: lib.dgnn_config_lcb_critical_value(int(visits)))
+
+    @staticmethod
+    def get_intp_value(points, x):
+        xs = np.asarray([p[0] for p in points], dtype=np.int32)
+        ys = np.asarray([p[1] for p in points], dtype=np.float32)
+        return lib.dgnn_intp_value(xs.ctypes.data_as(_ip), ys.ctypes.data_as(_fp), len(points), int(x))
+
+
+def argmax_f32(values):
+    """dg_mcts::asm::argmax_f32 (src/libdg_mcts/asm/argmax.rs:24-78); None when the maximum is not finite."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    i = lib.dgnn_argmax_f32(v.ctypes.data_as(_fp), v.size)
+    if i == -2:
+        raise Error(BAD_ARGUMENT, "argmax_f32")
+    return None if i < 0 else i
+
+
+def choose(items, cutoff_percentile, temperature, at):
+    """dg_mcts::choose::choose (src/libdg_mcts/choose.rs:54-88) -> (index, cumulative weight) or None."""
+    v = np.ascontiguousarray(items, dtype=np.int32)
+    index, cum = ctypes.c_int(), ctypes.c_double()
+    r = lib.dgnn_choose(v.ctypes.data_as(_ip), v.size, cutoff_percentile, temperature, at, ctypes.byref(index), ctypes.byref(cum))
+    if r < 0:
+        raise Error(r, "choose")
+    return (index.value, cum.value) if r == 1 else None
+
+
+class Child:
+    def __init__(self, count, vcount, value, value_std, has_child):
+        self._c, self._v, self._value, self._std, self._has = count, vcount, value, value_std, has_child
+
+    def count(self): return self._c
+    def vcount(self): return self._v
+    def value(self): return self._value
+    def value_std(self): return self._std
+    def has_node(self): return bool(self._has)
+
+
+class Trace:
+    """NodeTrace (src/libdg_mcts/tree.rs:1387): [(node handle, colour, child index)]."""
+
+    def __init__(self, handle):
+        self._handle = handle
+
+    def __len__(self):
+        return lib.dgnn_trace_len(self._handle)
+
+    def __getitem__(self, i):
+        node, color, index = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        _check(lib.dgnn_trace_get(self._handle, int(i), ctypes.byref(node), ctypes.byref(color), ctypes.byref(index)), "Trace[]")
+        return node.value, color.value, index.value
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                lib.dgnn_trace_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+class Node:
+    """dg_mcts::tree::Node (src/libdg_mcts/tree.rs:1027-1384); owns its sub-tree."""
+
+    def __init__(self, to_move, value, prior):
+        p = np.ascontiguousarray(prior, dtype=np.float32).reshape(-1)
+        if p.size < NUM_MOVES:
+            raise Error(BAD_ARGUMENT, "Node")
+        self._handle = lib.dgnn_tree_node_new(int(to_move), float(value), p.ctypes.data_as(_fp))
+        if not self._handle:
+            raise Error(OUT_OF_MEMORY, "Node")
+
+    def with_(self, index):
+        c, v, has = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        val, std = ctypes.c_float(), ctypes.c_float()
+        _check(lib.dgnn_tree_node_child(self._handle, int(index), ctypes.byref(c), ctypes.byref(v), ctypes.byref(val),
+                                        ctypes.byref(std), ctypes.byref(has)), "Node.with")
+        return Child(c.value, v.value, val.value, std.value, has.value)
+
+    def _info(self):
+        tm, tc, vc, pc, iv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_float()
+        _check(lib.dgnn_tree_node_info(self._handle, ctypes.byref(tm), ctypes.byref(tc), ctypes.byref(vc), ctypes.byref(pc),
+                                       ctypes.byref(iv)), "Node.info")
+        return tm.value, tc.value, vc.value, pc.value, iv.value
+
+    to_move = property(lambda self: self._info()[0])
+    total_count = property(lambda self: self._info()[1])
+    vtotal_count = property(lambda self: self._info()[2])
+    pass_count = property(lambda self: self._info()[3])
+    initial_value = property(lambda self: self._info()[4])
+
+    @property
+    def prior(self):
+        out = np.empty(NUM_MOVES, dtype=np.float32)
+        _check(lib.dgnn_tree_node_prior(self._handle, out.ctypes.data_as(_fp)), "Node.prior")
+        return out
+
+    def disqualify(self, index):
+        _check(lib.dgnn_tree_node_disqualify(self._handle, int(index)), "Node.disqualify")
+
+    def softmax(self):
+        out = np.empty(NUM_MOVES, dtype=np.float32)
+        _check(lib.dgnn_tree_node_softmax(self._handle, out.ctypes.data_as(_fp)), "Node.softmax")
+        return out
+
+    def best(self, temperature, at=0.0):
+        value, index = ctypes.c_float(), ctypes.c_int()
+        _check(lib.dgnn_tree_node_best(self._handle, float(temperature), float(at), ctypes.byref(value), ctypes.byref(index)), "Node.best")
+        return value.value, index.value
+
+    def __del__(self):
+        try:
+            if self._handle:
+                lib.dgnn_tree_node_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+def probe(root):
+    """dg_mcts::tree::probe (src/libdg_mcts/tree.rs:1421-1470) without a board: -> Trace, or PROBE_NO_RESULT / PROBE_CONFLICT."""
+    out = ctypes.c_void_p()
+    r = lib.dgnn_tree_probe(root._handle, None, None, ctypes.byref(out))
+    if r == PROBE_FOUND:
+        return Trace(out)
+    if r in (PROBE_NO_RESULT, PROBE_CONFLICT):
+        return r
+    raise Error(r, "probe")
+
+
+def insert(trace, color, value, prior):
+    """dg_mcts::tree::insert (tree.rs:1482-1510)."""
+    p = np.ascontiguousarray(prior, dtype=np.float32).reshape(-1)
+    _check(lib.dgnn_tree_insert(trace._handle, int(color), float(value), p.ctypes.data_as(_fp)), "insert")
+
+
+def undo(trace, undo_expanding):
+    _check(lib.dgnn_tree_undo(trace._handle, int(bool(undo_expanding))), "undo")
+
+
+# ---- search driver (scope row f-2, second part): search.cpp ----
+
+class SelfplayStats(ctypes.Structure):
+    _fields_ = [("seconds", ctypes.c_double), ("games", ctypes.c_uint64), ("moves", ctypes.c_uint64),
+                ("evals", ctypes.c_uint64), ("conflicts", ctypes.c_uint64)]
+
+
+class SyntheticBoard:
+    """The rule-free synthetic game of search.cpp (NOT Go; for driving the search and the pipeline)."""
+
+    def __init__(self, seed):
+        self._handle = lib.dgnn_synthetic_board_new(int(seed))
+
+    def __del__(self):
+        try:
+            if self._handle:
+                lib.dgnn_synthetic_board_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+PREDICT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, _u16p, ctypes.c_int, _u16p, _u16p)
+
+
+def python_predictor(fn):
+    """Wraps `fn(features uint16 [n * 11552], n) -> (value fp16 [n], policy fp16 [n * 362])` as a dgnn_predict_fn
+    (tests: the CPU oracle as the predictor behind the search)."""
+    def thunk(_ctx, features, n, value_out, policy_out):
+        try:
+            f = np.ctypeslib.as_array(features, shape=(n * FEATURE_SIZE,))
+            value, policy = fn(f, n)
+            np.ctypeslib.as_array(value_out, shape=(n,))[:] = np.asarray(value).view(np.uint16).reshape(n)
+            np.ctypeslib.as_array(policy_out, shape=(n * NUM_MOVES,))[:] = np.asarray(policy).view(np.uint16).reshape(n * NUM_MOVES)
+            return OK
+        except Exception:   # noqa: BLE001
+            return BAD_ARGUMENT
+    return PREDICT_FN(thunk)
+
+
+def _predictor(pool):
+    """(callback, context) for search_run / selfplay_synthetic: a LeafPool, a python_predictor, or None for the
+    deterministic CPU stand-in."""
+    if pool is None:
+        return lib.dgnn_hash_predictor(), None
+    if isinstance(pool, PREDICT_FN):
+        return ctypes.cast(pool, ctypes.c_void_p), None
+    return lib.dgnn_pool_predictor(), pool._handle
+
+
+def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None):
+    """One search on `root` from a SyntheticBoard (worker_thread.rs:50-176 for a single search) -> (evals, conflicts)."""
+    fn, ctx = _predictor(pool)
+    evals, conflicts = ctypes.c_uint64(), ctypes.c_uint64()
+    _check(lib.dgnn_search_run(root._handle, lib.dgnn_synthetic_game_ops(), board._handle, fn, ctx, int(num_rollouts),
+                               int(num_threads), int(seed), ctypes.byref(evals), ctypes.byref(conflicts)), "search_run")
+    return evals.value, conflicts.value
+
+
+def selfplay_synthetic(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None):
+    fn, ctx = _predictor(pool)
+    stats = SelfplayStats()
+    _check(lib.dgnn_selfplay_synthetic(fn, ctx, int(num_games), int(num_moves), int(num_rollouts), int(threads_per_search),
+                                       int(seed), ctypes.byref(stats)), "selfplay_synthetic")
+    return {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts}

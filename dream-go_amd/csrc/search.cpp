@@ -1,0 +1,295 @@
+// Scope row f-2 (second part): the search driver around the tree -- what dream-go's worker pool does for one search
+// (src/libdg_mcts/pool/worker_thread.rs:50-176, pool/event.rs:45-59, pool/policy_helper.rs:28-134), with the game behind
+// callbacks and the neural network behind the Predictor::predict signature.
+//
+//   one rollout   clone the starting board, tree::probe (stones placed on the clone), pick a random symmetry, ask the game
+//                 for the features of the leaf, predict, rebuild the prior (legal candidates 0 / others -inf, symmetric
+//                 duplicates eliminated, network policy de-transformed and renormalised), tree::insert with the win rate
+//   termination   RolloutLimit: root.total_count >= limit (time_control/rollout_limit.rs:35-44); like the reference the
+//                 check happens before a probe, so with T threads up to T - 1 rollouts more may land
+//   determinism   every random choice comes from a seeded generator (the reference uses thread_rng() everywhere,
+//                 SURVEY.md section 7): with ONE search thread the visit counts are a pure function of (seed, network
+//                 outputs); with several threads they are not, exactly as in the reference (virtual loss + timing).
+//
+// Also here: a rule-free synthetic game and a synthetic self-play loop for throughput measurements of the whole
+// host + device pipeline (games x moves x rollouts through the tree and the LeafPool).  The synthetic game is NOT Go:
+// every empty point is a legal move, nothing is ever captured, features are pseudo-random bits of the position hash.
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "dgnn_internal.h"
+
+namespace dgnn {
+namespace {
+
+struct Rng {      // splitmix64
+    uint64_t state;
+    uint64_t next() { uint64_t z = (state += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+                      z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+    double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+// pool/policy_helper.rs:28-134 in one place
+void rebuild_prior(const dgnn_game_ops* ops, void* board, int to_move, int transform, const uint16_t* policy_f16, float* prior /*368*/)
+{
+    unsigned char candidate[DGNN_NUM_MOVES];
+    ops->candidates(board, to_move, candidate);
+    for (int i = 0; i < 368; ++i) prior[i] = -std::numeric_limits<float>::infinity();
+    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (candidate[i]) prior[i] = 0.0f;
+
+    // symmetric elimination: every point maps to the smallest index among its images under the board's own symmetries
+    int indices[DGNN_NUM_MOVES];
+    bool symmetric[8];
+    for (int t = 0; t < 8; ++t) symmetric[t] = t == 0 || (ops->is_symmetric && ops->is_symmetric(board, t));
+    indices[DGNN_NUM_POINTS] = DGNN_NUM_POINTS;
+    for (int i = 0; i < DGNN_NUM_POINTS; ++i) {
+        int target = i;
+        for (int t = 1; t < 8; ++t) if (symmetric[t]) target = std::min(target, dgnn_symmetry_apply(t, i));
+        indices[i] = target;
+        if (target != i) prior[i] = -std::numeric_limits<float>::infinity();
+    }
+
+    // add_valid_candidates (policy_helper.rs:87-103): de-transform the network's policy to the identity orientation
+    const int inverse = dgnn_symmetry_inverse(transform);
+    prior[DGNN_NUM_POINTS] += half_to_float(policy_f16[DGNN_NUM_POINTS]);
+    for (int i = 0; i < DGNN_NUM_POINTS; ++i) {
+        const int j = indices[dgnn_symmetry_apply(inverse, i)];
+        prior[j] += half_to_float(policy_f16[i]);
+    }
+
+    // normalize_policy (policy_helper.rs:112-134)
+    float sum = 0.0f;
+    int finite = 0;
+    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(prior[i])) { sum += prior[i]; ++finite; }
+    if (sum < 1e-6f) { for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(prior[i])) prior[i] = 1.0f / (float)finite; }
+    else { for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(prior[i])) prior[i] /= sum; }
+}
+
+struct SearchShared {
+    dgnn_tree_node* root;
+    const dgnn_game_ops* ops;
+    void* board;
+    dgnn_predict_fn predict;
+    void* predict_ctx;
+    int limit;
+    std::atomic<int> status{DGNN_OK};
+    std::atomic<uint64_t> evals{0}, conflicts{0};
+};
+
+void search_worker(SearchShared* s, uint64_t seed)
+{
+    Rng rng{seed};
+    std::vector<uint16_t> features(DGNN_FEATURE_SIZE), policy(DGNN_NUM_MOVES);
+    float prior[368];
+    dgnn_board_ops place_ops = {s->ops->place};
+    int idle_conflicts = 0;
+    while (s->status.load(std::memory_order_relaxed) == DGNN_OK) {
+        int total = 0;
+        dgnn_tree_node_info(s->root, nullptr, &total, nullptr, nullptr, nullptr);
+        if (total >= s->limit) break;                                        // rollout_limit.rs:35-44
+
+        void* board = s->ops->clone(s->board);
+        dgnn_trace* trace = nullptr;
+        const int r = dgnn_tree_probe(s->root, &place_ops, board, &trace);
+        if (r == DGNN_PROBE_CONFLICT) {                                      // worker_thread.rs:161-163: try again
+            s->ops->destroy(board);
+            s->conflicts.fetch_add(1, std::memory_order_relaxed);
+            if (++idle_conflicts > 64) std::this_thread::yield();
+            continue;
+        }
+        idle_conflicts = 0;
+        if (r != DGNN_PROBE_FOUND) { s->ops->destroy(board); break; }         // NoResult: the search is over (:164-166)
+
+        int last_color = 0;
+        dgnn_trace_get(trace, dgnn_trace_len(trace) - 1, nullptr, &last_color, nullptr);
+        const int to_move = 1 - last_color;                                  // event.rs:48-49
+        const int transform = (int)(rng.next() % 8);                         // event.rs:47
+        s->ops->features(board, to_move, transform, features.data());
+        uint16_t value = 0;
+        const int status = s->predict(s->predict_ctx, features.data(), 1, &value, policy.data());
+        if (status != DGNN_OK) {
+            dgnn_tree_undo(trace, 1);
+            dgnn_trace_free(trace);
+            s->ops->destroy(board);
+            s->status.store(status);
+            break;
+        }
+        rebuild_prior(s->ops, board, to_move, transform, policy.data(), prior);
+        const float winrate = 0.5f * half_to_float(value) + 0.5f;            // predictor.rs:50-52
+        dgnn_tree_insert(trace, to_move, winrate, prior);                    // worker_thread.rs:101-113
+        dgnn_trace_free(trace);
+        s->ops->destroy(board);
+        s->evals.fetch_add(1, std::memory_order_relaxed);
+    }
+}
+
+// ---- the rule-free synthetic game -------------------------------------------------------------------------------
+
+struct SyntheticBoard {
+    uint64_t hash;
+    unsigned char stones[DGNN_NUM_POINTS];
+    int moves;
+};
+
+void* syn_clone(void* b) { return new SyntheticBoard(*static_cast<SyntheticBoard*>(b)); }
+void syn_destroy(void* b) { delete static_cast<SyntheticBoard*>(b); }
+void syn_place(void* b, int color, int index)
+{
+    SyntheticBoard* s = static_cast<SyntheticBoard*>(b);
+    if (index >= 0 && index < DGNN_NUM_POINTS) s->stones[index] = (unsigned char)(color + 1);
+    Rng mix{s->hash ^ (0x100000001b3ull * (uint64_t)(index * 2 + color + 1))};
+    s->hash = mix.next();
+    ++s->moves;
+}
+void syn_features(void* b, int to_move, int transform, uint16_t* out)
+{
+    const SyntheticBoard* s = static_cast<SyntheticBoard*>(b);
+    Rng rng{s->hash ^ ((uint64_t)to_move << 32) ^ ((uint64_t)transform << 40)};
+    for (int i = 0; i < DGNN_FEATURE_SIZE; i += 16) {                        // Bernoulli(~0.19) bits, like batch_sizes.rs:44-52
+        const uint64_t a = rng.next(), c = rng.next(), d = rng.next();
+        const uint64_t bits = a & c & (d | (d >> 7));                        // p = 1/4 * ~3/4
+        for (int j = 0; j < 16; ++j) out[i + j] = ((bits >> (j * 3)) & 1u) ? 0x3c00 : 0;
+    }
+}
+void syn_candidates(void* b, int, unsigned char* out)
+{
+    const SyntheticBoard* s = static_cast<SyntheticBoard*>(b);
+    for (int i = 0; i < DGNN_NUM_POINTS; ++i) out[i] = s->stones[i] == 0;
+    out[DGNN_NUM_POINTS] = 1;
+}
+
+const dgnn_game_ops kSyntheticOps = {syn_clone, syn_destroy, syn_place, syn_features, syn_candidates, nullptr};
+
+// ---- predictors ---------------------------------------------------------------------------------------------------
+
+int pool_predict(void* ctx, const uint16_t* features, int n, uint16_t* value, uint16_t* policy)
+{
+    return dgnn_pool_predict(static_cast<dgnn_pool*>(ctx), features, n, value, policy);
+}
+
+// A deterministic CPU stand-in for the network (the role of the reference's Random / FakePredictor,
+// src/libdg_mcts/predictors/{random,fake}.rs): policy and value are a hash of the feature bits.
+int hash_predict(void*, const uint16_t* features, int n, uint16_t* value, uint16_t* policy)
+{
+    for (int b = 0; b < n; ++b) {
+        uint64_t h = 1469598103934665603ull;
+        const uint16_t* f = features + (size_t)b * DGNN_FEATURE_SIZE;
+        for (int i = 0; i < DGNN_FEATURE_SIZE; ++i) { h ^= f[i]; h *= 1099511628211ull; }
+        Rng rng{h};
+        float p[DGNN_NUM_MOVES], sum = 0.0f;
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) { const double u = rng.uniform(); p[i] = (float)(u * u * u); sum += p[i]; }
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) policy[(size_t)b * DGNN_NUM_MOVES + i] = float_to_half(p[i] / sum);
+        value[b] = float_to_half((float)(2.0 * rng.uniform() - 1.0) * 0.5f);
+    }
+    return DGNN_OK;
+}
+
+}  // namespace
+}  // namespace dgnn
+
+using namespace dgnn;
+
+extern "C" {
+
+const dgnn_game_ops* dgnn_synthetic_game_ops(void) { return &kSyntheticOps; }
+
+void* dgnn_synthetic_board_new(uint64_t seed)
+{
+    SyntheticBoard* b = new (std::nothrow) SyntheticBoard();
+    if (!b) return nullptr;
+    std::memset(b->stones, 0, sizeof(b->stones));
+    b->hash = seed;
+    b->moves = 0;
+    return b;
+}
+
+void dgnn_synthetic_board_free(void* board) { syn_destroy(board); }
+
+dgnn_predict_fn dgnn_hash_predictor(void) { return hash_predict; }
+dgnn_predict_fn dgnn_pool_predictor(void) { return pool_predict; }
+
+int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
+                    int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out)
+{
+    if (!root || !ops || !ops->clone || !ops->destroy || !ops->place || !ops->features || !ops->candidates || !predict ||
+        num_rollouts <= 0 || num_threads <= 0)
+        return DGNN_BAD_ARGUMENT;
+    SearchShared shared;
+    shared.root = root;
+    shared.ops = ops;
+    shared.board = board;
+    shared.predict = predict;
+    shared.predict_ctx = predict_ctx;
+    shared.limit = num_rollouts;
+    Rng seeds{seed};
+    if (num_threads == 1) {
+        search_worker(&shared, seeds.next());
+    } else {
+        std::vector<std::thread> threads;
+        for (int t = 0; t < num_threads; ++t) threads.emplace_back(search_worker, &shared, seeds.next());
+        for (std::thread& t : threads) t.join();
+    }
+    if (evals_out) *evals_out = shared.evals.load();
+    if (conflicts_out) *conflicts_out = shared.conflicts.load();
+    return shared.status.load();
+}
+
+// Synthetic self-play: `num_games` games in parallel (one thread each + `threads_per_search` search threads per move),
+// `num_moves` moves per game, `num_rollouts` rollouts per move on a fresh tree, every network call through `predict`.
+int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
+                            int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats)
+{
+    if (!predict || num_games <= 0 || num_moves <= 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats)
+        return DGNN_BAD_ARGUMENT;
+    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0};
+    std::atomic<int> status{DGNN_OK};
+    const auto t0 = std::chrono::steady_clock::now();
+
+    auto game = [&](int g) {
+        Rng rng{seed + 0x9e3779b97f4a7c15ull * (uint64_t)(g + 1)};
+        void* board = dgnn_synthetic_board_new(rng.next());
+        int to_move = DGNN_COLOR_BLACK;
+        std::vector<uint16_t> features(DGNN_FEATURE_SIZE), policy(DGNN_NUM_MOVES);
+        float prior[368];
+        for (int m = 0; m < num_moves && status.load() == DGNN_OK; ++m) {
+            // the root's own evaluation (the reference averages 8 symmetries here, lib.rs:83-130; one is enough for a
+            // throughput harness)
+            uint16_t value = 0;
+            syn_features(board, to_move, 0, features.data());
+            int st = predict(predict_ctx, features.data(), 1, &value, policy.data());
+            if (st != DGNN_OK) { status.store(st); break; }
+            rebuild_prior(&kSyntheticOps, board, to_move, 0, policy.data(), prior);
+            dgnn_tree_node* root = dgnn_tree_node_new(to_move, 0.5f * half_to_float(value) + 0.5f, prior);
+            uint64_t e = 0, c = 0;
+            st = dgnn_search_run(root, &kSyntheticOps, board, predict, predict_ctx, num_rollouts, threads_per_search, rng.next(), &e, &c);
+            evals.fetch_add(e + 1);
+            conflicts.fetch_add(c);
+            if (st != DGNN_OK) { status.store(st); dgnn_tree_node_free(root); break; }
+            float best_value = 0.0f;
+            int best = DGNN_NUM_POINTS;
+            dgnn_tree_node_best(root, m < 8 ? 0.8f : 0.0f, rng.uniform(), &best_value, &best);   // lib.rs:188-192, TEMPERATURE 0.8
+            dgnn_tree_node_free(root);
+            syn_place(board, to_move, best);
+            to_move = 1 - to_move;
+            moves.fetch_add(1);
+        }
+        dgnn_synthetic_board_free(board);
+    };
+    std::vector<std::thread> threads;
+    for (int g = 0; g < num_games; ++g) threads.emplace_back(game, g);
+    for (std::thread& t : threads) t.join();
+
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    stats->games = (uint64_t)num_games;
+    stats->moves = moves.load();
+    stats->evals = evals.load();
+    stats->conflicts = conflicts.load();
+    return status.load();
+}
+
+}  // extern "C"

@@ -1,0 +1,415 @@
+// Scope row f-2 (first part): the Monte-Carlo search tree of dream-go's libdg_mcts as a C++ library behind the C ABI.
+//
+//   Node, Child           src/libdg_mcts/tree.rs:259-360,1027-1095 (dense children here; the reference's sparse "small"
+//                         children are a memory optimisation with the same observable values)
+//   select                tree.rs:1329-1384: child values, first-play urgency (tree.rs:180-254), PUCT (tree.rs:41-178), argmax
+//                         (asm/argmax.rs:24-78, including which index wins a tie), "expanding" flag, virtual loss
+//   probe / undo / insert tree.rs:1397-1510;  UCT::update (incremental mean and sum of squares) tree.rs:125-160
+//   best / softmax        tree.rs:1262-1313, compare_children tree.rs:1524-1560, normal_lcb_m libdg_utils/lcb.rs:28-37,
+//                         choose libdg_mcts/choose.rs:23-106
+//   constants             VLOSS_CNT 32, UCT_EXP / FPU_REDUCE / CRITICAL_VALUE interpolation tables and get_intp_value,
+//                         libdg_utils/config.rs:181-195,289-305
+// The tree knows nothing about Go: the board is a pair of callbacks (place a stone while descending), legality is encoded
+// by the caller in the prior (-inf for illegal moves) exactly as the reference's policy_helper does.  Concurrency follows
+// the reference: atomic counters, one spin lock per node around the value update, the "expanding" flag against double
+// expansion; several threads may probe / insert into one tree.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "dgnn_internal.h"
+
+namespace dgnn {
+namespace {
+
+constexpr int kMoves = DGNN_NUM_MOVES;     // 362
+constexpr int kPadded = 368;               // tree.rs:1045: padded to a multiple of 8 for the SIMD loops
+constexpr int kVlossCnt = 32;              // config.rs:187
+constexpr int kMinLcbVisits = 80;          // tree.rs:34
+
+struct Point2 { int x; float y; };
+const Point2 kFpuReduce[] = {{0, 0.631571f}, {800, 0.431547f}, {1600, 0.656083f}, {3200, 0.429231f}, {6400, 0.514494f}};
+const Point2 kUctExp[] = {{0, 0.77392f}, {800, 1.05439f}, {1600, 1.22798f}, {3200, 0.813532f}, {6400, 0.764326f}};
+const Point2 kCriticalValue[] = {{0, 1.91753f}, {800, 1.86478f}, {1600, 1.86943f}, {3200, 2.20033f}, {6400, 1.78053f}};
+
+float intp_value(const Point2* points, int n, int x)   // config.rs:289-305
+{
+    int i = 0;
+    while (i < n && points[i].x < x) ++i;
+    if (i == n) return points[n - 1].y;
+    const Point2& x0 = points[i == 0 ? 0 : i - 1];
+    const Point2& x1 = points[i];
+    const float a = x0.x >= x1.x ? 0.5f : (float)(x - x0.x) / (float)(x1.x - x0.x);
+    return (1.0f - a) * x0.y + a * x1.y;
+}
+
+// asm/argmax.rs:24-78: groups of 8; within the running maximum the LAST group that holds a maximal element wins and
+// inside it the first such element; None (-1) when the winner is not finite.
+int argmax_f32(const float* v, int n)
+{
+    float so_far = -std::numeric_limits<float>::infinity();
+    int index = 0;
+    for (int g = 0; g < n / 8; ++g) {
+        float m = v[8 * g];
+        for (int j = 1; j < 8; ++j) m = std::max(m, v[8 * g + j]);
+        so_far = std::max(so_far, m);
+        for (int j = 0; j < 8; ++j)
+            if (v[8 * g + j] == so_far) { index = 8 * g + j; break; }
+    }
+    return std::isfinite(v[index]) ? index : -1;
+}
+
+struct SpinLock {
+    std::atomic_flag flag = ATOMIC_FLAG_INIT;
+    void lock() { while (flag.test_and_set(std::memory_order_acquire)) {} }
+    void unlock() { flag.clear(std::memory_order_release); }
+};
+
+}  // namespace
+
+struct TreeNode {
+    SpinLock lock;
+    int to_move;
+    float initial_value;
+    int pass_count = 0;
+    std::atomic<int> total_count{0};
+    std::atomic<int> vtotal_count{0};
+    float prior[kPadded];
+
+    std::atomic<int> count[kPadded];
+    std::atomic<int> vcount[kPadded];
+    std::atomic<unsigned char> expanding[kPadded];
+    std::atomic<TreeNode*> ptr[kPadded];
+    float value[kPadded];
+    float value_s[kPadded];
+
+    TreeNode(int color, float v, const float* p) : to_move(color), initial_value(v)
+    {
+        for (int i = 0; i < kPadded; ++i) {
+            prior[i] = i < kMoves ? p[i] : -std::numeric_limits<float>::infinity();   // tree.rs:1075-1076
+            count[i].store(0, std::memory_order_relaxed);
+            vcount[i].store(0, std::memory_order_relaxed);
+            expanding[i].store(0, std::memory_order_relaxed);
+            ptr[i].store(nullptr, std::memory_order_relaxed);
+            value[i] = v;                                                               // Child::with_value, tree.rs:276-285
+            value_s[i] = 0.0f;
+        }
+    }
+
+    ~TreeNode()
+    {
+        for (int i = 0; i < kMoves; ++i) delete ptr[i].load(std::memory_order_relaxed);
+    }
+
+    int total(int i) const { return count[i].load(std::memory_order_relaxed) + vcount[i].load(std::memory_order_relaxed); }
+};
+
+struct TraceEntry { TreeNode* node; int color; int index; };
+struct Trace { std::vector<TraceEntry> entries; };
+
+namespace {
+
+// tree.rs:1329-1384.  Returns 1 found (index, value filled), 0 no result, -1 conflict.
+int select(TreeNode* node, bool apply_fpu, int* index_out, float* value_out)
+{
+    float value[kPadded];
+    for (int i = 0; i < kPadded; ++i) value[i] = node->value[i];
+
+    const int n = node->total_count.load(std::memory_order_relaxed) + node->vtotal_count.load(std::memory_order_relaxed);
+    if (apply_fpu) {                                                        // tree.rs:1342-1348, 180-254
+        const float fpu_reduce = intp_value(kFpuReduce, 5, n);
+        for (int i = 0; i < kPadded; ++i)
+            if (node->total(i) == 0) value[i] = std::max(value[i] - fpu_reduce, 0.0f);
+    }
+    for (int i = kMoves; i < kPadded; ++i) value[i] = -std::numeric_limits<float>::infinity();
+
+    const float sqrt_n = std::sqrt((float)(1 + n));                          // tree.rs:86-115
+    const float uct_exp_sqrt_n = intp_value(kUctExp, 5, n) * sqrt_n;
+    for (int i = 0; i < kPadded; ++i) {
+        const int c = node->total(i);
+        const float bonus = c == 0 ? uct_exp_sqrt_n : uct_exp_sqrt_n / (float)(1 + c);
+        value[i] = value[i] + node->prior[i] * bonus;
+    }
+
+    const int max_i = argmax_f32(value, kPadded);
+    if (max_i < 0) return 0;
+    const bool was_expanding = node->expanding[max_i].exchange(1, std::memory_order_acq_rel) != 0;   // set_expanding, tree.rs:445-449
+    if (was_expanding && node->ptr[max_i].load(std::memory_order_acquire) == nullptr) return -1;
+    node->vcount[max_i].fetch_add(kVlossCnt, std::memory_order_relaxed);
+    node->vtotal_count.fetch_add(kVlossCnt, std::memory_order_relaxed);
+    *index_out = max_i;
+    *value_out = value[max_i];
+    return 1;
+}
+
+void undo(const Trace& trace, bool undo_expanding)                          // tree.rs:1397-1409
+{
+    for (const TraceEntry& e : trace.entries) {
+        e.node->vtotal_count.fetch_sub(kVlossCnt, std::memory_order_relaxed);
+        e.node->vcount[e.index].fetch_sub(kVlossCnt, std::memory_order_relaxed);
+        if (undo_expanding && e.node->ptr[e.index].load(std::memory_order_acquire) == nullptr)
+            e.node->expanding[e.index].store(0, std::memory_order_release);
+    }
+}
+
+float value_std(const TreeNode* node, int i)                                 // tree.rs:351-358
+{
+    return std::sqrt(node->value_s[i] / ((float)node->count[i].load(std::memory_order_relaxed) + 1e-5f));
+}
+
+float normal_lcb_m(float p_hat, float p_std, int n, int m)                  // lcb.rs:28-37
+{
+    if (n <= 0) return 0.0f;
+    return p_hat - intp_value(kCriticalValue, 5, m) * p_std / std::sqrt((float)n);
+}
+
+// compare_children, tree.rs:1524-1560: < 0 when a is the worse candidate
+int compare_children(const TreeNode* node, int a, int b)
+{
+    const int ac = node->count[a].load(std::memory_order_relaxed), bc = node->count[b].load(std::memory_order_relaxed);
+    if (ac >= kMinLcbVisits && bc >= kMinLcbVisits) {
+        const int m = node->total_count.load(std::memory_order_relaxed);
+        const float al = normal_lcb_m(node->value[a], value_std(node, a), ac, m);
+        const float bl = normal_lcb_m(node->value[b], value_std(node, b), bc, m);
+        if (al != bl) return al < bl ? -1 : 1;
+    }
+    if (ac != bc) return ac < bc ? -1 : 1;
+    if (node->prior[a] != node->prior[b]) return node->prior[a] < node->prior[b] ? -1 : 1;
+    if (node->value[a] != node->value[b]) return node->value[a] < node->value[b] ? -1 : 1;
+    return 0;
+}
+
+}  // namespace
+}  // namespace dgnn
+
+using namespace dgnn;
+
+extern "C" {
+
+float dgnn_config_uct_exp(int visits) { return intp_value(kUctExp, 5, visits); }
+float dgnn_config_fpu_reduce(int visits) { return intp_value(kFpuReduce, 5, visits); }
+float dgnn_config_lcb_critical_value(int visits) { return intp_value(kCriticalValue, 5, visits); }
+int dgnn_config_vloss_cnt(void) { return kVlossCnt; }
+
+float dgnn_intp_value(const int* xs, const float* ys, int n, int x)
+{
+    if (!xs || !ys || n <= 0 || n > 64) return std::numeric_limits<float>::quiet_NaN();
+    Point2 pts[64];
+    for (int i = 0; i < n; ++i) { pts[i].x = xs[i]; pts[i].y = ys[i]; }
+    return intp_value(pts, n, x);
+}
+
+int dgnn_argmax_f32(const float* values, int n)
+{
+    if (!values || n <= 0 || n % 8 != 0) return -2;
+    return argmax_f32(values, n);
+}
+
+dgnn_tree_node* dgnn_tree_node_new(int to_move, float value, const float* prior)
+{
+    if (!prior) return nullptr;
+    return reinterpret_cast<dgnn_tree_node*>(new (std::nothrow) TreeNode(to_move, value, prior));
+}
+
+void dgnn_tree_node_free(dgnn_tree_node* node) { delete reinterpret_cast<TreeNode*>(node); }
+
+int dgnn_tree_probe(dgnn_tree_node* root, const dgnn_board_ops* ops, void* board, dgnn_trace** out)
+{
+    if (!root || !out) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    Trace* trace = new (std::nothrow) Trace();
+    if (!trace) return DGNN_OUT_OF_MEMORY;
+    trace->entries.reserve(16);
+    TreeNode* current = reinterpret_cast<TreeNode*>(root);
+
+    for (;;) {                                                               // tree.rs:1421-1470
+        int next_child = 0;
+        float next_value = 0.0f;
+        const int r = select(current, !trace->entries.empty(), &next_child, &next_value);
+        if (r < 0) { undo(*trace, false); delete trace; return DGNN_PROBE_CONFLICT; }
+        if (r == 0) { delete trace; return DGNN_PROBE_NO_RESULT; }            // (the reference leaks the partial trace's virtual loss here too)
+        trace->entries.push_back({current, current->to_move, next_child});
+        if (next_child != kMoves - 1) {
+            if (ops && ops->place) ops->place(board, current->to_move, next_child);
+        } else if (current->pass_count >= 1) {
+            break;                                                           // at least two consecutive passes
+        }
+        TreeNode* child = current->ptr[next_child].load(std::memory_order_acquire);
+        if (!child) break;
+        current = child;
+    }
+    *out = reinterpret_cast<dgnn_trace*>(trace);
+    return DGNN_PROBE_FOUND;
+}
+
+int dgnn_trace_len(const dgnn_trace* trace) { return trace ? (int)reinterpret_cast<const Trace*>(trace)->entries.size() : 0; }
+
+int dgnn_trace_get(const dgnn_trace* trace, int i, dgnn_tree_node** node, int* color, int* index)
+{
+    if (!trace) return DGNN_BAD_ARGUMENT;
+    const Trace* t = reinterpret_cast<const Trace*>(trace);
+    if (i < 0 || i >= (int)t->entries.size()) return DGNN_BAD_ARGUMENT;
+    if (node) *node = reinterpret_cast<dgnn_tree_node*>(t->entries[i].node);
+    if (color) *color = t->entries[i].color;
+    if (index) *index = t->entries[i].index;
+    return DGNN_OK;
+}
+
+void dgnn_trace_free(dgnn_trace* trace) { delete reinterpret_cast<Trace*>(trace); }
+
+int dgnn_tree_undo(dgnn_trace* trace, int undo_expanding)
+{
+    if (!trace) return DGNN_BAD_ARGUMENT;
+    undo(*reinterpret_cast<Trace*>(trace), undo_expanding != 0);
+    return DGNN_OK;
+}
+
+int dgnn_tree_insert(const dgnn_trace* handle, int color, float value, const float* prior)
+{
+    if (!handle || !prior) return DGNN_BAD_ARGUMENT;
+    const Trace* trace = reinterpret_cast<const Trace*>(handle);
+    if (!trace->entries.empty()) {                                           // tree.rs:1482-1507
+        const TraceEntry& last = trace->entries.back();
+        TreeNode* next = new (std::nothrow) TreeNode(color, value, prior);
+        if (!next) return DGNN_OUT_OF_MEMORY;
+        if (last.index == kMoves - 1) next->pass_count = last.node->pass_count + 1;
+        TreeNode* expected = nullptr;
+        if (!last.node->ptr[last.index].compare_exchange_strong(expected, next, std::memory_order_acq_rel))
+            delete next;                                                     // double expansion behind two passes
+    }
+    for (const TraceEntry& e : trace->entries) {                              // UCT::update, tree.rs:125-160
+        TreeNode* node = e.node;
+        const float v = color == node->to_move ? value : 1.0f - value;
+        node->total_count.fetch_add(1, std::memory_order_relaxed);
+        node->vtotal_count.fetch_sub(kVlossCnt, std::memory_order_relaxed);
+        node->lock.lock();
+        const float prev_value = node->value[e.index];
+        const float prev_value_s = node->value_s[e.index];
+        const int prev_count = node->count[e.index].fetch_add(1, std::memory_order_relaxed);
+        const float next_value = prev_value + (v - prev_value) / (float)(prev_count + 1);
+        node->value[e.index] = next_value;
+        node->value_s[e.index] = prev_value_s + (v - prev_value) * (v - next_value);
+        node->vcount[e.index].fetch_sub(kVlossCnt, std::memory_order_relaxed);
+        node->lock.unlock();
+    }
+    return DGNN_OK;
+}
+
+int dgnn_tree_node_child(const dgnn_tree_node* handle, int index, int* count, int* vcount, float* value, float* value_std_out,
+                         int* has_child)
+{
+    if (!handle || index < 0 || index >= kMoves) return DGNN_BAD_ARGUMENT;
+    const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
+    if (count) *count = node->count[index].load();
+    if (vcount) *vcount = node->vcount[index].load();
+    if (value) *value = node->value[index];
+    if (value_std_out) *value_std_out = value_std(node, index);
+    if (has_child) *has_child = node->ptr[index].load() != nullptr;
+    return DGNN_OK;
+}
+
+int dgnn_tree_node_info(const dgnn_tree_node* handle, int* to_move, int* total_count, int* vtotal_count, int* pass_count,
+                        float* initial_value)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
+    if (to_move) *to_move = node->to_move;
+    if (total_count) *total_count = node->total_count.load();
+    if (vtotal_count) *vtotal_count = node->vtotal_count.load();
+    if (pass_count) *pass_count = node->pass_count;
+    if (initial_value) *initial_value = node->initial_value;
+    return DGNN_OK;
+}
+
+int dgnn_tree_node_prior(const dgnn_tree_node* handle, float* prior_out)
+{
+    if (!handle || !prior_out) return DGNN_BAD_ARGUMENT;
+    std::memcpy(prior_out, reinterpret_cast<const TreeNode*>(handle)->prior, kMoves * sizeof(float));
+    return DGNN_OK;
+}
+
+int dgnn_tree_node_disqualify(dgnn_tree_node* handle, int index)             // tree.rs:1315-1320
+{
+    if (!handle || index < 0 || index >= kMoves) return DGNN_BAD_ARGUMENT;
+    TreeNode* node = reinterpret_cast<TreeNode*>(handle);
+    node->value[index] = -std::numeric_limits<float>::infinity();
+    node->count[index].store(0);
+    return DGNN_OK;
+}
+
+int dgnn_tree_node_softmax(const dgnn_tree_node* handle, float* out)         // tree.rs:1293-1307
+{
+    if (!handle || !out) return DGNN_BAD_ARGUMENT;
+    const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
+    float total = 0.0f;
+    for (int i = 0; i < kMoves; ++i) total += (float)node->count[i].load();
+    for (int i = 0; i < kMoves; ++i) {
+        const int c = node->count[i].load();
+        out[i] = c != 0 ? (float)c / total : 0.0f;
+    }
+    return DGNN_OK;
+}
+
+// choose, libdg_mcts/choose.rs:23-106 on integer visit counts
+int dgnn_choose(const int* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out)
+{
+    if (!items || n <= 0 || !index_out) return DGNN_BAD_ARGUMENT;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += (double)items[i];
+    // percentile: walk the items from the largest down until (1 - cutoff) of the total is covered
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a] < items[b]; });
+    const double max_value = total * (1.0 - cutoff_percentile);
+    double so_far = 0.0;
+    int threshold = 0;
+    bool found = false;
+    for (int k = n - 1; k >= 0; --k) {
+        so_far += (double)items[order[k]];
+        if (so_far >= max_value) { threshold = items[order[k]]; found = true; break; }
+    }
+    if (!found) return 0;
+    const double kept_total = so_far;
+    std::vector<double> cum(n, std::numeric_limits<double>::quiet_NaN());
+    double cum_total = 0.0;
+    for (int i = 0; i < n; ++i)
+        if (items[i] >= threshold) { cum_total += std::pow((double)items[i] / kept_total, temperature); cum[i] = cum_total; }
+    const double target = at * cum_total;
+    for (int i = 0; i < n; ++i)
+        if (cum[i] >= target) { *index_out = i; if (cum_out) *cum_out = cum[i]; return 1; }
+    return 0;
+}
+
+int dgnn_tree_node_best(const dgnn_tree_node* handle, float temperature, double at, float* value_out, int* index_out)
+{
+    if (!handle || !value_out || !index_out) return DGNN_BAD_ARGUMENT;
+    const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
+    if (temperature <= 9e-2f) {                                              // greedy, tree.rs:1263-1268
+        int best = -1;
+        for (int i = 0; i < kMoves; ++i) {
+            if (node->count[i].load() == 0) continue;                        // children.nonzero()
+            if (best < 0 || compare_children(node, best, i) <= 0) best = i;  // Iterator::max_by keeps the LAST maximum
+        }
+        if (best < 0) best = kMoves - 1;
+        *index_out = best;
+        *value_out = node->value[best];
+        return DGNN_OK;
+    }
+    int visits[kMoves];
+    for (int i = 0; i < kMoves; ++i) visits[i] = node->count[i].load();
+    int chosen = 0;
+    if (dgnn_choose(visits, kMoves, 0.5, 1.0 / (double)temperature, at, &chosen, nullptr) == 1) {
+        *index_out = chosen;
+        *value_out = node->value[chosen];
+    } else {
+        *index_out = kMoves - 1;                                             // no valid moves, tree.rs:1279
+        *value_out = node->initial_value;
+    }
+    return DGNN_OK;
+}
+
+}  // extern "C"

@@ -280,6 +280,91 @@ int dgnn_b85_decode(const char* text, size_t len, uint8_t* out, size_t capacity,
 size_t dgnn_sgf_played(char* out, size_t capacity, int color, int packed_index, int num_rollout, const float* softmax,
                        int has_value, float value, int prior_index, const char* explain);
 
+/* ============================================================================================================
+ * Search tree (scope row f-2, first part), tree.cpp: dream-go's PUCT tree with first-play urgency, virtual loss and
+ * the "expanding" flag (src/libdg_mcts/tree.rs), without any Go knowledge: legality is in the prior (-inf), the board
+ * is a callback that is told which stones the descent places.
+ * ============================================================================================================ */
+#define DGNN_COLOR_BLACK 0
+#define DGNN_COLOR_WHITE 1
+#define DGNN_PROBE_FOUND      1     /* ProbeResult::Found    (tree.rs:996-1004) */
+#define DGNN_PROBE_NO_RESULT  0     /* ProbeResult::NoResult: no child with a finite value */
+#define DGNN_PROBE_CONFLICT  -7     /* ProbeResult::Conflict: the chosen child is being expanded by somebody else */
+
+typedef struct dgnn_tree_node dgnn_tree_node;   /* Node, tree.rs:1027-1051 */
+typedef struct dgnn_trace dgnn_trace;           /* NodeTrace = Vec<(node, colour, child index)>, tree.rs:1387 */
+typedef struct dgnn_board_ops {
+    void (*place)(void* board, int color, int packed_index);   /* Board::place during the descent, tree.rs:1452 */
+} dgnn_board_ops;
+
+/* config::get_uct_exp / get_fpu_reduce / get_lcb_critical_value / VLOSS_CNT and the interpolation they use
+ * (src/libdg_utils/config.rs:181-195, 289-330). */
+float dgnn_config_uct_exp(int visits);
+float dgnn_config_fpu_reduce(int visits);
+float dgnn_config_lcb_critical_value(int visits);
+int dgnn_config_vloss_cnt(void);
+float dgnn_intp_value(const int* xs, const float* ys, int n, int x);
+/* asm::argmax_f32 (src/libdg_mcts/asm/argmax.rs:24-78), n a multiple of 8; -1 when the maximum is not finite. */
+int dgnn_argmax_f32(const float* values, int n);
+
+/* Node::new(to_move, value, prior[>= 362]) (tree.rs:1070-1090); a node owns its sub-tree. */
+dgnn_tree_node* dgnn_tree_node_new(int to_move, float value, const float* prior);
+void dgnn_tree_node_free(dgnn_tree_node* node);
+/* probe (tree.rs:1421-1470): returns DGNN_PROBE_FOUND with *out = the trace, DGNN_PROBE_NO_RESULT or DGNN_PROBE_CONFLICT
+ * (virtual losses of the partial descent undone).  ops / board may be NULL. */
+int dgnn_tree_probe(dgnn_tree_node* root, const dgnn_board_ops* ops, void* board, dgnn_trace** out);
+int dgnn_trace_len(const dgnn_trace* trace);
+int dgnn_trace_get(const dgnn_trace* trace, int i, dgnn_tree_node** node, int* color, int* index);
+void dgnn_trace_free(dgnn_trace* trace);
+/* undo (tree.rs:1397-1409) and insert + UCT::update (tree.rs:1482-1510, 125-160); neither frees the trace. */
+int dgnn_tree_undo(dgnn_trace* trace, int undo_expanding);
+int dgnn_tree_insert(const dgnn_trace* trace, int color, float value /* win rate of `color`, 0..1 */, const float* prior);
+/* Child / Node accessors (tree.rs:326-358, 1027-1051). */
+int dgnn_tree_node_child(const dgnn_tree_node* node, int index, int* count, int* vcount, float* value, float* value_std, int* has_child);
+int dgnn_tree_node_info(const dgnn_tree_node* node, int* to_move, int* total_count, int* vtotal_count, int* pass_count, float* initial_value);
+int dgnn_tree_node_prior(const dgnn_tree_node* node, float* prior_out /* 362 */);
+int dgnn_tree_node_disqualify(dgnn_tree_node* node, int index);                              /* tree.rs:1315-1320 */
+int dgnn_tree_node_softmax(const dgnn_tree_node* node, float* out /* 362 */);                 /* tree.rs:1293-1307 */
+/* Node::best (tree.rs:1262-1283): greedy (LCB / visits / prior / value order) when temperature <= 0.09, else a visit-
+ * proportional draw with `at` in [0, 1) standing in for thread_rng(). */
+int dgnn_tree_node_best(const dgnn_tree_node* node, float temperature, double at, float* value_out, int* index_out);
+/* choose (src/libdg_mcts/choose.rs:54-88) on integer weights: 1 and *index_out / *cum_out when an item was chosen. */
+int dgnn_choose(const int* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out);
+
+/* ---- search driver (scope row f-2, second part), search.cpp ------------------------------------------------- */
+
+/* Predictor::predict (src/libdg_mcts/predictor.rs:92) as a C callback: n boards of 11552 fp16 features ->
+ * value[n], policy[n * 362] fp16; returns a DGNN_* status. */
+typedef int (*dgnn_predict_fn)(void* ctx, const uint16_t* features, int n, uint16_t* value_out, uint16_t* policy_out);
+dgnn_predict_fn dgnn_pool_predictor(void);    /* ctx = a dgnn_pool*: the HIP engine behind the cross-caller batcher */
+dgnn_predict_fn dgnn_hash_predictor(void);    /* ctx unused: deterministic CPU stand-in (role of predictors/{random,fake}.rs) */
+
+/* The game behind the search: what libdg_go provides in the reference (Board::clone / place,
+ * features::V1::get_features, the policy checker of pool/policy_helper.rs:36-48, symmetry::is_symmetric). */
+typedef struct dgnn_game_ops {
+    void* (*clone)(void* board);
+    void (*destroy)(void* board);
+    void (*place)(void* board, int color, int packed_index);                       /* 361 = pass is never placed */
+    void (*features)(void* board, int to_move, int symmetry, uint16_t* out /* 11552 */);
+    void (*candidates)(void* board, int to_move, unsigned char* out /* 362: 1 = may be searched */);
+    int (*is_symmetric)(void* board, int symmetry);                                /* may be NULL: no elimination */
+} dgnn_game_ops;
+
+/* One search on `root` from `board` (not modified): rollouts until root.total_count >= num_rollouts
+ * (pool/worker_thread.rs:50-176 + time_control/rollout_limit.rs:35-44).  All randomness derives from `seed`; with
+ * num_threads == 1 the resulting visit counts are a pure function of the seed and the predictor's outputs. */
+int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
+                    int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out);
+
+/* A rule-free synthetic game for throughput measurements (NOT Go: every empty point is legal, nothing is captured,
+ * features are pseudo-random bits of the position hash) and a self-play loop over it. */
+const dgnn_game_ops* dgnn_synthetic_game_ops(void);
+void* dgnn_synthetic_board_new(uint64_t seed);
+void dgnn_synthetic_board_free(void* board);
+typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, evals, conflicts; } dgnn_selfplay_stats;
+int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
+                            int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats);
+
 /* Library version / build info string (static). */
 const char* dgnn_version(void);
 

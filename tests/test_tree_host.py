@@ -1,0 +1,201 @@
+"""The search tree (scope row f-2, first part) through the C ABI, pinned to the reference's own tests:
+
+    src/libdg_mcts/tree.rs:1773-1946      visit_order, virtual_loss, value_update, undo_trace
+    src/libdg_utils/config.rs:352-375     intp_out_of_bounds_1/2, intp_lower_edge, intp_upper_edge, intp_mid
+    src/libdg_mcts/choose.rs:108-140      choose_1, choose_2
+
+The reference's tests run on an empty board, where every point is a legal move: the prior carries no -inf and the board
+callback has nothing to do, so the tree can be exercised without any Go rules.
+"""
+import numpy as np
+
+
+def _prior_distribution(rng):
+    """get_prior_distribution (tree.rs:1758-1771) on an empty board: random, normalised over the finite entries."""
+    prior = rng.random(368).astype(np.float32)
+    return prior / prior.sum()
+
+
+def test_visit_order(api):
+    """tree.rs:1773-1823."""
+    rng = np.random.default_rng(1)
+    root = api.Node(api.BLACK, 0.5, _prior_distribution(rng))
+    vloss = api.config.VLOSS_CNT
+    choices = []
+    prior = root.prior
+    while True:
+        trace = api.probe(root)
+        if isinstance(trace, api.Trace):
+            assert len(trace) == 1
+            i = trace[0][2]
+            assert i not in choices                     # never re-visit a child that has not finished expanding
+            choices.append(i)
+            assert root.with_(i).vcount() == vloss      # the virtual loss has been applied
+            assert root.vtotal_count == len(choices) * vloss
+            assert all(prior[o] >= prior[i] for o in choices)   # visited in the order of the prior
+        else:
+            assert all(root.with_(o).vcount() == vloss for o in choices)   # no virtual loss was added twice
+            assert root.vtotal_count == len(choices) * vloss
+            break
+        assert len(choices) <= 362
+    # the walk ends when a visited high-prior child (bonus / 33) outranks every unvisited one and is still "expanding"
+    assert 300 < len(choices) <= 362 and trace == api.PROBE_CONFLICT
+
+
+def test_virtual_loss(api):
+    """tree.rs:1825-1860."""
+    rng = np.random.default_rng(2)
+    root = api.Node(api.BLACK, 0.5, _prior_distribution(rng))
+    vloss = api.config.VLOSS_CNT
+    trace = api.probe(root)
+    i = trace[0][2]
+    assert root.with_(i).vcount() == vloss and root.vtotal_count == vloss
+    api.insert(trace, api.BLACK, 0.9, _prior_distribution(rng))
+    assert root.with_(i).vcount() == 0 and root.vtotal_count == 0
+    assert root.with_(i).count() == 1 and root.total_count == 1
+
+
+def test_value_update(api):
+    """tree.rs:1862-1925: two parallel probes below a pre-expanded child; incremental mean 0.9 -> 0.85 -> 0.8."""
+    vloss = api.config.VLOSS_CNT
+    root = api.Node(api.BLACK, 0.5, [1.0 if i == 60 else 0.0 for i in range(362)])
+    other_prior = [0.5 if i in (61, 62) else 0.0 for i in range(362)]
+    trace = api.probe(root)
+    api.insert(trace, api.BLACK, 0.9, other_prior)
+    assert 0.8999 <= root.with_(60).value() <= 0.9001
+    assert root.with_(60).count() == 1 and root.total_count == 1
+    assert root.with_(60).vcount() == 0 and root.vtotal_count == 0
+
+    trace_1, trace_2 = api.probe(root), api.probe(root)
+    assert trace_1[0][2] == 60 and trace_2[0][2] == 60
+    assert 61 in (trace_1[1][2], trace_2[1][2]) and 62 in (trace_1[1][2], trace_2[1][2])
+    # the value of the root's child is unchanged, only its virtual loss grew
+    assert root.with_(60).value() == np.float32(0.9)
+    assert root.with_(60).count() == 1 and root.total_count == 1
+    assert root.with_(60).vcount() == 2 * vloss and root.vtotal_count == 2 * vloss
+
+    api.insert(trace_1, api.WHITE, 0.2, other_prior)       # white at 0.2 is black at 0.8: (0.9 + 0.8) / 2
+    assert root.with_(60).value() == np.float32(0.85)
+    assert root.with_(60).count() == 2 and root.total_count == 2
+    assert root.with_(60).vcount() == vloss and root.vtotal_count == vloss
+
+    api.insert(trace_2, api.WHITE, 0.3, other_prior)
+    assert root.with_(60).value() == np.float32(0.8)
+    assert root.with_(60).count() == 3 and root.total_count == 3
+    assert root.with_(60).vcount() == 0 and root.vtotal_count == 0
+
+
+def test_undo_trace(api):
+    """tree.rs:1927-1945: the second probe hits the child the first one is still expanding and is undone."""
+    root = api.Node(api.BLACK, 0.5, [1.0 if i == 60 else 0.0 for i in range(362)])
+    assert isinstance(api.probe(root), api.Trace)
+    assert api.probe(root) == api.PROBE_CONFLICT
+    assert root.vtotal_count == api.config.VLOSS_CNT
+
+
+def test_undo_restores_the_expanding_flag(api):
+    """undo(trace, true) (tree.rs:1397-1409, used when a worker gives a probe up): the child can be chosen again."""
+    root = api.Node(api.BLACK, 0.5, [1.0 if i == 60 else 0.0 for i in range(362)])
+    trace = api.probe(root)
+    api.undo(trace, True)
+    assert root.vtotal_count == 0 and root.with_(60).vcount() == 0
+    again = api.probe(root)
+    assert isinstance(again, api.Trace) and again[0][2] == 60
+
+
+def test_no_result_when_every_prior_is_minus_infinity(api):
+    root = api.Node(api.BLACK, 0.5, [-np.inf] * 362)
+    assert api.probe(root) == api.PROBE_NO_RESULT
+
+
+def test_intp(api):
+    """config.rs:352-375."""
+    pts = [(0, 0.0), (100, 1.0)]
+    g = api.config.get_intp_value
+    assert g(pts, -100) == 0.0 and g(pts, 200) == 1.0 and g(pts, 0) == 0.0 and g(pts, 100) == 1.0
+    assert g(pts, 40) == np.float32(0.4)
+    # the shipped tables (config.rs:181-195) at their knots
+    assert api.config.get_uct_exp(0) == np.float32(0.77392) and api.config.get_uct_exp(800) == np.float32(1.05439)
+    assert api.config.get_fpu_reduce(6400) == np.float32(0.514494) and api.config.get_fpu_reduce(10 ** 6) == np.float32(0.514494)
+    assert api.config.get_lcb_critical_value(1600) == np.float32(1.86943)
+    assert api.config.VLOSS_CNT == 32
+
+
+def test_choose(api):
+    """choose.rs:108-140."""
+    assert api.choose([2, 1, 4, 3], 0.5, 1.0, 0.0) == (2, 4.0 / 7.0)
+    assert api.choose([4, 3, 2, 1], 0.5, 1.0, 1.0) == (1, 1.0)
+
+
+def test_argmax(api):
+    """asm/argmax.rs: first maximal element of the last 8-group that holds one; None when nothing is finite."""
+    v = np.full(368, -np.inf, dtype=np.float32)
+    assert api.argmax_f32(v) is None
+    v[5] = 1.0; v[100] = 3.0; v[200] = 2.0
+    assert api.argmax_f32(v) == 100
+    v[102] = 3.0                                       # same group: the first one wins
+    assert api.argmax_f32(v) == 100
+    v[300] = 3.0                                       # a later group with the same maximum wins
+    assert api.argmax_f32(v) == 300
+
+
+def test_best_and_softmax_follow_the_visit_counts(api):
+    """Node::softmax (tree.rs:1293-1307) and the greedy Node::best (tree.rs:1263-1268, compare_children :1524-1560)."""
+    prior = np.zeros(362, dtype=np.float32); prior[10] = 0.6; prior[20] = 0.4
+    root = api.Node(api.BLACK, 0.5, prior)
+    child_prior = np.full(362, 1.0 / 362, dtype=np.float32)
+    for value in (0.7, 0.6, 0.8, 0.4, 0.5, 0.9):
+        trace = api.probe(root)
+        api.insert(trace, api.WHITE if len(trace) % 2 else api.BLACK, value, child_prior)
+    counts = np.array([root.with_(i).count() for i in range(362)])
+    assert counts.sum() == 6 and counts[10] + counts[20] == 6
+    assert np.allclose(root.softmax(), counts / 6.0)
+    value, index = root.best(0.0)
+    assert index == int(np.argmax(counts)) and value == root.with_(index).value()
+    root.disqualify(index)                             # tree.rs:1315-1320
+    assert root.with_(index).count() == 0 and root.best(0.0)[1] != index
+    # temperature: a visit-proportional draw, `at` stands in for thread_rng() (tree.rs:1269-1281)
+    assert root.best(1.0, at=0.0)[1] in (10, 20)
+
+
+# ---- search driver (search.cpp) with the deterministic CPU stand-in for the network -----------------------------------
+
+def _visit_counts(root):
+    return np.array([root.with_(i).count() for i in range(362)])
+
+
+def _fresh_root(api):
+    prior = np.full(362, 1.0 / 362, dtype=np.float32)
+    return api.Node(api.BLACK, 0.5, prior)
+
+
+def test_seeded_single_thread_search_is_reproducible(api):
+    """The determinism the reference does not have (it draws from thread_rng everywhere): with one
+    search thread the visit counts are a pure function of the seed and the predictor's outputs."""
+    runs = []
+    for seed in (7, 7, 8):
+        root = _fresh_root(api)
+        evals, conflicts = api.search_run(root, api.SyntheticBoard(123), num_rollouts=200, num_threads=1, seed=seed)
+        assert evals == 200 and conflicts == 0 and root.total_count == 200 and root.vtotal_count == 0
+        runs.append(_visit_counts(root))
+    assert np.array_equal(runs[0], runs[1])
+    assert not np.array_equal(runs[0], runs[2])           # another seed draws other symmetries
+    assert runs[0].sum() == 200
+
+
+def test_multi_threaded_search_keeps_the_tree_consistent(api):
+    """Several threads in one tree (virtual loss + the expanding flag): every virtual loss is returned, every rollout
+    is counted once, the search stops within threads - 1 rollouts of the limit (worker_thread.rs:144-146)."""
+    root = _fresh_root(api)
+    evals, conflicts = api.search_run(root, api.SyntheticBoard(5), num_rollouts=400, num_threads=8, seed=1)
+    assert 400 <= root.total_count <= 400 + 7 and root.total_count == evals
+    assert root.vtotal_count == 0
+    counts = _visit_counts(root)
+    assert counts.sum() == root.total_count and all(root.with_(i).vcount() == 0 for i in np.nonzero(counts)[0])
+    assert np.isclose(root.softmax().sum(), 1.0)
+
+
+def test_synthetic_selfplay_counts_every_evaluation(api):
+    stats = api.selfplay_synthetic(num_games=3, num_moves=4, num_rollouts=20, threads_per_search=2, seed=11)
+    assert stats["games"] == 3 and stats["moves"] == 12
+    assert 12 * 21 <= stats["evals"] <= 12 * (21 + 1)      # 20 rollouts (+ up to threads - 1) + the root evaluation
