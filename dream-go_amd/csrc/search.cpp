@@ -99,7 +99,7 @@ void search_worker(SearchShared* s, uint64_t seed)
         if (r == DGNN_PROBE_CONFLICT) {                                      // worker_thread.rs:161-163: try again
             s->ops->destroy(board);
             s->conflicts.fetch_add(1, std::memory_order_relaxed);
-            if (++idle_conflicts > 64) std::this_thread::yield();
+            if (++idle_conflicts > 2) std::this_thread::yield();   // somebody else is expanding what we want: let them
             continue;
         }
         idle_conflicts = 0;
