@@ -155,7 +155,14 @@ SYMBOLS = [
     ("dgnn_go_is_symmetric", ctypes.c_int, [_vp, ctypes.c_int]),
     ("dgnn_go_features", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u16p]),
     ("dgnn_go_game_ops", _vp, []),
-    ("dgnn_selfplay_go", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vp, _ip]),
+    ("dgnn_selfplay_go", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vp, _ip,
+                                        ctypes.c_char_p, ctypes.c_size_t]),
+    ("dgnn_search_run_cached", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_full_forward", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _fp, _fp]),
+    ("dgnn_dirichlet_add", None, [_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64]),
+    ("dgnn_tree_node_forward", _vp, [_vp, ctypes.c_int]),
+    ("dgnn_tree_node_set_prior", ctypes.c_int, [_vp, _fp]),
     ("dgnn_pool_create", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
     ("dgnn_pool_destroy", None, [_vp]),
     ("dgnn_pool_predict", ctypes.c_int, [_vp, _u16p, ctypes.c_int, _u16p, _u16p]),
@@ -794,6 +801,20 @@ class Node:
     def disqualify(self, index):
         _check(lib.dgnn_tree_node_disqualify(self._handle, int(index)), "Node.disqualify")
 
+    def forward(self, index):
+        """Node::forward (tree.rs:1225-1250): consumes this node, returns the sub-tree below `index` as the new root (or None)."""
+        handle = lib.dgnn_tree_node_forward(self._handle, int(index))
+        self._handle = None
+        if not handle:
+            return None
+        node = Node.__new__(Node)
+        node._handle = handle
+        return node
+
+    def set_prior(self, prior):
+        p = np.ascontiguousarray(prior, dtype=np.float32).reshape(-1)
+        _check(lib.dgnn_tree_node_set_prior(self._handle, p.ctypes.data_as(_fp)), "Node.set_prior")
+
     def softmax(self):
         out = np.empty(NUM_MOVES, dtype=np.float32)
         _check(lib.dgnn_tree_node_softmax(self._handle, out.ctypes.data_as(_fp)), "Node.softmax")
@@ -838,7 +859,7 @@ def undo(trace, undo_expanding):
 
 class SelfplayStats(ctypes.Structure):
     _fields_ = [("seconds", ctypes.c_double), ("games", ctypes.c_uint64), ("moves", ctypes.c_uint64),
-                ("evals", ctypes.c_uint64), ("conflicts", ctypes.c_uint64)]
+                ("evals", ctypes.c_uint64), ("conflicts", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64)]
 
 
 class SyntheticBoard:
@@ -884,14 +905,38 @@ def _predictor(pool):
     return lib.dgnn_pool_predictor(), pool._handle
 
 
-def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None):
-    """One search on `root` from a Board or a SyntheticBoard (worker_thread.rs:50-176 for a single search) -> (evals, conflicts)."""
+def _game_ops(board):
+    return lib.dgnn_go_game_ops() if isinstance(board, Board) else lib.dgnn_synthetic_game_ops()
+
+
+def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None, cache=None):
+    """One search on `root` from a Board or a SyntheticBoard (worker_thread.rs:50-176 for a single search) ->
+    (predictor calls, probe conflicts), or (predictor calls, probe conflicts, cache hits) when a LruCache is given."""
     fn, ctx = _predictor(pool)
-    evals, conflicts = ctypes.c_uint64(), ctypes.c_uint64()
-    ops = lib.dgnn_go_game_ops() if isinstance(board, Board) else lib.dgnn_synthetic_game_ops()
-    _check(lib.dgnn_search_run(root._handle, ops, board._handle, fn, ctx, int(num_rollouts),
-                               int(num_threads), int(seed), ctypes.byref(evals), ctypes.byref(conflicts)), "search_run")
-    return evals.value, conflicts.value
+    evals, conflicts, hits = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    _check(lib.dgnn_search_run_cached(root._handle, _game_ops(board), board._handle, fn, ctx, cache._handle if cache is not None else None,
+                                      int(num_rollouts), int(num_threads), int(seed), ctypes.byref(evals), ctypes.byref(conflicts),
+                                      ctypes.byref(hits)), "search_run")
+    return (evals.value, conflicts.value) if cache is None else (evals.value, conflicts.value, hits.value)
+
+
+def full_forward(board, to_move, pool=None, cache=None):
+    """dg_mcts::full_forward (src/libdg_mcts/lib.rs:83-130) -> (win rate, prior [362] with -inf for non-candidates, symmetries evaluated)."""
+    fn, ctx = _predictor(pool)
+    value = ctypes.c_float()
+    policy = np.empty(368, dtype=np.float32)
+    n = lib.dgnn_full_forward(_game_ops(board), board._handle, int(to_move), fn, ctx, cache._handle if cache is not None else None,
+                              ctypes.byref(value), policy.ctypes.data_as(_fp))
+    if n < 0:
+        raise Error(n, "full_forward")
+    return value.value, policy[:NUM_MOVES].copy(), n
+
+
+def dirichlet_add(x, shape, beta, seed):
+    """dg_mcts::dirichlet::add_ex (src/libdg_mcts/dirichlet.rs:40-70) with a seeded generator; returns a new array."""
+    v = np.array(x, dtype=np.float32).reshape(-1)
+    lib.dgnn_dirichlet_add(v.ctypes.data_as(_fp), v.size, float(shape), float(beta), int(seed))
+    return v
 
 
 def selfplay_synthetic(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None):
@@ -966,13 +1011,19 @@ class Board:
             pass
 
 
-def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, return_moves=False):
+def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
+                return_sgf=False):
     fn, ctx = _predictor(pool)
     stats = SelfplayStats()
     moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
-    _check(lib.dgnn_selfplay_go(fn, ctx, int(num_games), int(num_moves), int(num_rollouts), int(threads_per_search), int(seed),
-                                ctypes.byref(stats), moves.ctypes.data_as(_ip) if moves is not None else None), "selfplay_go")
-    out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts}
+    sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 128)) if return_sgf else None
+    _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, int(num_games), int(num_moves), int(num_rollouts),
+                                int(threads_per_search), int(seed), ctypes.byref(stats), moves.ctypes.data_as(_ip) if moves is not None else None,
+                                sgf, len(sgf) if sgf is not None else 0), "selfplay_go")
+    out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts,
+           "cache_hits": stats.cache_hits}
     if return_moves:
         out["record"] = moves.reshape(num_games, num_moves)
+    if return_sgf:
+        out["sgf"] = sgf.value.decode("ascii").splitlines()
     return out

@@ -115,6 +115,11 @@ constexpr size_t kZeroPageBytes = 256;   // the image starts with a page of zero
 // Builds topo + image from tensors.  Returns a DGNN_* status.
 int build_network(Network& net);
 
+// search.cpp: pool/policy_helper.rs:28-134 on the game callbacks
+void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, float* policy, int* indices);
+void add_valid_candidates(float* dst, const uint16_t* src_f16, const int* indices, int transform);
+void normalize_policy(float* policy, float sum_to);
+
 // thread-local HIP error detail
 void set_last_hip_error(int code);
 

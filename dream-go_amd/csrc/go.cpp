@@ -17,7 +17,11 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <cmath>
+#include <cstdio>
+#include <limits>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -368,7 +372,8 @@ int go_is_symmetric(void* b, int symmetry)                                    //
     for (int p = 0; p < kPoints; ++p) if (g->inner.stone[p] != g->inner.stone[dgnn_symmetry_apply(symmetry, p)]) return 0;
     return 1;
 }
-const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric};
+uint64_t go_hash(void* b) { return static_cast<GoBoard*>(b)->hash; }      // BoardTuple, predictors/nn.rs:31-45
+const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric, go_hash};
 
 struct Rng2 {
     uint64_t state;
@@ -429,54 +434,88 @@ int dgnn_go_is_symmetric(const dgnn_go_board* b, int symmetry) { return (b && sy
 
 const dgnn_game_ops* dgnn_go_game_ops(void) { return &kGoOps; }
 
-// Self-play with the real board, ladders, super-ko and feature planes, every network call through `predict`.  What is NOT
-// the reference's self_play_one (self_play.rs:423-459): no scoring (is_scorable / Benson), so passing is disqualified and a
-// game is `num_moves` stones long (or ends when nothing is legal); no resignation, tree re-use, dirichlet noise or 8-fold
-// root ensemble.  Results are move sequences, returned as packed indices when `moves_out` (num_games * num_moves) is given.
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
-                     int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out)
+// Self-play on the real board, following self_play_one / Player::predict / predict (src/libdg_mcts/self_play.rs:423-459,
+// 331-368, lib.rs:144-200): random komi, per-player trees re-used across moves (Node::forward), win-rate driven rollout
+// budget max(0.1, 4w(1-w)) * num_rollouts, 8-symmetry root evaluation through the transposition cache, dirichlet noise on
+// the root prior, temperature 0.8 for the first eight stones, every network call through `predict`.
+// What is missing: scoring (is_scorable / Benson / ScoringSearch), so passing is disqualified at every move and a game is
+// `num_moves` stones long (or ends when nothing is legal); resignation; expert iteration.
+// moves_out (num_games * num_moves packed indices, -1 = not played) and sgf_out (one "(;GM[1]FF[4]SZ[19]KM[..]...)" record
+// per game, newline separated, cut off at sgf_capacity) may be NULL.
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_moves, int num_rollouts,
+                     int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
 {
     if (!predict || num_games <= 0 || num_moves <= 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats) return DGNN_BAD_ARGUMENT;
-    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0};
+    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0};
     std::atomic<int> status{DGNN_OK};
+    std::vector<std::string> records((size_t)num_games);
     const auto t0 = std::chrono::steady_clock::now();
 
     auto game = [&](int g) {
         Rng2 rng{seed + 0x9e3779b97f4a7c15ull * (uint64_t)(g + 1)};
-        GoBoard board(7.5f);
-        int to_move = DGNN_COLOR_BLACK;
-        std::vector<uint16_t> features(DGNN_FEATURE_SIZE), policy(DGNN_NUM_MOVES);
+        const double kv = rng.uniform();                                       // get_random_komi, lib.rs:210-224
+        const float komi = kv < 0.4 ? 7.5f : kv < 0.8 ? 6.5f : kv < 0.9 ? 0.5f : (float)((int)(rng.next() % 16) - 8) + 0.5f;
+        GoBoard board(komi);
+        dgnn_tree_node* roots[2] = {nullptr, nullptr};                         // Player::root of black / white
+        float winrate[2] = {0.5f, 0.5f};                                       // MovingAverage::new(0.5, 0.2)
+        char header[64];
+        std::snprintf(header, sizeof(header), "(;GM[1]FF[4]SZ[19]RU[Chinese]KM[%.1f]", (double)komi);   // game_result.rs:33,40 without DT / RE
+        std::string& sgf = records[(size_t)g];
+        sgf = header;
         if (moves_out) for (int m = 0; m < num_moves; ++m) moves_out[(size_t)g * num_moves + m] = -1;
-        for (int m = 0; m < num_moves && status.load() == DGNN_OK; ++m) {
-            unsigned char candidate[DGNN_NUM_MOVES];
-            go_candidates(&board, to_move, candidate);
-            float prior[368];
-            uint16_t value = 0;
-            features_v1(board, to_move, 0, features.data());
-            int st = predict(predict_ctx, features.data(), 1, &value, policy.data());
-            if (st != DGNN_OK) { status.store(st); break; }
-            float sum = 0.0f;
-            int legal = 0;
-            for (int i = 0; i < 368; ++i) prior[i] = -std::numeric_limits<float>::infinity();
-            for (int i = 0; i < kPoints; ++i) if (candidate[i]) { prior[i] = half_to_float(policy[i]); sum += prior[i]; ++legal; }
-            if (legal == 0) break;                                             // nothing but passing is left
-            for (int i = 0; i < kPoints; ++i) if (candidate[i]) prior[i] = sum > 1e-6f ? prior[i] / sum : 1.0f / (float)legal;
-            dgnn_tree_node* root = dgnn_tree_node_new(to_move, 0.5f * half_to_float(value) + 0.5f, prior);   // pass stays -inf
-            uint64_t e = 0, c = 0;
-            st = dgnn_search_run(root, &kGoOps, &board, predict, predict_ctx, num_rollouts, threads_per_search, rng.next(), &e, &c);
-            evals.fetch_add(e + 1);
+
+        for (int m = 0; m < num_moves && m < 722 && status.load() == DGNN_OK; ++m) {
+            const int me = m & 1;                                              // black starts, no passes: colours alternate
+            const float w = winrate[me];
+            const float scale = std::max(0.1f, 4.0f * w * (1.0f - w));        // Player::num_rollout, self_play.rs:234-241
+            const int limit = std::max(2, (int)(scale * (float)num_rollouts));
+
+            float value = 0.0f, prior[368];
+            int st = dgnn_full_forward(&kGoOps, &board, me, predict, predict_ctx, cache, &value, prior);   // lib.rs:154-159
+            if (st < 0) { status.store(st); break; }
+            evals.fetch_add((uint64_t)st);
+            prior[kPass] = -std::numeric_limits<float>::infinity();            // allow_pass == false (no scoring yet)
+            bool any = false;
+            for (int i = 0; i < kPoints; ++i) any = any || std::isfinite(prior[i]);
+            if (!any) break;
+            normalize_policy(prior, 1.0f);
+            dgnn_dirichlet_add(prior, DGNN_NUM_MOVES, 0.03f, 0.25f, rng.next());   // lib.rs:163-165
+
+            dgnn_tree_node* root = roots[me];                                  // lib.rs:170-186: re-use the tree or start one
+            roots[me] = nullptr;
+            if (root) dgnn_tree_node_set_prior(root, prior);
+            else root = dgnn_tree_node_new(me, value, prior);
+            dgnn_tree_node_disqualify(root, kPass);                            // self_play.rs:253-256
+            uint64_t e = 0, c = 0, h = 0;
+            st = dgnn_search_run_cached(root, &kGoOps, &board, predict, predict_ctx, cache, limit, threads_per_search, rng.next(), &e, &c, &h);
+            evals.fetch_add(e);
             conflicts.fetch_add(c);
+            hits.fetch_add(h);
             if (st != DGNN_OK) { status.store(st); dgnn_tree_node_free(root); break; }
+
             float best_value = 0.0f;
             int best = kPass;
             dgnn_tree_node_best(root, board.count < 8 ? 0.8f : 0.0f, rng.uniform(), &best_value, &best);   // lib.rs:188-192
-            dgnn_tree_node_free(root);
-            if (best == kPass || !board.is_valid(to_move, best)) break;
-            board.place(to_move, best);
+            if (best == kPass || !board.is_valid(me, best)) { dgnn_tree_node_free(root); break; }
+
+            float softmax[DGNN_NUM_MOVES];                                      // Played::from_mcts -> the f-4 record
+            dgnn_tree_node_softmax(root, softmax);
+            int total = 0;
+            dgnn_tree_node_info(root, nullptr, &total, nullptr, nullptr, nullptr);
+            char move[2048];
+            dgnn_sgf_played(move, sizeof(move), me, best, total, softmax, 1, best_value, -1, "");
+            sgf += move;
+
+            winrate[me] -= 0.2f * (winrate[me] - best_value);                  // MovingAverage::update, self_play.rs:56-58
+            roots[me] = dgnn_tree_node_forward(root, best);                    // self_play.rs:366, 447
+            if (roots[1 - me]) roots[1 - me] = dgnn_tree_node_forward(roots[1 - me], best);
+            board.place(me, best);
             if (moves_out) moves_out[(size_t)g * num_moves + m] = best;
-            to_move = 1 - to_move;
             moves.fetch_add(1);
         }
+        sgf += ")";
+        dgnn_tree_node_free(roots[0]);
+        dgnn_tree_node_free(roots[1]);
     };
     std::vector<std::thread> threads;
     for (int g = 0; g < num_games; ++g) threads.emplace_back(game, g);
@@ -486,6 +525,17 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, int num_games, 
     stats->moves = moves.load();
     stats->evals = evals.load();
     stats->conflicts = conflicts.load();
+    stats->cache_hits = hits.load();
+    if (sgf_out && sgf_capacity > 0) {
+        size_t used = 0;
+        for (const std::string& r : records) {
+            if (used + r.size() + 2 > sgf_capacity) break;
+            std::memcpy(sgf_out + used, r.data(), r.size());
+            used += r.size();
+            sgf_out[used++] = '\n';
+        }
+        sgf_out[used] = '\0';
+    }
     return status.load();
 }
 

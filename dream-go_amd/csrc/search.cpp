@@ -34,16 +34,16 @@ struct Rng {      // splitmix64
     double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
 };
 
-// pool/policy_helper.rs:28-134 in one place
-void rebuild_prior(const dgnn_game_ops* ops, void* board, int to_move, int transform, const uint16_t* policy_f16, float* prior /*368*/)
+}  // namespace
+
+// pool/policy_helper.rs:28-76: legal candidates 0, everything else -inf; `indices` maps every point to the smallest index
+// among its images under the board's own symmetries (and the duplicates are set to -inf)
+void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, float* policy /*368*/, int* indices /*362*/)
 {
     unsigned char candidate[DGNN_NUM_MOVES];
     ops->candidates(board, to_move, candidate);
-    for (int i = 0; i < 368; ++i) prior[i] = -std::numeric_limits<float>::infinity();
-    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (candidate[i]) prior[i] = 0.0f;
-
-    // symmetric elimination: every point maps to the smallest index among its images under the board's own symmetries
-    int indices[DGNN_NUM_MOVES];
+    for (int i = 0; i < 368; ++i) policy[i] = -std::numeric_limits<float>::infinity();
+    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (candidate[i]) policy[i] = 0.0f;
     bool symmetric[8];
     for (int t = 0; t < 8; ++t) symmetric[t] = t == 0 || (ops->is_symmetric && ops->is_symmetric(board, t));
     indices[DGNN_NUM_POINTS] = DGNN_NUM_POINTS;
@@ -51,23 +51,35 @@ void rebuild_prior(const dgnn_game_ops* ops, void* board, int to_move, int trans
         int target = i;
         for (int t = 1; t < 8; ++t) if (symmetric[t]) target = std::min(target, dgnn_symmetry_apply(t, i));
         indices[i] = target;
-        if (target != i) prior[i] = -std::numeric_limits<float>::infinity();
+        if (target != i) policy[i] = -std::numeric_limits<float>::infinity();
     }
+}
 
-    // add_valid_candidates (policy_helper.rs:87-103): de-transform the network's policy to the identity orientation
+// policy_helper.rs:87-103: de-transform the network's policy to the identity orientation and add it
+void add_valid_candidates(float* dst, const uint16_t* src_f16, const int* indices, int transform)
+{
     const int inverse = dgnn_symmetry_inverse(transform);
-    prior[DGNN_NUM_POINTS] += half_to_float(policy_f16[DGNN_NUM_POINTS]);
-    for (int i = 0; i < DGNN_NUM_POINTS; ++i) {
-        const int j = indices[dgnn_symmetry_apply(inverse, i)];
-        prior[j] += half_to_float(policy_f16[i]);
-    }
+    dst[DGNN_NUM_POINTS] += half_to_float(src_f16[DGNN_NUM_POINTS]);
+    for (int i = 0; i < DGNN_NUM_POINTS; ++i) dst[indices[dgnn_symmetry_apply(inverse, i)]] += half_to_float(src_f16[i]);
+}
 
-    // normalize_policy (policy_helper.rs:112-134)
+void normalize_policy(float* policy, float sum_to)                            // policy_helper.rs:112-134
+{
     float sum = 0.0f;
     int finite = 0;
-    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(prior[i])) { sum += prior[i]; ++finite; }
-    if (sum < 1e-6f) { for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(prior[i])) prior[i] = 1.0f / (float)finite; }
-    else { for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(prior[i])) prior[i] /= sum; }
+    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(policy[i])) { sum += policy[i]; ++finite; }
+    if (sum < 1e-6f) { for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(policy[i])) policy[i] = sum_to / (float)finite; }
+    else { const float scale = sum / sum_to; for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(policy[i])) policy[i] /= scale; }
+}
+
+namespace {
+
+void rebuild_prior(const dgnn_game_ops* ops, void* board, int to_move, int transform, const uint16_t* policy_f16, float* prior /*368*/)
+{
+    int indices[DGNN_NUM_MOVES];
+    create_initial_policy(ops, board, to_move, prior, indices);
+    add_valid_candidates(prior, policy_f16, indices, transform);
+    normalize_policy(prior, 1.0f);
 }
 
 struct SearchShared {
@@ -76,9 +88,10 @@ struct SearchShared {
     void* board;
     dgnn_predict_fn predict;
     void* predict_ctx;
+    dgnn_cache* cache = nullptr;        // transposition table (needs ops->hash), may be NULL
     int limit;
     std::atomic<int> status{DGNN_OK};
-    std::atomic<uint64_t> evals{0}, conflicts{0};
+    std::atomic<uint64_t> evals{0}, conflicts{0}, cache_hits{0};
 };
 
 void search_worker(SearchShared* s, uint64_t seed)
@@ -109,9 +122,20 @@ void search_worker(SearchShared* s, uint64_t seed)
         dgnn_trace_get(trace, dgnn_trace_len(trace) - 1, nullptr, &last_color, nullptr);
         const int to_move = 1 - last_color;                                  // event.rs:48-49
         const int transform = (int)(rng.next() % 8);                         // event.rs:47
-        s->ops->features(board, to_move, transform, features.data());
         uint16_t value = 0;
-        const int status = s->predict(s->predict_ctx, features.data(), 1, &value, policy.data());
+        int status = DGNN_OK;
+        const bool cached = s->cache && s->ops->hash;
+        const uint64_t key = cached ? s->ops->hash(board) : 0;
+        if (cached && dgnn_cache_fetch(s->cache, key, to_move, transform, &value, policy.data()) == 1) {   // event.rs:50-51
+            s->cache_hits.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            s->ops->features(board, to_move, transform, features.data());
+            status = s->predict(s->predict_ctx, features.data(), 1, &value, policy.data());
+            if (status == DGNN_OK) {
+                s->evals.fetch_add(1, std::memory_order_relaxed);
+                if (cached) dgnn_cache_insert(s->cache, key, to_move, transform, value, policy.data());    // worker_thread.rs:111
+            }
+        }
         if (status != DGNN_OK) {
             dgnn_tree_undo(trace, 1);
             dgnn_trace_free(trace);
@@ -124,7 +148,6 @@ void search_worker(SearchShared* s, uint64_t seed)
         dgnn_tree_insert(trace, to_move, winrate, prior);                    // worker_thread.rs:101-113
         dgnn_trace_free(trace);
         s->ops->destroy(board);
-        s->evals.fetch_add(1, std::memory_order_relaxed);
     }
 }
 
@@ -163,7 +186,9 @@ void syn_candidates(void* b, int, unsigned char* out)
     out[DGNN_NUM_POINTS] = 1;
 }
 
-const dgnn_game_ops kSyntheticOps = {syn_clone, syn_destroy, syn_place, syn_features, syn_candidates, nullptr};
+uint64_t syn_hash(void* b) { return static_cast<SyntheticBoard*>(b)->hash; }
+
+const dgnn_game_ops kSyntheticOps = {syn_clone, syn_destroy, syn_place, syn_features, syn_candidates, nullptr, syn_hash};
 
 // ---- predictors ---------------------------------------------------------------------------------------------------
 
@@ -216,6 +241,88 @@ dgnn_predict_fn dgnn_pool_predictor(void) { return pool_predict; }
 int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
                     int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out)
 {
+    return dgnn_search_run_cached(root, ops, board, predict, predict_ctx, nullptr, num_rollouts, num_threads, seed, evals_out,
+                                  conflicts_out, nullptr);
+}
+
+// lib.rs:83-130: value and policy of a position as the average over the eight symmetries; cached symmetries are not evaluated
+// again, the missing ones go to the predictor as ONE batch and are cached.
+int dgnn_full_forward(const dgnn_game_ops* ops, void* board, int to_move, dgnn_predict_fn predict, void* predict_ctx,
+                      dgnn_cache* cache, float* value_out, float* policy_out /* 368 */)
+{
+    if (!ops || !ops->features || !ops->candidates || !predict || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    float initial[368];
+    int indices[DGNN_NUM_MOVES];
+    create_initial_policy(ops, board, to_move, initial, indices);
+    for (int i = 0; i < 368; ++i) policy_out[i] = initial[i];
+    float value = 0.0f;
+    const bool cached = cache && ops->hash;
+    const uint64_t key = cached ? ops->hash(board) : 0;
+
+    std::vector<uint16_t> features, values(8), policies(8 * DGNN_NUM_MOVES);
+    int missing[8], num_missing = 0;
+    auto accumulate = [&](int t, uint16_t v, const uint16_t* p) {
+        float one[368];
+        for (int i = 0; i < 368; ++i) one[i] = initial[i];
+        add_valid_candidates(one, p, indices, t);
+        normalize_policy(one, 0.125f);
+        value += (0.5f * half_to_float(v) + 0.5f) * 0.125f;
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) policy_out[i] += one[i];
+    };
+    for (int t = 0; t < 8; ++t) {
+        uint16_t v = 0, p[DGNN_NUM_MOVES];
+        if (cached && dgnn_cache_fetch(cache, key, to_move, t, &v, p) == 1) { accumulate(t, v, p); continue; }
+        features.resize((size_t)(num_missing + 1) * DGNN_FEATURE_SIZE);
+        ops->features(board, to_move, t, features.data() + (size_t)num_missing * DGNN_FEATURE_SIZE);
+        missing[num_missing++] = t;
+    }
+    if (num_missing > 0) {
+        const int status = predict(predict_ctx, features.data(), num_missing, values.data(), policies.data());
+        if (status != DGNN_OK) return status;
+        for (int k = 0; k < num_missing; ++k) {
+            accumulate(missing[k], values[k], policies.data() + (size_t)k * DGNN_NUM_MOVES);
+            if (cached) dgnn_cache_insert(cache, key, to_move, missing[k], values[k], policies.data() + (size_t)k * DGNN_NUM_MOVES);
+        }
+    }
+    *value_out = value;
+    return num_missing;       // >= 0: how many symmetries had to be evaluated
+}
+
+// dirichlet::add_ex (dirichlet.rs:40-70): x <- (1 - beta) x + beta Dirichlet(shape) over the finite entries; gamma variates by
+// Marsaglia-Tsang with the shape < 1 boost, from a seeded generator instead of thread_rng().
+void dgnn_dirichlet_add(float* x, int n, float shape, float beta, uint64_t seed)
+{
+    if (!x || n <= 0 || !(shape > 0.0f) || !(shape < 1.0f)) return;
+    Rng rng{seed};
+    auto normal = [&]() {
+        const double u1 = std::max(rng.uniform(), 1e-300), u2 = rng.uniform();
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    };
+    auto gamma = [&](double k) {                       // k < 1: gamma(k + 1) * u^(1 / k)
+        const double d = k + 1.0 - 1.0 / 3.0, c = 1.0 / std::sqrt(9.0 * d);
+        for (;;) {
+            double xn, v;
+            do { xn = normal(); v = 1.0 + c * xn; } while (v <= 0.0);
+            v = v * v * v;
+            const double u = rng.uniform();
+            if (u < 1.0 - 0.0331 * xn * xn * xn * xn || std::log(std::max(u, 1e-300)) < 0.5 * xn * xn + d * (1.0 - v + std::log(v)))
+                return d * v * std::pow(std::max(rng.uniform(), 1e-300), 1.0 / k);
+        }
+    };
+    std::vector<double> g((size_t)n, 0.0);
+    double g_sum = 0.0;
+    int count = 0;
+    do {
+        g_sum = 0.0; count = 0;
+        for (int i = 0; i < n; ++i) if (std::isfinite(x[i])) { g[i] = gamma(shape); g_sum += g[i]; ++count; }
+    } while (count > 0 && !(g_sum > std::numeric_limits<double>::min()));
+    for (int i = 0; i < n; ++i) if (std::isfinite(x[i])) x[i] = (1.0f - beta) * x[i] + beta * (float)(g[i] / g_sum);
+}
+
+int dgnn_search_run_cached(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
+                           dgnn_cache* cache, int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out,
+                           uint64_t* conflicts_out, uint64_t* cache_hits_out)
+{
     if (!root || !ops || !ops->clone || !ops->destroy || !ops->place || !ops->features || !ops->candidates || !predict ||
         num_rollouts <= 0 || num_threads <= 0)
         return DGNN_BAD_ARGUMENT;
@@ -225,6 +332,7 @@ int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board,
     shared.board = board;
     shared.predict = predict;
     shared.predict_ctx = predict_ctx;
+    shared.cache = cache;
     shared.limit = num_rollouts;
     Rng seeds{seed};
     if (num_threads == 1) {
@@ -236,6 +344,7 @@ int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board,
     }
     if (evals_out) *evals_out = shared.evals.load();
     if (conflicts_out) *conflicts_out = shared.conflicts.load();
+    if (cache_hits_out) *cache_hits_out = shared.cache_hits.load();
     return shared.status.load();
 }
 
@@ -289,6 +398,7 @@ int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_
     stats->moves = moves.load();
     stats->evals = evals.load();
     stats->conflicts = conflicts.load();
+    stats->cache_hits = 0;
     return status.load();
 }
 

@@ -332,6 +332,30 @@ int dgnn_tree_node_prior(const dgnn_tree_node* handle, float* prior_out)
     return DGNN_OK;
 }
 
+// Node::forward (tree.rs:1225-1250): the sub-tree below `index` becomes the root, everything else is freed.  A pass that was
+// never expanded yields a fresh node that only records the pass; any other unexpanded child yields NULL.
+dgnn_tree_node* dgnn_tree_node_forward(dgnn_tree_node* handle, int index)
+{
+    if (!handle || index < 0 || index >= kMoves) return nullptr;
+    TreeNode* node = reinterpret_cast<TreeNode*>(handle);
+    TreeNode* next = node->ptr[index].exchange(nullptr);
+    if (!next && index == kMoves - 1) {
+        float prior[kMoves];
+        for (float& v : prior) v = 0.0f;
+        next = new (std::nothrow) TreeNode(1 - node->to_move, 0.5f, prior);
+        if (next) next->pass_count = node->pass_count + 1;
+    }
+    delete node;
+    return reinterpret_cast<dgnn_tree_node*>(next);
+}
+
+int dgnn_tree_node_set_prior(dgnn_tree_node* handle, const float* prior)     // lib.rs:176-183: a re-used tree gets the new root prior
+{
+    if (!handle || !prior) return DGNN_BAD_ARGUMENT;
+    std::memcpy(reinterpret_cast<TreeNode*>(handle)->prior, prior, kMoves * sizeof(float));
+    return DGNN_OK;
+}
+
 int dgnn_tree_node_disqualify(dgnn_tree_node* handle, int index)             // tree.rs:1315-1320
 {
     if (!handle || index < 0 || index >= kMoves) return DGNN_BAD_ARGUMENT;

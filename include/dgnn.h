@@ -348,6 +348,7 @@ typedef struct dgnn_game_ops {
     void (*features)(void* board, int to_move, int symmetry, uint16_t* out /* 11552 */);
     void (*candidates)(void* board, int to_move, unsigned char* out /* 362: 1 = may be searched */);
     int (*is_symmetric)(void* board, int symmetry);                                /* may be NULL: no elimination */
+    uint64_t (*hash)(void* board);                                                 /* may be NULL: no transposition cache */
 } dgnn_game_ops;
 
 /* One search on `root` from `board` (not modified): rollouts until root.total_count >= num_rollouts
@@ -356,12 +357,30 @@ typedef struct dgnn_game_ops {
 int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
                     int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out);
 
+/* The same with the transposition cache of NnPredictor in front of the predictor (pool/event.rs:50-51,
+ * pool/worker_thread.rs:111): needs ops->hash; cache may be NULL.  *evals_out counts predictor calls only. */
+int dgnn_search_run_cached(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
+                           dgnn_cache* cache, int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out,
+                           uint64_t* conflicts_out, uint64_t* cache_hits_out);
+/* full_forward (src/libdg_mcts/lib.rs:83-130): win rate and prior (368 floats, -inf = not a candidate) of a position as the
+ * average over the eight symmetries, the uncached ones evaluated as ONE batch.  Returns the number of symmetries evaluated
+ * (>= 0) or a negative status. */
+int dgnn_full_forward(const dgnn_game_ops* ops, void* board, int to_move, dgnn_predict_fn predict, void* predict_ctx,
+                      dgnn_cache* cache, float* value_out, float* policy_out);
+/* dirichlet::add_ex (src/libdg_mcts/dirichlet.rs:40-70) with a seeded generator; the reference calls it with shape 0.03 and
+ * beta = DIRICHLET_NOISE (0.25 in self-play, config.rs:165-166). */
+void dgnn_dirichlet_add(float* x, int n, float shape, float beta, uint64_t seed);
+/* Node::forward (tree.rs:1225-1250): the sub-tree below `index` becomes the root and is returned (NULL when it was never
+ * expanded, except for a pass); `node` and the rest of its tree are freed.  set_prior: lib.rs:176-183. */
+dgnn_tree_node* dgnn_tree_node_forward(dgnn_tree_node* node, int index);
+int dgnn_tree_node_set_prior(dgnn_tree_node* node, const float* prior /* 362 */);
+
 /* A rule-free synthetic game for throughput measurements (NOT Go: every empty point is legal, nothing is captured,
  * features are pseudo-random bits of the position hash) and a self-play loop over it. */
 const dgnn_game_ops* dgnn_synthetic_game_ops(void);
 void* dgnn_synthetic_board_new(uint64_t seed);
 void dgnn_synthetic_board_free(void* board);
-typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, evals, conflicts; } dgnn_selfplay_stats;
+typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, evals, conflicts, cache_hits; } dgnn_selfplay_stats;
 int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
                             int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats);
 
@@ -389,11 +408,13 @@ int dgnn_go_is_symmetric(const dgnn_go_board* board, int symmetry);          /* 
 int dgnn_go_features(const dgnn_go_board* board, int to_move, int symmetry, uint16_t* out);
 /* The board as the game behind dgnn_search_run (a dgnn_go_board* is the `board` argument). */
 const dgnn_game_ops* dgnn_go_game_ops(void);
-/* Self-play on the real board (rules, super-ko, ladders, feature planes) through `predict`; no scoring, so passing is
- * disqualified and a game is num_moves stones long.  moves_out (num_games * num_moves packed indices, -1 = not played)
- * may be NULL. */
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
-                     int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out);
+/* Self-play on the real board following self_play_one / Player::predict / predict (src/libdg_mcts/self_play.rs:423-459,
+ * 331-368, lib.rs:144-200): random komi, per-player trees re-used across moves, win-rate driven rollout budget, 8-symmetry
+ * root evaluation through `cache` (may be NULL), dirichlet noise, temperature for the first eight stones.  No scoring yet:
+ * passing is disqualified and a game is num_moves stones long.  moves_out (num_games * num_moves packed indices, -1 = not
+ * played) and sgf_out (one record per game in the reference's per-move format, newline separated) may be NULL. */
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_moves, int num_rollouts,
+                     int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
 
 /* Library version / build info string (static). */
 const char* dgnn_version(void);

@@ -213,3 +213,54 @@ def test_search_and_selfplay_on_the_real_board(api):
         for m, index in enumerate(game):
             assert replay.is_valid(m % 2, index % 19, index // 19)
             replay.place(m % 2, index % 19, index // 19)
+
+
+def test_full_forward_of_the_empty_board(api):
+    """full_forward (src/libdg_mcts/lib.rs:83-130): every symmetry is evaluated, the candidates are what the initial policy
+    leaves (symmetric duplicates removed: on the empty board one eighth of the points, incl. the diagonals and the centre,
+    = 55, plus pass), the result sums to one, and a second call is served from the transposition cache."""
+    b = api.Board(7.5)
+    value, prior, n = api.full_forward(b, B)
+    assert n == 8 and 0.0 <= value <= 1.0
+    finite = np.isfinite(prior)
+    assert finite.sum() == 56 and finite[361]
+    assert np.isclose(prior[finite].sum(), 1.0, atol=1e-5)
+    cache = api.LruCache(1000)
+    first = api.full_forward(b, B, cache=cache)
+    second = api.full_forward(b, B, cache=cache)
+    assert first[2] == 8 and second[2] == 0                        # the count is the number of predictor calls
+    assert np.array_equal(first[1], second[1]) and first[0] == second[0]
+    assert np.array_equal(first[1], prior)                         # the cache does not change the answer
+    b.place(B, 3, 4)                                               # nothing symmetric about this one
+    _, prior, n = api.full_forward(b, W)
+    assert n == 8 and np.isfinite(prior).sum() == 361 and prior[4 * 19 + 3] == -np.inf
+
+
+def test_cached_search_reports_hits_and_same_tree(api):
+    b = api.Board(7.5)
+    b.place(B, 3, 3)
+    prior = np.full(362, 1.0 / 361, dtype=np.float32); prior[3 * 19 + 3] = -np.inf; prior[361] = -np.inf
+    cache = api.LruCache(10_000)
+    counts = []
+    for _ in range(2):
+        root = api.Node(W, 0.5, prior)
+        evals, conflicts, hits = api.search_run(root, b, num_rollouts=60, num_threads=1, seed=4, cache=cache)
+        counts.append((evals, hits, np.array([root.with_(i).count() for i in range(362)])))
+    assert counts[0][0] + counts[0][1] == 60 and counts[1][0] == 0 and counts[1][1] == 60     # second search: all from the cache
+    assert np.array_equal(counts[0][2], counts[1][2])
+    plain = api.Node(W, 0.5, prior)
+    api.search_run(plain, b, num_rollouts=60, num_threads=1, seed=4)
+    assert np.array_equal(counts[0][2], np.array([plain.with_(i).count() for i in range(362)]))
+
+
+def test_selfplay_records_games_in_the_reference_format(api):
+    out = api.selfplay_go(num_games=2, num_moves=5, num_rollouts=10, threads_per_search=1, seed=3, cache=api.LruCache(5000),
+                          return_moves=True, return_sgf=True)
+    assert len(out["sgf"]) == 2
+    for game, record in zip(out["sgf"], out["record"]):
+        assert game.startswith("(;GM[1]FF[4]SZ[19]RU[Chinese]KM[") and game.endswith(")")
+        assert game.count(";B[") + game.count(";W[") == 5
+        letters = "abcdefghijklmnopqrs"
+        for m, index in enumerate(record):                         # the SGF vertex is the move that was played (CGoban, sgf.rs:36-43)
+            x, y = index % 19, index // 19
+            assert ";%s[%s%s]" % ("BW"[m % 2], letters[x], letters[y]) in game

@@ -199,3 +199,38 @@ def test_synthetic_selfplay_counts_every_evaluation(api):
     stats = api.selfplay_synthetic(num_games=3, num_moves=4, num_rollouts=20, threads_per_search=2, seed=11)
     assert stats["games"] == 3 and stats["moves"] == 12
     assert 12 * 21 <= stats["evals"] <= 12 * (21 + 1)      # 20 rollouts (+ up to threads - 1) + the root evaluation
+
+
+def test_forward_keeps_the_sub_tree(api):
+    """Node::forward (src/libdg_mcts/tree.rs:1225-1250): the child's statistics become the new root."""
+    root = _fresh_root(api)
+    api.search_run(root, api.SyntheticBoard(9), num_rollouts=300, num_threads=1, seed=2)
+    counts = _visit_counts(root)
+    best = int(np.argmax(counts))
+    below = root.with_(best).count()
+    child = root.forward(best)
+    assert child is not None and child.to_move == api.WHITE
+    assert child.total_count == below - 1                         # the visit that expanded the child is not one of its own
+    assert _visit_counts(child).sum() == child.total_count
+    assert api.Node(api.BLACK, 0.5, np.full(362, 1.0 / 362, dtype=np.float32)).forward(17) is None    # nothing below: no tree
+
+
+def test_set_prior_replaces_the_prior_only(api):
+    root = _fresh_root(api)
+    api.search_run(root, api.SyntheticBoard(9), num_rollouts=50, num_threads=1, seed=2)
+    before = _visit_counts(root)
+    prior = np.random.default_rng(0).dirichlet(np.ones(362)).astype(np.float32)
+    root.set_prior(prior)
+    assert np.array_equal(before, _visit_counts(root))
+    assert np.allclose(root.prior, prior)
+
+
+def test_dirichlet_noise(api):
+    """dirichlet::add_ex (src/libdg_mcts/dirichlet.rs:40-70, tests 80-101): mixes beta of a Dirichlet(shape) sample into the
+    finite entries, keeps -inf entries, preserves the sum."""
+    x = np.full(362, 1.0 / 300, dtype=np.float32); x[300:] = -np.inf
+    y = api.dirichlet_add(x, 0.03, 0.25, seed=5)
+    assert np.all(np.isneginf(y[300:])) and np.all(np.isfinite(y[:300])) and np.all(y[:300] >= 0.75 / 300 - 1e-7)
+    assert np.isclose(y[:300].sum(), 1.0, atol=1e-4)
+    assert np.array_equal(y, api.dirichlet_add(x, 0.03, 0.25, seed=5)) and not np.array_equal(y, api.dirichlet_add(x, 0.03, 0.25, seed=6))
+    assert np.array_equal(api.dirichlet_add(x, 0.03, 0.0, seed=5), x)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Self-play on the REAL board through the whole pipeline: Go rules, super-ko, ladder reader and V1 feature planes (go.cpp) ->
 search tree + driver (tree.cpp, search.cpp) -> LeafPool / batcher (batcher.cpp) -> HIP engine, PCIe-inclusive, random-init
-network.  What it is not: there is no scoring yet, so passing is disqualified and a game is --moves
-stones long; no resignation, tree re-use, dirichlet noise or 8-fold root ensemble.  Prints one JSON line.
+network.  The game loop follows self_play_one / Player::predict (random komi, per-player trees re-used across moves, win-rate
+driven rollout budget, 8-fold root ensemble, dirichlet noise, transposition cache).  What it is not:
+there is no scoring yet, so passing is disqualified and a game is --moves stones long; no resignation.  Prints one JSON line;
+--sgf FILE writes the game records (reference per-move format).
 
     python tools/selfplay_go.py [--games 64] [--moves 8] [--rollouts 800] [--threads 8] [--blocks 20 --channels 256]
 """
@@ -29,15 +31,22 @@ def main():
     ap.add_argument("--max-batches", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
+    ap.add_argument("--sgf", default=None)
     args = ap.parse_args()
 
     net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
     batcher = api.Batcher(net, args.max_batch, args.max_batches)
     pool = api.LeafPool(batcher, args.max_batches)
     api.selfplay_go(2, 1, 16, 2, seed=1, pool=pool)          # warm: workspace, weight upload
+    cache = api.LruCache(args.cache, 8) if args.cache > 0 else None
     before = batcher.stats()
-    stats = api.selfplay_go(args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool)
+    stats = api.selfplay_go(args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
+                            return_sgf=args.sgf is not None)
     after = batcher.stats()
+    if args.sgf:
+        with open(args.sgf, "w") as f:
+            f.write("\n".join(stats["sgf"]) + "\n")
     pool.close()
     boards, batches = after["boards"] - before["boards"], after["batches"] - before["batches"]
     moves_per_s = stats["moves"] / stats["seconds"]
@@ -45,8 +54,9 @@ def main():
         "metric": "go_selfplay", "evals_per_sec": stats["evals"] / stats["seconds"], "moves_per_sec": moves_per_s,
         "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": args.games, "moves_per_game": args.moves,
         "rollouts_per_move": args.rollouts, "search_threads_per_game": args.threads, "mean_device_batch": boards / max(batches, 1),
-        "probe_conflicts": stats["conflicts"], "seconds": stats["seconds"], "net": f"{args.blocks}x{args.channels}",
-        "note": "real board / ladders / feature planes (go.cpp), fixed game length (no scoring yet), PCIe-inclusive, no transposition cache",
+        "probe_conflicts": stats["conflicts"], "cache_hits": stats["cache_hits"], "cache_entries": args.cache,
+        "seconds": stats["seconds"], "net": f"{args.blocks}x{args.channels}",
+        "note": "real board / ladders / feature planes (go.cpp), self_play_one game loop, fixed game length (no scoring yet), PCIe-inclusive",
     }))
 
 
