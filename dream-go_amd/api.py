@@ -159,6 +159,14 @@ SYMBOLS = [
                                         ctypes.c_char_p, ctypes.c_size_t]),
     ("dgnn_search_run_cached", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_go_scoring_ops", _vp, []),
+    ("dgnn_go_benson", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("dgnn_go_is_scorable", ctypes.c_int, [_vp]),
+    ("dgnn_go_score", ctypes.c_int, [_vp, _ip, _ip]),
+    ("dgnn_go_stone_status", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("dgnn_go_result_sgf", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
+    ("dgnn_choose_f64", ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                       _ip, ctypes.POINTER(ctypes.c_double)]),
     ("dgnn_full_forward", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _fp, _fp]),
     ("dgnn_dirichlet_add", None, [_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64]),
     ("dgnn_tree_node_forward", _vp, [_vp, ctypes.c_int]),
@@ -859,7 +867,8 @@ def undo(trace, undo_expanding):
 
 class SelfplayStats(ctypes.Structure):
     _fields_ = [("seconds", ctypes.c_double), ("games", ctypes.c_uint64), ("moves", ctypes.c_uint64),
-                ("evals", ctypes.c_uint64), ("conflicts", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64)]
+                ("evals", ctypes.c_uint64), ("conflicts", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64),
+                ("games_ended", ctypes.c_uint64)]
 
 
 class SyntheticBoard:
@@ -905,27 +914,30 @@ def _predictor(pool):
     return lib.dgnn_pool_predictor(), pool._handle
 
 
-def _game_ops(board):
-    return lib.dgnn_go_game_ops() if isinstance(board, Board) else lib.dgnn_synthetic_game_ops()
+def _game_ops(board, scoring=False):
+    if isinstance(board, Board):
+        return lib.dgnn_go_scoring_ops() if scoring else lib.dgnn_go_game_ops()
+    return lib.dgnn_synthetic_game_ops()
 
 
-def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None, cache=None):
+def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None, cache=None, scoring=False):
     """One search on `root` from a Board or a SyntheticBoard (worker_thread.rs:50-176 for a single search) ->
-    (predictor calls, probe conflicts), or (predictor calls, probe conflicts, cache hits) when a LruCache is given."""
+    (predictor calls, probe conflicts), or (predictor calls, probe conflicts, cache hits) when a LruCache is given.
+    scoring=True searches a Board as a ScoringSearch (options.rs:141-163) instead of a StandardSearch."""
     fn, ctx = _predictor(pool)
     evals, conflicts, hits = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-    _check(lib.dgnn_search_run_cached(root._handle, _game_ops(board), board._handle, fn, ctx, cache._handle if cache is not None else None,
+    _check(lib.dgnn_search_run_cached(root._handle, _game_ops(board, scoring), board._handle, fn, ctx, cache._handle if cache is not None else None,
                                       int(num_rollouts), int(num_threads), int(seed), ctypes.byref(evals), ctypes.byref(conflicts),
                                       ctypes.byref(hits)), "search_run")
     return (evals.value, conflicts.value) if cache is None else (evals.value, conflicts.value, hits.value)
 
 
-def full_forward(board, to_move, pool=None, cache=None):
+def full_forward(board, to_move, pool=None, cache=None, scoring=False):
     """dg_mcts::full_forward (src/libdg_mcts/lib.rs:83-130) -> (win rate, prior [362] with -inf for non-candidates, symmetries evaluated)."""
     fn, ctx = _predictor(pool)
     value = ctypes.c_float()
     policy = np.empty(368, dtype=np.float32)
-    n = lib.dgnn_full_forward(_game_ops(board), board._handle, int(to_move), fn, ctx, cache._handle if cache is not None else None,
+    n = lib.dgnn_full_forward(_game_ops(board, scoring), board._handle, int(to_move), fn, ctx, cache._handle if cache is not None else None,
                               ctypes.byref(value), policy.ctypes.data_as(_fp))
     if n < 0:
         raise Error(n, "full_forward")
@@ -996,6 +1008,32 @@ class Board:
     def is_symmetric(self, transform):
         return bool(lib.dgnn_go_is_symmetric(self._handle, int(transform)))
 
+    def benson(self, color):
+        """BensonImpl::new(board, color) (utils/benson.rs:62-190) -> uint8 [19, 19] indexed [y, x]: 1 = is_alive, 2 = is_eye."""
+        out = np.empty(NUM_POINTS, dtype=np.uint8)
+        _check(lib.dgnn_go_benson(self._handle, int(color), out.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))), "Board.benson")
+        return out.reshape(19, 19)
+
+    def is_scorable(self):
+        return bool(lib.dgnn_go_is_scorable(self._handle))
+
+    def get_score(self):
+        black, white = ctypes.c_int(), ctypes.c_int()
+        _check(lib.dgnn_go_score(self._handle, ctypes.byref(black), ctypes.byref(white)), "Board.get_score")
+        return black.value, white.value
+
+    def get_stone_status(self):
+        """Score::get_stone_status(board, board) -> uint8 [19, 19] bit masks (STONE_ALIVE / DEAD / SEKI, TERRITORY_BLACK / WHITE)."""
+        out = np.empty(NUM_POINTS, dtype=np.uint8)
+        _check(lib.dgnn_go_stone_status(self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))), "Board.get_stone_status")
+        return out.reshape(19, 19)
+
+    def result_sgf(self):
+        """(RE[] value, "TB[..]TW[..]") of GameResult::Ended (game_result.rs:35-93)."""
+        winner, territory = ctypes.create_string_buffer(32), ctypes.create_string_buffer(4 * 361 + 8)
+        _check(lib.dgnn_go_result_sgf(self._handle, winner, len(winner), territory, len(territory)), "Board.result_sgf")
+        return winner.value.decode("ascii"), territory.value.decode("ascii")
+
     def get_features(self, to_move, symmetry=0):
         """features::V1::get_features::<HWC, f16> -> float16 [361, 32]."""
         out = np.empty(FEATURE_SIZE, dtype=np.uint16)
@@ -1011,17 +1049,35 @@ class Board:
             pass
 
 
+STONE_ALIVE, STONE_DEAD, STONE_SEKI, TERRITORY_BLACK, TERRITORY_WHITE = 1, 2, 4, 8, 16
+
+
+def choose_f64(items, cutoff_percentile, temperature, at):
+    """choose (src/libdg_mcts/choose.rs:54-88) on real weights -> (index, cumulative value) or None."""
+    v = np.ascontiguousarray(items, dtype=np.float64)
+    index, cum = ctypes.c_int(), ctypes.c_double()
+    r = lib.dgnn_choose_f64(v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), v.size, float(cutoff_percentile), float(temperature), float(at),
+                            ctypes.byref(index), ctypes.byref(cum))
+    if r < 0:
+        raise Error(r, "choose_f64")
+    return (index.value, cum.value) if r == 1 else None
+
+
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
                 return_sgf=False):
+    """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
+    (0 = the reference's 722)."""
     fn, ctx = _predictor(pool)
     stats = SelfplayStats()
+    if num_moves <= 0 or num_moves > 722:
+        num_moves = 722
     moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
-    sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 128)) if return_sgf else None
+    sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
     _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, int(num_games), int(num_moves), int(num_rollouts),
                                 int(threads_per_search), int(seed), ctypes.byref(stats), moves.ctypes.data_as(_ip) if moves is not None else None,
                                 sgf, len(sgf) if sgf is not None else 0), "selfplay_go")
     out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts,
-           "cache_hits": stats.cache_hits}
+           "cache_hits": stats.cache_hits, "games_ended": stats.games_ended}
     if return_moves:
         out["record"] = moves.reshape(num_games, num_moves)
     if return_sgf:

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <cmath>
 #include <cstdio>
+#include <ctime>
 #include <limits>
 #include <new>
 #include <string>
@@ -355,6 +356,229 @@ void features_v1(const GoBoard& b, int to_move, int symmetry, uint16_t* out)
     }
 }
 
+
+// ---- Benson's unconditional life, Tromp-Taylor score, stone status (utils/benson.rs, utils/score.rs) ----
+enum : unsigned char { kStatusNone = 0, kStatusBlock = 1, kStatusRegion = 2 };      // benson.rs:48-53
+
+struct Bits { uint64_t w[6]; void set(int i) { w[i >> 6] |= 1ull << (i & 63); } bool get(int i) const { return (w[i >> 6] >> (i & 63)) & 1; } };
+
+// Benson::new (benson.rs:62-78) over AllBlocksImpl / AllRegionsImpl (:231-253, :300-333).  The reference's variant of the
+// algorithm, kept as it is: a region is every point reachable from an EMPTY point without crossing a stone of `color`
+// (so it holds the opponent's stones too); it is vital to a block when EVERY one of its points -- stones included -- is
+// adjacent to the block (is_vital :207-209 over adjacencies_of, board_fast.rs:154-159).
+void benson(const Fast& b, int color, unsigned char* status)
+{
+    const unsigned char mine = (unsigned char)(color + 1);
+    struct Group { short first, count; bool live; };
+    short block_points[kPoints], region_points[kPoints], queue[kPoints];
+    short region_id[kPoints];
+    Group blocks[kPoints], regions[kPoints];
+    Bits block_adjacent[kPoints / 2 + 2];                                     // only used for index < num_blocks (<= 181 blocks of one colour)
+    int num_blocks = 0, num_regions = 0, used = 0;
+    short block_of[kPoints];
+    std::memset(status, kStatusNone, kPoints);
+    std::memset(block_of, 0xff, sizeof(block_of));
+    std::memset(region_id, 0xff, sizeof(region_id));
+
+    for (int p = 0; p < kPoints; ++p) {                                       // blocks of `color` with everything next to them
+        if (b.stone[p] != mine || block_of[p] >= 0) continue;
+        Group& g = blocks[num_blocks];
+        g = {(short)used, 0, true};
+        Bits& adjacent = block_adjacent[num_blocks];
+        std::memset(&adjacent, 0, sizeof(adjacent));
+        int head = 0, tail = 0;
+        queue[tail++] = (short)p;
+        block_of[p] = (short)num_blocks;
+        while (head < tail) {
+            const int q = queue[head++];
+            block_points[used++] = (short)q;
+            for (int d = 0; d < 4; ++d) {
+                const int r = neighbour(q, d);
+                if (r < 0) continue;
+                adjacent.set(r);
+                if (b.stone[r] == mine && block_of[r] < 0) { block_of[r] = (short)num_blocks; queue[tail++] = (short)r; }
+            }
+        }
+        g.count = (short)(used - g.first);
+        ++num_blocks;
+    }
+
+    used = 0;
+    for (int p = 0; p < kPoints; ++p) {                                       // regions enclosed by `color`
+        if (b.stone[p] != kEmpty || region_id[p] >= 0) continue;
+        Group& g = regions[num_regions];
+        g = {(short)used, 0, true};
+        bool has_neighbour = false;
+        int head = 0, tail = 0;
+        queue[tail++] = (short)p;
+        region_id[p] = (short)num_regions;
+        while (head < tail) {
+            const int q = queue[head++];
+            region_points[used++] = (short)q;
+            for (int d = 0; d < 4; ++d) {
+                const int r = neighbour(q, d);
+                if (r < 0) continue;
+                if (b.stone[r] == mine) has_neighbour = true;
+                else if (region_id[r] < 0) { region_id[r] = (short)num_regions; queue[tail++] = (short)r; }
+            }
+        }
+        g.count = (short)(used - g.first);
+        if (!has_neighbour) { used = g.first; for (int i = 0; i < g.count; ++i) region_id[region_points[g.first + i]] = (short)kPoints; continue; }   // benson.rs:324-328
+        ++num_regions;
+    }
+    if (num_blocks == 0 || num_regions == 0) return;
+
+    // vital[r] = the blocks region r is vital to: only blocks next to its first point can qualify
+    std::vector<short> vital_first((size_t)num_regions + 1, 0), vital;
+    for (int r = 0; r < num_regions; ++r) {
+        vital_first[r] = (short)vital.size();
+        const int p0 = region_points[regions[r].first];
+        short seen[4]; int n_seen = 0;
+        for (int d = 0; d < 4; ++d) {
+            const int q = neighbour(p0, d);
+            if (q < 0 || b.stone[q] != mine) continue;
+            const short k = block_of[q];
+            if (std::find(seen, seen + n_seen, k) != seen + n_seen) continue;
+            seen[n_seen++] = k;
+            bool all = true;
+            for (int i = 0; i < regions[r].count && all; ++i) all = block_adjacent[k].get(region_points[regions[r].first + i]);
+            if (all) vital.push_back(k);
+        }
+    }
+    vital_first[num_regions] = (short)vital.size();
+
+    auto mark = [&](const short* points, const Group& g, unsigned char value) { for (int i = 0; i < g.count; ++i) status[points[g.first + i]] = value; };
+    for (int k = 0; k < num_blocks; ++k) mark(block_points, blocks[k], kStatusBlock);
+    for (int r = 0; r < num_regions; ++r) mark(region_points, regions[r], kStatusRegion);
+    for (int r = 0; r < num_regions; ++r)                                    // remove_non_vital_regions, :136-152
+        if (vital_first[r] == vital_first[r + 1]) { regions[r].live = false; mark(region_points, regions[r], kStatusNone); }
+
+    std::vector<int> healthy((size_t)num_blocks);
+    for (bool changed = true; changed;) {                                     // :73-75
+        changed = false;
+        std::fill(healthy.begin(), healthy.end(), 0);                         // remove_non_alive_blocks, :95-112
+        for (int r = 0; r < num_regions; ++r)
+            if (regions[r].live) for (int i = vital_first[r]; i < vital_first[r + 1]; ++i) ++healthy[vital[i]];
+        for (int k = 0; k < num_blocks; ++k)
+            if (blocks[k].live && healthy[k] < 2) { blocks[k].live = false; mark(block_points, blocks[k], kStatusNone); changed = true; }
+        for (int r = 0; r < num_regions; ++r) {                               // remove_non_surrounded_regions, :116-132
+            if (!regions[r].live) continue;
+            bool surrounded = true;
+            for (int i = 0; i < regions[r].count && surrounded; ++i) {
+                const int q = region_points[regions[r].first + i];
+                for (int d = 0; d < 4; ++d) {
+                    const int n = neighbour(q, d);
+                    if (n >= 0 && b.stone[n] == mine && status[n] != kStatusBlock) { surrounded = false; break; }
+                }
+            }
+            if (!surrounded) { regions[r].live = false; mark(region_points, regions[r], kStatusNone); changed = true; }
+        }
+    }
+}
+
+bool is_scorable(const Fast& b)                                               // score.rs:105-117
+{
+    unsigned char black[kPoints], white[kPoints];
+    benson(b, 0, black);
+    benson(b, 1, white);
+    for (int p = 0; p < kPoints; ++p) {
+        const bool ok = b.stone[p] == kEmpty ? (black[p] == kStatusRegion || white[p] == kStatusRegion)
+                      : b.stone[p] == 1      ? (black[p] == kStatusBlock || white[p] == kStatusRegion)
+                                             : (white[p] == kStatusBlock || black[p] == kStatusRegion);
+        if (!ok) return false;
+    }
+    return true;
+}
+
+// get_territory_distance (score.rs:248-283): 0 on a stone of `color`, the distance through empty points elsewhere, 0xff if unreachable
+void territory_distance(const Fast& b, int color, unsigned char* distance)
+{
+    short queue[kPoints];
+    int head = 0, tail = 0;
+    std::memset(distance, 0xff, kPoints);
+    for (int p = 0; p < kPoints; ++p) if (b.stone[p] == color + 1) { distance[p] = 0; queue[tail++] = (short)p; }
+    while (head < tail) {                                                      // unit steps: breadth first gives what the relaxation converges to
+        const int q = queue[head++];
+        for (int d = 0; d < 4; ++d) {
+            const int r = neighbour(q, d);
+            if (r >= 0 && b.stone[r] == kEmpty && distance[r] == 0xff) { distance[r] = (unsigned char)(distance[q] + 1); queue[tail++] = (short)r; }
+        }
+    }
+}
+
+void tt_score(const Fast& b, int* black_out, int* white_out)                  // get_tt_score, score.rs:220-239
+{
+    unsigned char black[kPoints], white[kPoints];
+    territory_distance(b, 0, black);
+    territory_distance(b, 1, white);
+    int nb = 0, nw = 0;
+    for (int p = 0; p < kPoints; ++p) {
+        if (black[p] == 0) ++nb;
+        else if (white[p] == 0) ++nw;
+        else if (white[p] == 0xff) ++nb;
+        else if (black[p] == 0xff) ++nw;
+    }
+    *black_out = nb;
+    *white_out = nw;
+}
+
+// get_stone_status(self, finished = self) (score.rs:146-186) as one bit mask per point
+void stone_status(const Fast& b, unsigned char* out)
+{
+    unsigned char black[kPoints], white[kPoints], distance_black[kPoints], distance_white[kPoints];
+    benson(b, 0, black);
+    benson(b, 1, white);
+    Fast cleaned = b;                                                          // clear_board, :197-211
+    for (int p = 0; p < kPoints; ++p)
+        if ((b.stone[p] == 2 && white[p] != kStatusBlock) || (b.stone[p] == 1 && black[p] != kStatusBlock)) cleaned.stone[p] = kEmpty;
+    territory_distance(cleaned, 0, distance_black);
+    territory_distance(cleaned, 1, distance_white);
+    for (int p = 0; p < kPoints; ++p) {
+        unsigned char m = 0;
+        if (b.stone[p] == 2) m = white[p] == kStatusBlock ? (DGNN_STONE_ALIVE | DGNN_TERRITORY_WHITE) : black[p] == kStatusRegion ? (DGNN_STONE_DEAD | DGNN_TERRITORY_BLACK) : (DGNN_STONE_SEKI | DGNN_TERRITORY_WHITE);
+        else if (b.stone[p] == 1) m = black[p] == kStatusBlock ? (DGNN_STONE_ALIVE | DGNN_TERRITORY_BLACK) : white[p] == kStatusRegion ? (DGNN_STONE_DEAD | DGNN_TERRITORY_WHITE) : (DGNN_STONE_SEKI | DGNN_TERRITORY_BLACK);
+        else if (distance_black[p] != 0xff && distance_white[p] == 0xff) m = DGNN_TERRITORY_BLACK;
+        else if (distance_white[p] != 0xff && distance_black[p] == 0xff) m = DGNN_TERRITORY_WHITE;
+        out[p] = m;
+    }
+}
+
+std::string sgf_vertex(int p) { return std::string(1, (char)('a' + p % kN)) + (char)('a' + p / kN); }      // CGoban::to_sgf, sgf.rs:36-43
+
+std::string winner_sgf(const GoBoard& g, const unsigned char* status)         // get_winner_as_sgf, game_result.rs:82-93
+{
+    float black = 0.0f, white = g.komi;
+    for (int p = 0; p < kPoints; ++p) { if (status[p] & DGNN_TERRITORY_BLACK) black += 1.0f; if (status[p] & DGNN_TERRITORY_WHITE) white += 1.0f; }
+    char text[32];
+    if (black > white) std::snprintf(text, sizeof(text), "B+%.1f", (double)(black - white));
+    else if (white > black) std::snprintf(text, sizeof(text), "W+%.1f", (double)(white - black));
+    else std::snprintf(text, sizeof(text), "0");
+    return text;
+}
+
+std::string territory_sgf(const unsigned char* status)                        // get_territory_as_sgf, game_result.rs:53-72
+{
+    std::string black, white;
+    for (int p = 0; p < kPoints; ++p) {
+        if (status[p] & DGNN_TERRITORY_WHITE) white += "[" + sgf_vertex(p) + "]";
+        else if (status[p] & DGNN_TERRITORY_BLACK) black += "[" + sgf_vertex(p) + "]";
+    }
+    return (black.empty() ? "" : "TB") + black + (white.empty() ? "" : "TW") + white;
+}
+
+// is_eye (options.rs:192-213): an empty point with enough of one's own stones around it
+bool is_simple_eye(const Fast& b, int color, int p)
+{
+    const int x = p % kN, y = p / kN;
+    auto filled = [&](int dx, int dy) { const int u = x + dx, v = y + dy; return u >= 0 && u < kN && v >= 0 && v < kN && b.stone[v * kN + u] == color + 1; };
+    const int cross = filled(1, 0) + filled(-1, 0) + filled(0, 1) + filled(0, -1);
+    const int diagonal = filled(1, 1) + filled(1, -1) + filled(-1, 1) + filled(-1, -1);
+    const bool edge_x = x == 0 || x == 18, edge_y = y == 0 || y == 18;
+    if (edge_x && edge_y) return cross >= 2 && diagonal >= 1;
+    if (edge_x || edge_y) return cross >= 3 && diagonal >= 2;
+    return cross >= 4 && diagonal >= 3;
+}
+
 // ---- game callbacks for the search driver ----
 void* go_clone(void* b) { return new GoBoard(*static_cast<GoBoard*>(b)); }
 void go_destroy(void* b) { delete static_cast<GoBoard*>(b); }
@@ -373,7 +597,18 @@ int go_is_symmetric(void* b, int symmetry)                                    //
     return 1;
 }
 uint64_t go_hash(void* b) { return static_cast<GoBoard*>(b)->hash; }      // BoardTuple, predictors/nn.rs:31-45
+void go_candidates_scoring(void* b, int to_move, unsigned char* out)          // ScoringPolicyChecker, options.rs:110-139
+{
+    const GoBoard* g = static_cast<GoBoard*>(b);
+    unsigned char black[kPoints], white[kPoints];
+    benson(g->inner, 0, black);
+    benson(g->inner, 1, white);
+    for (int p = 0; p < kPoints; ++p)
+        out[p] = black[p] != kStatusRegion && white[p] != kStatusRegion && g->is_valid(to_move, p) && !is_simple_eye(g->inner, to_move, p);
+    out[kPass] = 0;
+}
 const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric, go_hash};
+const dgnn_game_ops kGoScoringOps = {go_clone, go_destroy, go_place, go_features, go_candidates_scoring, go_is_symmetric, go_hash};
 
 struct Rng2 {
     uint64_t state;
@@ -433,20 +668,60 @@ int dgnn_go_features(const dgnn_go_board* b, int to_move, int symmetry, uint16_t
 int dgnn_go_is_symmetric(const dgnn_go_board* b, int symmetry) { return (b && symmetry >= 0 && symmetry < 8) ? go_is_symmetric((void*)b, symmetry) : 0; }
 
 const dgnn_game_ops* dgnn_go_game_ops(void) { return &kGoOps; }
+const dgnn_game_ops* dgnn_go_scoring_ops(void) { return &kGoScoringOps; }
 
-// Self-play on the real board, following self_play_one / Player::predict / predict (src/libdg_mcts/self_play.rs:423-459,
-// 331-368, lib.rs:144-200): random komi, per-player trees re-used across moves (Node::forward), win-rate driven rollout
-// budget max(0.1, 4w(1-w)) * num_rollouts, 8-symmetry root evaluation through the transposition cache, dirichlet noise on
-// the root prior, temperature 0.8 for the first eight stones, every network call through `predict`.
-// What is missing: scoring (is_scorable / Benson / ScoringSearch), so passing is disqualified at every move and a game is
-// `num_moves` stones long (or ends when nothing is legal); resignation; expert iteration.
-// moves_out (num_games * num_moves packed indices, -1 = not played) and sgf_out (one "(;GM[1]FF[4]SZ[19]KM[..]...)" record
-// per game, newline separated, cut off at sgf_capacity) may be NULL.
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_moves, int num_rollouts,
+int dgnn_go_benson(const dgnn_go_board* b, int color, unsigned char* status_out)
+{
+    if (!b || !status_out || (color != 0 && color != 1)) return DGNN_BAD_ARGUMENT;
+    benson(CGO(b)->inner, color, status_out);
+    return DGNN_OK;
+}
+int dgnn_go_is_scorable(const dgnn_go_board* b) { return b ? (is_scorable(CGO(b)->inner) ? 1 : 0) : 0; }
+int dgnn_go_score(const dgnn_go_board* b, int* black_out, int* white_out)     // Score::get_score, score.rs:130-136
+{
+    if (!b || !black_out || !white_out) return DGNN_BAD_ARGUMENT;
+    *black_out = *white_out = 0;
+    if (CGO(b)->hash != 0) tt_score(CGO(b)->inner, black_out, white_out);
+    return DGNN_OK;
+}
+int dgnn_go_stone_status(const dgnn_go_board* b, unsigned char* status_out)
+{
+    if (!b || !status_out) return DGNN_BAD_ARGUMENT;
+    stone_status(CGO(b)->inner, status_out);
+    return DGNN_OK;
+}
+int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_capacity, char* territory_out, size_t territory_capacity)
+{
+    if (!b) return DGNN_BAD_ARGUMENT;
+    unsigned char status[kPoints];
+    stone_status(CGO(b)->inner, status);
+    const std::string winner = winner_sgf(*CGO(b), status), territory = territory_sgf(status);
+    if ((winner_out && winner.size() + 1 > winner_capacity) || (territory_out && territory.size() + 1 > territory_capacity)) return DGNN_BAD_ARGUMENT;
+    if (winner_out) std::memcpy(winner_out, winner.c_str(), winner.size() + 1);
+    if (territory_out) std::memcpy(territory_out, territory.c_str(), territory.size() + 1);
+    return DGNN_OK;
+}
+
+// Self-play on the real board, following self_play_one / Player::predict / predict_aux / predict
+// (src/libdg_mcts/self_play.rs:423-459, 331-420, 243-274, lib.rs:144-200):
+//   * random komi (lib.rs:210-224); two players, each with a tree re-used across moves (Node::forward) and a moving average
+//     of the win rate that sets the rollout budget max(0.1, 4w(1-w)) * num_rollouts (self_play.rs:234-241);
+//   * while the board is not scorable (Score::is_scorable) the search is a ScoringSearch: no pass, nothing inside a Benson
+//     eye, deterministic (no dirichlet noise, temperature 0); once it is scorable a StandardSearch with noise may pass;
+//   * a search with nothing to play passes (self_play.rs:347-350); two passes on a scorable board end the game;
+//   * a budget of one rollout or less plays from the 8-symmetry policy alone (self_play.rs:369-399);
+//   * the record is GameResult::Ended (game_result.rs:35-41): header, RE[], the moves, TB / TW.
+// `max_moves` caps the stones per game below the reference's 722 (0 = 722) so a measurement can be bounded; a game cut
+// off there is recorded like one that reached 722.  Not built: resignation (the reference's self-play has none either,
+// only policy_play), expert iteration.
+// moves_out (num_games * max_moves packed indices of the stones in order, -1 = not played) and sgf_out (one record per game,
+// newline separated, cut off at sgf_capacity) may be NULL.
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int max_moves, int num_rollouts,
                      int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
 {
-    if (!predict || num_games <= 0 || num_moves <= 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats) return DGNN_BAD_ARGUMENT;
-    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0};
+    if (!predict || num_games <= 0 || max_moves < 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats) return DGNN_BAD_ARGUMENT;
+    if (max_moves == 0 || max_moves > 722) max_moves = 722;
+    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0};
     std::atomic<int> status{DGNN_OK};
     std::vector<std::string> records((size_t)num_games);
     const auto t0 = std::chrono::steady_clock::now();
@@ -458,64 +733,98 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
         GoBoard board(komi);
         dgnn_tree_node* roots[2] = {nullptr, nullptr};                         // Player::root of black / white
         float winrate[2] = {0.5f, 0.5f};                                       // MovingAverage::new(0.5, 0.2)
-        char header[64];
-        std::snprintf(header, sizeof(header), "(;GM[1]FF[4]SZ[19]RU[Chinese]KM[%.1f]", (double)komi);   // game_result.rs:33,40 without DT / RE
-        std::string& sgf = records[(size_t)g];
-        sgf = header;
-        if (moves_out) for (int m = 0; m < num_moves; ++m) moves_out[(size_t)g * num_moves + m] = -1;
+        std::string sgf;
+        int pass_count = 0;
+        bool finished = false;
+        if (moves_out) for (int m = 0; m < max_moves; ++m) moves_out[(size_t)g * max_moves + m] = -1;
 
-        for (int m = 0; m < num_moves && m < 722 && status.load() == DGNN_OK; ++m) {
-            const int me = m & 1;                                              // black starts, no passes: colours alternate
+        // one turn per iteration, black first; the turn cap only guards against two players passing for ever on a board
+        // that never becomes scorable (the reference would spin there)
+        for (int turn = 0; board.count < max_moves && turn < 4 * 722 && status.load() == DGNN_OK; ++turn) {
+            const int me = turn & 1;
+            const bool allow_pass = is_scorable(board.inner);                  // self_play.rs:437
+            const dgnn_game_ops* ops = allow_pass ? &kGoOps : &kGoScoringOps;   // predict_aux, self_play.rs:243-274
+            const bool deterministic = !allow_pass;                            // ScoringSearch::deterministic, options.rs:160-162
             const float w = winrate[me];
-            const float scale = std::max(0.1f, 4.0f * w * (1.0f - w));        // Player::num_rollout, self_play.rs:234-241
-            const int limit = std::max(2, (int)(scale * (float)num_rollouts));
+            const int limit = (int)(std::max(0.1f, 4.0f * w * (1.0f - w)) * (float)num_rollouts);   // Player::num_rollout
 
             float value = 0.0f, prior[368];
-            int st = dgnn_full_forward(&kGoOps, &board, me, predict, predict_ctx, cache, &value, prior);   // lib.rs:154-159
+            int st = dgnn_full_forward(ops, &board, me, predict, predict_ctx, cache, &value, prior);   // lib.rs:154-159
             if (st < 0) { status.store(st); break; }
             evals.fetch_add((uint64_t)st);
-            prior[kPass] = -std::numeric_limits<float>::infinity();            // allow_pass == false (no scoring yet)
             bool any = false;
-            for (int i = 0; i < kPoints; ++i) any = any || std::isfinite(prior[i]);
-            if (!any) break;
-            normalize_policy(prior, 1.0f);
-            dgnn_dirichlet_add(prior, DGNN_NUM_MOVES, 0.03f, 0.25f, rng.next());   // lib.rs:163-165
+            for (int i = 0; i < DGNN_NUM_MOVES; ++i) any = any || std::isfinite(prior[i]);
 
-            dgnn_tree_node* root = roots[me];                                  // lib.rs:170-186: re-use the tree or start one
-            roots[me] = nullptr;
-            if (root) dgnn_tree_node_set_prior(root, prior);
-            else root = dgnn_tree_node_new(me, value, prior);
-            dgnn_tree_node_disqualify(root, kPass);                            // self_play.rs:253-256
-            uint64_t e = 0, c = 0, h = 0;
-            st = dgnn_search_run_cached(root, &kGoOps, &board, predict, predict_ctx, cache, limit, threads_per_search, rng.next(), &e, &c, &h);
-            evals.fetch_add(e);
-            conflicts.fetch_add(c);
-            hits.fetch_add(h);
-            if (st != DGNN_OK) { status.store(st); dgnn_tree_node_free(root); break; }
-
-            float best_value = 0.0f;
-            int best = kPass;
-            dgnn_tree_node_best(root, board.count < 8 ? 0.8f : 0.0f, rng.uniform(), &best_value, &best);   // lib.rs:188-192
-            if (best == kPass || !board.is_valid(me, best)) { dgnn_tree_node_free(root); break; }
-
-            float softmax[DGNN_NUM_MOVES];                                      // Played::from_mcts -> the f-4 record
-            dgnn_tree_node_softmax(root, softmax);
-            int total = 0;
-            dgnn_tree_node_info(root, nullptr, &total, nullptr, nullptr, nullptr);
+            int played = kPass;
             char move[2048];
-            dgnn_sgf_played(move, sizeof(move), me, best, total, softmax, 1, best_value, -1, "");
+            move[0] = '\0';
+            if (limit > 1) {
+                dgnn_tree_node* root = roots[me];
+                roots[me] = nullptr;
+                if (!any) {                                                    // nothing to search: value is not finite, pass (self_play.rs:347-350)
+                    dgnn_tree_node_free(root);
+                    dgnn_sgf_played(move, sizeof(move), me, kPass, 0, nullptr, 0, 0.0f, -1, "");
+                } else {
+                    if (!deterministic) dgnn_dirichlet_add(prior, DGNN_NUM_MOVES, 0.03f, 0.25f, rng.next());   // lib.rs:163-165
+                    if (root) { if (!allow_pass) dgnn_tree_node_disqualify(root, kPass); dgnn_tree_node_set_prior(root, prior); }   // lib.rs:170-181
+                    else root = dgnn_tree_node_new(me, value, prior);
+                    uint64_t e = 0, c = 0, h = 0;
+                    st = dgnn_search_run_cached(root, ops, &board, predict, predict_ctx, cache, limit, threads_per_search, rng.next(), &e, &c, &h);
+                    evals.fetch_add(e);
+                    conflicts.fetch_add(c);
+                    hits.fetch_add(h);
+                    if (st != DGNN_OK) { status.store(st); dgnn_tree_node_free(root); break; }
+                    float best_value = 0.0f;
+                    dgnn_tree_node_best(root, (!deterministic && board.count < 8) ? 0.8f : 0.0f, rng.uniform(), &best_value, &played);   // lib.rs:188-192
+                    if (!std::isfinite(best_value) || played < 0 || (played != kPass && !board.is_valid(me, played))) {
+                        played = kPass;
+                        dgnn_tree_node_free(root);
+                        dgnn_sgf_played(move, sizeof(move), me, kPass, 0, nullptr, 0, 0.0f, -1, "");
+                    } else {
+                        float softmax[DGNN_NUM_MOVES];                          // Played::from_mcts, self_play.rs:120-137
+                        dgnn_tree_node_softmax(root, softmax);
+                        int total = 0;
+                        dgnn_tree_node_info(root, nullptr, &total, nullptr, nullptr, nullptr);
+                        dgnn_sgf_played(move, sizeof(move), me, played, total, softmax, 1, best_value, -1, "");
+                        winrate[me] -= 0.2f * (winrate[me] - best_value);      // MovingAverage::update, self_play.rs:56-58
+                        roots[me] = dgnn_tree_node_forward(root, played);
+                    }
+                }
+            } else {                                                           // policy play, self_play.rs:369-399
+                if (!allow_pass) prior[kPass] = -std::numeric_limits<float>::infinity();
+                double scaled[DGNN_NUM_MOVES];
+                for (int i = 0; i < DGNN_NUM_MOVES; ++i) scaled[i] = (double)prior[i];
+                if (dgnn_choose_f64(scaled, DGNN_NUM_MOVES, 0.5, 1.0 / 0.8, rng.uniform(), &played, nullptr) != 1) played = kPass;
+                if (played < 0 || (played != kPass && !board.is_valid(me, played))) played = kPass;
+                dgnn_sgf_played(move, sizeof(move), me, played, 1, prior, 1, value, -1, "");
+                winrate[me] -= 0.2f * (winrate[me] - value);
+                if (roots[me]) roots[me] = dgnn_tree_node_forward(roots[me], played);
+            }
             sgf += move;
 
-            winrate[me] -= 0.2f * (winrate[me] - best_value);                  // MovingAverage::update, self_play.rs:56-58
-            roots[me] = dgnn_tree_node_forward(root, best);                    // self_play.rs:366, 447
-            if (roots[1 - me]) roots[1 - me] = dgnn_tree_node_forward(roots[1 - me], best);
-            board.place(me, best);
-            if (moves_out) moves_out[(size_t)g * num_moves + m] = best;
-            moves.fetch_add(1);
+            if (played == kPass) {                                             // self_play.rs:441-450
+                if (++pass_count >= 2 && is_scorable(board.inner)) { finished = true; break; }
+            } else {
+                pass_count = 0;
+                if (moves_out) moves_out[(size_t)g * max_moves + board.count] = played;
+                board.place(me, played);
+                moves.fetch_add(1);
+            }
+            if (roots[1 - me]) roots[1 - me] = dgnn_tree_node_forward(roots[1 - me], played);   // players[1].forward, self_play.rs:453
         }
-        sgf += ")";
+        if (finished) ended.fetch_add(1);
         dgnn_tree_node_free(roots[0]);
         dgnn_tree_node_free(roots[1]);
+
+        unsigned char point_status[kPoints];                                   // GameResult::Ended, game_result.rs:35-41
+        stone_status(board.inner, point_status);
+        char header[160], date[40];
+        const std::time_t now = std::time(nullptr);
+        std::tm utc;
+        gmtime_r(&now, &utc);
+        std::strftime(date, sizeof(date), "%Y-%m-%dT%H:%M:%S+0000", &utc);
+        std::snprintf(header, sizeof(header), "(;GM[1]FF[4]DT[%s]SZ[19]RU[Chinese]KM[%.1f]RE[%s]", date, (double)komi, winner_sgf(board, point_status).c_str());
+        records[(size_t)g] = header + sgf + territory_sgf(point_status) + ")";
     };
     std::vector<std::thread> threads;
     for (int g = 0; g < num_games; ++g) threads.emplace_back(game, g);
@@ -526,6 +835,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
     stats->evals = evals.load();
     stats->conflicts = conflicts.load();
     stats->cache_hits = hits.load();
+    stats->games_ended = ended.load();
     if (sgf_out && sgf_capacity > 0) {
         size_t used = 0;
         for (const std::string& r : records) {

@@ -399,6 +399,7 @@ int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_
     stats->evals = evals.load();
     stats->conflicts = conflicts.load();
     stats->cache_hits = 0;
+    stats->games_ended = 0;
     return status.load();
 }
 

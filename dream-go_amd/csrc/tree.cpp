@@ -378,19 +378,21 @@ int dgnn_tree_node_softmax(const dgnn_tree_node* handle, float* out)         // 
     return DGNN_OK;
 }
 
-// choose, libdg_mcts/choose.rs:23-106 on integer visit counts
-int dgnn_choose(const int* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out)
+// choose, libdg_mcts/choose.rs:23-106
+extern "C++" {
+template <typename T>
+static int choose_impl(const T* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out)
 {
     if (!items || n <= 0 || !index_out) return DGNN_BAD_ARGUMENT;
     double total = 0.0;
-    for (int i = 0; i < n; ++i) total += (double)items[i];
+    for (int i = 0; i < n; ++i) if (std::isfinite((double)items[i])) total += (double)items[i];     // choose.rs:69-72
     // percentile: walk the items from the largest down until (1 - cutoff) of the total is covered
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a] < items[b]; });
     const double max_value = total * (1.0 - cutoff_percentile);
     double so_far = 0.0;
-    int threshold = 0;
+    T threshold = 0;
     bool found = false;
     for (int k = n - 1; k >= 0; --k) {
         so_far += (double)items[order[k]];
@@ -406,6 +408,16 @@ int dgnn_choose(const int* items, int n, double cutoff_percentile, double temper
     for (int i = 0; i < n; ++i)
         if (cum[i] >= target) { *index_out = i; if (cum_out) *cum_out = cum[i]; return 1; }
     return 0;
+}
+}  // extern "C++"
+
+int dgnn_choose(const int* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out)
+{
+    return choose_impl(items, n, cutoff_percentile, temperature, at, index_out, cum_out);
+}
+int dgnn_choose_f64(const double* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out)
+{
+    return choose_impl(items, n, cutoff_percentile, temperature, at, index_out, cum_out);
 }
 
 int dgnn_tree_node_best(const dgnn_tree_node* handle, float temperature, double at, float* value_out, int* index_out)

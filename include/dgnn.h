@@ -330,6 +330,8 @@ int dgnn_tree_node_softmax(const dgnn_tree_node* node, float* out /* 362 */);   
 int dgnn_tree_node_best(const dgnn_tree_node* node, float temperature, double at, float* value_out, int* index_out);
 /* choose (src/libdg_mcts/choose.rs:54-88) on integer weights: 1 and *index_out / *cum_out when an item was chosen. */
 int dgnn_choose(const int* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out);
+/* The same on real weights (a policy with -inf for illegal moves, as the policy play of self_play.rs:383-388 calls it). */
+int dgnn_choose_f64(const double* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out);
 
 /* ---- search driver (scope row f-2, second part), search.cpp ------------------------------------------------- */
 
@@ -380,7 +382,7 @@ int dgnn_tree_node_set_prior(dgnn_tree_node* node, const float* prior /* 362 */)
 const dgnn_game_ops* dgnn_synthetic_game_ops(void);
 void* dgnn_synthetic_board_new(uint64_t seed);
 void dgnn_synthetic_board_free(void* board);
-typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, evals, conflicts, cache_hits; } dgnn_selfplay_stats;
+typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, evals, conflicts, cache_hits, games_ended; } dgnn_selfplay_stats;
 int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
                             int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats);
 
@@ -407,13 +409,32 @@ int dgnn_go_is_symmetric(const dgnn_go_board* board, int symmetry);          /* 
  * dgnn_forward for one board. */
 int dgnn_go_features(const dgnn_go_board* board, int to_move, int symmetry, uint16_t* out);
 /* The board as the game behind dgnn_search_run (a dgnn_go_board* is the `board` argument). */
-const dgnn_game_ops* dgnn_go_game_ops(void);
+const dgnn_game_ops* dgnn_go_game_ops(void);        /* StandardSearch: every legal move and pass (options.rs:44-82) */
+const dgnn_game_ops* dgnn_go_scoring_ops(void);     /* ScoringSearch: no pass, no point inside a Benson eye of either colour, no filling of
+                                                       one's own simple eye (options.rs:110-214) */
+
+/* Benson's unconditional life as the reference computes it (src/libdg_go/utils/benson.rs:62-190): per point 0 = neither,
+ * 1 = stone of an unconditionally alive block of `color` (is_alive), 2 = point of a region vital to one (is_eye). */
+int dgnn_go_benson(const dgnn_go_board* board, int color, unsigned char* status_out /* 361 */);
+int dgnn_go_is_scorable(const dgnn_go_board* board);                             /* Score::is_scorable, utils/score.rs:105-117 */
+int dgnn_go_score(const dgnn_go_board* board, int* black_out, int* white_out);   /* Score::get_score (Tromp-Taylor, no komi), :130-136, 220-239 */
+/* Score::get_stone_status(board, board) (utils/score.rs:146-186) as a bit mask per point. */
+#define DGNN_STONE_ALIVE 1
+#define DGNN_STONE_DEAD 2
+#define DGNN_STONE_SEKI 4
+#define DGNN_TERRITORY_BLACK 8
+#define DGNN_TERRITORY_WHITE 16
+int dgnn_go_stone_status(const dgnn_go_board* board, unsigned char* status_out /* 361 */);
+/* The RE[] value ("B+3.5", "W+0.5", "0") and the TB[..]TW[..] properties of GameResult::Ended
+ * (src/libdg_mcts/game_result.rs:35-93).  Either output may be NULL. */
+int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winner_capacity, char* territory_out, size_t territory_capacity);
 /* Self-play on the real board following self_play_one / Player::predict / predict (src/libdg_mcts/self_play.rs:423-459,
- * 331-368, lib.rs:144-200): random komi, per-player trees re-used across moves, win-rate driven rollout budget, 8-symmetry
- * root evaluation through `cache` (may be NULL), dirichlet noise, temperature for the first eight stones.  No scoring yet:
- * passing is disqualified and a game is num_moves stones long.  moves_out (num_games * num_moves packed indices, -1 = not
- * played) and sgf_out (one record per game in the reference's per-move format, newline separated) may be NULL. */
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_moves, int num_rollouts,
+ * 331-420, lib.rs:144-200): random komi, per-player trees re-used across moves, win-rate driven rollout budget, 8-symmetry
+ * root evaluation through `cache` (may be NULL); a deterministic ScoringSearch without pass until the board is scorable, a
+ * StandardSearch with dirichlet noise after; two passes on a scorable board end the game (stats->games_ended counts those).
+ * max_moves caps the stones per game (0 = the reference's 722).  moves_out (num_games * max_moves packed indices, -1 = not
+ * played) and sgf_out (one GameResult::Ended record per game, game_result.rs:35-41, newline separated) may be NULL. */
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int max_moves, int num_rollouts,
                      int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
 
 /* Library version / build info string (static). */

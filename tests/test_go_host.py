@@ -258,7 +258,7 @@ def test_selfplay_records_games_in_the_reference_format(api):
                           return_moves=True, return_sgf=True)
     assert len(out["sgf"]) == 2
     for game, record in zip(out["sgf"], out["record"]):
-        assert game.startswith("(;GM[1]FF[4]SZ[19]RU[Chinese]KM[") and game.endswith(")")
+        assert game.startswith("(;GM[1]FF[4]DT[") and "]SZ[19]RU[Chinese]KM[" in game and game.endswith(")")
         assert game.count(";B[") + game.count(";W[") == 5
         letters = "abcdefghijklmnopqrs"
         for m, index in enumerate(record):                         # the SGF vertex is the move that was played (CGoban, sgf.rs:36-43)
@@ -288,3 +288,177 @@ def test_real_games_reach_the_reference_positions(api):
         assert final == g["final_position"], g["name"]
         if table is not None:
             assert gen.hash_of(final, table) == g["zobrist_hash"]
+
+
+# ---- Benson, score, stone status (utils/benson.rs, utils/score.rs) -------------------------------------------------------
+
+def _senseis_example():
+    """The blocks and regions of benson.rs:375-566 (FakeAllBlocks / FakeAllRegions): a 6x6 diagram from Sensei's Library."""
+    blocks = [
+        ([(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 3), (1, 4), (2, 4), (2, 5)], [(1, 1), (1, 2), (2, 3), (3, 4), (3, 5), (1, 5), (0, 4)]),
+        ([(0, 5)], [(0, 4), (1, 5)]),
+        ([(2, 1)], [(2, 0), (2, 2), (1, 1), (3, 1)]),
+        ([(4, 5)], [(3, 5), (5, 5), (4, 4)]),
+        ([(3, 0), (4, 0), (4, 1), (5, 1), (5, 2), (5, 3), (5, 4)], [(2, 0), (5, 0), (5, 5), (3, 1), (4, 2), (4, 3), (4, 4)]),
+    ]
+    regions = [
+        ([(0, 4)], [(0, 5), (0, 3), (1, 4)]),
+        ([(1, 5)], [(0, 5), (2, 5), (1, 4)]),
+        ([(2, 0)], [(1, 0), (3, 0), (2, 1)]),
+        ([(5, 0)], [(5, 1), (4, 0)]),
+        ([(5, 5)], [(5, 4), (4, 5)]),
+        ([(1, 1), (1, 2), (2, 2), (2, 3), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (4, 2), (4, 3), (4, 4)],
+         [(0, 1), (0, 2), (1, 0), (1, 3), (1, 4), (2, 1), (2, 4), (2, 5), (3, 0), (4, 1), (4, 5), (5, 2), (5, 3), (5, 4)]),
+    ]
+    return blocks, regions
+
+
+def test_benson_restatement_reproduces_the_reference_example():
+    """benson.rs:571-599: exactly these twelve points are not `valid` (alive stones and the eyes they live on)."""
+    from oracle import benson as restated
+    status = restated.benson(*_senseis_example())
+    invalid = {(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (1, 0), (1, 3), (1, 4), (1, 5), (2, 4), (2, 5)}
+    assert {p for p, s in status.items() if s != restated.NONE} == invalid
+
+
+def test_benson_matches_the_restatement_on_random_positions(api):
+    from oracle import benson as restated
+    rng = np.random.default_rng(11)
+    interesting = 0
+    for trial in range(40):
+        board, stones = api.Board(0.5), {}
+        density = (0.5, 0.75, 0.9, 0.97)[trial % 4]                # dense boards are where alive groups appear
+        for index in rng.permutation(361):
+            if rng.random() > density:
+                continue
+            x, y = int(index % 19), int(index // 19)
+            color = int(rng.random() < (0.5 if trial % 3 else 0.8))
+            if board.is_valid(color, x, y):
+                board.place(color, x, y)
+        for y in range(19):
+            for x in range(19):
+                if board.at(x, y) is not None:
+                    stones[(x, y)] = board.at(x, y)
+        for color in (B, W):
+            got = board.benson(color)
+            assert np.array_equal(got, np.array(restated.benson_of_position(stones, color), dtype=np.uint8)), (trial, color)
+            interesting += int(got.any())
+    assert interesting >= 10                                       # the comparison was not all-zero boards
+
+
+def test_benson_eyes_and_empty(api):
+    """benson.rs:601-609 (empty_is_all_valid) and :655-676 (eyes)."""
+    assert not api.Board(0.5).benson(B).any()
+    b = api.Board(0.5)
+    for x, y in ((0, 1), (1, 1), (2, 0), (2, 1), (3, 1), (4, 0), (4, 1)):
+        b.place(W, x, y)
+    b.place(B, 0, 0)
+    status = b.benson(W)
+    for y in range(19):
+        for x in range(19):
+            if b.at(x, y) == W:
+                assert status[y, x] == 1
+            elif (x, y) in ((0, 0), (1, 0), (3, 0)):
+                assert status[y, x] == 2
+
+
+def test_scores(api):
+    """score.rs:289-353: score_black, score_white, score_black_white, checker_board_black / white."""
+    b = api.Board(7.5); b.place(B, 0, 0)
+    assert not b.is_scorable() and b.get_score() == (361, 0)
+    b = api.Board(7.5); b.place(W, 0, 0)
+    assert not b.is_scorable() and b.get_score() == (0, 361)
+    b = api.Board(7.5)
+    for x, y in ((1, 0), (0, 1), (1, 1), (1, 2), (0, 3), (1, 3)):
+        b.place(W, x, y)
+    for x, y in ((2, 0), (2, 1), (2, 2), (2, 3), (0, 4), (1, 4), (2, 4)):
+        b.place(B, x, y)
+    assert not b.is_scorable() and b.get_score() == (353, 8)
+    for color, expected in ((B, (361, 0)), (W, (0, 361))):
+        b = api.Board(0.5)
+        for y in range(19):
+            for x in range(1, 19, 2):
+                b.place(color, x, y)
+        assert b.is_scorable() and b.get_score() == expected
+    assert api.Board(7.5).get_score() == (0, 0)                    # score.rs:131-135: nothing played
+
+
+def test_eyes_should_be_territory(api):
+    """score.rs:355-405, and the RE[] / TB / TW text GameResult::Ended makes of it (game_result.rs:46-93)."""
+    b = api.Board(0.5)
+    for x, y in ((0, 1), (1, 1), (2, 0), (2, 1), (3, 1), (4, 0), (4, 1)):
+        b.place(W, x, y)
+    b.place(B, 0, 0); b.place(B, 9, 9)
+    status = b.get_stone_status()
+    for y in range(19):
+        for x in range(19):
+            if b.at(x, y) == W:
+                assert status[y, x] == api.STONE_ALIVE | api.TERRITORY_WHITE
+            elif (x, y) == (0, 0):
+                assert status[y, x] == api.STONE_DEAD | api.TERRITORY_WHITE
+            elif (x, y) == (9, 9):
+                assert status[y, x] == api.STONE_SEKI | api.TERRITORY_BLACK
+            else:
+                assert status[y, x] == api.TERRITORY_WHITE
+    winner, territory = b.result_sgf()
+    assert winner == "W+359.5"                                      # 360 points + 0.5 komi against the one seki stone
+    assert territory.startswith("TB[jj]TW[aa][ba]") and territory.count("[") == 361
+
+
+def test_scoring_search_candidates(api):
+    """ScoringPolicyChecker (options.rs:110-139): no pass, no Benson eye of either colour, no own simple eye (is_eye :192-213,
+    tests :221-258 corner / side / middle)."""
+    b = api.Board(0.5)
+    for x, y in ((0, 1), (1, 1), (2, 0), (2, 1), (3, 1), (4, 0), (4, 1)):
+        b.place(W, x, y)
+    _, prior, _ = api.full_forward(b, B, scoring=True)
+    assert prior[361] == -np.inf and prior[0 * 19 + 1] == -np.inf and prior[0 * 19 + 3] == -np.inf    # white's two eyes
+    assert np.isfinite(prior[5 * 19 + 5])
+    _, standard, _ = api.full_forward(b, B)
+    assert np.isfinite(standard[361])
+    for stones, eye in ((((1, 0), (0, 1), (1, 1)), (0, 0)),                                          # corner
+                        (((3, 0), (5, 0), (4, 1), (3, 1), (5, 1)), (4, 0)),                           # side
+                        (((3, 4), (5, 4), (4, 3), (4, 5), (3, 3), (5, 3), (3, 5)), (4, 4))):          # middle
+        b = api.Board(0.5)
+        for x, y in stones:
+            b.place(B, x, y)
+        _, prior, _ = api.full_forward(b, B, scoring=True)
+        assert prior[eye[1] * 19 + eye[0]] == -np.inf
+        _, prior, _ = api.full_forward(b, W, scoring=True)
+        # for white the point is either a suicide or a legal move: it is not excluded for being an eye
+        assert np.isfinite(prior[eye[1] * 19 + eye[0]]) == b.is_valid(W, *eye)
+
+
+def test_choose_on_a_policy(api):
+    """choose.rs:54-88 on real weights: -inf entries are ignored by the total and never chosen."""
+    p = np.array([0.1, -np.inf, 0.6, 0.3, -np.inf])
+    assert api.choose_f64(p, 0.5, 1.0, 0.0)[0] == 2
+    picks = {api.choose_f64(p, 0.05, 1.0, at)[0] for at in np.linspace(0.0, 1.0, 21)}
+    assert picks == {0, 2, 3}
+    assert api.choose_f64(p, 0.5, 1.0, 1.0)[0] == 2               # the lower half of the mass (0.1, 0.3) is cut off
+
+
+def test_selfplay_plays_games_to_the_end(api):
+    """self_play_one (self_play.rs:423-459) with the deterministic hash predictor: tiny budgets, but whole games: every record
+    is a GameResult::Ended record, every stone was legal, and a game that ended did so on a scorable board after two passes."""
+    out = api.selfplay_go(num_games=2, num_moves=0, num_rollouts=12, threads_per_search=1, seed=5, cache=api.LruCache(20000),
+                          return_moves=True, return_sgf=True)
+    assert out["games"] == 2 and len(out["sgf"]) == 2
+    import re
+    for game, record in zip(out["sgf"], out["record"]):
+        assert re.match(r"^\(;GM\[1\]FF\[4\]DT\[\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d\+0000\]SZ\[19\]RU\[Chinese\]KM\[-?\d+\.5\]RE\[(0|[BW]\+\d+\.\d)\];[BW]\[", game)
+        assert game.endswith(")")
+        replay = api.Board(float(re.search(r"KM\[(-?\d+\.5)\]", game).group(1)))
+        moves = re.findall(r";([BW])\[([a-s]{2})?\]", game)
+        stones = [m for m in moves if m[1]]
+        assert len(stones) == int((record >= 0).sum())
+        for (colour, vertex), index in zip(stones, record):
+            x, y = ord(vertex[0]) - 97, ord(vertex[1]) - 97
+            assert index == 19 * y + x and replay.is_valid("BW".index(colour), x, y)
+            replay.place("BW".index(colour), x, y)
+        assert [c for c, _ in moves] == ["B", "W"] * (len(moves) // 2) + ["B"] * (len(moves) % 2)     # turns alternate, passes included
+        if len(stones) < 722:                                       # ended by two passes
+            assert moves[-1][1] == "" and moves[-2][1] == "" and replay.is_scorable()
+            winner, territory = replay.result_sgf()
+            assert "RE[%s]" % winner in game and game.endswith(territory + ")")
+    assert out["games_ended"] == sum(int((r >= 0).sum()) < 722 for r in out["record"])

@@ -2,9 +2,10 @@
 """Self-play on the REAL board through the whole pipeline: Go rules, super-ko, ladder reader and V1 feature planes (go.cpp) ->
 search tree + driver (tree.cpp, search.cpp) -> LeafPool / batcher (batcher.cpp) -> HIP engine, PCIe-inclusive, random-init
 network.  The game loop follows self_play_one / Player::predict (random komi, per-player trees re-used across moves, win-rate
-driven rollout budget, 8-fold root ensemble, dirichlet noise, transposition cache).  What it is not:
-there is no scoring yet, so passing is disqualified and a game is --moves stones long; no resignation.  Prints one JSON line;
---sgf FILE writes the game records (reference per-move format).
+driven rollout budget, 8-fold root ensemble, ScoringSearch until the board is scorable / StandardSearch with dirichlet noise
+after, two passes on a scorable board end the game, transposition cache).  --moves N caps the stones per game so that a
+measurement is bounded; --moves 0 plays whole games (the reference's cap of 722 stones) and reports measured games/hour.
+Prints one JSON line; --sgf FILE writes the game records (GameResult::Ended format).
 
     python tools/selfplay_go.py [--games 64] [--moves 8] [--rollouts 800] [--threads 8] [--blocks 20 --channels 256]
 """
@@ -24,7 +25,7 @@ from dream_go_amd import api, synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=64)
-    ap.add_argument("--moves", type=int, default=8)
+    ap.add_argument("--moves", type=int, default=8, help="stones per game, 0 = whole games")
     ap.add_argument("--rollouts", type=int, default=800)
     ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
     ap.add_argument("--max-batch", type=int, default=256)
@@ -52,11 +53,14 @@ def main():
     moves_per_s = stats["moves"] / stats["seconds"]
     print(json.dumps({
         "metric": "go_selfplay", "evals_per_sec": stats["evals"] / stats["seconds"], "moves_per_sec": moves_per_s,
-        "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": args.games, "moves_per_game": args.moves,
+        "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": args.games, "moves_cap": args.moves,
+        "games_ended_by_passes": stats["games_ended"], "mean_stones_per_game": stats["moves"] / args.games,
+        "games_per_hour_measured": (args.games * 3600 / stats["seconds"]) if args.moves == 0 else None,
+        "evals_per_move": stats["evals"] / max(stats["moves"], 1),
         "rollouts_per_move": args.rollouts, "search_threads_per_game": args.threads, "mean_device_batch": boards / max(batches, 1),
         "probe_conflicts": stats["conflicts"], "cache_hits": stats["cache_hits"], "cache_entries": args.cache,
         "seconds": stats["seconds"], "net": f"{args.blocks}x{args.channels}",
-        "note": "real board / ladders / feature planes (go.cpp), self_play_one game loop, fixed game length (no scoring yet), PCIe-inclusive",
+        "note": "real board / ladders / feature planes / Benson scoring (go.cpp), self_play_one game loop, PCIe-inclusive, random-init net",
     }))
 
 
