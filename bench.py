@@ -193,8 +193,8 @@ def main():
             },
             "derived": {
                 "games_per_hour_est": value * 3600.0 / (250 * 800),
-                "assumption": "250 moves x 800 leaf evaluations per move, no cache hits (no MCTS driver yet; "
-                              "SURVEY.md 8f-1/8f-2)",
+                "assumption": "250 moves x 800 leaf evaluations per move, no cache hits, inputs resident; the measured "
+                              "figure through board + search + pool is tools/selfplay_go.py (DESIGN.md section 8)",
             },
         }
         # the reference's own harness style (`dream_go --bench`, src/dg/bench/forward.rs:28-47): one thread, one workspace,
