@@ -716,10 +716,15 @@ int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_c
 // only policy_play), expert iteration.
 // moves_out (num_games * max_moves packed indices of the stones in order, -1 = not played) and sgf_out (one record per game,
 // newline separated, cut off at sgf_capacity) may be NULL.
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int max_moves, int num_rollouts,
-                     int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
+// Sharding: the games of this call are the global game ids first_game, first_game + game_stride, ...;
+// a game's random stream is a function of (seed, global id) only, so `world` ranks calling with first_game = rank and
+// game_stride = world play the games one rank would.
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int first_game, int game_stride,
+                     int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out,
+                     char* sgf_out, size_t sgf_capacity)
 {
-    if (!predict || num_games <= 0 || max_moves < 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats) return DGNN_BAD_ARGUMENT;
+    if (!predict || num_games <= 0 || first_game < 0 || game_stride <= 0 || max_moves < 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats)
+        return DGNN_BAD_ARGUMENT;
     if (max_moves == 0 || max_moves > 722) max_moves = 722;
     std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0};
     std::atomic<int> status{DGNN_OK};
@@ -727,7 +732,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
     const auto t0 = std::chrono::steady_clock::now();
 
     auto game = [&](int g) {
-        Rng2 rng{seed + 0x9e3779b97f4a7c15ull * (uint64_t)(g + 1)};
+        Rng2 rng{seed + 0x9e3779b97f4a7c15ull * (uint64_t)(first_game + g * game_stride + 1)};
         const double kv = rng.uniform();                                       // get_random_komi, lib.rs:210-224
         const float komi = kv < 0.4 ? 7.5f : kv < 0.8 ? 6.5f : kv < 0.9 ? 0.5f : (float)((int)(rng.next() % 16) - 8) + 0.5f;
         GoBoard board(komi);

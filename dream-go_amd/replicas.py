@@ -59,3 +59,38 @@ def fnv1a(data):
     for byte in np.asarray(data, dtype=np.uint8).tobytes():
         h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+def games_of_rank(num_games, world, rank):
+    """Games are sharded `game_id mod world` (owner_of_game) -> (count, first_game, game_stride) for dgnn_selfplay_go."""
+    num_games, world, rank = int(num_games), int(world), int(rank)
+    count = (num_games - rank + world - 1) // world if rank < num_games else 0
+    return count, rank, world
+
+
+def selfplay_sharded(api, dist, torch, num_games, num_moves, num_rollouts, threads_per_search, seed, pool=None, cache=None,
+                     return_moves=False, return_sgf=False, device="cpu"):
+    """One self-play job over all ranks (BASELINE.json configs[3]): every rank plays its games against its own engine, pool and
+    transposition cache, nothing is exchanged while the games run, the counters are summed and the clock is the slowest
+    rank's.  `dist` may be None (one rank).  Returns this rank's result with the job totals under "job"."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    count, first, stride = games_of_rank(num_games, world, rank)
+    if dist is not None:
+        dist.barrier()
+    if count > 0:
+        out = api.selfplay_go(count, num_moves, num_rollouts, threads_per_search, seed=seed, pool=pool, cache=cache,
+                              return_moves=return_moves, return_sgf=return_sgf, first_game=first, game_stride=stride)
+    else:
+        out = {"seconds": 0.0, "games": 0, "moves": 0, "evals": 0, "conflicts": 0, "cache_hits": 0, "games_ended": 0}
+    out["game_ids"] = [first + i * stride for i in range(count)]
+    keys = ("games", "moves", "evals", "conflicts", "cache_hits", "games_ended")
+    if dist is not None:
+        job = {k: sum_over_ranks(dist, torch, out[k], device=device) for k in keys}
+        job["seconds"] = max_over_ranks(dist, torch, out["seconds"], device=device)
+    else:
+        job = {k: out[k] for k in keys}
+        job["seconds"] = out["seconds"]
+    job["world"] = world
+    out["job"] = job
+    return out

@@ -433,9 +433,12 @@ int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winn
  * root evaluation through `cache` (may be NULL); a deterministic ScoringSearch without pass until the board is scorable, a
  * StandardSearch with dirichlet noise after; two passes on a scorable board end the game (stats->games_ended counts those).
  * max_moves caps the stones per game (0 = the reference's 722).  moves_out (num_games * max_moves packed indices, -1 = not
- * played) and sgf_out (one GameResult::Ended record per game, game_result.rs:35-41, newline separated) may be NULL. */
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int max_moves, int num_rollouts,
-                     int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
+ * played) and sgf_out (one GameResult::Ended record per game, game_result.rs:35-41, newline separated) may be NULL.
+ * The call plays the global game ids first_game, first_game + game_stride, ... (num_games of them); a game's random
+ * stream depends on (seed, global id) only, so ranks sharding games `id mod world` play what one rank would. */
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int first_game, int game_stride,
+                     int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out,
+                     char* sgf_out, size_t sgf_capacity);
 
 /* Library version / build info string (static). */
 const char* dgnn_version(void);

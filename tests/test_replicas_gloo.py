@@ -75,3 +75,44 @@ def test_shard_covers_everything_once():
             sizes = [len(replicas.shard(n, world, r)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
     assert [replicas.owner_of_game(g, 8) for g in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+
+
+def _selfplay_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.package()
+    from dream_go_amd import api, replicas
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = replicas.selfplay_sharded(api, dist, torch, num_games=5, num_moves=6, num_rollouts=12, threads_per_search=1, seed=21,
+                                        return_moves=True)
+        results[rank] = dict(ids=out["game_ids"], record=out["record"].tolist(), job=out["job"], evals=out["evals"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_games_sharded_over_two_ranks_are_the_games_one_rank_plays():
+    """SURVEY.md section 8e / BASELINE.json configs[3]: games are sharded `id mod world`; with one search thread and the seeded
+    hash predictor a game is a function of (seed, game id), so two ranks together play exactly what one rank plays alone, and
+    the job counters are the sums."""
+    from dream_go_amd import api, replicas
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as manager:
+        results = manager.dict()
+        procs = [ctx.Process(target=_selfplay_worker, args=(r, world, port, results)) for port in [_free_port()] for r in range(world)]
+        [p.start() for p in procs]
+        [p.join(180) for p in procs]
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        r0, r1 = dict(results[0]), dict(results[1])
+    alone = replicas.selfplay_sharded(api, None, torch, num_games=5, num_moves=6, num_rollouts=12, threads_per_search=1, seed=21,
+                                      return_moves=True)
+    assert r0["ids"] == [0, 2, 4] and r1["ids"] == [1, 3] and alone["game_ids"] == [0, 1, 2, 3, 4]
+    merged = {g: rec for r in (r0, r1) for g, rec in zip(r["ids"], r["record"])}
+    assert [merged[g] for g in range(5)] == alone["record"].tolist()
+    assert r0["job"] == r1["job"] and r0["job"]["games"] == 5 and r0["job"]["moves"] == 30 and r0["job"]["world"] == 2
+    assert r0["job"]["evals"] == r0["evals"] + r1["evals"] == alone["job"]["evals"]
+    assert [replicas.games_of_rank(5, 8, r)[0] for r in range(8)] == [1, 1, 1, 1, 1, 0, 0, 0]

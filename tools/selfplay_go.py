@@ -19,12 +19,12 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 graft.package()
-from dream_go_amd import api, synth  # noqa: E402
+from dream_go_amd import api, replicas, synth  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--games", type=int, default=64)
+    ap.add_argument("--games", type=int, default=64, help="games in the whole job (sharded game_id mod world over the ranks)")
     ap.add_argument("--moves", type=int, default=8, help="stones per game, 0 = whole games")
     ap.add_argument("--rollouts", type=int, default=800)
     ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
@@ -36,32 +36,58 @@ def main():
     ap.add_argument("--sgf", default=None)
     args = ap.parse_args()
 
-    net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
-    batcher = api.Batcher(net, args.max_batch, args.max_batches)
+    # one process per GPU (python -m torch.distributed.run --nproc-per-node N tools/selfplay_go.py ...): every rank owns an
+    # engine, a batcher, a pool and a cache; rank 0's weights are broadcast once over RCCL; nothing else is exchanged
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    device = local_rank
+
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1 if rank == 0 else 100 + rank)))
+    broadcast = None
+    if dist is not None:
+        sys.path.insert(0, ROOT)
+        import bench
+        broadcast = bench.broadcast_weights(net, device, torch, dist, replicas)
+    batcher = api.Batcher(net, args.max_batch, args.max_batches, device=device)
     pool = api.LeafPool(batcher, args.max_batches)
     api.selfplay_go(2, 1, 16, 2, seed=1, pool=pool)          # warm: workspace, weight upload
     cache = api.LruCache(args.cache, 8) if args.cache > 0 else None
     before = batcher.stats()
-    stats = api.selfplay_go(args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
-                            return_sgf=args.sgf is not None)
+    stats = replicas.selfplay_sharded(api, dist, torch, args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
+                                      return_sgf=args.sgf is not None, device=f"cuda:{device}" if dist is not None else "cpu")
     after = batcher.stats()
     if args.sgf:
-        with open(args.sgf, "w") as f:
-            f.write("\n".join(stats["sgf"]) + "\n")
+        with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
+            f.write("\n".join(stats.get("sgf", [])) + "\n")
     pool.close()
     boards, batches = after["boards"] - before["boards"], after["batches"] - before["batches"]
-    moves_per_s = stats["moves"] / stats["seconds"]
-    print(json.dumps({
-        "metric": "go_selfplay", "evals_per_sec": stats["evals"] / stats["seconds"], "moves_per_sec": moves_per_s,
-        "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": args.games, "moves_cap": args.moves,
-        "games_ended_by_passes": stats["games_ended"], "mean_stones_per_game": stats["moves"] / args.games,
-        "games_per_hour_measured": (args.games * 3600 / stats["seconds"]) if args.moves == 0 else None,
-        "evals_per_move": stats["evals"] / max(stats["moves"], 1),
-        "rollouts_per_move": args.rollouts, "search_threads_per_game": args.threads, "mean_device_batch": boards / max(batches, 1),
-        "probe_conflicts": stats["conflicts"], "cache_hits": stats["cache_hits"], "cache_entries": args.cache,
-        "seconds": stats["seconds"], "net": f"{args.blocks}x{args.channels}",
-        "note": "real board / ladders / feature planes / Benson scoring (go.cpp), self_play_one game loop, PCIe-inclusive, random-init net",
-    }))
+    if dist is not None:
+        boards, batches = replicas.sum_over_ranks(dist, torch, boards, f"cuda:{device}"), replicas.sum_over_ranks(dist, torch, batches, f"cuda:{device}")
+    job = stats["job"]
+    if rank == 0:
+        moves_per_s = job["moves"] / job["seconds"]
+        print(json.dumps({
+            "metric": "go_selfplay", "n_gpus": world, "evals_per_sec": job["evals"] / job["seconds"], "moves_per_sec": moves_per_s,
+            "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": job["games"], "moves_cap": args.moves,
+            "games_ended_by_passes": job["games_ended"], "mean_stones_per_game": job["moves"] / max(job["games"], 1),
+            "games_per_hour_measured": (job["games"] * 3600 / job["seconds"]) if args.moves == 0 else None,
+            "evals_per_move": job["evals"] / max(job["moves"], 1),
+            "rollouts_per_move": args.rollouts, "search_threads_per_game": args.threads, "mean_device_batch": boards / max(batches, 1),
+            "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
+            "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
+            "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
+            "sharding": "game_id mod world, one engine + batcher + pool + cache per rank, no data-path collective",
+            "note": "real board / ladders / feature planes / Benson scoring (go.cpp), self_play_one game loop, PCIe-inclusive, random-init net",
+        }))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
