@@ -163,6 +163,7 @@ SYMBOLS = [
     ("dgnn_go_scoring_ops", _vp, []),
     ("dgnn_go_benson", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_go_is_scorable", ctypes.c_int, [_vp]),
+    ("dgnn_go_check", ctypes.c_int, [_vp]),
     ("dgnn_go_score", ctypes.c_int, [_vp, _ip, _ip]),
     ("dgnn_go_stone_status", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_go_result_sgf", ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]),
@@ -1017,6 +1018,10 @@ class Board:
 
     def is_scorable(self):
         return bool(lib.dgnn_go_is_scorable(self._handle))
+
+    def check(self):
+        """True when the incremental block / liberty bookkeeping equals a from-scratch flood fill."""
+        return bool(lib.dgnn_go_check(self._handle))
 
     def get_score(self):
         black, white = ctypes.c_int(), ctypes.c_int()

@@ -55,27 +55,37 @@ struct Zobrist {
 };
 const Zobrist& zobrist() { static const Zobrist z; return z; }
 
-inline int neighbour(int p, int d)
-{
-    const int x = p % kN + kDx[d], y = p / kN + kDy[d];
-    return (x < 0 || x >= kN || y < 0 || y >= kN) ? -1 : y * kN + x;
-}
+struct Neighbours {
+    short table[kPoints][4];
+    Neighbours()
+    {
+        for (int p = 0; p < kPoints; ++p)
+            for (int d = 0; d < 4; ++d) {
+                const int x = p % kN + kDx[d], y = p / kN + kDy[d];
+                table[p][d] = (short)((x < 0 || x >= kN || y < 0 || y >= kN) ? -1 : y * kN + x);
+            }
+    }
+};
+const Neighbours kNeighbours;
+inline int neighbour(int p, int d) { return kNeighbours.table[p][d]; }
 
 struct Fast {                         // BoardFast
     unsigned char stone[kPoints];
     unsigned char visited[kPoints];
-    short head[kPoints];              // block id = smallest point of the block (any unique id would do)
-    short libs[kPoints];              // liberties of the block, stored at every stone
+    short head[kPoints];              // block id = one of the block's points (any unique id would do)
+    short libs[kPoints];              // liberties of the block, valid at the block's head stone only
+    short next[kPoints];              // circular list of the block's stones (the reference's next_link, board_fast.rs:37-60)
 
-    Fast() { std::memset(stone, 0, sizeof(stone)); std::memset(visited, 0, sizeof(visited)); std::memset(head, 0, sizeof(head)); std::memset(libs, 0, sizeof(libs)); }
+    Fast() { std::memset(stone, 0, sizeof(stone)); std::memset(visited, 0, sizeof(visited)); std::memset(head, 0, sizeof(head)); std::memset(libs, 0, sizeof(libs)); std::memset(next, 0, sizeof(next)); }
 
-    void rebuild()
+    // From-scratch flood fill of blocks and liberties: the checker of the incremental bookkeeping in place()
+    // (dgnn_go_check, tests/test_go_host.py), not used while playing.
+    bool consistent() const
     {
         bool done[kPoints] = {false};
         short lib_stamp[kPoints];                       // liberty already counted for block number lib_stamp[r]
         std::memset(lib_stamp, 0xff, sizeof(lib_stamp));
         short stack[kPoints];
-        short members[kPoints];
         for (int p = 0; p < kPoints; ++p) {
             if (stone[p] == kEmpty || done[p]) continue;
             int top = 0, count = 0, nlibs = 0;
@@ -83,7 +93,8 @@ struct Fast {                         // BoardFast
             done[p] = true;
             while (top > 0) {
                 const int q = stack[--top];
-                members[count++] = (short)q;
+                ++count;
+                if (head[q] != head[p]) return false;                           // one block, one id
                 for (int d = 0; d < 4; ++d) {
                     const int r = neighbour(q, d);
                     if (r < 0) continue;
@@ -91,12 +102,17 @@ struct Fast {                         // BoardFast
                     else if (stone[r] == stone[p] && !done[r]) { done[r] = true; stack[top++] = (short)r; }
                 }
             }
-            for (int i = 0; i < count; ++i) { head[members[i]] = (short)p; libs[members[i]] = (short)nlibs; }
+            const int h = head[p];
+            if (h < 0 || h >= kPoints || stone[h] != stone[p] || head[h] != h || libs[h] != nlibs) return false;
+            int listed = 0, r = p;                                              // the circular list holds exactly the block
+            do { if (stone[r] != stone[p] || head[r] != h || ++listed > count) return false; r = next[r]; } while (r != p);
+            if (listed != count) return false;
         }
+        return true;
     }
 
-    int n_liberty(int p) const { return libs[p]; }                            // board_fast.rs:169-173
-    bool has_n_liberty(int p, int n) const { return libs[p] >= n; }
+    int n_liberty(int p) const { return libs[head[p]]; }                      // board_fast.rs:169-173
+    bool has_n_liberty(int p, int n) const { return libs[head[p]] >= n; }
 
     bool is_valid(int color, int p) const                                     // board_fast.rs:213-241
     {
@@ -121,71 +137,118 @@ struct Fast {                         // BoardFast
             const int h = head[q];
             if (std::find(seen, seen + 4, h) != seen + 4) continue;
             seen[d] = h;
-            for (int r = 0; r < kPoints; ++r) if (stone[r] == 2 - color && head[r] == h) adjust ^= zobrist().table[1 - color][r];
+            int r = q;
+            do { adjust ^= zobrist().table[1 - color][r]; r = next[r]; } while (r != q);
         }
         return adjust;
     }
 
-    // board_fast.rs:420-463: no legality check; opponent blocks left without liberties are captured, one's own are not
+    // board_fast.rs:420-463: no legality check; opponent blocks left without liberties are captured, one's own are not.
+    // Incremental like the reference's: the stone takes a liberty from each adjacent opponent block, blocks at zero are
+    // lifted (every lifted stone is a new liberty of each of its own-colour neighbours' blocks), adjacent own blocks are
+    // spliced into one list, and only the merged block's liberties are counted again.
     uint64_t place(int color, int p)
     {
+        static thread_local unsigned int stamp[kPoints];
+        static thread_local unsigned int serial = 0;
+        const unsigned char mine = (unsigned char)(color + 1), theirs = (unsigned char)(2 - color);
         uint64_t hash = zobrist().table[color][p];
-        stone[p] = (unsigned char)(color + 1);
+        stone[p] = mine;
         visited[p] = 1;
-        rebuild();
-        bool captured = false;
-        for (int d = 0; d < 4; ++d) {
+        head[p] = (short)p;
+        next[p] = (short)p;
+        libs[p] = 0;
+
+        int seen[4], n_seen = 0;
+        for (int d = 0; d < 4; ++d) {                                          // one liberty less for every adjacent opponent block
             const int q = neighbour(p, d);
-            if (q < 0 || stone[q] != 2 - color || libs[q] != 0) continue;
+            if (q < 0 || stone[q] != theirs) continue;
             const int h = head[q];
-            for (int r = 0; r < kPoints; ++r)
-                if (stone[r] == 2 - color && head[r] == h) { stone[r] = kEmpty; hash ^= zobrist().table[1 - color][r]; }
-            captured = true;
+            if (std::find(seen, seen + n_seen, h) != seen + n_seen) continue;
+            seen[n_seen++] = h;
+            if (--libs[h] > 0) continue;
+            int r = q;                                                         // captured
+            do {
+                stone[r] = kEmpty;
+                hash ^= zobrist().table[1 - color][r];
+                int near[4], n_near = 0;
+                for (int e = 0; e < 4; ++e) {
+                    const int a = neighbour(r, e);
+                    if (a < 0 || stone[a] != mine) continue;
+                    const int ha = head[a];
+                    if (std::find(near, near + n_near, ha) != near + n_near) continue;
+                    near[n_near++] = ha;
+                    ++libs[ha];
+                }
+                r = next[r];
+            } while (r != q);
         }
-        if (captured) rebuild();
+
+        for (int d = 0; d < 4; ++d) {                                          // splice the adjacent own blocks into p's list
+            const int q = neighbour(p, d);
+            if (q < 0 || stone[q] != mine || head[q] == p) continue;
+            int r = q;
+            do { head[r] = (short)p; r = next[r]; } while (r != q);
+            std::swap(next[p], next[q]);
+        }
+
+        if (++serial == 0) { std::memset(stamp, 0, sizeof(stamp)); serial = 1; }
+        int nlibs = 0, r = p;                                                  // liberties of the merged block
+        do {
+            for (int d = 0; d < 4; ++d) {
+                const int a = neighbour(r, d);
+                if (a >= 0 && stone[a] == kEmpty && stamp[a] != serial) { stamp[a] = serial; ++nlibs; }
+            }
+            r = next[r];
+        } while (r != p);
+        libs[p] = (short)nlibs;
         return hash;
     }
 
     int n_liberty_if(int color, int p) const                                  // board_fast.rs:484-541
     {
-        bool seen[kPoints] = {false};
+        static thread_local unsigned int stamp[kPoints];                      // "seen in call number serial"
+        static thread_local unsigned int serial = 0;
+        if (++serial == 0) { std::memset(stamp, 0, sizeof(stamp)); serial = 1; }
         int num = 0;
-        seen[p] = true;
-        int captured[4] = {-1, -1, -1, -1}, connected[4] = {-1, -1, -1, -1};
+        stamp[p] = serial;
+        int captured[4] = {-1, -1, -1, -1}, connected[4] = {-1, -1, -1, -1}, connected_at[4] = {-1, -1, -1, -1};
         for (int d = 0; d < 4; ++d) {
             const int q = neighbour(p, d);
             if (q < 0) continue;
             if (stone[q] == color + 1) {
-                if (std::find(connected, connected + 4, (int)head[q]) == connected + 4) connected[d] = head[q];
+                if (std::find(connected, connected + 4, (int)head[q]) == connected + 4) { connected[d] = head[q]; connected_at[d] = q; }
             } else if (stone[q] == 2 - color) {
-                if (libs[q] == 1) { captured[d] = head[q]; seen[q] = true; ++num; }
+                if (libs[head[q]] == 1) { captured[d] = head[q]; stamp[q] = serial; ++num; }
             } else {
-                seen[q] = true;
+                stamp[q] = serial;
                 ++num;
             }
         }
         for (int c = 0; c < 4; ++c) {
             if (connected[c] < 0) continue;
-            for (int s = 0; s < kPoints; ++s) {
-                if (stone[s] != color + 1 || head[s] != connected[c]) continue;
+            int s = connected_at[c];
+            do {
                 for (int d = 0; d < 4; ++d) {
                     const int a = neighbour(s, d);
-                    if (a < 0 || seen[a]) continue;
-                    seen[a] = true;
+                    if (a < 0 || stamp[a] == serial) continue;
+                    stamp[a] = serial;
                     if (stone[a] == kEmpty) ++num;
-                    else if (std::find(captured, captured + 4, (int)head[a]) != captured + 4 && stone[a] == 2 - color) ++num;
+                    else if (stone[a] == 2 - color && std::find(captured, captured + 4, (int)head[a]) != captured + 4) ++num;
                 }
-            }
+                s = next[s];
+            } while (s != connected_at[c]);
         }
         return num;
     }
 
     int a_liberty(int p) const                                                // board_fast.rs:181-191
     {
-        for (int s = 0; s < kPoints; ++s) {
-            if (stone[s] != stone[p] || head[s] != head[p]) continue;
+        int s = p;
+        do {
             for (int d = 0; d < 4; ++d) { const int q = neighbour(s, d); if (q >= 0 && stone[q] == kEmpty) return q; }
-        }
+            s = next[s];
+        } while (s != p);
         return -1;
     }
 };
@@ -194,13 +257,14 @@ struct Fast {                         // BoardFast
 
 bool can_escape_with_capture(const Fast& b, int color, int p)                 // ladder.rs:34-42
 {
-    for (int s = 0; s < kPoints; ++s) {
-        if (b.stone[s] != b.stone[p] || b.head[s] != b.head[p]) continue;
+    int s = p;
+    do {
         for (int d = 0; d < 4; ++d) {
             const int q = neighbour(s, d);
             if (q >= 0 && b.stone[q] == 2 - color && !b.has_n_liberty(q, 2)) return true;
         }
-    }
+        s = b.next[s];
+    } while (s != p);
     return false;
 }
 
@@ -210,7 +274,7 @@ bool may_start_ladder(const Fast& b, int color, int p)
 {
     for (int d = 0; d < 4; ++d) {
         const int q = neighbour(p, d);
-        if (q >= 0 && b.stone[q] == 2 - color && b.libs[q] == 2) return true;
+        if (q >= 0 && b.stone[q] == 2 - color && b.n_liberty(q) == 2) return true;
     }
     return false;
 }
@@ -676,6 +740,7 @@ int dgnn_go_benson(const dgnn_go_board* b, int color, unsigned char* status_out)
     benson(CGO(b)->inner, color, status_out);
     return DGNN_OK;
 }
+int dgnn_go_check(const dgnn_go_board* b) { return b && CGO(b)->inner.consistent() ? 1 : 0; }
 int dgnn_go_is_scorable(const dgnn_go_board* b) { return b ? (is_scorable(CGO(b)->inner) ? 1 : 0) : 0; }
 int dgnn_go_score(const dgnn_go_board* b, int* black_out, int* white_out)     // Score::get_score, score.rs:130-136
 {

@@ -14,6 +14,8 @@
 // the reference: atomic counters, one spin lock per node around the value update, the "expanding" flag against double
 // expansion; several threads may probe / insert into one tree.
 #include <algorithm>
+#include <immintrin.h>
+
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -49,7 +51,7 @@ float intp_value(const Point2* points, int n, int x)   // config.rs:289-305
 
 // asm/argmax.rs:24-78: groups of 8; within the running maximum the LAST group that holds a maximal element wins and
 // inside it the first such element; None (-1) when the winner is not finite.
-int argmax_f32(const float* v, int n)
+int argmax_f32_scalar(const float* v, int n)
 {
     float so_far = -std::numeric_limits<float>::infinity();
     int index = 0;
@@ -62,6 +64,31 @@ int argmax_f32(const float* v, int n)
     }
     return std::isfinite(v[index]) ? index : -1;
 }
+
+// The same answer with 256-bit vectors (the reference's is AVX2 as well): the running maximum ends as the global maximum
+// M, and the index ends in the last group that holds an element equal to M, at its first such element.
+__attribute__((target("avx2")))
+int argmax_f32_avx2(const float* v, int n)
+{
+    const int groups = n / 8;
+    if (groups == 0) return std::isfinite(v[0]) ? 0 : -1;
+    __m256 best = _mm256_loadu_ps(v);
+    for (int g = 1; g < groups; ++g) best = _mm256_max_ps(best, _mm256_loadu_ps(v + 8 * g));
+    __m128 m4 = _mm_max_ps(_mm256_castps256_ps128(best), _mm256_extractf128_ps(best, 1));
+    m4 = _mm_max_ps(m4, _mm_movehl_ps(m4, m4));
+    m4 = _mm_max_ss(m4, _mm_shuffle_ps(m4, m4, 1));
+    const float top = _mm_cvtss_f32(m4);
+    if (!std::isfinite(top)) return (top != top) ? argmax_f32_scalar(v, n) : -1;          // NaN: take the scalar walk; +-inf: None
+    const __m256 vtop = _mm256_set1_ps(top);
+    for (int g = groups - 1; g >= 0; --g) {
+        const int mask = _mm256_movemask_ps(_mm256_cmp_ps(_mm256_loadu_ps(v + 8 * g), vtop, _CMP_EQ_OQ));
+        if (mask) return 8 * g + __builtin_ctz((unsigned)mask);
+    }
+    return argmax_f32_scalar(v, n);
+}
+
+const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+int argmax_f32(const float* v, int n) { return kHaveAvx2 ? argmax_f32_avx2(v, n) : argmax_f32_scalar(v, n); }
 
 struct SpinLock {
     std::atomic_flag flag = ATOMIC_FLAG_INIT;
@@ -113,27 +140,51 @@ struct Trace { std::vector<TraceEntry> entries; };
 
 namespace {
 
+// FPU::apply + UCT::get (tree.rs:180-254, 86-115): value[i] <- fpu(value[i]) + prior[i] * bonus(total[i])
+void puct_scalar(const TreeNode* node, bool apply_fpu, float fpu_reduce, float uct_exp_sqrt_n, float* value)
+{
+    for (int i = 0; i < kPadded; ++i) {
+        const int c = node->total(i);
+        float v = node->value[i];
+        if (apply_fpu && c == 0) v = std::max(v - fpu_reduce, 0.0f);
+        const float bonus = c == 0 ? uct_exp_sqrt_n : uct_exp_sqrt_n / (float)(1 + c);
+        value[i] = v + node->prior[i] * bonus;
+    }
+}
+
+// The reference's own formulation (tree.rs:63-115: cmpeq / div / mul / add on 8 lanes, no fused multiply-add), so both
+// variants give the same bits.  The counters are read as plain ints: aligned 32-bit loads, racing with other search
+// threads exactly as the reference's do.
+__attribute__((target("avx2")))
+void puct_avx2(const TreeNode* node, bool apply_fpu, float fpu_reduce, float uct_exp_sqrt_n, float* value)
+{
+    static_assert(sizeof(std::atomic<int>) == sizeof(int), "atomic<int> must be a plain int");
+    const int* count = reinterpret_cast<const int*>(&node->count[0]);
+    const int* vcount = reinterpret_cast<const int*>(&node->vcount[0]);
+    const __m256 u = _mm256_set1_ps(uct_exp_sqrt_n), fpu = _mm256_set1_ps(fpu_reduce), zero_ps = _mm256_setzero_ps();
+    const __m256i zero = _mm256_setzero_si256(), one = _mm256_set1_epi32(1);
+    for (int i = 0; i < kPadded; i += 8) {
+        const __m256i c = _mm256_add_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(count + i)),
+                                           _mm256_loadu_si256(reinterpret_cast<const __m256i*>(vcount + i)));
+        const __m256 is_zero = _mm256_castsi256_ps(_mm256_cmpeq_epi32(c, zero));
+        __m256 v = _mm256_loadu_ps(node->value + i);
+        if (apply_fpu) v = _mm256_blendv_ps(v, _mm256_max_ps(_mm256_sub_ps(v, fpu), zero_ps), is_zero);
+        const __m256 bonus = _mm256_blendv_ps(_mm256_div_ps(u, _mm256_cvtepi32_ps(_mm256_add_epi32(c, one))), u, is_zero);
+        _mm256_storeu_ps(value + i, _mm256_add_ps(v, _mm256_mul_ps(_mm256_loadu_ps(node->prior + i), bonus)));
+    }
+}
+
 // tree.rs:1329-1384.  Returns 1 found (index, value filled), 0 no result, -1 conflict.
 int select(TreeNode* node, bool apply_fpu, int* index_out, float* value_out)
 {
     float value[kPadded];
-    for (int i = 0; i < kPadded; ++i) value[i] = node->value[i];
-
     const int n = node->total_count.load(std::memory_order_relaxed) + node->vtotal_count.load(std::memory_order_relaxed);
-    if (apply_fpu) {                                                        // tree.rs:1342-1348, 180-254
-        const float fpu_reduce = intp_value(kFpuReduce, 5, n);
-        for (int i = 0; i < kPadded; ++i)
-            if (node->total(i) == 0) value[i] = std::max(value[i] - fpu_reduce, 0.0f);
-    }
-    for (int i = kMoves; i < kPadded; ++i) value[i] = -std::numeric_limits<float>::infinity();
-
+    const float fpu_reduce = apply_fpu ? intp_value(kFpuReduce, 5, n) : 0.0f;  // tree.rs:1342-1348
     const float sqrt_n = std::sqrt((float)(1 + n));                          // tree.rs:86-115
     const float uct_exp_sqrt_n = intp_value(kUctExp, 5, n) * sqrt_n;
-    for (int i = 0; i < kPadded; ++i) {
-        const int c = node->total(i);
-        const float bonus = c == 0 ? uct_exp_sqrt_n : uct_exp_sqrt_n / (float)(1 + c);
-        value[i] = value[i] + node->prior[i] * bonus;
-    }
+    if (kHaveAvx2) puct_avx2(node, apply_fpu, fpu_reduce, uct_exp_sqrt_n, value);
+    else puct_scalar(node, apply_fpu, fpu_reduce, uct_exp_sqrt_n, value);
+    for (int i = kMoves; i < kPadded; ++i) value[i] = -std::numeric_limits<float>::infinity();
 
     const int max_i = argmax_f32(value, kPadded);
     if (max_i < 0) return 0;

@@ -416,6 +416,8 @@ const dgnn_game_ops* dgnn_go_scoring_ops(void);     /* ScoringSearch: no pass, n
 /* Benson's unconditional life as the reference computes it (src/libdg_go/utils/benson.rs:62-190): per point 0 = neither,
  * 1 = stone of an unconditionally alive block of `color` (is_alive), 2 = point of a region vital to one (is_eye). */
 int dgnn_go_benson(const dgnn_go_board* board, int color, unsigned char* status_out /* 361 */);
+/* 1 when the incremental block / liberty bookkeeping equals a from-scratch flood fill of the position (a self-test hook). */
+int dgnn_go_check(const dgnn_go_board* board);
 int dgnn_go_is_scorable(const dgnn_go_board* board);                             /* Score::is_scorable, utils/score.rs:105-117 */
 int dgnn_go_score(const dgnn_go_board* board, int* black_out, int* white_out);   /* Score::get_score (Tromp-Taylor, no komi), :130-136, 220-239 */
 /* Score::get_stone_status(board, board) (utils/score.rs:146-186) as a bit mask per point. */

@@ -39,6 +39,7 @@ def replay(api, moves):
         c = 0 if colour == "B" else 1
         assert board.is_valid(c, x, 18 - y), "invalid move %d: %s %s" % (n + 1, colour, vertex)
         board.place(c, x, 18 - y)
+        assert board.check(), "block / liberty bookkeeping broken after move %d" % (n + 1)
     return board
 
 

@@ -462,3 +462,37 @@ def test_selfplay_plays_games_to_the_end(api):
             winner, territory = replay.result_sgf()
             assert "RE[%s]" % winner in game and game.endswith(territory + ")")
     assert out["games_ended"] == sum(int((r >= 0).sum()) < 722 for r in out["record"])
+
+
+def test_incremental_bookkeeping_equals_a_flood_fill(api):
+    """place() keeps blocks and liberties incrementally (merges, captures of several blocks at once, snap-backs); after every
+    stone of dense random games -- legal moves and, now and then, an illegal one (place() does not check) -- the state must
+    equal a from-scratch flood fill, and the liberty counts must equal a brute-force count."""
+    rng = np.random.default_rng(5)
+    for game in range(6):
+        b = api.Board(0.5)
+        color = 0
+        for move in range(500):
+            points = rng.permutation(361)
+            for index in points:
+                x, y = int(index % 19), int(index // 19)
+                if b.is_valid(color, x, y) or (b.at(x, y) is None and rng.random() < 0.002):
+                    b.place(color, x, y)
+                    break
+            else:
+                break
+            assert b.check(), (game, move)
+            color ^= 1
+        stones = {(x, y): b.at(x, y) for y in range(19) for x in range(19) if b.at(x, y) is not None}
+        for (x, y), c in list(stones.items())[::7]:                 # brute-force liberties of a sample of blocks
+            todo, block, liberties = [(x, y)], {(x, y)}, set()
+            while todo:
+                u, v = todo.pop()
+                for s, t in ((u + 1, v), (u - 1, v), (u, v + 1), (u, v - 1)):
+                    if not (0 <= s < 19 and 0 <= t < 19):
+                        continue
+                    if (s, t) not in stones:
+                        liberties.add((s, t))
+                    elif stones[(s, t)] == c and (s, t) not in block:
+                        block.add((s, t)); todo.append((s, t))
+            assert b.get_n_liberty(x, y) == len(liberties)

@@ -137,6 +137,17 @@ def test_argmax(api):
     assert api.argmax_f32(v) == 100
     v[300] = 3.0                                       # a later group with the same maximum wins
     assert api.argmax_f32(v) == 300
+    rng = np.random.default_rng(1)                     # the vector implementation against the rule, with many ties
+    for _ in range(300):
+        v = rng.integers(0, 4, 368).astype(np.float32)
+        v[rng.random(368) < 0.3] = -np.inf
+        so_far, index = -np.inf, 0
+        for g in range(46):
+            so_far = max(so_far, v[8 * g:8 * g + 8].max())
+            hit = np.nonzero(v[8 * g:8 * g + 8] == so_far)[0]
+            if hit.size:
+                index = 8 * g + int(hit[0])
+        assert api.argmax_f32(v) == (index if np.isfinite(v[index]) else None)
 
 
 def test_best_and_softmax_follow_the_visit_counts(api):
