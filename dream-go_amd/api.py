@@ -156,7 +156,7 @@ SYMBOLS = [
     ("dgnn_go_features", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u16p]),
     ("dgnn_go_game_ops", _vp, []),
     ("dgnn_selfplay_go", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_uint64, _vp, _ip,
+                                        ctypes.c_int, ctypes.c_uint64, _vp, _ip,
                                         ctypes.c_char_p, ctypes.c_size_t]),
     ("dgnn_search_run_cached", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
@@ -1070,16 +1070,18 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
-                return_sgf=False, first_game=0, game_stride=1):
+                return_sgf=False, first_game=0, game_stride=1, num_parallel=0):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
-    (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks)."""
+    (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
+    num_parallel of them run at a time (0 = all)."""
     fn, ctx = _predictor(pool)
     stats = SelfplayStats()
     if num_moves <= 0 or num_moves > 722:
         num_moves = 722
     moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
-    _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, int(num_games), int(first_game), int(game_stride),
+    _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, int(num_games), int(num_parallel), int(first_game),
+                                int(game_stride),
                                 int(num_moves), int(num_rollouts),
                                 int(threads_per_search), int(seed), ctypes.byref(stats), moves.ctypes.data_as(_ip) if moves is not None else None,
                                 sgf, len(sgf) if sgf is not None else 0), "selfplay_go")

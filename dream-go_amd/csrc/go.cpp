@@ -784,12 +784,15 @@ int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_c
 // Sharding: the games of this call are the global game ids first_game, first_game + game_stride, ...;
 // a game's random stream is a function of (seed, global id) only, so `world` ranks calling with first_game = rank and
 // game_stride = world play the games one rank would.
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int first_game, int game_stride,
-                     int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out,
-                     char* sgf_out, size_t sgf_capacity)
+// Concurrency (self_play, self_play.rs:478-495): min(num_parallel, num_games) game threads, each taking the next unplayed game
+// until num_games are done, so the device sees a steady number of games instead of a tail (num_parallel <= 0: all at once).
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_parallel, int first_game,
+                     int game_stride, int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats,
+                     int* moves_out, char* sgf_out, size_t sgf_capacity)
 {
     if (!predict || num_games <= 0 || first_game < 0 || game_stride <= 0 || max_moves < 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats)
         return DGNN_BAD_ARGUMENT;
+    if (num_parallel <= 0 || num_parallel > num_games) num_parallel = num_games;
     if (max_moves == 0 || max_moves > 722) max_moves = 722;
     std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0};
     std::atomic<int> status{DGNN_OK};
@@ -896,8 +899,10 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
         std::snprintf(header, sizeof(header), "(;GM[1]FF[4]DT[%s]SZ[19]RU[Chinese]KM[%.1f]RE[%s]", date, (double)komi, winner_sgf(board, point_status).c_str());
         records[(size_t)g] = header + sgf + territory_sgf(point_status) + ")";
     };
+    std::atomic<int> next_game{0};
     std::vector<std::thread> threads;
-    for (int g = 0; g < num_games; ++g) threads.emplace_back(game, g);
+    for (int t = 0; t < num_parallel; ++t)
+        threads.emplace_back([&] { for (int g; (g = next_game.fetch_add(1)) < num_games && status.load() == DGNN_OK;) game(g); });
     for (std::thread& t : threads) t.join();
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->games = (uint64_t)num_games;

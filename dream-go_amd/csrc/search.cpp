@@ -112,7 +112,10 @@ void search_worker(SearchShared* s, uint64_t seed)
         if (r == DGNN_PROBE_CONFLICT) {                                      // worker_thread.rs:161-163: try again
             s->ops->destroy(board);
             s->conflicts.fetch_add(1, std::memory_order_relaxed);
-            if (++idle_conflicts > 2) std::this_thread::yield();   // somebody else is expanding what we want: let them
+            // somebody else is expanding what we want: let them -- yield first, then sleep for about the time a leaf
+            // evaluation takes, so that the threads of a narrow tree (late in a game) do not spin on cores others need
+            if (++idle_conflicts > 8) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            else if (idle_conflicts > 2) std::this_thread::yield();
             continue;
         }
         idle_conflicts = 0;

@@ -437,10 +437,12 @@ int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winn
  * max_moves caps the stones per game (0 = the reference's 722).  moves_out (num_games * max_moves packed indices, -1 = not
  * played) and sgf_out (one GameResult::Ended record per game, game_result.rs:35-41, newline separated) may be NULL.
  * The call plays the global game ids first_game, first_game + game_stride, ... (num_games of them); a game's random
- * stream depends on (seed, global id) only, so ranks sharding games `id mod world` play what one rank would. */
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int first_game, int game_stride,
-                     int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats, int* moves_out,
-                     char* sgf_out, size_t sgf_capacity);
+ * stream depends on (seed, global id) only, so ranks sharding games `id mod world` play what one rank would.
+ * min(num_parallel, num_games) games run at a time, each game thread taking the next unplayed game (self_play.rs:478-495;
+ * num_parallel <= 0: all at once). */
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_parallel, int first_game,
+                     int game_stride, int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats,
+                     int* moves_out, char* sgf_out, size_t sgf_capacity);
 
 /* Library version / build info string (static). */
 const char* dgnn_version(void);

@@ -496,3 +496,12 @@ def test_incremental_bookkeeping_equals_a_flood_fill(api):
                     elif stones[(s, t)] == c and (s, t) not in block:
                         block.add((s, t)); todo.append((s, t))
             assert b.get_n_liberty(x, y) == len(liberties)
+
+
+def test_selfplay_with_fewer_games_in_flight_plays_the_same_games(api):
+    """self_play (self_play.rs:478-495) keeps num_parallel games in flight and starts the next one when a game ends; a game is a
+    function of (seed, game id), so the records do not depend on how many run at a time."""
+    kw = dict(num_games=5, num_moves=6, num_rollouts=10, threads_per_search=1, seed=13, return_moves=True)
+    all_at_once = api.selfplay_go(**kw)
+    two_at_a_time = api.selfplay_go(num_parallel=2, **kw)
+    assert np.array_equal(all_at_once["record"], two_at_a_time["record"]) and two_at_a_time["moves"] == 30

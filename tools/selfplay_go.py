@@ -25,6 +25,7 @@ from dream_go_amd import api, replicas, synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=64, help="games in the whole job (sharded game_id mod world over the ranks)")
+    ap.add_argument("--parallel", type=int, default=0, help="games in flight per rank (the reference's --num-games); 0 = all of the rank's games")
     ap.add_argument("--moves", type=int, default=8, help="stones per game, 0 = whole games")
     ap.add_argument("--rollouts", type=int, default=800)
     ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
@@ -60,7 +61,8 @@ def main():
     cache = api.LruCache(args.cache, 8) if args.cache > 0 else None
     before = batcher.stats()
     stats = replicas.selfplay_sharded(api, dist, torch, args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
-                                      return_sgf=args.sgf is not None, device=f"cuda:{device}" if dist is not None else "cpu")
+                                      return_sgf=args.sgf is not None, device=f"cuda:{device}" if dist is not None else "cpu",
+                                      num_parallel=args.parallel)
     after = batcher.stats()
     if args.sgf:
         with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
@@ -74,7 +76,7 @@ def main():
         moves_per_s = job["moves"] / job["seconds"]
         print(json.dumps({
             "metric": "go_selfplay", "n_gpus": world, "evals_per_sec": job["evals"] / job["seconds"], "moves_per_sec": moves_per_s,
-            "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": job["games"], "moves_cap": args.moves,
+            "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": job["games"], "games_in_flight_per_rank": args.parallel or None, "moves_cap": args.moves,
             "games_ended_by_passes": job["games_ended"], "mean_stones_per_game": job["moves"] / max(job["games"], 1),
             "games_per_hour_measured": (job["games"] * 3600 / job["seconds"]) if args.moves == 0 else None,
             "evals_per_move": job["evals"] / max(job["moves"], 1),
