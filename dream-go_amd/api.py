@@ -156,7 +156,7 @@ SYMBOLS = [
     ("dgnn_go_features", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u16p]),
     ("dgnn_go_game_ops", _vp, []),
     ("dgnn_selfplay_go", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_int, ctypes.c_uint64, _vp, _ip,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vp, _ip,
                                         ctypes.c_char_p, ctypes.c_size_t]),
     ("dgnn_search_run_cached", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
@@ -870,7 +870,7 @@ def undo(trace, undo_expanding):
 class SelfplayStats(ctypes.Structure):
     _fields_ = [("seconds", ctypes.c_double), ("games", ctypes.c_uint64), ("moves", ctypes.c_uint64),
                 ("evals", ctypes.c_uint64), ("conflicts", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64),
-                ("games_ended", ctypes.c_uint64)]
+                ("games_ended", ctypes.c_uint64), ("ex_it_searches", ctypes.c_uint64)]
 
 
 class SyntheticBoard:
@@ -1070,7 +1070,7 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
-                return_sgf=False, first_game=0, game_stride=1, num_parallel=0):
+                return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
     (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
     num_parallel of them run at a time (0 = all)."""
@@ -1082,11 +1082,11 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
     _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, int(num_games), int(num_parallel), int(first_game),
                                 int(game_stride),
-                                int(num_moves), int(num_rollouts),
+                                int(num_moves), int(num_rollouts), int(ex_it_rollouts),
                                 int(threads_per_search), int(seed), ctypes.byref(stats), moves.ctypes.data_as(_ip) if moves is not None else None,
                                 sgf, len(sgf) if sgf is not None else 0), "selfplay_go")
     out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts,
-           "cache_hits": stats.cache_hits, "games_ended": stats.games_ended}
+           "cache_hits": stats.cache_hits, "games_ended": stats.games_ended, "ex_it_searches": stats.ex_it_searches}
     if return_moves:
         out["record"] = moves.reshape(num_games, num_moves)
     if return_sgf:

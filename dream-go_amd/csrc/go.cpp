@@ -777,8 +777,9 @@ int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_c
 //   * a budget of one rollout or less plays from the 8-symmetry policy alone (self_play.rs:369-399);
 //   * the record is GameResult::Ended (game_result.rs:35-41): header, RE[], the moves, TB / TW.
 // `max_moves` caps the stones per game below the reference's 722 (0 = 722) so a measurement can be bounded; a game cut
-// off there is recorded like one that reached 722.  Not built: resignation (the reference's self-play has none either,
-// only policy_play), expert iteration.
+// off there is recorded like one that reached 722.  num_ex_it_rollouts > 0 turns expert iteration on (--ex-it,
+// self_play.rs:277-319).  Not built: resignation (the reference's self-play has none either, only policy_play), the
+// pretty-printed variation the reference stores as C[] with every searched move.
 // moves_out (num_games * max_moves packed indices of the stones in order, -1 = not played) and sgf_out (one record per game,
 // newline separated, cut off at sgf_capacity) may be NULL.
 // Sharding: the games of this call are the global game ids first_game, first_game + game_stride, ...;
@@ -787,14 +788,14 @@ int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_c
 // Concurrency (self_play, self_play.rs:478-495): min(num_parallel, num_games) game threads, each taking the next unplayed game
 // until num_games are done, so the device sees a steady number of games instead of a tail (num_parallel <= 0: all at once).
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_parallel, int first_game,
-                     int game_stride, int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats,
-                     int* moves_out, char* sgf_out, size_t sgf_capacity)
+                     int game_stride, int max_moves, int num_rollouts, int num_ex_it_rollouts, int threads_per_search, uint64_t seed,
+                     dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
 {
     if (!predict || num_games <= 0 || first_game < 0 || game_stride <= 0 || max_moves < 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats)
         return DGNN_BAD_ARGUMENT;
     if (num_parallel <= 0 || num_parallel > num_games) num_parallel = num_games;
     if (max_moves == 0 || max_moves > 722) max_moves = 722;
-    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0};
+    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0}, ex_it_searches{0};
     std::atomic<int> status{DGNN_OK};
     std::vector<std::string> records((size_t)num_games);
     const auto t0 = std::chrono::steady_clock::now();
@@ -821,55 +822,89 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
             const float w = winrate[me];
             const int limit = (int)(std::max(0.1f, 4.0f * w * (1.0f - w)) * (float)num_rollouts);   // Player::num_rollout
 
-            float value = 0.0f, prior[368];
-            int st = dgnn_full_forward(ops, &board, me, predict, predict_ctx, cache, &value, prior);   // lib.rs:154-159
-            if (st < 0) { status.store(st); break; }
-            evals.fetch_add((uint64_t)st);
-            bool any = false;
-            for (int i = 0; i < DGNN_NUM_MOVES; ++i) any = any || std::isfinite(prior[i]);
+            // predict (lib.rs:144-200) behind predict_aux (self_play.rs:243-274): the root ensemble, noise unless deterministic,
+            // the starting tree re-used with its prior replaced, the search, the best move.  Returns the tree (the caller owns
+            // it) or NULL when there is nothing to search (*value_out is then not finite) or on an error (status is set).
+            auto search = [&](int limit, dgnn_tree_node* start, float* value_out, int* index_out) -> dgnn_tree_node* {
+                float value = 0.0f, prior[368];
+                *value_out = std::numeric_limits<float>::quiet_NaN();
+                *index_out = kPass;
+                int st = dgnn_full_forward(ops, &board, me, predict, predict_ctx, cache, &value, prior);   // lib.rs:154-159
+                if (st < 0) { status.store(st); dgnn_tree_node_free(start); return nullptr; }
+                evals.fetch_add((uint64_t)st);
+                bool any = false;
+                for (int i = 0; i < DGNN_NUM_MOVES; ++i) any = any || std::isfinite(prior[i]);
+                if (!any) { dgnn_tree_node_free(start); return nullptr; }
+                if (!deterministic) dgnn_dirichlet_add(prior, DGNN_NUM_MOVES, 0.03f, 0.25f, rng.next());   // lib.rs:163-165
+                dgnn_tree_node* root = start;
+                if (root) { if (!allow_pass) dgnn_tree_node_disqualify(root, kPass); dgnn_tree_node_set_prior(root, prior); }   // lib.rs:170-181
+                else root = dgnn_tree_node_new(me, value, prior);
+                uint64_t e = 0, c = 0, h = 0;
+                st = dgnn_search_run_cached(root, ops, &board, predict, predict_ctx, cache, limit, threads_per_search, rng.next(), &e, &c, &h);
+                evals.fetch_add(e);
+                conflicts.fetch_add(c);
+                hits.fetch_add(h);
+                if (st != DGNN_OK) { status.store(st); dgnn_tree_node_free(root); return nullptr; }
+                dgnn_tree_node_best(root, (!deterministic && board.count < 8) ? 0.8f : 0.0f, rng.uniform(), value_out, index_out);   // lib.rs:188-192
+                return root;
+            };
+            // Played::from_mcts (self_play.rs:120-137): TR[] = the best move of the tree's prior, TV[] = the tree's size, P[] = its
+            // visit distribution.  (The reference also stores a pretty-printed principal variation as C[]; not reproduced.)
+            auto record_mcts = [&](char* out, size_t capacity, int point, float value, const dgnn_tree_node* tree) {
+                float softmax[DGNN_NUM_MOVES], tree_prior[DGNN_NUM_MOVES + 6];
+                dgnn_tree_node_softmax(tree, softmax);
+                dgnn_tree_node_prior(tree, tree_prior);
+                for (int i = DGNN_NUM_MOVES; i < DGNN_NUM_MOVES + 6; ++i) tree_prior[i] = -std::numeric_limits<float>::infinity();
+                int prior_index = dgnn_argmax_f32(tree_prior, DGNN_NUM_MOVES + 6);
+                if (prior_index < 0) prior_index = kPass;                      // Node::prior, tree.rs:1285-1289
+                int total = 0;
+                dgnn_tree_node_info(tree, nullptr, &total, nullptr, nullptr, nullptr);
+                dgnn_sgf_played(out, capacity, me, point, total, softmax, 1, value, prior_index, "");
+            };
+            // Player::ex_it (self_play.rs:277-305) behind is_good_candidate (:315-319): one move in twenty gets a fresh, full-size
+            // search whose visit distribution and value replace the record's; the move that was chosen stays
+            auto expert_iteration = [&](char* out, size_t capacity, int point) -> bool {
+                if (num_ex_it_rollouts <= 0 || rng.uniform() >= 0.05) return false;
+                float value;
+                int ignored;
+                dgnn_tree_node* tree = search(num_ex_it_rollouts, nullptr, &value, &ignored);
+                if (!tree) return false;
+                if (std::isfinite(value)) record_mcts(out, capacity, point, value, tree);
+                dgnn_tree_node_free(tree);
+                ex_it_searches.fetch_add(1);
+                return std::isfinite(value);
+            };
 
             int played = kPass;
             char move[2048];
             move[0] = '\0';
-            if (limit > 1) {
-                dgnn_tree_node* root = roots[me];
+            if (limit > 1) {                                                   // Player::predict, self_play.rs:340-368
+                dgnn_tree_node* start = roots[me];
                 roots[me] = nullptr;
-                if (!any) {                                                    // nothing to search: value is not finite, pass (self_play.rs:347-350)
+                float best_value;
+                dgnn_tree_node* root = search(limit, start, &best_value, &played);
+                if (status.load() != DGNN_OK) break;
+                if (!root || !std::isfinite(best_value) || played < 0 || (played != kPass && !board.is_valid(me, played))) {
+                    played = kPass;                                            // nothing to play: pass (self_play.rs:347-350)
                     dgnn_tree_node_free(root);
                     dgnn_sgf_played(move, sizeof(move), me, kPass, 0, nullptr, 0, 0.0f, -1, "");
                 } else {
-                    if (!deterministic) dgnn_dirichlet_add(prior, DGNN_NUM_MOVES, 0.03f, 0.25f, rng.next());   // lib.rs:163-165
-                    if (root) { if (!allow_pass) dgnn_tree_node_disqualify(root, kPass); dgnn_tree_node_set_prior(root, prior); }   // lib.rs:170-181
-                    else root = dgnn_tree_node_new(me, value, prior);
-                    uint64_t e = 0, c = 0, h = 0;
-                    st = dgnn_search_run_cached(root, ops, &board, predict, predict_ctx, cache, limit, threads_per_search, rng.next(), &e, &c, &h);
-                    evals.fetch_add(e);
-                    conflicts.fetch_add(c);
-                    hits.fetch_add(h);
-                    if (st != DGNN_OK) { status.store(st); dgnn_tree_node_free(root); break; }
-                    float best_value = 0.0f;
-                    dgnn_tree_node_best(root, (!deterministic && board.count < 8) ? 0.8f : 0.0f, rng.uniform(), &best_value, &played);   // lib.rs:188-192
-                    if (!std::isfinite(best_value) || played < 0 || (played != kPass && !board.is_valid(me, played))) {
-                        played = kPass;
-                        dgnn_tree_node_free(root);
-                        dgnn_sgf_played(move, sizeof(move), me, kPass, 0, nullptr, 0, 0.0f, -1, "");
-                    } else {
-                        float softmax[DGNN_NUM_MOVES];                          // Played::from_mcts, self_play.rs:120-137
-                        dgnn_tree_node_softmax(root, softmax);
-                        int total = 0;
-                        dgnn_tree_node_info(root, nullptr, &total, nullptr, nullptr, nullptr);
-                        dgnn_sgf_played(move, sizeof(move), me, played, total, softmax, 1, best_value, -1, "");
-                        winrate[me] -= 0.2f * (winrate[me] - best_value);      // MovingAverage::update, self_play.rs:56-58
-                        roots[me] = dgnn_tree_node_forward(root, played);
-                    }
+                    if (!expert_iteration(move, sizeof(move), played)) record_mcts(move, sizeof(move), played, best_value, root);
+                    winrate[me] -= 0.2f * (winrate[me] - best_value);          // MovingAverage::update, self_play.rs:56-58
+                    roots[me] = dgnn_tree_node_forward(root, played);
                 }
-            } else {                                                           // policy play, self_play.rs:369-399
+            } else {                                                           // policy play, self_play.rs:369-405
+                float value = 0.0f, prior[368];
+                const int st = dgnn_full_forward(ops, &board, me, predict, predict_ctx, cache, &value, prior);
+                if (st < 0) { status.store(st); break; }
+                evals.fetch_add((uint64_t)st);
                 if (!allow_pass) prior[kPass] = -std::numeric_limits<float>::infinity();
                 double scaled[DGNN_NUM_MOVES];
                 for (int i = 0; i < DGNN_NUM_MOVES; ++i) scaled[i] = (double)prior[i];
                 if (dgnn_choose_f64(scaled, DGNN_NUM_MOVES, 0.5, 1.0 / 0.8, rng.uniform(), &played, nullptr) != 1) played = kPass;
                 if (played < 0 || (played != kPass && !board.is_valid(me, played))) played = kPass;
-                dgnn_sgf_played(move, sizeof(move), me, played, 1, prior, 1, value, -1, "");
+                if (!expert_iteration(move, sizeof(move), played)) dgnn_sgf_played(move, sizeof(move), me, played, 1, prior, 1, value, -1, "");
+                if (status.load() != DGNN_OK) break;
                 winrate[me] -= 0.2f * (winrate[me] - value);
                 if (roots[me]) roots[me] = dgnn_tree_node_forward(roots[me], played);
             }
@@ -911,6 +946,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
     stats->conflicts = conflicts.load();
     stats->cache_hits = hits.load();
     stats->games_ended = ended.load();
+    stats->ex_it_searches = ex_it_searches.load();
     if (sgf_out && sgf_capacity > 0) {
         size_t used = 0;
         for (const std::string& r : records) {

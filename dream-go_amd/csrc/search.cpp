@@ -403,6 +403,7 @@ int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_
     stats->conflicts = conflicts.load();
     stats->cache_hits = 0;
     stats->games_ended = 0;
+    stats->ex_it_searches = 0;
     return status.load();
 }
 

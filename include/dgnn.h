@@ -382,7 +382,7 @@ int dgnn_tree_node_set_prior(dgnn_tree_node* node, const float* prior /* 362 */)
 const dgnn_game_ops* dgnn_synthetic_game_ops(void);
 void* dgnn_synthetic_board_new(uint64_t seed);
 void dgnn_synthetic_board_free(void* board);
-typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, evals, conflicts, cache_hits, games_ended; } dgnn_selfplay_stats;
+typedef struct dgnn_selfplay_stats { double seconds; uint64_t games, moves, evals, conflicts, cache_hits, games_ended, ex_it_searches; } dgnn_selfplay_stats;
 int dgnn_selfplay_synthetic(dgnn_predict_fn predict, void* predict_ctx, int num_games, int num_moves, int num_rollouts,
                             int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats);
 
@@ -439,10 +439,12 @@ int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winn
  * The call plays the global game ids first_game, first_game + game_stride, ... (num_games of them); a game's random
  * stream depends on (seed, global id) only, so ranks sharding games `id mod world` play what one rank would.
  * min(num_parallel, num_games) games run at a time, each game thread taking the next unplayed game (self_play.rs:478-495;
- * num_parallel <= 0: all at once). */
+ * num_parallel <= 0: all at once).  num_rollouts <= 10 gives the policy-play mode (the budget falls to one rollout,
+ * self_play.rs:369-405); num_ex_it_rollouts > 0 is --ex-it: one move in twenty is re-searched with that budget and the
+ * search's distribution replaces the record's (self_play.rs:277-319). */
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_parallel, int first_game,
-                     int game_stride, int max_moves, int num_rollouts, int threads_per_search, uint64_t seed, dgnn_selfplay_stats* stats,
-                     int* moves_out, char* sgf_out, size_t sgf_capacity);
+                     int game_stride, int max_moves, int num_rollouts, int num_ex_it_rollouts, int threads_per_search, uint64_t seed,
+                     dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
 
 /* Library version / build info string (static). */
 const char* dgnn_version(void);

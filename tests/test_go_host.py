@@ -505,3 +505,25 @@ def test_selfplay_with_fewer_games_in_flight_plays_the_same_games(api):
     all_at_once = api.selfplay_go(**kw)
     two_at_a_time = api.selfplay_go(num_parallel=2, **kw)
     assert np.array_equal(all_at_once["record"], two_at_a_time["record"]) and two_at_a_time["moves"] == 30
+
+
+def test_policy_play_and_expert_iteration(api):
+    """BASELINE.json configs[4] (--ex-it --num-rollout 1): with a budget of one rollout every move is drawn from the 8-symmetry
+    policy (self_play.rs:369-405; Played::from_forward has one rollout, which Played::fmt prints without TV[] / P[]); with expert iteration about one move in twenty carries a full search instead
+    (self_play.rs:277-319: TV[] = that search's size, TR[] = its prior's best move), and the move sequence is NOT changed by it."""
+    import re
+    kw = dict(num_games=2, num_moves=40, num_rollouts=1, threads_per_search=1, seed=17, return_moves=True, return_sgf=True)
+    plain = api.selfplay_go(**kw)
+    assert plain["ex_it_searches"] == 0 and plain["conflicts"] == 0
+    for game in plain["sgf"]:
+        assert "TV[" not in game and "TR[" not in game and game.count("V[") == 40
+    assert plain["evals"] <= 2 * 40 * 8 + 16                       # at most eight evaluations per move: no search ran
+    ex_it = api.selfplay_go(ex_it_rollouts=30, **kw)
+    assert ex_it["ex_it_searches"] >= 1
+    sizes = [int(v) for game in ex_it["sgf"] for v in re.findall(r"TV\[(\d+)\]", game)]
+    assert sizes.count(30) == ex_it["ex_it_searches"] and set(sizes) == {30}
+    assert sum(game.count("TR[") for game in ex_it["sgf"]) == ex_it["ex_it_searches"]
+    # the expert's search draws from the game's random stream, so only the moves before the first such search must agree
+    first = min(len(re.findall(r";[BW]\[", game.split("TV[30]")[0])) for game in ex_it["sgf"] if "TV[30]" in game)
+    for a, b in zip(plain["record"], ex_it["record"]):
+        assert np.array_equal(a[:max(first - 1, 0)], b[:max(first - 1, 0)])
