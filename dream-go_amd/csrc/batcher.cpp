@@ -130,6 +130,8 @@ struct Batcher {
     std::mutex mutex;               // batch.rs:60-73: the list lock
     std::vector<uint16_t> features;
     std::vector<uint64_t> tags;
+    std::vector<std::vector<uint16_t>> spare_features;   // buffers of retired batches, so that the queue does not grow from zero
+    std::vector<std::vector<uint64_t>> spare_tags;       // (and fault its pages in) under the lock after every hand-over
     std::atomic<int> num_batches{0};
     std::atomic<uint64_t> boards_evaluated{0}, batches_evaluated{0};
 };
@@ -351,10 +353,17 @@ int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch
     if (!batch) { b->num_batches.fetch_sub(1); return DGNN_OUT_OF_MEMORY; }
     const size_t split = size >= (size_t)b->max_batch_size ? size - b->max_batch_size : 0;     // batch.rs:106
     batch->owner = b;
-    batch->features.assign(b->features.begin() + split * DGNN_FEATURE_SIZE, b->features.end());   // split_off: the NEWEST entries
-    batch->tags.assign(b->tags.begin() + split, b->tags.end());
-    b->features.resize(split * DGNN_FEATURE_SIZE);
-    b->tags.resize(split);
+    if (split == 0) {                                                           // everything goes: hand the buffers over, no copy under the lock
+        batch->features.swap(b->features);
+        batch->tags.swap(b->tags);
+        if (!b->spare_features.empty()) { b->features.swap(b->spare_features.back()); b->spare_features.pop_back(); }
+        if (!b->spare_tags.empty()) { b->tags.swap(b->spare_tags.back()); b->spare_tags.pop_back(); }
+    } else {
+        batch->features.assign(b->features.begin() + split * DGNN_FEATURE_SIZE, b->features.end());   // split_off: the NEWEST entries
+        batch->tags.assign(b->tags.begin() + split, b->tags.end());
+        b->features.resize(split * DGNN_FEATURE_SIZE);
+        b->tags.resize(split);
+    }
     *out = reinterpret_cast<dgnn_batch*>(batch.release());
     return DGNN_OK;
 }
@@ -413,6 +422,16 @@ void dgnn_batch_destroy(dgnn_batch* batch)
     if (!batch) return;
     Batch* bt = reinterpret_cast<Batch*>(batch);
     retire(bt);
+    {
+        Batcher* b = bt->owner;
+        std::lock_guard<std::mutex> lock(b->mutex);
+        if (b->spare_features.size() < (size_t)b->max_batches + 1 && bt->features.capacity() > 0) {
+            bt->features.clear();
+            bt->tags.clear();
+            b->spare_features.emplace_back(std::move(bt->features));
+            b->spare_tags.emplace_back(std::move(bt->tags));
+        }
+    }
     delete bt;
 }
 
