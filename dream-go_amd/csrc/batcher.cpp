@@ -134,6 +134,9 @@ struct Batcher {
     std::vector<std::vector<uint64_t>> spare_tags;       // (and fault its pages in) under the lock after every hand-over
     std::atomic<int> num_batches{0};
     std::atomic<uint64_t> boards_evaluated{0}, batches_evaluated{0};
+    std::atomic<int> refs{1};       // the handle + every batch split off it: a batch may outlive dgnn_batcher_destroy
+
+    void release() { if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
 };
 
 // ------------------------------------------------------------------------------------------------ leaf pool
@@ -313,7 +316,7 @@ int dgnn_batcher_create(dgnn_network* net, int device, int max_batch_size, int m
     return DGNN_OK;
 }
 
-void dgnn_batcher_destroy(dgnn_batcher* batcher) { delete reinterpret_cast<Batcher*>(batcher); }
+void dgnn_batcher_destroy(dgnn_batcher* batcher) { if (batcher) reinterpret_cast<Batcher*>(batcher)->release(); }
 
 int dgnn_batcher_push(dgnn_batcher* batcher, const uint16_t* features, uint64_t tag)
 {
@@ -353,6 +356,7 @@ int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch
     if (!batch) { b->num_batches.fetch_sub(1); return DGNN_OUT_OF_MEMORY; }
     const size_t split = size >= (size_t)b->max_batch_size ? size - b->max_batch_size : 0;     // batch.rs:106
     batch->owner = b;
+    b->refs.fetch_add(1, std::memory_order_relaxed);
     if (split == 0) {                                                           // everything goes: hand the buffers over, no copy under the lock
         batch->features.swap(b->features);
         batch->tags.swap(b->tags);
@@ -432,6 +436,7 @@ void dgnn_batch_destroy(dgnn_batch* batch)
             b->spare_tags.emplace_back(std::move(bt->tags));
         }
     }
+    bt->owner->release();
     delete bt;
 }
 
