@@ -172,6 +172,8 @@ SYMBOLS = [
     ("dgnn_full_forward", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _fp, _fp]),
     ("dgnn_dirichlet_add", None, [_fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64]),
     ("dgnn_tree_node_forward", _vp, [_vp, ctypes.c_int]),
+    ("dgnn_tree_node_min_promote", ctypes.c_int, [_vp]),
+    ("dgnn_rollout_limit_is_done", ctypes.c_int, [_vp, ctypes.c_int]),
     ("dgnn_tree_node_set_prior", ctypes.c_int, [_vp, _fp]),
     ("dgnn_pool_create", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
     ("dgnn_pool_destroy", None, [_vp]),
@@ -820,6 +822,13 @@ class Node:
         node = Node.__new__(Node)
         node._handle = handle
         return node
+
+    def min_promote_rollouts(self):
+        return lib.dgnn_tree_node_min_promote(self._handle)
+
+    def is_done(self, limit):
+        """time_control::is_done with RolloutLimit::new(limit) (time_control/mod.rs:86-101)."""
+        return lib.dgnn_rollout_limit_is_done(self._handle, int(limit)) == 1
 
     def set_prior(self, prior):
         p = np.ascontiguousarray(prior, dtype=np.float32).reshape(-1)

@@ -102,9 +102,7 @@ void search_worker(SearchShared* s, uint64_t seed)
     dgnn_board_ops place_ops = {s->ops->place};
     int idle_conflicts = 0;
     while (s->status.load(std::memory_order_relaxed) == DGNN_OK) {
-        int total = 0;
-        dgnn_tree_node_info(s->root, nullptr, &total, nullptr, nullptr, nullptr);
-        if (total >= s->limit) break;                                        // rollout_limit.rs:35-44
+        if (dgnn_rollout_limit_is_done(s->root, s->limit) == 1) break;        // worker_thread.rs:149, time_control/mod.rs:86-101
 
         void* board = s->ops->clone(s->board);
         dgnn_trace* trace = nullptr;

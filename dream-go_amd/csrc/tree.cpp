@@ -400,6 +400,34 @@ dgnn_tree_node* dgnn_tree_node_forward(dgnn_tree_node* handle, int index)
     return reinterpret_cast<dgnn_tree_node*>(next);
 }
 
+// min_promote_rollouts (time_control/mod.rs:48-73): the lead of the most visited child over the runner-up
+int dgnn_tree_node_min_promote(const dgnn_tree_node* handle)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
+    int top = 0, count_1 = -1, count_2 = 0;
+    for (int i = 0; i < kMoves; ++i) {
+        const int c = node->count[i].load(std::memory_order_relaxed);
+        if (c > count_1) { count_1 = c; top = i; }
+    }
+    for (int i = 0; i < kMoves; ++i) {
+        const int c = node->count[i].load(std::memory_order_relaxed);
+        if (i != top && c > count_2) count_2 = c;
+    }
+    return count_1 > count_2 ? count_1 - count_2 : 0;
+}
+
+// time_control::is_done over RolloutLimit (time_control/mod.rs:86-101, rollout_limit.rs:35-44): the limit is reached, or --
+// EARLY-C -- the runner-up cannot catch up with the most visited child in the rollouts that remain.
+int dgnn_rollout_limit_is_done(const dgnn_tree_node* handle, int limit)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    const int total = reinterpret_cast<const TreeNode*>(handle)->total_count.load(std::memory_order_relaxed);
+    if (total == 0) return 0;
+    if (total >= limit) return 1;
+    return dgnn_tree_node_min_promote(handle) > limit - total ? 1 : 0;
+}
+
 int dgnn_tree_node_set_prior(dgnn_tree_node* handle, const float* prior)     // lib.rs:176-183: a re-used tree gets the new root prior
 {
     if (!handle || !prior) return DGNN_BAD_ARGUMENT;

@@ -323,6 +323,12 @@ int dgnn_tree_insert(const dgnn_trace* trace, int color, float value /* win rate
 int dgnn_tree_node_child(const dgnn_tree_node* node, int index, int* count, int* vcount, float* value, float* value_std, int* has_child);
 int dgnn_tree_node_info(const dgnn_tree_node* node, int* to_move, int* total_count, int* vtotal_count, int* pass_count, float* initial_value);
 int dgnn_tree_node_prior(const dgnn_tree_node* node, float* prior_out /* 362 */);
+/* min_promote_rollouts (src/libdg_mcts/time_control/mod.rs:48-73): visits of the most visited child minus the runner-up's. */
+int dgnn_tree_node_min_promote(const dgnn_tree_node* node);
+/* time_control::is_done for a RolloutLimit (time_control/mod.rs:86-101, rollout_limit.rs:35-44): 1 when root.total_count has
+ * reached `limit`, or (EARLY-C) when the runner-up cannot overtake the most visited child in the rollouts that remain;
+ * 0 otherwise and for an unvisited root.  The search workers stop on it (pool/worker_thread.rs:149). */
+int dgnn_rollout_limit_is_done(const dgnn_tree_node* node, int limit);
 int dgnn_tree_node_disqualify(dgnn_tree_node* node, int index);                              /* tree.rs:1315-1320 */
 int dgnn_tree_node_softmax(const dgnn_tree_node* node, float* out /* 362 */);                 /* tree.rs:1293-1307 */
 /* Node::best (tree.rs:1262-1283): greedy (LCB / visits / prior / value order) when temperature <= 0.09, else a visit-

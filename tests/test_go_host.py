@@ -198,7 +198,8 @@ def test_search_and_selfplay_on_the_real_board(api):
     root = api.Node(W, 0.5, prior)
     evals, _ = api.search_run(root, b, num_rollouts=60, num_threads=1, seed=4)
     counts = np.array([root.with_(i).count() for i in range(362)])
-    assert evals == 60 and counts.sum() == 60 and counts[3 * 19 + 3] == 0 and counts[361] == 0
+    # the search ends at the limit or as soon as the runner-up cannot catch up any more (EARLY-C, time_control/mod.rs:86-101)
+    assert evals == counts.sum() <= 60 and root.is_done(60) and counts[3 * 19 + 3] == 0 and counts[361] == 0
     assert b.count() == 1                                          # the search works on clones
     # symmetric duplicates are eliminated below the root: after black (3, 3) white's replies come in mirror pairs
     # (transpose), so no child of the root's children... (checked through the prior of an expanded child)
@@ -246,7 +247,8 @@ def test_cached_search_reports_hits_and_same_tree(api):
         root = api.Node(W, 0.5, prior)
         evals, conflicts, hits = api.search_run(root, b, num_rollouts=60, num_threads=1, seed=4, cache=cache)
         counts.append((evals, hits, np.array([root.with_(i).count() for i in range(362)])))
-    assert counts[0][0] + counts[0][1] == 60 and counts[1][0] == 0 and counts[1][1] == 60     # second search: all from the cache
+    assert counts[0][0] + counts[0][1] == counts[0][2].sum() <= 60                            # (EARLY-C may stop before the limit)
+    assert counts[1][0] == 0 and counts[1][1] == counts[0][2].sum()                           # second search: all from the cache
     assert np.array_equal(counts[0][2], counts[1][2])
     plain = api.Node(W, 0.5, prior)
     api.search_run(plain, b, num_rollouts=60, num_threads=1, seed=4)
@@ -521,9 +523,9 @@ def test_policy_play_and_expert_iteration(api):
     ex_it = api.selfplay_go(ex_it_rollouts=30, **kw)
     assert ex_it["ex_it_searches"] >= 1
     sizes = [int(v) for game in ex_it["sgf"] for v in re.findall(r"TV\[(\d+)\]", game)]
-    assert sizes.count(30) == ex_it["ex_it_searches"] and set(sizes) == {30}
+    assert len(sizes) == ex_it["ex_it_searches"] and all(1 < n <= 30 for n in sizes)     # EARLY-C may stop a search before its limit
     assert sum(game.count("TR[") for game in ex_it["sgf"]) == ex_it["ex_it_searches"]
     # the expert's search draws from the game's random stream, so only the moves before the first such search must agree
-    first = min(len(re.findall(r";[BW]\[", game.split("TV[30]")[0])) for game in ex_it["sgf"] if "TV[30]" in game)
+    first = min(len(re.findall(r";[BW]\[", game.split("TV[")[0])) for game in ex_it["sgf"] if "TV[" in game)
     for a, b in zip(plain["record"], ex_it["record"]):
         assert np.array_equal(a[:max(first - 1, 0)], b[:max(first - 1, 0)])

@@ -187,11 +187,13 @@ def test_seeded_single_thread_search_is_reproducible(api):
     for seed in (7, 7, 8):
         root = _fresh_root(api)
         evals, conflicts = api.search_run(root, api.SyntheticBoard(123), num_rollouts=200, num_threads=1, seed=seed)
-        assert evals == 200 and conflicts == 0 and root.total_count == 200 and root.vtotal_count == 0
+        # the search ends at the limit, or before it once the runner-up cannot catch up (time_control/mod.rs:86-101)
+        assert evals == root.total_count <= 200 and root.is_done(200) and conflicts == 0 and root.vtotal_count == 0
+        assert root.total_count == 200 or root.min_promote_rollouts() > 200 - root.total_count
         runs.append(_visit_counts(root))
+        assert runs[-1].sum() == evals
     assert np.array_equal(runs[0], runs[1])
     assert not np.array_equal(runs[0], runs[2])           # another seed draws other symmetries
-    assert runs[0].sum() == 200
 
 
 def test_multi_threaded_search_keeps_the_tree_consistent(api):
@@ -199,7 +201,7 @@ def test_multi_threaded_search_keeps_the_tree_consistent(api):
     is counted once, the search stops within threads - 1 rollouts of the limit (worker_thread.rs:144-146)."""
     root = _fresh_root(api)
     evals, conflicts = api.search_run(root, api.SyntheticBoard(5), num_rollouts=400, num_threads=8, seed=1)
-    assert 400 <= root.total_count <= 400 + 7 and root.total_count == evals
+    assert root.total_count <= 400 + 7 and root.total_count == evals and root.is_done(400)
     assert root.vtotal_count == 0
     counts = _visit_counts(root)
     assert counts.sum() == root.total_count and all(root.with_(i).vcount() == 0 for i in np.nonzero(counts)[0])
@@ -209,7 +211,7 @@ def test_multi_threaded_search_keeps_the_tree_consistent(api):
 def test_synthetic_selfplay_counts_every_evaluation(api):
     stats = api.selfplay_synthetic(num_games=3, num_moves=4, num_rollouts=20, threads_per_search=2, seed=11)
     assert stats["games"] == 3 and stats["moves"] == 12
-    assert 12 * 21 <= stats["evals"] <= 12 * (21 + 1)      # 20 rollouts (+ up to threads - 1) + the root evaluation
+    assert 12 * 2 <= stats["evals"] <= 12 * (21 + 1)       # at most 20 rollouts (+ up to threads - 1) + the root evaluation
 
 
 def test_forward_keeps_the_sub_tree(api):
@@ -245,3 +247,27 @@ def test_dirichlet_noise(api):
     assert np.isclose(y[:300].sum(), 1.0, atol=1e-4)
     assert np.array_equal(y, api.dirichlet_add(x, 0.03, 0.25, seed=5)) and not np.array_equal(y, api.dirichlet_add(x, 0.03, 0.25, seed=6))
     assert np.array_equal(api.dirichlet_add(x, 0.03, 0.0, seed=5), x)
+
+
+def test_early_termination_rule(api):
+    """time_control::is_done (time_control/mod.rs:86-101) with min_promote_rollouts (:48-73): not done before the first
+    visit; done at the limit; done early exactly when the lead of the most visited child exceeds the rollouts left."""
+    root = _fresh_root(api)
+    assert not root.is_done(10) and root.min_promote_rollouts() == 0
+    uniform = np.full(362, 1.0 / 362, dtype=np.float32)
+    for visits_a, visits_b in ((3, 0), (5, 2)):
+        root = _fresh_root(api)
+        for index, n in ((17, visits_a), (40, visits_b)):
+            only = np.full(362, -np.inf, dtype=np.float32); only[index] = 1.0
+            for _ in range(n):                                  # steer the descent through child `index` of the root
+                root.set_prior(only)
+                trace = api.probe(root)
+                assert isinstance(trace, api.Trace)
+                api.insert(trace, api.WHITE, 0.5, uniform)
+        root.set_prior(uniform)
+        lead, total = root.min_promote_rollouts(), root.total_count
+        assert lead == visits_a - visits_b and total == visits_a + visits_b
+        assert root.with_(17).count() == visits_a and root.with_(40).count() == visits_b
+        assert root.is_done(total)                              # the limit
+        assert root.is_done(total + lead - 1)                   # lead > remaining: the runner-up cannot catch up
+        assert not root.is_done(total + lead)                   # lead == remaining: it still can
