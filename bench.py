@@ -220,13 +220,22 @@ def main():
             dv = float(np.abs(got.value.astype(np.float32)[:n] - ref_value.view(np.float16).astype(np.float32)).max())
             dp = float(np.abs(got.policy.astype(np.float32)[:n * 362] - ref_policy.view(np.float16).astype(np.float32)).max())
             out["parity_vs_oracle"] = {"boards": n, "max_abs_value_diff": dv, "max_abs_policy_diff": dp, "tolerance": 1e-3}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
 
     ws.release()
     net.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a file and would otherwise
+        # land AFTER this line at exit: flush the C streams first so that the JSON line is the last thing on stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

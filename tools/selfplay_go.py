@@ -73,9 +73,10 @@ def main():
     if dist is not None:
         boards, batches = replicas.sum_over_ranks(dist, torch, boards, f"cuda:{device}"), replicas.sum_over_ranks(dist, torch, batches, f"cuda:{device}")
     job = stats["job"]
+    line = None
     if rank == 0:
         moves_per_s = job["moves"] / job["seconds"]
-        print(json.dumps({
+        line = json.dumps({
             "metric": "go_selfplay", "n_gpus": world, "evals_per_sec": job["evals"] / job["seconds"], "moves_per_sec": moves_per_s,
             "games_per_hour_at_250_moves": moves_per_s * 3600 / 250, "games": job["games"], "games_in_flight_per_rank": args.parallel or None, "moves_cap": args.moves,
             "games_ended_by_passes": job["games_ended"], "mean_stones_per_game": job["moves"] / max(job["games"], 1),
@@ -87,10 +88,15 @@ def main():
             "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
             "sharding": "game_id mod world, one engine + batcher + pool + cache per rank, no data-path collective",
             "note": "real board / ladders / feature planes / Benson scoring (go.cpp), self_play_one game loop, PCIe-inclusive, random-init net",
-        }))
+        })
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:                 # after RCCL's C-stdio banner (see bench.py): the JSON line is the last line on stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
