@@ -227,6 +227,9 @@ def main():
     ws.release()
     net.destroy()
     if dist is not None:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)   # every rank empties its C stdio (RCCL's banner) BEFORE the barrier rank 0 prints after
         dist.barrier()
         dist.destroy_process_group()
     if line is not None:

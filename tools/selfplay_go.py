@@ -90,6 +90,9 @@ def main():
             "note": "real board / ladders / feature planes / Benson scoring (go.cpp), self_play_one game loop, PCIe-inclusive, random-init net",
         })
     if dist is not None:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)   # every rank empties its C stdio (RCCL's banner) BEFORE the barrier rank 0 prints after
         dist.barrier()
         dist.destroy_process_group()
     if line is not None:                 # after RCCL's C-stdio banner (see bench.py): the JSON line is the last line on stdout
