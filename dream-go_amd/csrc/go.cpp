@@ -1,5 +1,6 @@
-// Scope row f-3: the Go board, the ladder reader and the V1 feature planes of dream-go's libdg_go, as a C++ library behind
-// the C ABI -- what produces the INPUT of the hot path.
+// Scope row f-3: the Go board, the ladder reader, the V1 feature planes, Benson / scoring of dream-go's libdg_go, and the
+// self-play game loop of libdg_mcts on top of them, as a C++ library behind the C ABI -- what produces the INPUT of the hot
+// path and turns its outputs into game records.
 //
 //   rules        src/libdg_go/board_fast.rs:200-470 (Tromp-Taylor placement: opponent blocks without liberties are
 //                removed, one's own are NOT -- "place" never checks legality), is_valid (:213-241, no suicide),
@@ -9,10 +10,14 @@
 //   ladders      src/libdg_go/utils/ladder.rs:34-170 (capture and escape readers, neighbour order E, N, W, S as in
 //                iter/adjacent_iter.rs:41-43)
 //   features     src/libdg_go/utils/features.rs:99-251: 32 planes, HWC, fp16
-//   candidates   src/libdg_mcts/options.rs:44-48 (pass or a valid move), symmetry::is_symmetric (symmetry.rs:136-144)
-// Blocks and liberty counts are recomputed by flood fill after every placement (361 points); the reference maintains them
-// incrementally in packed words, with the same observable counts.  Zobrist numbers are this build's own (splitmix64 of a
-// fixed seed): only equality of hashes is observable.
+//   candidates   src/libdg_mcts/options.rs:44-214 (StandardSearch: pass or a valid move; ScoringSearch: no pass, no Benson
+//                eye, no own simple eye), symmetry::is_symmetric (symmetry.rs:136-144)
+//   scoring      src/libdg_go/utils/benson.rs:55-333, utils/score.rs:105-283, src/libdg_mcts/game_result.rs:26-93
+//   self-play    src/libdg_mcts/self_play.rs:216-505, lib.rs:144-224
+// Blocks (head id + circular stone list) and liberty counts are kept incrementally by place(), like the reference's packed
+// words, with the same observable counts; Fast::consistent() is the from-scratch flood fill they are tested against.
+// Zobrist numbers are this build's own (splitmix64 of a fixed seed): only equality of hashes is observable; the positions
+// of the reference's three real-game tests reproduce its expected hashes under its own table (tests/golden/).
 #include <algorithm>
 #include <atomic>
 #include <chrono>

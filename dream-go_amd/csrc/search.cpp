@@ -5,15 +5,19 @@
 //   one rollout   clone the starting board, tree::probe (stones placed on the clone), pick a random symmetry, ask the game
 //                 for the features of the leaf, predict, rebuild the prior (legal candidates 0 / others -inf, symmetric
 //                 duplicates eliminated, network policy de-transformed and renormalised), tree::insert with the win rate
-//   termination   RolloutLimit: root.total_count >= limit (time_control/rollout_limit.rs:35-44); like the reference the
-//                 check happens before a probe, so with T threads up to T - 1 rollouts more may land
+//   termination   time_control::is_done over a RolloutLimit (time_control/mod.rs:86-101, rollout_limit.rs:35-44): the limit, or
+//                 EARLY-C -- the runner-up cannot catch up in the rollouts that remain; like the reference the check
+//                 happens before a probe, so with T threads up to T - 1 rollouts more may land
+//   cache         an optional transposition table is asked before the features are built (pool/event.rs:50-51) and filled
+//                 after a prediction (worker_thread.rs:111)
 //   determinism   every random choice comes from a seeded generator (the reference uses thread_rng() everywhere,
 //                 SURVEY.md section 7): with ONE search thread the visit counts are a pure function of (seed, network
 //                 outputs); with several threads they are not, exactly as in the reference (virtual loss + timing).
 //
-// Also here: a rule-free synthetic game and a synthetic self-play loop for throughput measurements of the whole
-// host + device pipeline (games x moves x rollouts through the tree and the LeafPool).  The synthetic game is NOT Go:
-// every empty point is a legal move, nothing is ever captured, features are pseudo-random bits of the position hash.
+// Also here: full_forward (the 8-symmetry root evaluation, lib.rs:83-130), dirichlet noise (dirichlet.rs:40-70), and a
+// rule-free synthetic game with a synthetic self-play loop for throughput measurements of the host + device pipeline
+// without Go rules.  The synthetic game is NOT Go: every empty point is a legal move, nothing is ever captured, features
+// are pseudo-random bits of the position hash.  The real game is go.cpp.
 #include <atomic>
 #include <chrono>
 #include <cmath>
