@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="boards the CPU oracle evaluates for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="boards the CPU oracle evaluates for cpu_baseline (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
     return ap.parse_args()

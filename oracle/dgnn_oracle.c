@@ -121,7 +121,8 @@ uint16_t dgo_f32_to_f16(float f)
 
 void dgo_f16_to_f32_array(const uint16_t* src, float* dst, size_t n)
 {
-    for (size_t i = 0; i < n; ++i) dst[i] = dgo_f16_to_f32(src[i]);
+#pragma omp parallel for schedule(static) if (n > 65536)
+    for (long i = 0; i < (long)n; ++i) dst[i] = dgo_f16_to_f32(src[i]);
 }
 
 void dgo_f32_to_f16_array(const float* src, uint16_t* dst, size_t n)
@@ -182,6 +183,7 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
     if (!xf || !wf || !bf) { free(xf); free(wf); free(bf); return DGO_OUT_OF_MEMORY; }
 
     dgo_f16_to_f32_array(x, xf, num_pos * cin);
+#pragma omp parallel for schedule(static)
     for (int co = 0; co < cout; ++co) {
         bf[co] = dgo_f16_to_f32(bias[co]);
         for (int tap = 0; tap < 9; ++tap)
@@ -190,21 +192,24 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
                     dgo_f16_to_f32(w[((size_t)co * 9 + tap) * cin + ci]);
     }
 
-    const long num_rows = (long)batch * size;
+    /* Work units = (board, block of output channels): the 9 * cin * DGO_CO_BLOCK weights of a unit stay in the core's
+     * cache while it walks the 361 positions of its board.  The arithmetic of an output is untouched by the loop order:
+     * k runs tap-major then channel, one fp32 fma per product, in order. */
+    const long num_blocks = (cout + DGO_CO_BLOCK - 1) / DGO_CO_BLOCK;
+    const long num_units = (long)batch * num_blocks;
 
-#pragma omp parallel for schedule(static)
-    for (long row = 0; row < num_rows; ++row) {
-        const int b = (int)(row / size);
-        const int yy = (int)(row % size);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long unit = 0; unit < num_units; ++unit) {
+        const int b = (int)(unit / num_blocks);
+        const int co0 = (int)(unit % num_blocks) * DGO_CO_BLOCK;
+        const int co_end = (co0 + DGO_CO_BLOCK < cout) ? DGO_CO_BLOCK : cout - co0;
 
-        for (int xx = 0; xx < size; ++xx) {
-            const size_t out_pos = ((size_t)b * size + yy) * size + xx;
-
-            for (int co0 = 0; co0 < cout; co0 += DGO_CO_BLOCK) {
+        for (int yy = 0; yy < size; ++yy) {
+            for (int xx = 0; xx < size; ++xx) {
+                const size_t out_pos = ((size_t)b * size + yy) * size + xx;
                 float acc[DGO_CO_BLOCK];
                 for (int j = 0; j < DGO_CO_BLOCK; ++j) acc[j] = 0.0f;
 
-                /* k runs tap-major then channel: one fp32 fma per product, in order */
                 for (int tap = 0; tap < 9; ++tap) {
                     const int sy = yy + tap / 3 - 1;
                     const int sx = xx + tap % 3 - 1;
@@ -220,7 +225,6 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
                     }
                 }
 
-                const int co_end = (co0 + DGO_CO_BLOCK < cout) ? DGO_CO_BLOCK : cout - co0;
                 for (int j = 0; j < co_end; ++j) {
                     const int co = co0 + j;
                     float t = fmaf(alpha1, acc[j], bf[co]);
