@@ -558,3 +558,45 @@ def test_synthetic_selfplay_through_the_pool(api, synth):
     assert stats["moves"] == 24 and stats["evals"] == pooled["boards"]
     assert pooled["batches"] <= pooled["boards"]           # how much is coalesced depends on timing
     print(f"synthetic self-play: {stats['evals']} evals in {pooled['batches']} device batches, {stats['conflicts']} probe conflicts")
+
+
+# --------------------------------------------------------------------------------------------- the Go rows (f-3) on the GPU
+
+def test_real_board_features_through_the_engine(api, oracle, synth):
+    """The input contract end to end: feature planes of real positions (all eight symmetries), not synthetic
+    bits, through the HIP engine and through the oracle."""
+    text = synth.to_json(synth.make_tensors(2, 64, seed=81))
+    rng = np.random.default_rng(2)
+    board, color, planes = api.Board(6.5), 0, []
+    for move in range(96):
+        for index in rng.permutation(361):
+            if board.is_valid(color, int(index % 19), int(index // 19)):
+                board.place(color, int(index % 19), int(index // 19))
+                break
+        color ^= 1
+        if move % 12 == 11:
+            planes.append(board.get_features(color, symmetry=len(planes) % 8))
+    features = np.stack(planes).astype(np.float16).reshape(-1)
+    assert len(planes) == 8
+    _compare(api, oracle, text, features, len(planes), "real-board feature planes (8 positions, 8 symmetries)")
+
+
+def test_go_selfplay_through_the_pool(api, synth):
+    """Board + ladders + feature planes + search + transposition cache + pool + HIP engine in one piece: every stone legal,
+    every evaluation accounted for by the batcher."""
+    text = synth.to_json(synth.make_tensors(2, 64, seed=83))
+    net = api.Network.from_json(text)
+    batcher = api.Batcher(net, max_batch_size=64, max_batches=2)
+    pool = api.LeafPool(batcher, num_workers=2)
+    out = api.selfplay_go(num_games=6, num_moves=10, num_rollouts=40, threads_per_search=4, seed=5, pool=pool,
+                          cache=api.LruCache(50_000, 4), return_moves=True, return_sgf=True)
+    pooled = batcher.stats()
+    pool.close()
+    assert out["moves"] == 60 and out["evals"] == pooled["boards"] and out["cache_hits"] > 0
+    for game, record in zip(out["sgf"], out["record"]):
+        replay = api.Board(7.5)
+        for m, index in enumerate(record):
+            assert index >= 0 and replay.is_valid(m % 2, int(index % 19), int(index // 19))
+            replay.place(m % 2, int(index % 19), int(index // 19))
+        assert game.count("TV[") == 10 and game.count("P[") == 10
+    print(f"go self-play: {out['evals']} evals in {pooled['batches']} device batches, {out['cache_hits']} cache hits")
