@@ -71,8 +71,22 @@ def broadcast_weights(net, device, torch, dist, replicas):
     return mode, nbytes
 
 
+def effective_cpus():
+    """The cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box of the pool
+    shows 256 logical CPUs but grants 16 CPUs of time, /sys/fs/cgroup/cpu.max = "1600000 100000")."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(text, features, batch, sample):
     """The CPU oracle (a port of the reference semantics; the reference has no CPU NN path) on the host cores."""
+    os.environ["OMP_NUM_THREADS"] = str(effective_cpus())        # before libgomp is loaded: one thread per usable core
     from oracle import oracle
     tensors, _ = oracle.load_weights(text)
     net = oracle.OracleNetwork(tensors)
