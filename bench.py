@@ -86,8 +86,8 @@ def effective_cpus():
 
 def cpu_baseline(text, features, batch, sample):
     """The CPU oracle (a port of the reference semantics; the reference has no CPU NN path) on the host cores."""
-    os.environ["OMP_NUM_THREADS"] = str(effective_cpus())        # before libgomp is loaded: one thread per usable core
     from oracle import oracle
+    oracle.lib().dgo_set_num_threads(effective_cpus())            # one thread per usable core
     tensors, _ = oracle.load_weights(text)
     net = oracle.OracleNetwork(tensors)
     sample = min(sample, batch)

@@ -427,3 +427,14 @@ int dgo_num_threads(void)
     return 1;
 #endif
 }
+
+/* For the timed CPU baseline: one thread per usable core (the OpenMP runtime may already have been initialised by another
+ * library of the process with a different count).  The results do not depend on the number of threads. */
+void dgo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

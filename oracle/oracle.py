@@ -201,6 +201,8 @@ def lib():
         L.dgo_f16_to_f32.argtypes = [ctypes.c_uint16]
         L.dgo_f16_to_f32.restype = ctypes.c_float
         L.dgo_num_threads.restype = ctypes.c_int
+        L.dgo_set_num_threads.argtypes = [ctypes.c_int]
+        L.dgo_set_num_threads.restype = None
         _lib = L
     return _lib
 
