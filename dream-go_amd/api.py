@@ -155,9 +155,9 @@ SYMBOLS = [
     ("dgnn_go_is_symmetric", ctypes.c_int, [_vp, ctypes.c_int]),
     ("dgnn_go_features", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u16p]),
     ("dgnn_go_game_ops", _vp, []),
-    ("dgnn_selfplay_go", ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vp, _ip,
-                                        ctypes.c_char_p, ctypes.c_size_t]),
+    ("dgnn_selfplay_go", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _ip, ctypes.c_char_p, ctypes.c_size_t]),
+    ("dgnn_search_run_batched", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("dgnn_search_run_cached", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("dgnn_go_scoring_ops", _vp, []),
@@ -876,6 +876,12 @@ def undo(trace, undo_expanding):
 
 # ---- search driver (scope row f-2, second part): search.cpp ----
 
+class SelfplayParams(ctypes.Structure):
+    _fields_ = [("num_games", ctypes.c_int), ("num_parallel", ctypes.c_int), ("first_game", ctypes.c_int), ("game_stride", ctypes.c_int),
+                ("max_moves", ctypes.c_int), ("num_rollouts", ctypes.c_int), ("num_ex_it_rollouts", ctypes.c_int),
+                ("threads_per_search", ctypes.c_int), ("leaves_per_thread", ctypes.c_int), ("seed", ctypes.c_uint64)]
+
+
 class SelfplayStats(ctypes.Structure):
     _fields_ = [("seconds", ctypes.c_double), ("games", ctypes.c_uint64), ("moves", ctypes.c_uint64),
                 ("evals", ctypes.c_uint64), ("conflicts", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64),
@@ -931,15 +937,15 @@ def _game_ops(board, scoring=False):
     return lib.dgnn_synthetic_game_ops()
 
 
-def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None, cache=None, scoring=False):
+def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None, cache=None, scoring=False, leaves_per_thread=1):
     """One search on `root` from a Board or a SyntheticBoard (worker_thread.rs:50-176 for a single search) ->
     (predictor calls, probe conflicts), or (predictor calls, probe conflicts, cache hits) when a LruCache is given.
     scoring=True searches a Board as a ScoringSearch (options.rs:141-163) instead of a StandardSearch."""
     fn, ctx = _predictor(pool)
     evals, conflicts, hits = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-    _check(lib.dgnn_search_run_cached(root._handle, _game_ops(board, scoring), board._handle, fn, ctx, cache._handle if cache is not None else None,
-                                      int(num_rollouts), int(num_threads), int(seed), ctypes.byref(evals), ctypes.byref(conflicts),
-                                      ctypes.byref(hits)), "search_run")
+    _check(lib.dgnn_search_run_batched(root._handle, _game_ops(board, scoring), board._handle, fn, ctx,
+                                       cache._handle if cache is not None else None, int(num_rollouts), int(num_threads), int(leaves_per_thread),
+                                       int(seed), ctypes.byref(evals), ctypes.byref(conflicts), ctypes.byref(hits)), "search_run")
     return (evals.value, conflicts.value) if cache is None else (evals.value, conflicts.value, hits.value)
 
 
@@ -1079,7 +1085,7 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
-                return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0):
+                return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
     (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
     num_parallel of them run at a time (0 = all)."""
@@ -1089,11 +1095,11 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
         num_moves = 722
     moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
-    _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, int(num_games), int(num_parallel), int(first_game),
-                                int(game_stride),
-                                int(num_moves), int(num_rollouts), int(ex_it_rollouts),
-                                int(threads_per_search), int(seed), ctypes.byref(stats), moves.ctypes.data_as(_ip) if moves is not None else None,
-                                sgf, len(sgf) if sgf is not None else 0), "selfplay_go")
+    params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
+                            int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(seed))
+    _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, ctypes.byref(params), ctypes.byref(stats),
+                                moves.ctypes.data_as(_ip) if moves is not None else None, sgf, len(sgf) if sgf is not None else 0),
+           "selfplay_go")
     out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts,
            "cache_hits": stats.cache_hits, "games_ended": stats.games_ended, "ex_it_searches": stats.ex_it_searches}
     if return_moves:

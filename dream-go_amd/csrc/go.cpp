@@ -792,12 +792,17 @@ int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_c
 // game_stride = world play the games one rank would.
 // Concurrency (self_play, self_play.rs:478-495): min(num_parallel, num_games) game threads, each taking the next unplayed game
 // until num_games are done, so the device sees a steady number of games instead of a tail (num_parallel <= 0: all at once).
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_parallel, int first_game,
-                     int game_stride, int max_moves, int num_rollouts, int num_ex_it_rollouts, int threads_per_search, uint64_t seed,
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
 {
-    if (!predict || num_games <= 0 || first_game < 0 || game_stride <= 0 || max_moves < 0 || num_rollouts <= 0 || threads_per_search <= 0 || !stats)
-        return DGNN_BAD_ARGUMENT;
+    if (!predict || !params || !stats) return DGNN_BAD_ARGUMENT;
+    const int num_games = params->num_games, first_game = params->first_game, game_stride = params->game_stride > 0 ? params->game_stride : 1;
+    const int num_rollouts = params->num_rollouts, num_ex_it_rollouts = params->num_ex_it_rollouts;
+    const int threads_per_search = params->threads_per_search > 0 ? params->threads_per_search : 1;
+    const int leaves_per_thread = params->leaves_per_thread > 0 ? params->leaves_per_thread : 1;
+    const uint64_t seed = params->seed;
+    int num_parallel = params->num_parallel, max_moves = params->max_moves;
+    if (num_games <= 0 || first_game < 0 || max_moves < 0 || num_rollouts <= 0 || leaves_per_thread > 64) return DGNN_BAD_ARGUMENT;
     if (num_parallel <= 0 || num_parallel > num_games) num_parallel = num_games;
     if (max_moves == 0 || max_moves > 722) max_moves = 722;
     std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0}, ex_it_searches{0};
@@ -845,7 +850,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
                 if (root) { if (!allow_pass) dgnn_tree_node_disqualify(root, kPass); dgnn_tree_node_set_prior(root, prior); }   // lib.rs:170-181
                 else root = dgnn_tree_node_new(me, value, prior);
                 uint64_t e = 0, c = 0, h = 0;
-                st = dgnn_search_run_cached(root, ops, &board, predict, predict_ctx, cache, limit, threads_per_search, rng.next(), &e, &c, &h);
+                st = dgnn_search_run_batched(root, ops, &board, predict, predict_ctx, cache, limit, threads_per_search, leaves_per_thread, rng.next(), &e, &c, &h);
                 evals.fetch_add(e);
                 conflicts.fetch_add(c);
                 hits.fetch_add(h);

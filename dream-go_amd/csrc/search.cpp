@@ -94,65 +94,100 @@ struct SearchShared {
     void* predict_ctx;
     dgnn_cache* cache = nullptr;        // transposition table (needs ops->hash), may be NULL
     int limit;
+    int leaves_per_thread = 1;
     std::atomic<int> status{DGNN_OK};
     std::atomic<uint64_t> evals{0}, conflicts{0}, cache_hits{0};
 };
 
+// One worker.  The reference's worker has ONE leaf in flight (probe, predict, insert); with leaves_per_thread = K this one
+// collects up to K leaves first -- every probe leaves its virtual loss behind, so the next probe goes elsewhere, exactly as
+// if K threads had probed one after the other -- and sends them to the predictor in ONE call.  K = 1 is the reference's
+// loop.  On a host with few cores this replaces K threads (and K wake-ups per round trip) by one, and it keeps a search
+// with one thread deterministic while K leaves are on the device.
 void search_worker(SearchShared* s, uint64_t seed)
 {
+    struct Leaf { void* board; dgnn_trace* trace; int to_move; int transform; uint64_t key; };
+    const int capacity = std::max(1, s->leaves_per_thread);
     Rng rng{seed};
-    std::vector<uint16_t> features(DGNN_FEATURE_SIZE), policy(DGNN_NUM_MOVES);
+    std::vector<uint16_t> features((size_t)capacity * DGNN_FEATURE_SIZE), policy((size_t)capacity * DGNN_NUM_MOVES), value((size_t)capacity);
+    std::vector<Leaf> leaves;
+    leaves.reserve((size_t)capacity);
     float prior[368];
     dgnn_board_ops place_ops = {s->ops->place};
+    const bool cached = s->cache && s->ops->hash;
     int idle_conflicts = 0;
-    while (s->status.load(std::memory_order_relaxed) == DGNN_OK) {
-        if (dgnn_rollout_limit_is_done(s->root, s->limit) == 1) break;        // worker_thread.rs:149, time_control/mod.rs:86-101
 
-        void* board = s->ops->clone(s->board);
-        dgnn_trace* trace = nullptr;
-        const int r = dgnn_tree_probe(s->root, &place_ops, board, &trace);
-        if (r == DGNN_PROBE_CONFLICT) {                                      // worker_thread.rs:161-163: try again
-            s->ops->destroy(board);
-            s->conflicts.fetch_add(1, std::memory_order_relaxed);
-            // somebody else is expanding what we want: let them -- yield first, then sleep for about the time a leaf
-            // evaluation takes, so that the threads of a narrow tree (late in a game) do not spin on cores others need
-            if (++idle_conflicts > 8) std::this_thread::sleep_for(std::chrono::microseconds(50));
-            else if (idle_conflicts > 2) std::this_thread::yield();
+    auto finish = [&](const Leaf& leaf, uint16_t v, const uint16_t* p) {         // worker_thread.rs:101-113
+        rebuild_prior(s->ops, leaf.board, leaf.to_move, leaf.transform, p, prior);
+        dgnn_tree_insert(leaf.trace, leaf.to_move, 0.5f * half_to_float(v) + 0.5f, prior);   // predictor.rs:50-52
+        dgnn_trace_free(leaf.trace);
+        s->ops->destroy(leaf.board);
+    };
+
+    bool over = false;
+    while (!over && s->status.load(std::memory_order_relaxed) == DGNN_OK) {
+        leaves.clear();
+        bool conflict = false;
+        while ((int)leaves.size() < capacity) {
+            // before EVERY probe, as the reference's worker does (worker_thread.rs:149, time_control/mod.rs:86-101); the leaves
+            // this worker still holds are not in total_count yet, so they are counted against the limit here
+            if (dgnn_rollout_limit_is_done(s->root, s->limit) == 1) { over = true; break; }
+            int total = 0;
+            dgnn_tree_node_info(s->root, nullptr, &total, nullptr, nullptr, nullptr);
+            if (total + (int)leaves.size() >= s->limit) break;
+            void* board = s->ops->clone(s->board);
+            dgnn_trace* trace = nullptr;
+            const int r = dgnn_tree_probe(s->root, &place_ops, board, &trace);
+            if (r != DGNN_PROBE_FOUND) {
+                s->ops->destroy(board);
+                if (r == DGNN_PROBE_CONFLICT) { conflict = true; s->conflicts.fetch_add(1, std::memory_order_relaxed); }   // :161-163
+                else over = true;                                             // NoResult: the search is over (:164-166)
+                break;
+            }
+            Leaf leaf{board, trace, 0, 0, 0};
+            int last_color = 0;
+            dgnn_trace_get(trace, dgnn_trace_len(trace) - 1, nullptr, &last_color, nullptr);
+            leaf.to_move = 1 - last_color;                                    // event.rs:48-49
+            leaf.transform = (int)(rng.next() % 8);                           // event.rs:47
+            leaf.key = cached ? s->ops->hash(board) : 0;
+            uint16_t v = 0;
+            if (cached && dgnn_cache_fetch(s->cache, leaf.key, leaf.to_move, leaf.transform, &v, policy.data()) == 1) {   // event.rs:50-51
+                s->cache_hits.fetch_add(1, std::memory_order_relaxed);
+                finish(leaf, v, policy.data());
+                continue;
+            }
+            s->ops->features(board, leaf.to_move, leaf.transform, features.data() + leaves.size() * DGNN_FEATURE_SIZE);
+            leaves.push_back(leaf);
+        }
+
+        if (leaves.empty()) {
+            if (conflict) {
+                // somebody else is expanding what we want: let them -- yield first, then sleep for about the time a leaf
+                // evaluation takes, so that the threads of a narrow tree (late in a game) do not spin on cores others need
+                if (++idle_conflicts > 8) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                else if (idle_conflicts > 2) std::this_thread::yield();
+            }
             continue;
         }
         idle_conflicts = 0;
-        if (r != DGNN_PROBE_FOUND) { s->ops->destroy(board); break; }         // NoResult: the search is over (:164-166)
 
-        int last_color = 0;
-        dgnn_trace_get(trace, dgnn_trace_len(trace) - 1, nullptr, &last_color, nullptr);
-        const int to_move = 1 - last_color;                                  // event.rs:48-49
-        const int transform = (int)(rng.next() % 8);                         // event.rs:47
-        uint16_t value = 0;
-        int status = DGNN_OK;
-        const bool cached = s->cache && s->ops->hash;
-        const uint64_t key = cached ? s->ops->hash(board) : 0;
-        if (cached && dgnn_cache_fetch(s->cache, key, to_move, transform, &value, policy.data()) == 1) {   // event.rs:50-51
-            s->cache_hits.fetch_add(1, std::memory_order_relaxed);
-        } else {
-            s->ops->features(board, to_move, transform, features.data());
-            status = s->predict(s->predict_ctx, features.data(), 1, &value, policy.data());
-            if (status == DGNN_OK) {
-                s->evals.fetch_add(1, std::memory_order_relaxed);
-                if (cached) dgnn_cache_insert(s->cache, key, to_move, transform, value, policy.data());    // worker_thread.rs:111
-            }
-        }
+        const int n = (int)leaves.size();
+        const int status = s->predict(s->predict_ctx, features.data(), n, value.data(), policy.data());
         if (status != DGNN_OK) {
-            dgnn_tree_undo(trace, 1);
-            dgnn_trace_free(trace);
-            s->ops->destroy(board);
+            for (const Leaf& leaf : leaves) {
+                dgnn_tree_undo(leaf.trace, 1);
+                dgnn_trace_free(leaf.trace);
+                s->ops->destroy(leaf.board);
+            }
             s->status.store(status);
             break;
         }
-        rebuild_prior(s->ops, board, to_move, transform, policy.data(), prior);
-        const float winrate = 0.5f * half_to_float(value) + 0.5f;            // predictor.rs:50-52
-        dgnn_tree_insert(trace, to_move, winrate, prior);                    // worker_thread.rs:101-113
-        dgnn_trace_free(trace);
-        s->ops->destroy(board);
+        s->evals.fetch_add((uint64_t)n, std::memory_order_relaxed);
+        for (int i = 0; i < n; ++i) {
+            const uint16_t* p = policy.data() + (size_t)i * DGNN_NUM_MOVES;
+            if (cached) dgnn_cache_insert(s->cache, leaves[i].key, leaves[i].to_move, leaves[i].transform, value[i], p);    // worker_thread.rs:111
+            finish(leaves[i], value[i], p);
+        }
     }
 }
 
@@ -328,8 +363,16 @@ int dgnn_search_run_cached(dgnn_tree_node* root, const dgnn_game_ops* ops, void*
                            dgnn_cache* cache, int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out,
                            uint64_t* conflicts_out, uint64_t* cache_hits_out)
 {
+    return dgnn_search_run_batched(root, ops, board, predict, predict_ctx, cache, num_rollouts, num_threads, 1, seed, evals_out,
+                                   conflicts_out, cache_hits_out);
+}
+
+int dgnn_search_run_batched(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
+                            dgnn_cache* cache, int num_rollouts, int num_threads, int leaves_per_thread, uint64_t seed,
+                            uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out)
+{
     if (!root || !ops || !ops->clone || !ops->destroy || !ops->place || !ops->features || !ops->candidates || !predict ||
-        num_rollouts <= 0 || num_threads <= 0)
+        num_rollouts <= 0 || num_threads <= 0 || leaves_per_thread <= 0 || leaves_per_thread > 64)
         return DGNN_BAD_ARGUMENT;
     SearchShared shared;
     shared.root = root;
@@ -339,6 +382,7 @@ int dgnn_search_run_cached(dgnn_tree_node* root, const dgnn_game_ops* ops, void*
     shared.predict_ctx = predict_ctx;
     shared.cache = cache;
     shared.limit = num_rollouts;
+    shared.leaves_per_thread = leaves_per_thread;
     Rng seeds{seed};
     if (num_threads == 1) {
         search_worker(&shared, seeds.next());

@@ -370,6 +370,13 @@ int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board,
 int dgnn_search_run_cached(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
                            dgnn_cache* cache, int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out,
                            uint64_t* conflicts_out, uint64_t* cache_hits_out);
+/* The same with up to `leaves_per_thread` (1..64) leaves per worker in flight: a worker probes that many leaves one after the
+ * other (each probe's virtual loss steers the next one elsewhere), evaluates them in ONE predictor call and inserts them.
+ * 1 is the reference's worker.  One thread with K leaves keeps the search a pure function of (seed, network outputs) while K
+ * boards are on the device, and on a host with few cores it replaces K threads and their wake-ups by one. */
+int dgnn_search_run_batched(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
+                            dgnn_cache* cache, int num_rollouts, int num_threads, int leaves_per_thread, uint64_t seed,
+                            uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out);
 /* full_forward (src/libdg_mcts/lib.rs:83-130): win rate and prior (368 floats, -inf = not a candidate) of a position as the
  * average over the eight symmetries, the uncached ones evaluated as ONE batch.  Returns the number of symmetries evaluated
  * (>= 0) or a negative status. */
@@ -447,9 +454,21 @@ int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winn
  * min(num_parallel, num_games) games run at a time, each game thread taking the next unplayed game (self_play.rs:478-495;
  * num_parallel <= 0: all at once).  num_rollouts <= 10 gives the policy-play mode (the budget falls to one rollout,
  * self_play.rs:369-405); num_ex_it_rollouts > 0 is --ex-it: one move in twenty is re-searched with that budget and the
- * search's distribution replaces the record's (self_play.rs:277-319). */
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, int num_games, int num_parallel, int first_game,
-                     int game_stride, int max_moves, int num_rollouts, int num_ex_it_rollouts, int threads_per_search, uint64_t seed,
+ * search's distribution replaces the record's (self_play.rs:277-319).  With threads_per_search = 1 a game is a function of
+ * (seed, game id, network outputs) for any leaves_per_thread: deterministic self-play with many leaves on the device. */
+typedef struct dgnn_selfplay_params {
+    int num_games;            /* games this call plays */
+    int num_parallel;         /* games in flight (--num-games of the reference); <= 0: all at once */
+    int first_game;           /* global id of the first game, */
+    int game_stride;          /*   and the distance to the next one (sharding `id mod world`); <= 0: 1 */
+    int max_moves;            /* cap on the stones per game; 0 = the reference's 722 */
+    int num_rollouts;         /* --num-rollout; <= 10 gives policy play */
+    int num_ex_it_rollouts;   /* --ex-it with this --num-ex-it-rollout; 0 = off */
+    int threads_per_search;   /* search threads per game (--num-threads); <= 0: 1 */
+    int leaves_per_thread;    /* leaves a search thread sends to the predictor per call (dgnn_search_run_batched); <= 0: 1 */
+    uint64_t seed;
+} dgnn_selfplay_params;
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
 
 /* Library version / build info string (static). */

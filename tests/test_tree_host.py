@@ -271,3 +271,49 @@ def test_early_termination_rule(api):
         assert root.is_done(total)                              # the limit
         assert root.is_done(total + lead - 1)                   # lead > remaining: the runner-up cannot catch up
         assert not root.is_done(total + lead)                   # lead == remaining: it still can
+
+
+def test_many_leaves_per_thread_stay_deterministic(api):
+    """dgnn_search_run_batched: one worker with K leaves in flight probes them one after the other (virtual loss steers each
+    probe away from the previous ones), evaluates them in ONE predictor call and inserts them -- still a pure function of the
+    seed, unlike K threads; every virtual loss is returned; K = 1 is the plain search."""
+    calls = []
+
+    def predictor(features, n):
+        calls.append(n)
+        f = np.asarray(features).view(np.float16).reshape(n, -1).astype(np.float32)
+        value = np.tanh(f[:, ::97].sum(axis=1) * 0.05 - 0.5).astype(np.float16)
+        logits = f[:, :362 * 8].reshape(n, 362, 8).sum(axis=2) * 0.5
+        policy = np.exp(logits - logits.max(axis=1, keepdims=True))
+        return value, (policy / policy.sum(axis=1, keepdims=True)).astype(np.float16)
+
+    fn = api.python_predictor(predictor)
+    runs = {}
+    for leaves in (1, 8, 8):
+        calls.clear()
+        root = _fresh_root(api)
+        evals, conflicts = api.search_run(root, api.SyntheticBoard(77), num_rollouts=120, num_threads=1, seed=3, pool=fn,
+                                          leaves_per_thread=leaves)
+        assert evals == root.total_count <= 120 and root.vtotal_count == 0 and root.is_done(120)
+        assert conflicts == 0 or leaves > 1
+        assert sum(calls) == evals and max(calls) <= leaves
+        if leaves == 8:
+            assert max(calls) == 8 and len(calls) < evals / 4          # the leaves really travel together
+        runs.setdefault(leaves, []).append(_visit_counts(root))
+    assert np.array_equal(runs[8][0], runs[8][1])
+    plain = _fresh_root(api)
+    api.search_run(plain, api.SyntheticBoard(77), num_rollouts=120, num_threads=1, seed=3, pool=fn)
+    assert np.array_equal(runs[1][0], _visit_counts(plain))
+
+
+def test_selfplay_with_batched_leaves_is_a_function_of_the_seed(api):
+    kw = dict(num_games=3, num_moves=8, num_rollouts=30, threads_per_search=1, leaves_per_thread=6, seed=19, return_moves=True)
+    a, b = api.selfplay_go(**kw), api.selfplay_go(num_parallel=1, **kw)
+    # (a later probe of the same worker may run into the leaf an earlier one is holding: that ends the collection and is counted
+    # as a conflict -- deterministically)
+    assert np.array_equal(a["record"], b["record"]) and a["evals"] == b["evals"] and a["conflicts"] == b["conflicts"]
+    for record in a["record"]:
+        replay = api.Board(7.5)
+        for m, index in enumerate(record):
+            assert replay.is_valid(m % 2, int(index % 19), int(index // 19))
+            replay.place(m % 2, int(index % 19), int(index // 19))

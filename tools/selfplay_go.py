@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rollouts", type=int, default=800, help="--num-rollout; 1 = policy play (BASELINE.json configs[4])")
     ap.add_argument("--ex-it", type=int, default=0, metavar="ROLLOUTS", help="expert iteration with this --num-ex-it-rollout (0 = off)")
     ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
+    ap.add_argument("--leaves", type=int, default=1, help="leaves a search thread keeps in flight per predictor call (1 = the reference's worker)")
     ap.add_argument("--max-batch", type=int, default=256)
     ap.add_argument("--max-batches", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=20)
@@ -63,7 +64,7 @@ def main():
     before = batcher.stats()
     stats = replicas.selfplay_sharded(api, dist, torch, args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
                                       return_sgf=args.sgf is not None, device=f"cuda:{device}" if dist is not None else "cpu",
-                                      num_parallel=args.parallel, ex_it_rollouts=args.ex_it)
+                                      num_parallel=args.parallel, ex_it_rollouts=args.ex_it, leaves_per_thread=args.leaves)
     after = batcher.stats()
     if args.sgf:
         with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
@@ -82,7 +83,7 @@ def main():
             "games_ended_by_passes": job["games_ended"], "mean_stones_per_game": job["moves"] / max(job["games"], 1),
             "games_per_hour_measured": (job["games"] * 3600 / job["seconds"]) if args.moves == 0 else None,
             "evals_per_move": job["evals"] / max(job["moves"], 1),
-            "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "mean_device_batch": boards / max(batches, 1),
+            "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1),
             "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
             "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
             "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
