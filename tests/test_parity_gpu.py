@@ -600,3 +600,23 @@ def test_go_selfplay_through_the_pool(api, synth):
             replay.place(m % 2, int(index % 19), int(index // 19))
         assert game.count("TV[") == 10 and game.count("P[") == 10
     print(f"go self-play: {out['evals']} evals in {pooled['batches']} device batches, {out['cache_hits']} cache hits")
+
+
+def test_selfplay_on_the_engine_is_a_function_of_the_seed(api, synth):
+    """north_star: visit counts bit-identical under a fixed seed -- here for whole self-play games on the HIP engine: one search
+    thread per game with 8 leaves in flight, games coalesced by the pool into device batches whose composition depends on timing
+    and on how many games run at a time.  The engine's result for a board does not depend on what else is in the batch (a board is
+    one workgroup, the contraction order is fixed), so the records must not depend on it either."""
+    text = synth.to_json(synth.make_tensors(3, 64, seed=85))
+    net = api.Network.from_json(text)
+    records = []
+    for parallel, max_batch in ((0, 64), (2, 16), (0, 7)):
+        batcher = api.Batcher(net, max_batch_size=max_batch, max_batches=2)
+        pool = api.LeafPool(batcher, num_workers=2)
+        out = api.selfplay_go(num_games=6, num_moves=12, num_rollouts=48, threads_per_search=1, leaves_per_thread=8, seed=23, pool=pool,
+                              num_parallel=parallel, return_moves=True)
+        stats = batcher.stats()
+        pool.close()
+        records.append(out["record"])
+        print(f"games in flight {parallel or 6}, max batch {max_batch}: {out['evals']} evals in {stats['batches']} device batches")
+    assert np.array_equal(records[0], records[1]) and np.array_equal(records[0], records[2])
