@@ -879,7 +879,8 @@ def undo(trace, undo_expanding):
 class SelfplayParams(ctypes.Structure):
     _fields_ = [("num_games", ctypes.c_int), ("num_parallel", ctypes.c_int), ("first_game", ctypes.c_int), ("game_stride", ctypes.c_int),
                 ("max_moves", ctypes.c_int), ("num_rollouts", ctypes.c_int), ("num_ex_it_rollouts", ctypes.c_int),
-                ("threads_per_search", ctypes.c_int), ("leaves_per_thread", ctypes.c_int), ("seed", ctypes.c_uint64)]
+                ("threads_per_search", ctypes.c_int), ("leaves_per_thread", ctypes.c_int), ("cache_entries_per_game", ctypes.c_int),
+                ("seed", ctypes.c_uint64)]
 
 
 class SelfplayStats(ctypes.Structure):
@@ -1085,7 +1086,7 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
-                return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1):
+                return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1, cache_per_game=0):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
     (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
     num_parallel of them run at a time (0 = all)."""
@@ -1096,7 +1097,7 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
     params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
-                            int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(seed))
+                            int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed))
     _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, ctypes.byref(params), ctypes.byref(stats),
                                 moves.ctypes.data_as(_ip) if moves is not None else None, sgf, len(sgf) if sgf is not None else 0),
            "selfplay_go")

@@ -801,6 +801,8 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
     const int threads_per_search = params->threads_per_search > 0 ? params->threads_per_search : 1;
     const int leaves_per_thread = params->leaves_per_thread > 0 ? params->leaves_per_thread : 1;
     const uint64_t seed = params->seed;
+    const int private_cache = params->cache_entries_per_game;
+    dgnn_cache* const shared_cache = cache;
     int num_parallel = params->num_parallel, max_moves = params->max_moves;
     if (num_games <= 0 || first_game < 0 || max_moves < 0 || num_rollouts <= 0 || leaves_per_thread > 64) return DGNN_BAD_ARGUMENT;
     if (num_parallel <= 0 || num_parallel > num_games) num_parallel = num_games;
@@ -815,6 +817,11 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
         const double kv = rng.uniform();                                       // get_random_komi, lib.rs:210-224
         const float komi = kv < 0.4 ? 7.5f : kv < 0.8 ? 6.5f : kv < 0.9 ? 0.5f : (float)((int)(rng.next() % 16) - 8) + 0.5f;
         GoBoard board(komi);
+        // The transposition table is keyed like the reference's (zobrist hash + colour, predictors/nn.rs:31-45) although the
+        // feature planes also hold the last moves and the ko state: WHICH of two such positions fills an entry first depends
+        // on timing when games share the table.  A table of the game's own keeps the game a function of the seed.
+        dgnn_cache* cache = shared_cache;
+        if (private_cache > 0 && dgnn_cache_create((size_t)private_cache, 1, &cache) != DGNN_OK) { status.store(DGNN_OUT_OF_MEMORY); return; }
         dgnn_tree_node* roots[2] = {nullptr, nullptr};                         // Player::root of black / white
         float winrate[2] = {0.5f, 0.5f};                                       // MovingAverage::new(0.5, 0.2)
         std::string sgf;
@@ -933,6 +940,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
         if (finished) ended.fetch_add(1);
         dgnn_tree_node_free(roots[0]);
         dgnn_tree_node_free(roots[1]);
+        if (private_cache > 0) dgnn_cache_destroy(cache);
 
         unsigned char point_status[kPoints];                                   // GameResult::Ended, game_result.rs:35-41
         stone_status(board.inner, point_status);

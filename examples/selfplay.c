@@ -1,0 +1,63 @@
+/* Self-play from plain C: board, search, pool and engine behind one call.
+ *
+ *   gcc -std=c99 -Iinclude examples/selfplay.c -Ldream-go_amd/lib -ldgnn_hip -Wl,-rpath,$PWD/dream-go_amd/lib -o selfplay
+ *   ./selfplay                          (no weights: the deterministic CPU stand-in predictor, no GPU needed)
+ *   ./selfplay dream_go.json 64 800     (weights file, games, rollouts: HIP engine behind the leaf pool)
+ *
+ * Prints one GameResult::Ended record per game (src/libdg_mcts/game_result.rs:35-41), the format dream-go's trainer reads. */
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "dgnn.h"
+
+int main(int argc, char** argv)
+{
+    const char* path = argc > 1 ? argv[1] : NULL;
+    dgnn_selfplay_params params;
+    dgnn_selfplay_stats stats;
+    dgnn_network* net = NULL;
+    dgnn_batcher* batcher = NULL;
+    dgnn_pool* pool = NULL;
+    dgnn_predict_fn predict = dgnn_hash_predictor();
+    void* predict_ctx = NULL;
+    size_t capacity;
+    char* sgf;
+    int status;
+
+    params.num_games = argc > 2 ? atoi(argv[2]) : 2;
+    params.num_parallel = 0;
+    params.first_game = 0;
+    params.game_stride = 1;
+    params.max_moves = path ? 0 : 30;          /* whole games on the engine, a short demonstration without it */
+    params.num_rollouts = argc > 3 ? atoi(argv[3]) : 40;
+    params.num_ex_it_rollouts = 0;
+    params.threads_per_search = 1;             /* one thread with several leaves in flight: reproducible for a fixed seed */
+    params.leaves_per_thread = 8;
+    params.cache_entries_per_game = 20001;     /* a table per game, not a shared one: see dgnn_selfplay_go in dgnn.h */
+    params.seed = 2024;
+
+    if (path) {
+        if ((status = dgnn_network_load(path, &net)) != DGNN_OK) { fprintf(stderr, "%s: %s\n", path, dgnn_status_string(status)); return 1; }
+        if ((status = dgnn_batcher_create(net, 0, 256, 3, &batcher)) != DGNN_OK ||
+            (status = dgnn_pool_create(batcher, 3, &pool)) != DGNN_OK) {
+            fprintf(stderr, "pool: %s (hip %d)\n", dgnn_status_string(status), dgnn_last_hip_error());
+            return 1;
+        }
+        predict = dgnn_pool_predictor();
+        predict_ctx = pool;
+    }
+    capacity = (size_t)params.num_games * ((size_t)(params.max_moves ? params.max_moves : 722) * 1100 + 4 * 722 * 6 + 2048);
+    sgf = (char*)malloc(capacity);
+    if (!sgf) return 1;
+    status = dgnn_selfplay_go(predict, predict_ctx, NULL, &params, &stats, NULL, sgf, capacity);
+    if (status != DGNN_OK) { fprintf(stderr, "self-play: %s\n", dgnn_status_string(status)); return 1; }
+    fputs(sgf, stdout);
+    fprintf(stderr, "%llu games, %llu stones, %llu evaluations (%llu from the cache) in %.2f s\n", (unsigned long long)stats.games,
+            (unsigned long long)stats.moves, (unsigned long long)stats.evals, (unsigned long long)stats.cache_hits, stats.seconds);
+
+    free(sgf);
+    if (pool) dgnn_pool_destroy(pool);
+    if (batcher) dgnn_batcher_destroy(batcher);
+    if (net) dgnn_network_destroy(net);
+    return 0;
+}

@@ -455,7 +455,9 @@ int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winn
  * num_parallel <= 0: all at once).  num_rollouts <= 10 gives the policy-play mode (the budget falls to one rollout,
  * self_play.rs:369-405); num_ex_it_rollouts > 0 is --ex-it: one move in twenty is re-searched with that budget and the
  * search's distribution replaces the record's (self_play.rs:277-319).  With threads_per_search = 1 a game is a function of
- * (seed, game id, network outputs) for any leaves_per_thread: deterministic self-play with many leaves on the device. */
+ * (seed, game id, network outputs) for any leaves_per_thread: deterministic self-play with many leaves on the device --
+ * provided the games do not share a transposition table (cache == NULL or cache_entries_per_game > 0): the table is keyed
+ * like the reference's, by stones and colour only, while the feature planes also hold the last moves and the ko state. */
 typedef struct dgnn_selfplay_params {
     int num_games;            /* games this call plays */
     int num_parallel;         /* games in flight (--num-games of the reference); <= 0: all at once */
@@ -466,6 +468,8 @@ typedef struct dgnn_selfplay_params {
     int num_ex_it_rollouts;   /* --ex-it with this --num-ex-it-rollout; 0 = off */
     int threads_per_search;   /* search threads per game (--num-threads); <= 0: 1 */
     int leaves_per_thread;    /* leaves a search thread sends to the predictor per call (dgnn_search_run_batched); <= 0: 1 */
+    int cache_entries_per_game; /* > 0: every game gets a transposition table of its own with this many entries instead of the
+                                   shared `cache` -- needed for reproducible games, see below */
     uint64_t seed;
 } dgnn_selfplay_params;
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,

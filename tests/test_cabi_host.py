@@ -217,3 +217,23 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     # without a weights file it reports the reference's MissingWeights and exits non-zero (no GPU needed for that)
     run = subprocess.run([str(exe), str(tmp_path / "nothing.json")], capture_output=True, text=True)
     assert run.returncode == 1 and "missing weights" in run.stderr
+
+
+def test_selfplay_example_in_c(tmp_path):
+    """examples/selfplay.c: the host rows (board, search, cache, game records) from strict C99 through the same header; without
+    a weights file it plays on the CPU stand-in predictor, so it runs here."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "selfplay_example"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "selfplay.c"), "-L" + os.path.join(root, "dream-go_amd", "lib"),
+                    "-ldgnn_hip", "-Wl,-rpath," + os.path.join(root, "dream-go_amd", "lib"), "-o", str(exe)], check=True)
+    first = subprocess.run([str(exe)], capture_output=True, text=True, check=True)
+    again = subprocess.run([str(exe)], capture_output=True, text=True, check=True)
+    games = first.stdout.strip().splitlines()
+    assert len(games) == 2 and all(g.startswith("(;GM[1]FF[4]DT[") and g.endswith(")") for g in games)
+    assert all(len(re.findall(r";[BW]\[[a-s]{2}\]", g)) == 30 for g in games)
+    strip = lambda text: re.sub(r"DT\[[^\]]*\]", "", text)          # the date is the only thing that may differ between two runs
+    assert strip(first.stdout) == strip(again.stdout)
+    assert "2 games, 60 stones" in first.stderr

@@ -307,8 +307,10 @@ def test_many_leaves_per_thread_stay_deterministic(api):
 
 
 def test_selfplay_with_batched_leaves_is_a_function_of_the_seed(api):
-    kw = dict(num_games=3, num_moves=8, num_rollouts=30, threads_per_search=1, leaves_per_thread=6, seed=19, return_moves=True)
+    kw = dict(num_games=3, num_moves=8, num_rollouts=30, threads_per_search=1, leaves_per_thread=6, seed=19, return_moves=True,
+              cache_per_game=5000)       # a table per game: a shared one makes games depend on each other's timing (dgnn.h)
     a, b = api.selfplay_go(**kw), api.selfplay_go(num_parallel=1, **kw)
+    assert a["cache_hits"] == b["cache_hits"] > 0
     # (a later probe of the same worker may run into the leaf an earlier one is holding: that ends the collection and is counted
     # as a conflict -- deterministically)
     assert np.array_equal(a["record"], b["record"]) and a["evals"] == b["evals"] and a["conflicts"] == b["conflicts"]

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
+    ap.add_argument("--cache-per-game", type=int, default=0, help="> 0: a private table per game (reproducible games) instead of the shared one")
     ap.add_argument("--sgf", default=None)
     args = ap.parse_args()
 
@@ -64,7 +65,7 @@ def main():
     before = batcher.stats()
     stats = replicas.selfplay_sharded(api, dist, torch, args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
                                       return_sgf=args.sgf is not None, device=f"cuda:{device}" if dist is not None else "cpu",
-                                      num_parallel=args.parallel, ex_it_rollouts=args.ex_it, leaves_per_thread=args.leaves)
+                                      num_parallel=args.parallel, ex_it_rollouts=args.ex_it, leaves_per_thread=args.leaves, cache_per_game=args.cache_per_game)
     after = batcher.stats()
     if args.sgf:
         with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
