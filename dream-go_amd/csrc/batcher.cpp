@@ -206,6 +206,8 @@ struct LeafPool {
 
 }  // namespace dgnn
 
+const uint16_t* dgnn::symmetry_map(int transform) { return tables().map[transform & 7]; }
+
 using namespace dgnn;
 
 extern "C" {

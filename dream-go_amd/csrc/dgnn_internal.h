@@ -13,6 +13,9 @@
 
 namespace dgnn {
 
+// map[i] = packed index of `transform` applied to point i (pass maps to pass); batcher.cpp
+const uint16_t* symmetry_map(int transform);
+
 // ----------------------------------------------------------------------------------------------
 // fp16 helpers (host).  Same rounding as llvm.convert.to.fp16 (src/libdg_utils/types/fp16.rs:53-70).
 // ----------------------------------------------------------------------------------------------

@@ -113,6 +113,9 @@ struct Fast {                         // BoardFast
             do { if (stone[r] != stone[p] || head[r] != h || ++listed > count) return false; r = next[r]; } while (r != p);
             if (listed != count) return false;
         }
+        for (int p = 0; p < kPoints; ++p)                                       // the shortcuts of n_liberty_if against its general path
+            if (stone[p] == kEmpty)
+                for (int c = 0; c < 2; ++c) if (n_liberty_if_impl(c, p, true) != n_liberty_if_impl(c, p, false)) return false;
         return true;
     }
 
@@ -210,29 +213,56 @@ struct Fast {                         // BoardFast
         return hash;
     }
 
-    int n_liberty_if(int color, int p) const                                  // board_fast.rs:484-541
+    int n_liberty_if(int color, int p) const { return n_liberty_if_impl(color, p, true); }   // board_fast.rs:484-541
+
+    int n_liberty_if_impl(int color, int p, bool shortcuts) const
     {
+        // what touches p: empty points, own blocks it would join, opponent blocks it would capture
+        int empties[4], n_empty = 0, own[4], own_at[4], n_own = 0;
+        bool captures = false;
+        for (int d = 0; d < 4; ++d) {
+            const int q = neighbour(p, d);
+            if (q < 0) continue;
+            if (stone[q] == kEmpty) empties[n_empty++] = q;
+            else if (stone[q] == color + 1) {
+                const int h = head[q];
+                if (std::find(own, own + n_own, h) == own + n_own) { own[n_own] = h; own_at[n_own++] = q; }
+            } else if (libs[head[q]] == 1) captures = true;
+        }
+        if (shortcuts && !captures && n_own == 0) return n_empty;             // a lone stone
+        if (shortcuts && !captures && n_own == 1) {
+            // one block joined, nothing captured: its liberties without p, plus p's empty neighbours it does not touch yet
+            int num = libs[own[0]] - 1;
+            for (int i = 0; i < n_empty; ++i) {
+                bool touches = false;
+                for (int d = 0; d < 4 && !touches; ++d) {
+                    const int a = neighbour(empties[i], d);
+                    touches = a >= 0 && a != p && stone[a] == color + 1 && head[a] == own[0];
+                }
+                if (!touches) ++num;
+            }
+            return num;
+        }
+
+        // the general case: the union of everything, counted once with a per-call stamp
         static thread_local unsigned int stamp[kPoints];                      // "seen in call number serial"
         static thread_local unsigned int serial = 0;
         if (++serial == 0) { std::memset(stamp, 0, sizeof(stamp)); serial = 1; }
         int num = 0;
         stamp[p] = serial;
-        int captured[4] = {-1, -1, -1, -1}, connected[4] = {-1, -1, -1, -1}, connected_at[4] = {-1, -1, -1, -1};
+        int captured[4] = {-1, -1, -1, -1};
         for (int d = 0; d < 4; ++d) {
             const int q = neighbour(p, d);
             if (q < 0) continue;
-            if (stone[q] == color + 1) {
-                if (std::find(connected, connected + 4, (int)head[q]) == connected + 4) { connected[d] = head[q]; connected_at[d] = q; }
-            } else if (stone[q] == 2 - color) {
+            if (stone[q] == 2 - color) {
                 if (libs[head[q]] == 1) { captured[d] = head[q]; stamp[q] = serial; ++num; }
-            } else {
+            } else if (stone[q] == kEmpty) {
                 stamp[q] = serial;
                 ++num;
             }
         }
-        for (int c = 0; c < 4; ++c) {
-            if (connected[c] < 0) continue;
-            int s = connected_at[c];
+        for (int c = 0; c < n_own; ++c) {
+            int s = own_at[c];
             do {
                 for (int d = 0; d < 4; ++d) {
                     const int a = neighbour(s, d);
@@ -242,7 +272,7 @@ struct Fast {                         // BoardFast
                     else if (stone[a] == 2 - color && std::find(captured, captured + 4, (int)head[a]) != captured + 4) ++num;
                 }
                 s = next[s];
-            } while (s != connected_at[c]);
+            } while (s != own_at[c]);
         }
         return num;
     }
@@ -385,7 +415,8 @@ void features_v1(const GoBoard& b, int to_move, int symmetry, uint16_t* out)
 {
     const uint16_t one = 0x3c00;
     std::memset(out, 0, DGNN_FEATURE_SIZE * sizeof(uint16_t));
-    auto at = [&](int plane, int point) -> uint16_t& { return out[32 * dgnn_symmetry_apply(symmetry, point) + plane]; };
+    const uint16_t* map = symmetry_map(symmetry);
+    auto at = [&](int plane, int point) -> uint16_t& { return out[32 * map[point] + plane]; };
     const int opponent = 1 - to_move;
 
     for (int i = 0; i < 2; ++i)                                               // planes 3, 4: the two most recent moves
@@ -662,7 +693,8 @@ void go_candidates(void* b, int to_move, unsigned char* out)                  //
 int go_is_symmetric(void* b, int symmetry)                                    // symmetry.rs:136-144
 {
     const GoBoard* g = static_cast<GoBoard*>(b);
-    for (int p = 0; p < kPoints; ++p) if (g->inner.stone[p] != g->inner.stone[dgnn_symmetry_apply(symmetry, p)]) return 0;
+    const uint16_t* map = symmetry_map(symmetry);
+    for (int p = 0; p < kPoints; ++p) if (g->inner.stone[p] != g->inner.stone[map[p]]) return 0;
     return 1;
 }
 uint64_t go_hash(void* b) { return static_cast<GoBoard*>(b)->hash; }      // BoardTuple, predictors/nn.rs:31-45
