@@ -164,14 +164,16 @@ def main():
 
     # ---- roofline of the dominant kernel: the C -> C residual convolution (2 per block)
     c = info["num_channels"]
-    conv_flops = 2.0 * 9 * c * c * 361 * args.batch            # algorithmic FLOPs per launch
-    conv_ms = tower_ms / max(tower_launches, 1)
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    conv_flops = 2.0 * 9 * c * c * 361 * args.batch            # algorithmic FLOPs per convolution
+    convs_per_launch = max(1, round(2 * info["num_blocks"] * args.steps / max(tower_launches, 1)))   # 1, or 2 * blocks (tower kernel)
+    launch_ms = tower_ms / max(tower_launches, 1)
+    achieved = conv_flops * convs_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
     roofline = {
         "bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
-        "kernel": f"residual 3x3 convolution C->C ({ws.conv_kernel()})", "launch_us": conv_ms * 1e3,
-        "launches_timed": tower_launches, "flops_per_launch": conv_flops,
+        "kernel": f"residual 3x3 convolution C->C ({ws.conv_kernel()})", "launch_us": launch_ms * 1e3,
+        "launches_timed": tower_launches, "convolutions_per_launch": convs_per_launch,
+        "flops_per_launch": conv_flops * convs_per_launch, "us_per_convolution": launch_ms * 1e3 / convs_per_launch,
     }
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/profile.sh +
     # tools/pmc_summary.py); only quoted when the profile was taken on this workload and this kernel

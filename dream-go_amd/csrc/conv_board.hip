@@ -143,21 +143,19 @@ static_assert(Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
 // 256 workgroups fetch their 205 KiB of z at the same moment: 52 MB at HBM speed, 8 us of a 90 us kernel.)
 // ABL = ablation bits for measurements only (results are garbage): 1 drops the MFMAs, 2 the in-loop DMA, 4 the in-loop
 // B-fragment reads, 8 the counted vmcnt waits of the k-steps (DMA still issued).
+// One convolution of one workgroup: board `b`, channel block `nb`.  A __device__ function so that the per-layer kernel
+// and the whole-tower kernel below share it; `lds` is the workgroup's S::LdsBytes of shared memory.
 template <int NS, int SKIP, bool RELU, int ABL>
-__global__ __launch_bounds__(kThreads)
-void conv3x3_board_kernel(ConvBoardLaunch a)
+__device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb)
 {
     using S = Split<NS>;
     constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD;
-    __shared__ __attribute__((aligned(16))) char lds[S::LdsBytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % NS;                        // channel slice
     const int g = wave / NS;                         // row group
-    const int b = blockIdx.x;
-    const int nb = blockIdx.y;
     const int cin = a.cin;
     const int cout = a.cout;
     const int nchunks = cin / 32;
@@ -451,11 +449,39 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
         wait_vmcnt<0>();
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
-            unsigned long long* out = a.timing + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+            unsigned long long* out = a.timing + ((long)(nb * gridDim.x + b) * 8 + wave) * 4;
             out[0] = t_start; out[1] = t_loop; out[2] = t_epilogue; out[3] = t_end;
         }
     }
     wait_vmcnt<0>();        // the tail's surplus DMA (slabs past the last step) must not outlive the workgroup's LDS
+}
+
+template <int NS, int SKIP, bool RELU, int ABL>
+__global__ __launch_bounds__(kThreads)
+void conv3x3_board_kernel(ConvBoardLaunch a)
+{
+    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
+    conv_board_body<NS, SKIP, RELU, ABL>(a, lds, blockIdx.x, blockIdx.y);
+}
+
+// The whole residual tower of one board in one workgroup.  A board's convolutions depend on that board only, and with
+// NS = C_out / 32 a workgroup writes every channel of its board, so the layers need no grid-wide synchronisation: between
+// two layers the workgroup waits for its own stores and meets at a barrier (workgroup-scope release / acquire: the CU's
+// vector L1 is write-through and shared by the workgroup's waves).  Workgroups drift apart, so prologues, HBM write bursts
+// and epilogues of different boards no longer fall on the same instants, and there are no launch gaps.
+// `layers` = 2 * blocks descriptors in HBM (conv_1 / conv_2 of every block: alpha2 == 0 / != 0), all with relu and
+// cin = cout = 32 * NS.
+template <int NS>
+__global__ __launch_bounds__(kThreads)
+void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
+{
+    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
+    for (int i = 0; i < count; ++i) {
+        const ConvBoardLaunch a = layers[i];
+        if (a.alpha2 != 0.0f) conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0);
+        else conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0);
+        __syncthreads();        // includes the workgroup-scope fences: this board's y is visible to this workgroup's loads
+    }
 }
 
 // [B][361][C] NHWC -> [B][C / 8][400][8]; pad rows / columns are written as zero.
@@ -538,6 +564,26 @@ int conv_board_pick_ns(int batch, int cout)
         if ((ns == 2 || ns == 4 || ns == 8) && slices % ns == 0) best = ns;
     }
     return best;
+}
+
+bool tower_board_supported(int batch, int channels)
+{
+    const int slices = channels / 32;
+    return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || slices == 4 || slices == 8) &&
+           conv_board_pick_ns(batch, channels) == slices;
+}
+
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream)
+{
+    if (batch <= 0 || count <= 0) return hipSuccess;
+    if (!tower_board_supported(batch, channels)) return hipErrorInvalidValue;
+    const dim3 grid(batch, 1);
+    switch (channels / 32) {
+        case 8: hipLaunchKernelGGL((tower_board_kernel<8>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+        case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)

@@ -73,6 +73,10 @@ struct ConvBoardLaunch {
 bool conv_board_supported(int cin, int cout);
 int conv_board_pick_ns(int batch, int cout);   // 32-channel slices per workgroup the launcher will use
 hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream);
+// The residual tower as ONE launch, a workgroup per board walking all `count` layers (descriptors in HBM; conv_1 / conv_2 of
+// every block, relu, C -> C).  Only where a workgroup owns all channels of its board: conv_board_pick_ns(batch, C) == C / 32.
+bool tower_board_supported(int batch, int channels);
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream);
 // Layout changes at the two ends of the tower: [B][361][C] NHWC <-> [B][C / 8][400][8].  C a multiple of 8.
 hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
 hipError_t launch_board_to_nhwc(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);

@@ -159,7 +159,8 @@ int dgnn_workspace_sync(dgnn_workspace* ws);
  *   total_ms    elapsed time of all passes
  *   tower_ms    summed elapsed time of the residual-tower launches only (event pairs recorded on the
  *               same stream around the residual convolutions of every pass)
- *   tower_launches  number of residual convolution launches those events bracket (2 * blocks * steps)
+ *   tower_launches  number of kernel launches those events bracket: 2 * blocks * steps with one launch per convolution,
+ *               steps where the whole tower is one launch (dgnn_workspace_conv_kernel() == "tower_board_kernel")
  * Any out pointer may be NULL. */
 int dgnn_forward_timed(dgnn_workspace* ws, int steps, float* total_ms, float* tower_ms, int* tower_launches);
 

@@ -620,3 +620,31 @@ def test_selfplay_on_the_engine_is_a_function_of_the_seed(api, synth):
         records.append(out["record"])
         print(f"games in flight {parallel or 6}, max batch {max_batch}: {out['evals']} evals in {stats['batches']} device batches")
     assert np.array_equal(records[0], records[1]) and np.array_equal(records[0], records[2])
+
+
+# --------------------------------------------------------------------------------------------- the tower as one launch
+
+@pytest.mark.parametrize("blocks,channels,batch", [(3, 64, 5), (2, 128, 200), (2, 256, 192), (3, 64, 256)])
+def test_tower_kernel_equals_one_launch_per_layer(api, synth, blocks, channels, batch, monkeypatch):
+    """tower_board_kernel walks all layers of a board in one workgroup (no grid-wide synchronisation is needed: a board's
+    convolutions depend on that board only).  It runs the same code per layer as conv3x3_board_kernel, so the outputs must be
+    bit-identical to the per-layer launches (DGNN_TOWER=0), and it must only be chosen where a workgroup owns a whole board."""
+    text = synth.to_json(synth.make_tensors(blocks, channels, seed=91))
+    features = synth.make_features(batch, seed=92)
+    outputs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DGNN_TOWER", mode)
+        net = api.Network.from_json(text)
+        with net.get_workspace(batch) as ws:
+            outputs[mode] = (ws.conv_kernel(), api.forward(ws, features).unwrap())
+        net.destroy()
+    assert outputs["1"][0] == "tower_board_kernel" and outputs["0"][0] == "conv3x3_board_kernel"
+    assert np.array_equal(outputs["1"][1][0].view(np.uint16), outputs["0"][1][0].view(np.uint16))
+    assert np.array_equal(outputs["1"][1][1].view(np.uint16), outputs["0"][1][1].view(np.uint16))
+
+
+def test_tower_kernel_is_not_used_when_a_board_is_split_over_workgroups(api, synth):
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 256, seed=93)))
+    with net.get_workspace(8) as ws:                       # 8 boards of 256 channels: NS = 2, four workgroups per board
+        assert ws.conv_kernel() == "conv3x3_board_kernel"
+    net.destroy()
