@@ -177,8 +177,11 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     const uint16_t* const w_wave = a.w + (long)(nb * NS + wn) * 1024 + lane * 8;
 
     // fragment f of k-step `st` of this wave's filter slice -> ring slot `slot`
+    // steps past the last one belong to the next layer when there is one to hand over to (tower_board_kernel)
+    const int nsteps_total = nchunks * 9;
+    const uint16_t* const w_next_wave = a.w_next ? a.w_next + (long)(nb * NS + wn) * 1024 + lane * 8 - (long)nsteps_total * step_halfs : w_wave;
     auto issue_w_piece = [&](int st, int slot, int f) {
-        const uint16_t* src = w_wave + (long)st * step_halfs;
+        const uint16_t* src = (st >= nsteps_total ? w_next_wave : w_wave) + (long)st * step_halfs;
         char* const dst = lds + kWBase + wave * S::RingBytes + slot * S::SlabBytes;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 512),
                                          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
@@ -252,10 +255,12 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     };
 
     // ---- prologue: chunk 0 and the first three filter slabs ----
+    if (!a.carry_in) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) issue_x(0, 0, j);
+        for (int j = 0; j < 4; ++j) issue_x(0, 0, j);
 #pragma unroll
-    for (int s = 0; s < kRing; ++s) issue_w(s, s);
+        for (int s = 0; s < kRing; ++s) issue_w(s, s);
+    }
     wait_vmcnt<0>();
     __syncthreads();
 
@@ -441,7 +446,13 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
             }
             const auto sx = __builtin_amdgcn_permlane32_swap(out[0].x, out[1].x, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(out[0].y, out[1].y, false, false);
-            *reinterpret_cast<uint4*>(yb + ((ct * 4 + k0) * kRows + row) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            const uint4 unit = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            *reinterpret_cast<uint4*>(yb + ((ct * 4 + k0) * kRows + row) * 8) = unit;
+            // hand-over: channels 0..31 are the next layer's first input chunk; its place is activation buffer 0, which
+            // nobody reads any more (the last chunk sits in buffer 1, and the barrier that ended it came after every
+            // wave's last DMA into buffer 0 had landed)
+            if (ct == 0 && wn == 0 && nb == 0 && a.w_next != nullptr)
+                *reinterpret_cast<uint4*>(lds + (k0 + hi) * kSlotBytes + (kHalo + row) * 16) = unit;
         }
         if (rt + 2 < RT) load_z(rt + 2);
     }
@@ -477,10 +488,12 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
     for (int i = 0; i < count; ++i) {
+        // the descriptors carry the hand-over fields (w_next, carry_in); a layer ends with its own loads and stores waited
+        // for, and the next one starts with a barrier behind workgroup-scope fences (__syncthreads): this board's y is
+        // visible to this workgroup's loads
         const ConvBoardLaunch a = layers[i];
         if (a.alpha2 != 0.0f) conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0);
         else conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0);
-        __syncthreads();        // includes the workgroup-scope fences: this board's y is visible to this workgroup's loads
     }
 }
 

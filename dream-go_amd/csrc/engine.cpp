@@ -277,6 +277,8 @@ int enqueue_forward(Workspace* ws, int tower_pair)
         a.z = c.alpha2 != 0.0f ? z : nullptr;
         a.y = y;
         a.timing = nullptr;
+        a.w_next = nullptr;
+        a.carry_in = 0;
         a.batch = ws->active;
         a.cin = c.cin;
         a.cout = c.cout;
@@ -301,6 +303,7 @@ int enqueue_forward(Workspace* ws, int tower_pair)
                     a.x = x; a.w = (const uint16_t*)(image + p.w_board_offset); a.bias = (const uint16_t*)(image + p.b_offset);
                     a.z = p.alpha2 != 0.0f ? z : nullptr; a.y = y; a.timing = nullptr; a.batch = ws->batch; a.cin = p.cin; a.cout = p.cout;
                     a.alpha1 = p.alpha1; a.alpha2 = p.alpha2; a.relu = 1;
+                    a.w_next = nullptr; a.carry_in = 0;
                     layers.push_back(a);
                 };
                 for (int i = 0; i < t.num_blocks; ++i) {
@@ -309,6 +312,9 @@ int enqueue_forward(Workspace* ws, int tower_pair)
                     describe(t.res2[i], ws->d_act[tmp], ws->d_act[c], ws->d_act[next]);
                     c = next;
                 }
+                const char* carry = std::getenv("DGNN_TOWER_CARRY");          // =0: no hand-over between the layers (A/B)
+                if (!(carry && std::atoi(carry) == 0))
+                    for (size_t l = 0; l + 1 < layers.size(); ++l) { layers[l].w_next = layers[l + 1].w; layers[l + 1].carry_in = 1; }
                 if (!ws->d_tower_layers) DGNN_HIP(hipMalloc((void**)&ws->d_tower_layers, layers.size() * sizeof(ConvBoardLaunch)));
                 DGNN_HIP(hipMemcpy(ws->d_tower_layers, layers.data(), layers.size() * sizeof(ConvBoardLaunch), hipMemcpyHostToDevice));
                 ws->tower_layers_ready = true;
@@ -447,7 +453,7 @@ static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint
         ConvBoardLaunch a;
         a.x = d_xb; a.w = d_w; a.bias = d_b; a.z = alpha2 != 0.0f ? d_zb : nullptr; a.y = d_yb;
         a.batch = batch; a.cin = cin; a.cout = cout; a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
-        a.timing = nullptr;
+        a.timing = nullptr; a.w_next = nullptr; a.carry_in = 0;
         // instrumentation: DGNN_CONV_TIMING=1 prints where the workgroups spend their cycles (s_memtime stamps)
         const char* ab = std::getenv("DGNN_CONV_TIMING");
         const size_t num_wg = (size_t)batch * (cout / 256);

@@ -61,6 +61,11 @@ struct ConvBoardLaunch {
     uint16_t* y;           // output [batch][cout / 8][400][8] fp16; pad rows < 384 are written as zero, rows 384..399
                            //        are never written (must be zero from initialisation)
     unsigned long long* timing;   // instrumentation: [workgroup][wave][4] s_memtime stamps (start, loop, epilogue, end) or nullptr
+    // Layer-to-layer hand-over inside tower_board_kernel (both zero for a launch per layer):
+    const uint16_t* w_next;       // filter of the NEXT layer: its first three slabs are fetched by this layer's last three steps
+                                  // (which otherwise read the padding) and its first input chunk -- this layer's channels
+                                  // 0..31 -- is left in LDS by the epilogue
+    int carry_in;                 // the previous layer did that for this one: no prologue loads
     int batch;
     int cin;               // multiple of 32
     int cout;              // multiple of 64
