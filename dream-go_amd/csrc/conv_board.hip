@@ -263,7 +263,6 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     }
     wait_vmcnt<0>();
     __syncthreads();
-
     const unsigned long long t_loop = a.timing ? __builtin_amdgcn_s_memtime() : 0;
 
     // zc_c >= 0: this chunk also folds units 6 * zc_c .. 6 * zc_c + 5 of the skip input into the accumulators (SKIP == 2;
@@ -367,7 +366,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
         // chunk boundary: this wave's pieces of the next chunk landed at tap 8's wait (issued at taps 0..3, at
         // least 5 slabs ago); its reads of this chunk retired with the MFMAs above.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
     int first_loop_chunk = 0;
@@ -546,11 +545,11 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
             if (skip == 2) {
                 switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 2: DGNN_BOARD(2, true, 2); break;
                                   case 3: DGNN_BOARD(2, true, 3); break; case 4: DGNN_BOARD(2, true, 4); break;
-                                  default: DGNN_BOARD(2, true, 8); break; }
+                                  case 16: DGNN_BOARD(2, true, 16); break; default: DGNN_BOARD(2, true, 8); break; }
             } else {
                 switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 2: DGNN_BOARD(0, true, 2); break;
                                   case 3: DGNN_BOARD(0, true, 3); break; case 4: DGNN_BOARD(0, true, 4); break;
-                                  default: DGNN_BOARD(0, true, 8); break; }
+                                  case 16: DGNN_BOARD(0, true, 16); break; default: DGNN_BOARD(0, true, 8); break; }
             }
             return;
         }
@@ -611,7 +610,7 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)
     const char* const abl = std::getenv("DGNN_CONV_ABLATE");
     const int ablate = abl ? std::atoi(abl) : 0;
     switch (conv_board_pick_ns(args.batch, args.cout)) {
-        case 8: launch_board_variant<8>(args, skip, relu, ablate >= 1 && ablate <= 8 ? ablate : 0, stream); break;
+        case 8: launch_board_variant<8>(args, skip, relu, ablate >= 1 && ablate <= 16 ? ablate : 0, stream); break;
         case 4: launch_board_variant<4>(args, skip, relu, 0, stream); break;
         default: launch_board_variant<2>(args, skip, relu, 0, stream); break;
     }

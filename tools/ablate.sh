@@ -1,11 +1,12 @@
 #!/bin/bash
 # Component pricing of the residual convolution (results of ablated runs are garbage; only the timing matters).
-#   1 = no MFMA, 2 = no in-loop DMA, 4 = no in-loop B-fragment reads, 3 = neither MFMA nor DMA, 8 = DMA issued but never waited for
+#   1 = no MFMA, 2 = no in-loop DMA, 4 = no in-loop B-fragment reads, 3 = neither MFMA nor DMA, 8 = DMA issued but never waited for,
+#   16 = no barrier at the chunk boundaries (what a barrier-free K loop could gain at most)
 out=${1:-gpurun_out/ablate.jsonl}
 : > "$out"
-for ab in 0 1 2 4 3 8; do
+for ab in 0 1 2 4 3 8 16; do
   echo "# ablate=$ab" >> "$out"
-  DGNN_CONV=${VARIANT:-board} DGNN_CONV_ABLATE=$ab python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | tail -1 >> "$out"
+  DGNN_TOWER=0 DGNN_CONV=${VARIANT:-board} DGNN_CONV_ABLATE=$ab python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | tail -1 >> "$out"
 done
 python - "$out" <<'PY'
 import json, sys
