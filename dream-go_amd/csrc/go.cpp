@@ -528,8 +528,9 @@ void benson(const Fast& b, int color, unsigned char* status)
     }
     if (num_blocks == 0 || num_regions == 0) return;
 
-    // vital[r] = the blocks region r is vital to: only blocks next to its first point can qualify
-    std::vector<short> vital_first((size_t)num_regions + 1, 0), vital;
+    // vital[r] = the blocks region r is vital to: only blocks next to its first point can qualify (at most four)
+    short vital_first[kPoints + 1], vital_store[4 * kPoints];
+    struct { short* data; int count; void push_back(short v) { data[count++] = v; } int size() const { return count; } } vital{vital_store, 0};
     for (int r = 0; r < num_regions; ++r) {
         vital_first[r] = (short)vital.size();
         const int p0 = region_points[regions[r].first];
@@ -553,12 +554,12 @@ void benson(const Fast& b, int color, unsigned char* status)
     for (int r = 0; r < num_regions; ++r)                                    // remove_non_vital_regions, :136-152
         if (vital_first[r] == vital_first[r + 1]) { regions[r].live = false; mark(region_points, regions[r], kStatusNone); }
 
-    std::vector<int> healthy((size_t)num_blocks);
+    short healthy[kPoints];
     for (bool changed = true; changed;) {                                     // :73-75
         changed = false;
-        std::fill(healthy.begin(), healthy.end(), 0);                         // remove_non_alive_blocks, :95-112
+        std::fill(healthy, healthy + num_blocks, (short)0);                   // remove_non_alive_blocks, :95-112
         for (int r = 0; r < num_regions; ++r)
-            if (regions[r].live) for (int i = vital_first[r]; i < vital_first[r + 1]; ++i) ++healthy[vital[i]];
+            if (regions[r].live) for (int i = vital_first[r]; i < vital_first[r + 1]; ++i) ++healthy[vital_store[i]];
         for (int k = 0; k < num_blocks; ++k)
             if (blocks[k].live && healthy[k] < 2) { blocks[k].live = false; mark(block_points, blocks[k], kStatusNone); changed = true; }
         for (int r = 0; r < num_regions; ++r) {                               // remove_non_surrounded_regions, :116-132

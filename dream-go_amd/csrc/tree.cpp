@@ -116,15 +116,18 @@ struct TreeNode {
 
     TreeNode(int color, float v, const float* p) : to_move(color), initial_value(v)
     {
-        for (int i = 0; i < kPadded; ++i) {
-            prior[i] = i < kMoves ? p[i] : -std::numeric_limits<float>::infinity();   // tree.rs:1075-1076
-            count[i].store(0, std::memory_order_relaxed);
-            vcount[i].store(0, std::memory_order_relaxed);
-            expanding[i].store(0, std::memory_order_relaxed);
-            ptr[i].store(nullptr, std::memory_order_relaxed);
-            value[i] = v;                                                               // Child::with_value, tree.rs:276-285
-            value_s[i] = 0.0f;
-        }
+        // 10.7 KB per node and one node per rollout: block operations instead of 368 x 7 element stores.  The node is not
+        // visible to any other thread before the constructor returns (dgnn_tree_insert publishes it with a CAS).
+        static_assert(sizeof(std::atomic<int>) == sizeof(int) && sizeof(std::atomic<unsigned char>) == 1 &&
+                      sizeof(std::atomic<TreeNode*>) == sizeof(TreeNode*), "plain layouts");
+        std::memcpy(prior, p, kMoves * sizeof(float));
+        for (int i = kMoves; i < kPadded; ++i) prior[i] = -std::numeric_limits<float>::infinity();   // tree.rs:1075-1076
+        std::memset(static_cast<void*>(count), 0, sizeof(count));
+        std::memset(static_cast<void*>(vcount), 0, sizeof(vcount));
+        std::memset(static_cast<void*>(expanding), 0, sizeof(expanding));
+        std::memset(static_cast<void*>(ptr), 0, sizeof(ptr));
+        std::fill(value, value + kPadded, v);                                           // Child::with_value, tree.rs:276-285
+        std::memset(value_s, 0, sizeof(value_s));
     }
 
     ~TreeNode()
