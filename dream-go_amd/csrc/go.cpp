@@ -825,7 +825,7 @@ int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_c
 // game_stride = world play the games one rank would.
 // Concurrency (self_play, self_play.rs:478-495): min(num_parallel, num_games) game threads, each taking the next unplayed game
 // until num_games are done, so the device sees a steady number of games instead of a tail (num_parallel <= 0: all at once).
-int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
+int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* shared_cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
 {
     if (!predict || !params || !stats) return DGNN_BAD_ARGUMENT;
@@ -835,7 +835,6 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
     const int leaves_per_thread = params->leaves_per_thread > 0 ? params->leaves_per_thread : 1;
     const uint64_t seed = params->seed;
     const int private_cache = params->cache_entries_per_game;
-    dgnn_cache* const shared_cache = cache;
     int num_parallel = params->num_parallel, max_moves = params->max_moves;
     if (num_games <= 0 || first_game < 0 || max_moves < 0 || num_rollouts <= 0 || leaves_per_thread > 64) return DGNN_BAD_ARGUMENT;
     if (num_parallel <= 0 || num_parallel > num_games) num_parallel = num_games;
@@ -875,7 +874,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
             // predict (lib.rs:144-200) behind predict_aux (self_play.rs:243-274): the root ensemble, noise unless deterministic,
             // the starting tree re-used with its prior replaced, the search, the best move.  Returns the tree (the caller owns
             // it) or NULL when there is nothing to search (*value_out is then not finite) or on an error (status is set).
-            auto search = [&](int limit, dgnn_tree_node* start, float* value_out, int* index_out) -> dgnn_tree_node* {
+            auto search = [&](int rollouts, dgnn_tree_node* start, float* value_out, int* index_out) -> dgnn_tree_node* {
                 float value = 0.0f, prior[368];
                 *value_out = std::numeric_limits<float>::quiet_NaN();
                 *index_out = kPass;
@@ -890,7 +889,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
                 if (root) { if (!allow_pass) dgnn_tree_node_disqualify(root, kPass); dgnn_tree_node_set_prior(root, prior); }   // lib.rs:170-181
                 else root = dgnn_tree_node_new(me, value, prior);
                 uint64_t e = 0, c = 0, h = 0;
-                st = dgnn_search_run_batched(root, ops, &board, predict, predict_ctx, cache, limit, threads_per_search, leaves_per_thread, rng.next(), &e, &c, &h);
+                st = dgnn_search_run_batched(root, ops, &board, predict, predict_ctx, cache, rollouts, threads_per_search, leaves_per_thread, rng.next(), &e, &c, &h);
                 evals.fetch_add(e);
                 conflicts.fetch_add(c);
                 hits.fetch_add(h);
