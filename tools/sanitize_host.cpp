@@ -1,0 +1,30 @@
+// Driver for tools/sanitize_host.sh: whole self-play jobs on the CPU stand-in predictor (whole games with per-game tables and
+// batched leaves; expert iteration with four racing search threads and a shared table; games started as others end; the
+// synthetic game with eight threads per search), so that AddressSanitizer / UBSan / ThreadSanitizer see the host rows at work.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "dgnn.h"
+int main() {
+    for (int mode = 0; mode < 3; ++mode) {
+        dgnn_selfplay_params p{};
+        p.num_games = 6; p.num_parallel = mode == 2 ? 2 : 0; p.first_game = 0; p.game_stride = 1; p.max_moves = mode == 0 ? 0 : 60;
+        p.num_rollouts = mode == 0 ? 24 : 40; p.num_ex_it_rollouts = mode == 1 ? 30 : 0; p.threads_per_search = mode == 0 ? 1 : 4;
+        p.leaves_per_thread = mode == 0 ? 6 : 2; p.cache_entries_per_game = mode == 0 ? 3000 : 0; p.seed = 5 + mode;
+        dgnn_cache* cache = nullptr;
+        if (mode != 0) dgnn_cache_create(20000, 4, &cache);
+        dgnn_selfplay_stats st;
+        std::vector<int> moves((size_t)6 * 722, -1);
+        std::vector<char> sgf((size_t)6 * (722 * 1100 + 40000));
+        int rc = dgnn_selfplay_go(dgnn_hash_predictor(), nullptr, cache, &p, &st, moves.data(), sgf.data(), sgf.size());
+        std::printf("mode %d rc %d games %llu moves %llu evals %llu hits %llu conflicts %llu ended %llu exit %llu\n", mode, rc,
+                    (unsigned long long)st.games, (unsigned long long)st.moves, (unsigned long long)st.evals, (unsigned long long)st.cache_hits,
+                    (unsigned long long)st.conflicts, (unsigned long long)st.games_ended, (unsigned long long)st.ex_it_searches);
+        if (cache) dgnn_cache_destroy(cache);
+    }
+    // synthetic self-play with many threads
+    dgnn_selfplay_stats st;
+    int rc = dgnn_selfplay_synthetic(dgnn_hash_predictor(), nullptr, 4, 4, 60, 8, 3, &st);
+    std::printf("synthetic rc %d evals %llu\n", rc, (unsigned long long)st.evals);
+    return 0;
+}

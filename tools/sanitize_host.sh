@@ -1,0 +1,26 @@
+#!/bin/sh
+# Sanitizer runs of the host rows (board, search, tree, cache, formats) on the CPU -- GPU sanitizers are not available on the
+# pool.  The engine entry points the batcher links against are stubbed (the CPU stand-in predictor never calls them).
+#   tools/sanitize_host.sh            AddressSanitizer + UBSan, then ThreadSanitizer
+# Expected: ASan / UBSan silent.  TSan reports only the search tree's documented plain reads: the PUCT loop reads the children's
+# counters and values without locks while other threads update them (tree.cpp puct_*; the reference does the same, tree.rs:63-115).
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+SRC="$ROOT/dream-go_amd/csrc"
+TMP="${TMPDIR:-/tmp}/dgnn_sanitize"
+mkdir -p "$TMP"
+cat > "$TMP/stubs.cpp" <<'STUBS'
+#include "dgnn.h"
+extern "C" {
+int dgnn_network_get_workspace(dgnn_network*, int, int, dgnn_workspace**) { return -1; }
+int dgnn_forward_n(dgnn_workspace*, const uint16_t*, int, uint16_t*, uint16_t*) { return -1; }
+void dgnn_workspace_release(dgnn_workspace*) {}
+}
+STUBS
+FILES="$SRC/go.cpp $SRC/batcher.cpp $SRC/formats.cpp $SRC/tree.cpp $SRC/search.cpp $SRC/loader.cpp $TMP/stubs.cpp $ROOT/tools/sanitize_host.cpp"
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/asan" -lpthread
+echo "== AddressSanitizer + UBSan"; "$TMP/asan"
+g++ -O1 -g -std=c++17 -fsanitize=thread -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/tsan" -lpthread
+echo "== ThreadSanitizer"; TSAN_OPTIONS="halt_on_error=0" "$TMP/tsan" > "$TMP/tsan.out" 2>&1 || true
+grep -A6 "WARNING: ThreadSanitizer" "$TMP/tsan.out" | grep -E "#0" | sed 's/0x[0-9a-f]* //' | awk '{print $2, $3}' | sort | uniq -c | sort -rn
+tail -4 "$TMP/tsan.out"
