@@ -22,6 +22,26 @@ int main() {
                     (unsigned long long)st.conflicts, (unsigned long long)st.games_ended, (unsigned long long)st.ex_it_searches);
         if (cache) dgnn_cache_destroy(cache);
     }
+    {   // through the leaf pool: batcher, worker threads, wake-ups (the engine behind it is the script's CPU stand-in)
+        dgnn_batcher* batcher = nullptr;
+        dgnn_pool* pool = nullptr;
+        dgnn_cache* cache = nullptr;
+        dgnn_batcher_create(reinterpret_cast<dgnn_network*>(0x10), 0, 32, 3, &batcher);
+        dgnn_pool_create(batcher, 3, &pool);
+        dgnn_cache_create(20000, 4, &cache);
+        dgnn_selfplay_params p{};
+        p.num_games = 12; p.num_parallel = 8; p.game_stride = 1; p.max_moves = 40; p.num_rollouts = 48; p.threads_per_search = 3;
+        p.leaves_per_thread = 3; p.seed = 77;
+        dgnn_selfplay_stats st;
+        int rc = dgnn_selfplay_go(dgnn_pool_predictor(), pool, cache, &p, &st, nullptr, nullptr, 0);
+        uint64_t boards = 0, batches = 0;
+        dgnn_batcher_stats(batcher, &boards, &batches);
+        std::printf("pool rc %d moves %llu evals %llu boards %llu batches %llu\n", rc, (unsigned long long)st.moves, (unsigned long long)st.evals,
+                    (unsigned long long)boards, (unsigned long long)batches);
+        dgnn_pool_destroy(pool);
+        dgnn_batcher_destroy(batcher);
+        dgnn_cache_destroy(cache);
+    }
     // synthetic self-play with many threads
     dgnn_selfplay_stats st;
     int rc = dgnn_selfplay_synthetic(dgnn_hash_predictor(), nullptr, 4, 4, 60, 8, 3, &st);

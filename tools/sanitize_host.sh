@@ -1,19 +1,26 @@
 #!/bin/sh
 # Sanitizer runs of the host rows (board, search, tree, cache, formats) on the CPU -- GPU sanitizers are not available on the
-# pool.  The engine entry points the batcher links against are stubbed (the CPU stand-in predictor never calls them).
+# pool.  The engine entry points the batcher links against are replaced by a CPU stand-in, so the leaf pool runs for real.
 #   tools/sanitize_host.sh            AddressSanitizer + UBSan, then ThreadSanitizer
 # Expected: ASan / UBSan silent.  TSan reports only the search tree's documented plain reads: the PUCT loop reads the children's
-# counters and values without locks while other threads update them (tree.cpp puct_*; the reference does the same, tree.rs:63-115).
+# counters and values without locks while other threads update them (tree.cpp puct_*; the reference does the same, tree.rs:63-115),
+# and a "mutex is already destroyed" pair on the leaf pool: a std::mutex (constexpr constructor, invisible to TSan) living at a
+# heap address where an earlier object's mutex was destroyed -- the accesses it flags are under that very mutex.
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 SRC="$ROOT/dream-go_amd/csrc"
 TMP="${TMPDIR:-/tmp}/dgnn_sanitize"
 mkdir -p "$TMP"
 cat > "$TMP/stubs.cpp" <<'STUBS'
+// A stand-in engine behind the batcher: "evaluates" a batch with the CPU stand-in predictor, so that the leaf pool, its worker
+// threads and the batcher run for real under the sanitizers.
 #include "dgnn.h"
 extern "C" {
-int dgnn_network_get_workspace(dgnn_network*, int, int, dgnn_workspace**) { return -1; }
-int dgnn_forward_n(dgnn_workspace*, const uint16_t*, int, uint16_t*, uint16_t*) { return -1; }
+int dgnn_network_get_workspace(dgnn_network*, int, int, dgnn_workspace** out) { *out = reinterpret_cast<dgnn_workspace*>(0x10); return DGNN_OK; }
+int dgnn_forward_n(dgnn_workspace*, const uint16_t* features, int n, uint16_t* value, uint16_t* policy)
+{
+    return dgnn_hash_predictor()(nullptr, features, n, value, policy);
+}
 void dgnn_workspace_release(dgnn_workspace*) {}
 }
 STUBS
