@@ -118,15 +118,20 @@ __device__ __forceinline__ void static_for(F&& f)
 // with the B-fragment reads ablated) -- saved cycles come back as a lower clock unless bytes moved per MFMA go down too.
 // Filter packing (host, pack_filter_board): [k-step][C_out / 32 slices][k16][64 lanes][8 halfs], k-step = chunk * 9 + tap,
 // lane l holds w[co = slice * 32 + (l & 31)][tap][ci = chunk * 32 + k16 * 16 + (l >> 5) * 8 .. + 8].
+//   NS = 1   1 slice x 4 row groups of 96 rows (3 row tiles per wave), FOUR waves: one wave per SIMD, half the MFMAs per
+//            SIMD and k-step of NS = 2 -- the latency variant for the smallest batches (twice the workgroups per board)
 template <int NS>
 struct Split {
     static constexpr int CT = 1;                       // 32-channel MFMA tiles per wave
-    static constexpr int RG = 8 / NS;                  // row groups
+    static constexpr int WAVES = NS == 1 ? 4 : 8;
+    static constexpr int Threads = WAVES * 64;
+    static constexpr int XP = (4 * kPieces + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
+    static constexpr int RG = WAVES / NS;              // row groups
     static constexpr int RT = 12 / RG;                 // 32-row MFMA tiles per wave
     static constexpr int W = 2;                        // DMA instructions (1 KiB fragments) per filter slab: k16 = 0, 1
     static constexpr int SlabBytes = W * 1024;
     static constexpr int RingBytes = kRing * SlabBytes;
-    static constexpr int LdsBytes = kWBase + 8 * RingBytes;
+    static constexpr int LdsBytes = kWBase + WAVES * RingBytes;
     static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step
     static constexpr int BD = NS == 8 ? 5 : NS == 4 ? 4 : 3;   // B-fragment registers in rotation: BD - 1 pairs of read-ahead
     // byte offset of the B fragment of pair i = k16 * RT + row tile relative to the lane's base row
@@ -149,7 +154,7 @@ template <int NS, int SKIP, bool RELU, int ABL>
 __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb)
 {
     using S = Split<NS>;
-    constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD;
+    constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -194,8 +199,8 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     // only three and repeat their third one (same bytes to the same place), so that every wave issues the same
     // number of DMA instructions and the vmcnt bookkeeping below is one set of constants.
     auto issue_x = [&](int chunk, int buf, int j) {
-        int p = wave + 8 * j;
-        if (p >= 4 * kPieces) p -= 8;
+        int p = wave + S::WAVES * j;
+        if (p >= 4 * kPieces) p -= S::WAVES;
         const int s = p / kPieces;
         const int i = p - s * kPieces;
         const uint16_t* src = x_board + ((long)(chunk * 4 + s) * kRows + i * 64) * 8;
@@ -257,7 +262,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     // ---- prologue: chunk 0 and the first three filter slabs ----
     if (!a.carry_in) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_x(0, 0, j);
+        for (int j = 0; j < XP; ++j) issue_x(0, 0, j);
 #pragma unroll
         for (int s = 0; s < kRing; ++s) issue_w(s, s);
     }
@@ -282,7 +287,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
             // DMA instructions issued after this step's slab: slab st is issued during step st - 3, the activation piece
             // of a step (taps 0..3 only) after its filter pieces:
             //     2 * W + |{TAP-3, TAP-2, TAP-1} mod 9  intersected with  {0,1,2,3}|
-            constexpr int N = 2 * W + ((TAP + 6) % 9 < 4) + ((TAP + 7) % 9 < 4) + ((TAP + 8) % 9 < 4);
+            constexpr int N = 2 * W + ((TAP + 6) % 9 < XP) + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP);
             if constexpr (!(ABL & 8)) wait_vmcnt<N>();
 
             // Hand-placed LDS reads (inline asm, waits counted here: hipcc would otherwise serialise
@@ -331,7 +336,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     });
-                    if constexpr (I == S::x_pair() && TAP < 4) {
+                    if constexpr (I == S::x_pair() && TAP < XP) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue_x(next_chunk, buf ^ 1, TAP);
                         __builtin_amdgcn_sched_barrier(0);
@@ -344,7 +349,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
             if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6 && ZC * 6 + TAP - 1 < RT) {
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
-                wait_vmcnt<W + (TAP < 4)>();
+                wait_vmcnt<W + (TAP < XP)>();
                 __builtin_amdgcn_sched_barrier(0);
                 add_z_unit(std::integral_constant<int, ZC * 6 + TAP - 1>(), std::integral_constant<int, 0>());
             }
@@ -364,7 +369,9 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
         step(std::integral_constant<int, 8>());
 
         // chunk boundary: this wave's pieces of the next chunk landed at tap 8's wait (issued at taps 0..3, at
-        // least 5 slabs ago); its reads of this chunk retired with the MFMAs above.
+        // least 5 slabs ago); its reads of this chunk retired with the MFMAs above.  With seven pieces per wave (taps 0..6)
+        // the last one is younger than that wait covers: only the filter pieces of the steps after it may stay in flight.
+        if constexpr (XP > 4) wait_vmcnt<W * (8 - (XP - 1))>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -467,7 +474,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
 }
 
 template <int NS, int SKIP, bool RELU, int ABL>
-__global__ __launch_bounds__(kThreads)
+__global__ __launch_bounds__(Split<NS>::Threads)
 void conv3x3_board_kernel(ConvBoardLaunch a)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
@@ -539,7 +546,7 @@ template <int NS>
 static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool relu, int ablate, hipStream_t stream)
 {
     const dim3 grid(args.batch, args.cout / (32 * NS));
-#define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(kThreads), 0, stream, args)
+#define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(Split<NS>::Threads), 0, stream, args)
     if constexpr (NS == 8) {
         if (ablate != 0 && relu && skip != 1) {      // measurement only (tools/ablate.sh), residual shapes
             if (skip == 2) {
@@ -569,11 +576,11 @@ int conv_board_pick_ns(int batch, int cout)
 {
     const int slices = cout / 32;
     int best = slices % 8 == 0 ? 8 : slices % 4 == 0 ? 4 : 2;
-    while (best > 2 && (long)batch * (slices / best) < 192) best /= 2;
+    while (best > 1 && (long)batch * (slices / best) < 192) best /= 2;
     const char* const force = std::getenv("DGNN_BOARD_NS");
     if (force) {
         const int ns = std::atoi(force);
-        if ((ns == 2 || ns == 4 || ns == 8) && slices % ns == 0) best = ns;
+        if ((ns == 1 || ns == 2 || ns == 4 || ns == 8) && slices % ns == 0) best = ns;
     }
     return best;
 }
@@ -581,8 +588,9 @@ int conv_board_pick_ns(int batch, int cout)
 bool tower_board_supported(int batch, int channels)
 {
     const int slices = channels / 32;
-    return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || slices == 4 || slices == 8) &&
-           conv_board_pick_ns(batch, channels) == slices;
+    // a workgroup per board: at 64 channels always (the layers are short, launches would dominate), at 128 / 256 channels
+    // once the boards alone fill most of the chip (below that the per-layer kernel splits a board over several workgroups)
+    return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || ((slices == 4 || slices == 8) && batch >= 192));
 }
 
 hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream)
@@ -612,7 +620,8 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)
     switch (conv_board_pick_ns(args.batch, args.cout)) {
         case 8: launch_board_variant<8>(args, skip, relu, ablate >= 1 && ablate <= 16 ? ablate : 0, stream); break;
         case 4: launch_board_variant<4>(args, skip, relu, 0, stream); break;
-        default: launch_board_variant<2>(args, skip, relu, 0, stream); break;
+        case 2: launch_board_variant<2>(args, skip, relu, 0, stream); break;
+        default: launch_board_variant<1>(args, skip, relu, 0, stream); break;
     }
     return hipGetLastError();
 }

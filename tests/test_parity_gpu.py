@@ -178,7 +178,7 @@ def test_board_kernel_asymmetric_taps(api, oracle, monkeypatch):
     (2, 64, 64, 0.5, False),
 ])
 @pytest.mark.parametrize("skip_mode", ["0", "1"])     # skip folded into the K loop (default) / added in the epilogue
-@pytest.mark.parametrize("ns", ["8", "4", "2"])       # 32-channel slices per workgroup (ignored when it does not divide C_out / 32)
+@pytest.mark.parametrize("ns", ["8", "4", "2", "1"])  # 32-channel slices per workgroup (ignored when it does not divide C_out / 32); 1 = four waves
 def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode, ns):
     monkeypatch.setenv("DGNN_BOARD_SKIP", skip_mode)
     monkeypatch.setenv("DGNN_BOARD_NS", ns)
@@ -197,7 +197,7 @@ def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout,
     assert mismatched <= 0.02 * got.size
 
 
-@pytest.mark.parametrize("ns", ["8", "4", "2"])
+@pytest.mark.parametrize("ns", ["8", "4", "2", "1"])
 def test_board_kernel_exact_under_full_load(api, monkeypatch, ns):
     """configs[2] layer shape at full size (256 boards = 256 workgroups, every CU busy): integer-valued data make the
     generic kernel a bit-exact reference; three runs must be identical (a DMA / ring race shows up as run-to-run
@@ -516,7 +516,8 @@ def test_leaf_pool_coalesces_callers(api, synth):
     assert not errors, errors[:3]
     assert stats["boards"] == sum(1 + (g + i) % 8 for g in range(24) for i in range(10))
     print(f"leaf pool: {calls} calls, {stats['boards']} boards in {stats['batches']} device batches")
-    assert stats["batches"] <= calls       # how much is coalesced depends on timing; correctness does not
+    # how much is coalesced depends on timing (a worker may even take a batch between two boards of one call); correctness does not
+    assert stats["batches"] <= stats["boards"]
 
 
 # --------------------------------------------------------------------------------------------- search (f-2) on the GPU
