@@ -571,7 +571,7 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
 }
 
 // Slices per workgroup: the largest that divides C_out / 32, unless a smaller one is needed to put a workgroup on most
-// of the 256 CUs (a launch has batch * C_out / (32 * NS) workgroups).  DGNN_BOARD_NS=2|4|8 overrides.
+// of the 256 CUs (a launch has batch * C_out / (32 * NS) workgroups).  DGNN_BOARD_NS=1|2|4|8 overrides.
 int conv_board_pick_ns(int batch, int cout)
 {
     const int slices = cout / 32;
