@@ -35,11 +35,14 @@ HIP_ERROR = -3
 BAD_ARGUMENT = -4
 OUT_OF_MEMORY = -5
 UNSUPPORTED = -6
+COMM_ERROR = -8
 
 NUM_FEATURES = 32
 NUM_POINTS = 361
 FEATURE_SIZE = 11552
 NUM_MOVES = 362
+PACKED_WORDS = 368
+RCCL_UNIQUE_ID_BYTES = 128
 
 # every symbol include/dgnn.h declares: (name, restype, argtypes)
 _u16p = ctypes.POINTER(ctypes.c_uint16)
@@ -47,6 +50,9 @@ _vp = ctypes.c_void_p
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 _ip = ctypes.POINTER(ctypes.c_int)
 _fp = ctypes.POINTER(ctypes.c_float)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
 SYMBOLS = [
     ("dgnn_status_string", ctypes.c_char_p, [ctypes.c_int]),
     ("dgnn_last_hip_error", ctypes.c_int, []),
@@ -178,6 +184,30 @@ SYMBOLS = [
     ("dgnn_pool_create", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
     ("dgnn_pool_destroy", None, [_vp]),
     ("dgnn_pool_predict", ctypes.c_int, [_vp, _u16p, ctypes.c_int, _u16p, _u16p]),
+    # round 2: packed features, layer-level dense / heads, RCCL inside the library, the multi-device pool
+    ("dgnn_forward_packed", ctypes.c_int, [_vp, _u32p, ctypes.c_int, _u16p, _u16p]),
+    ("dgnn_forward_submit_packed", ctypes.c_int, [_vp, _u32p, ctypes.c_int]),
+    ("dgnn_features_pack", ctypes.c_int, [_u16p, ctypes.c_int, _u32p]),
+    ("dgnn_features_unpack", ctypes.c_int, [_u32p, ctypes.c_int, _u16p]),
+    ("dgnn_workspace_packed_buffer", ctypes.c_int, [_vp, ctypes.POINTER(_u32p)]),
+    ("dgnn_layer_dense", ctypes.c_int, [ctypes.c_int, _u16p, ctypes.c_int, ctypes.c_int, _u16p, _u16p, ctypes.c_int, ctypes.c_float,
+                                        ctypes.c_int, _u16p]),
+    ("dgnn_layer_heads", ctypes.c_int, [ctypes.c_int, _u16p, _u16p, ctypes.c_int, _u16p, _u16p, _u16p, _u16p]),
+    ("dgnn_network_weight_image_reserve", ctypes.c_int, [_vp, ctypes.c_int, _vpp, ctypes.POINTER(ctypes.c_size_t)]),
+    ("dgnn_rccl_available", ctypes.c_int, []),
+    ("dgnn_last_rccl_error", ctypes.c_int, []),
+    ("dgnn_rccl_error_string", ctypes.c_char_p, [ctypes.c_int]),
+    ("dgnn_rccl_unique_id", ctypes.c_int, [_u8p]),
+    ("dgnn_rccl_comm_create", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _u8p, _vpp]),
+    ("dgnn_rccl_comm_wrap", ctypes.c_int, [_vp, ctypes.c_int, _vpp]),
+    ("dgnn_rccl_comm_info", ctypes.c_int, [_vp, _ip, _ip, _ip]),
+    ("dgnn_rccl_comm_destroy", None, [_vp]),
+    ("dgnn_broadcast_weights", ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    ("dgnn_broadcast_weights_devices", ctypes.c_int, [_vp, _ip, ctypes.c_int]),
+    ("dgnn_batch_forward_on", ctypes.c_int, [_vp, ctypes.c_int, _u16p, _u16p]),
+    ("dgnn_pool_create_devices", ctypes.c_int, [_vp, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_pool_create_callbacks", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_pool_stats", ctypes.c_int, [_vp, _ip, _u64p, _u64p, _u64p, _u64p, _u64p, ctypes.c_int]),
 ]
 
 
@@ -211,8 +241,11 @@ class Error(Exception):
     def __init__(self, status, where=""):
         self.status = status
         self.hip_error = lib.dgnn_last_hip_error() if status == HIP_ERROR else 0
+        self.rccl_error = lib.dgnn_last_rccl_error() if status == COMM_ERROR else 0
         text = lib.dgnn_status_string(status).decode("ascii")
         detail = f" (hipError_t {self.hip_error})" if self.hip_error else ""
+        if status == COMM_ERROR:
+            detail = f" (ncclResult_t {self.rccl_error}: {lib.dgnn_rccl_error_string(self.rccl_error).decode('ascii', 'replace')})"
         super().__init__(f"{where}: {text}{detail}" if where else text + detail)
 
 
@@ -397,6 +430,25 @@ class Network:
         _check(lib.dgnn_network_set_weight_image(self.handle, device, ctypes.c_void_p(src_ptr), num_bytes, int(src_on_device)),
                "set_weight_image")
 
+    def weight_image_reserve(self, device=0):
+        """-> (device pointer, bytes) without the upload when the device is touched for the first time (a broadcast receiver)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib.dgnn_network_weight_image_reserve(self.handle, device, ctypes.byref(p), ctypes.byref(n)), "weight_image_reserve")
+        return p.value, n.value
+
+    def broadcast_weights(self, comm, root=0):
+        """One RCCL broadcast of the packed weight image inside the library; the receivers adopt the sender's gates / temperature."""
+        _check(lib.dgnn_broadcast_weights(self.handle, comm.handle, int(root)), "broadcast_weights")
+
+    def broadcast_weights_devices(self, devices=None, num_devices=None):
+        """Single-process form: upload to devices[0], RCCL broadcast over xGMI to the others."""
+        if devices is None:
+            n = Device.len() if num_devices is None else int(num_devices)
+            _check(lib.dgnn_broadcast_weights_devices(self.handle, None, n), "broadcast_weights_devices")
+        else:
+            arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            _check(lib.dgnn_broadcast_weights_devices(self.handle, arr, len(devices)), "broadcast_weights_devices")
+
     def weight_checksum_device(self, device=0):
         c = ctypes.c_uint64()
         _check(lib.dgnn_network_weight_checksum_device(self.handle, device, ctypes.byref(c)), "weight_checksum_device")
@@ -457,6 +509,90 @@ def forward_n(workspace, features, count):
     _check(lib.dgnn_forward_n(workspace.handle, f.ctypes.data_as(_u16p), int(count),
                               value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "forward_n")
     return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+
+def features_pack(features, count):
+    """fp16 HWC features -> packed words [count][368] (include/dgnn.h: dgnn_forward_packed); Error(BAD_ARGUMENT) if not representable."""
+    f = _as_u16(features, "features")
+    if f.size != count * FEATURE_SIZE:
+        raise Error(BAD_ARGUMENT, "features_pack")
+    out = np.empty(count * PACKED_WORDS, dtype=np.uint32)
+    _check(lib.dgnn_features_pack(f.ctypes.data_as(_u16p), int(count), out.ctypes.data_as(_u32p)), "features_pack")
+    return out
+
+
+def features_unpack(packed, count):
+    p = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1)
+    out = np.empty(count * FEATURE_SIZE, dtype=np.uint16)
+    _check(lib.dgnn_features_unpack(p.ctypes.data_as(_u32p), int(count), out.ctypes.data_as(_u16p)), "features_unpack")
+    return out.view(np.float16)
+
+
+def forward_packed(workspace, packed, count):
+    """dg_nn::forward from packed features (1 472 bytes per board instead of 23 104)."""
+    p = np.ascontiguousarray(packed, dtype=np.uint32).reshape(-1)
+    if p.size != count * PACKED_WORDS:
+        raise Error(BAD_ARGUMENT, "forward_packed")
+    value = np.empty(count, dtype=np.uint16)
+    policy = np.empty(count * NUM_MOVES, dtype=np.uint16)
+    _check(lib.dgnn_forward_packed(workspace.handle, p.ctypes.data_as(_u32p), int(count),
+                                   value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "forward_packed")
+    return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+
+def layer_dense(x, batch, k_in, w_in_out, bias, n_out, alpha=1.0, relu=False, device=0):
+    """One Dense::forward (src/libdg_nn/layers/dense.rs:173-220) through the MFMA GEMM of the policy head."""
+    x = _as_u16(x, "x"); w = _as_u16(w_in_out, "w"); b = _as_u16(bias, "bias")
+    y = np.empty(batch * n_out, dtype=np.uint16)
+    _check(lib.dgnn_layer_dense(device, x.ctypes.data_as(_u16p), int(batch), int(k_in), w.ctypes.data_as(_u16p), b.ctypes.data_as(_u16p),
+                                int(n_out), float(alpha), int(relu), y.ctypes.data_as(_u16p)), "layer_dense")
+    return y
+
+
+def layer_heads(logits, value_features, batch, value_w, value_b, device=0):
+    """Soft-max over 362 logits + value Dense 722 -> 1 + tanh through heads.hip's softmax_value_kernel -> (policy, value) uint16."""
+    lg = _as_u16(logits, "logits"); vf = _as_u16(value_features, "value_features"); vw = _as_u16(value_w, "value_w"); vb = _as_u16(value_b, "value_b")
+    policy = np.empty(batch * NUM_MOVES, dtype=np.uint16)
+    value = np.empty(batch, dtype=np.uint16)
+    _check(lib.dgnn_layer_heads(device, lg.ctypes.data_as(_u16p), vf.ctypes.data_as(_u16p), int(batch), vw.ctypes.data_as(_u16p),
+                                vb.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p), value.ctypes.data_as(_u16p)), "layer_heads")
+    return policy, value
+
+
+class Comm:
+    """An RCCL communicator owned by libdgnn_hip.so (include/dgnn.h: dgnn_rccl_comm_create)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @staticmethod
+    def unique_id():
+        buf = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES)()
+        _check(lib.dgnn_rccl_unique_id(buf), "rccl_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, device, num_ranks, rank, unique_id):
+        buf = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_rccl_comm_create(int(device), int(num_ranks), int(rank), buf, ctypes.byref(out)), "rccl_comm_create")
+        return cls(out)
+
+    def info(self):
+        n, r, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib.dgnn_rccl_comm_info(self.handle, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)), "rccl_comm_info")
+        return {"num_ranks": n.value, "rank": r.value, "device": d.value}
+
+    def destroy(self):
+        if self.handle is not None:
+            lib.dgnn_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -631,11 +767,42 @@ class Batcher:
 class LeafPool:
     """A Predictor (src/libdg_mcts/predictor.rs:59-92) whose predict() coalesces across every calling thread."""
 
-    def __init__(self, batcher, num_workers=2):
+    def __init__(self, batcher, num_workers=2, _handle=None, _keep=None):
         self._batcher = batcher
+        self._keep = _keep
+        if _handle is not None:
+            self._handle = _handle
+            return
         out = ctypes.c_void_p()
         _check(lib.dgnn_pool_create(batcher._handle, int(num_workers), ctypes.byref(out)), "LeafPool")
         self._handle = out
+
+    @classmethod
+    def over_devices(cls, network, devices=None, max_batch_size=256, batches_per_device=2, workers_per_device=2):
+        """NnPredictor over several devices in ONE process (predictors/nn.rs:46-108): one queue, a batch goes to whichever
+        device has a worker free.  devices=None: Device.all()."""
+        out = ctypes.c_void_p()
+        arr, n = (None, 0) if devices is None else ((ctypes.c_int * len(devices))(*[int(d) for d in devices]), len(devices))
+        _check(lib.dgnn_pool_create_devices(network.handle, arr, n, int(max_batch_size), int(batches_per_device),
+                                            int(workers_per_device), ctypes.byref(out)), "LeafPool.over_devices")
+        return cls(None, _handle=out, _keep=network)
+
+    @classmethod
+    def over_callbacks(cls, predict_fn, predict_ctx=None, num_lanes=1, max_batch_size=256, batches_per_lane=2, workers_per_lane=1):
+        """The same pool over copies of a dgnn_predict_fn (e.g. lib.dgnn_hash_predictor()): no GPU needed."""
+        out = ctypes.c_void_p()
+        _check(lib.dgnn_pool_create_callbacks(predict_fn, predict_ctx, int(num_lanes), int(max_batch_size), int(batches_per_lane),
+                                              int(workers_per_lane), ctypes.byref(out)), "LeafPool.over_callbacks")
+        return cls(None, _handle=out, _keep=(predict_fn, predict_ctx))
+
+    def stats(self):
+        n, calls, boards, batches = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        lane_boards, lane_batches = (ctypes.c_uint64 * 64)(), (ctypes.c_uint64 * 64)()
+        _check(lib.dgnn_pool_stats(self._handle, ctypes.byref(n), ctypes.byref(calls), ctypes.byref(boards), ctypes.byref(batches),
+                                   lane_boards, lane_batches, 64), "LeafPool.stats")
+        k = min(n.value, 64)
+        return {"lanes": n.value, "calls": calls.value, "boards": boards.value, "batches": batches.value,
+                "lane_boards": list(lane_boards[:k]), "lane_batches": list(lane_batches[:k])}
 
     def predict(self, features, batch_size):
         f = _as_u16(features, "features")

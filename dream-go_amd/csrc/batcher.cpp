@@ -133,6 +133,7 @@ struct Batcher {
     std::vector<std::vector<uint16_t>> spare_features;   // buffers of retired batches, so that the queue does not grow from zero
     std::vector<std::vector<uint64_t>> spare_tags;       // (and fault its pages in) under the lock after every hand-over
     std::atomic<int> num_batches{0};
+    std::atomic<int> queued{0};     // == tags.size(), readable without the lock (the pool workers' wake-up predicate)
     std::atomic<uint64_t> boards_evaluated{0}, batches_evaluated{0};
     std::atomic<int> refs{1};       // the handle + every batch split off it: a batch may outlive dgnn_batcher_destroy
 
@@ -161,33 +162,61 @@ struct LeafRequest {
 };
 
 struct LeafPool {
-    Batcher* batcher = nullptr;
+    Batcher* batcher = nullptr;     // holds a reference (Batcher::refs) for the pool's lifetime
+    bool owns_batcher = false;      // created by dgnn_pool_create_devices / _callbacks: nobody else has a handle
+    // Lanes: where a worker evaluates its batches.  Either devices of the network (NnPredictor::predict round-robins
+    // Device::all(), src/libdg_mcts/predictors/nn.rs:84-108: here worker w is bound to lane w % lanes, so a batch goes to
+    // whichever device has a worker free) or, for tests and dry runs without a GPU, a predictor callback per lane.
+    std::vector<int> devices;
+    dgnn_predict_fn callback = nullptr;
+    void* callback_ctx = nullptr;
+    int num_lanes = 1;
+    std::unique_ptr<std::atomic<uint64_t>[]> lane_boards, lane_batches;
+
     std::vector<std::thread> workers;
     std::mutex mutex;
     std::condition_variable work;
     bool stopping = false;
     std::atomic<uint64_t> calls{0};
 
-    void run()
+    bool ready() const
+    {
+        return batcher->queued.load(std::memory_order_acquire) > 0 &&
+               batcher->num_batches.load(std::memory_order_acquire) < batcher->max_batches;
+    }
+    // state the predicate reads changes outside `mutex` (under the batcher's): passing through the mutex before the notify
+    // closes the window between a worker's predicate check and its going to sleep
+    void wake()
+    {
+        { std::lock_guard<std::mutex> lock(mutex); }
+        work.notify_one();
+    }
+
+    int evaluate(int lane, dgnn_batch* batch, int n, uint16_t* value, uint16_t* policy);
+
+    void run(int lane)
     {
         std::vector<uint16_t> value((size_t)batcher->max_batch_size), policy((size_t)batcher->max_batch_size * DGNN_NUM_MOVES);
         std::vector<uint64_t> tags((size_t)batcher->max_batch_size);
         for (;;) {
+            {
+                // sleep until there is something queued AND a batch slot free (signalled by dgnn_pool_predict and by every
+                // batch that retires); the timeout only covers boards pushed into the batcher behind the pool's back
+                std::unique_lock<std::mutex> lock(mutex);
+                work.wait_for(lock, std::chrono::milliseconds(20), [&] { return stopping || ready(); });
+                if (stopping) return;
+            }
             dgnn_batch* batch = nullptr;
             // take whatever is queued as soon as a batch slot is free: with max_batches batches in flight the queue
             // fills up behind them, which is what makes the batches large under load and keeps latency low when idle
             (void)dgnn_batcher_get_batch(reinterpret_cast<dgnn_batcher*>(batcher), 1, &batch);
-            if (!batch) {
-                std::unique_lock<std::mutex> lock(mutex);
-                if (stopping) return;
-                work.wait_for(lock, std::chrono::microseconds(200));
-                continue;
-            }
+            if (!batch) continue;
+            if (ready()) work.notify_one();         // more than one batch was queued: the next idle worker takes the rest
             const int n = dgnn_batch_size(batch);
             (void)dgnn_batch_tags(batch, tags.data());
-            const int status = dgnn_batch_forward(batch, value.data(), policy.data());
+            const int status = evaluate(lane, batch, n, value.data(), policy.data());
             dgnn_batch_destroy(batch);
-            work.notify_one();                      // a batch slot is free again
+            wake();                                 // a batch slot is free again
             for (int i = 0; i < n; ++i) {
                 LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
                 LeafRequest* r = slot->request;
@@ -327,6 +356,7 @@ int dgnn_batcher_push(dgnn_batcher* batcher, const uint16_t* features, uint64_t 
     std::lock_guard<std::mutex> lock(b->mutex);                                 // batch.rs:80-84
     b->features.insert(b->features.end(), features, features + DGNN_FEATURE_SIZE);
     b->tags.push_back(tag);
+    b->queued.store((int)b->tags.size(), std::memory_order_release);
     return DGNN_OK;
 }
 
@@ -370,6 +400,7 @@ int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch
         b->features.resize(split * DGNN_FEATURE_SIZE);
         b->tags.resize(split);
     }
+    b->queued.store((int)b->tags.size(), std::memory_order_release);
     *out = reinterpret_cast<dgnn_batch*>(batch.release());
     return DGNN_OK;
 }
@@ -403,6 +434,12 @@ static void retire(Batch* bt)
 
 int dgnn_batch_forward(dgnn_batch* batch, uint16_t* value_out, uint16_t* policy_out)
 {
+    if (!batch) return DGNN_BAD_ARGUMENT;
+    return dgnn_batch_forward_on(batch, reinterpret_cast<Batch*>(batch)->owner->device, value_out, policy_out);
+}
+
+int dgnn_batch_forward_on(dgnn_batch* batch, int device, uint16_t* value_out, uint16_t* policy_out)
+{
     if (!batch || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
     Batch* bt = reinterpret_cast<Batch*>(batch);
     Batcher* b = bt->owner;
@@ -410,7 +447,7 @@ int dgnn_batch_forward(dgnn_batch* batch, uint16_t* value_out, uint16_t* policy_
     const int n = (int)bt->tags.size();
 
     dgnn_workspace* ws = nullptr;
-    int status = dgnn_network_get_workspace(b->net, b->device, b->max_batch_size, &ws);
+    int status = dgnn_network_get_workspace(b->net, device, b->max_batch_size, &ws);
     if (status == DGNN_OK) {
         status = dgnn_forward_n(ws, bt->features.data(), n, value_out, policy_out);   // batch.rs:36 -> nn.rs:84-108
         dgnn_workspace_release(ws);
@@ -444,6 +481,41 @@ void dgnn_batch_destroy(dgnn_batch* batch)
 
 // ---- leaf pool
 
+int LeafPool::evaluate(int lane, dgnn_batch* batch, int n, uint16_t* value, uint16_t* policy)
+{
+    int status;
+    if (callback) {
+        status = callback(callback_ctx, dgnn_batch_features(batch), n, value, policy);
+        if (status == DGNN_OK) {
+            batcher->boards_evaluated.fetch_add((uint64_t)n, std::memory_order_relaxed);
+            batcher->batches_evaluated.fetch_add(1, std::memory_order_relaxed);
+        }
+    } else {
+        status = dgnn_batch_forward_on(batch, devices[lane], value, policy);
+    }
+    if (status == DGNN_OK) {
+        lane_boards[lane].fetch_add((uint64_t)n, std::memory_order_relaxed);
+        lane_batches[lane].fetch_add(1, std::memory_order_relaxed);
+    }
+    return status;
+}
+
+static int start_pool(std::unique_ptr<LeafPool>& pool, int workers_per_lane, dgnn_pool** out)
+{
+    pool->lane_boards.reset(new (std::nothrow) std::atomic<uint64_t>[pool->num_lanes]);
+    pool->lane_batches.reset(new (std::nothrow) std::atomic<uint64_t>[pool->num_lanes]);
+    if (!pool->lane_boards || !pool->lane_batches) return DGNN_OUT_OF_MEMORY;
+    for (int i = 0; i < pool->num_lanes; ++i) { pool->lane_boards[i] = 0; pool->lane_batches[i] = 0; }
+    pool->batcher->refs.fetch_add(1, std::memory_order_relaxed);   // the workers poll the batcher until they have joined
+    LeafPool* raw = pool.get();
+    for (int w = 0; w < workers_per_lane * pool->num_lanes; ++w) {
+        const int lane = w % pool->num_lanes;
+        pool->workers.emplace_back([raw, lane] { raw->run(lane); });
+    }
+    *out = reinterpret_cast<dgnn_pool*>(pool.release());
+    return DGNN_OK;
+}
+
 int dgnn_pool_create(dgnn_batcher* batcher, int num_workers, dgnn_pool** out)
 {
     if (!batcher || !out || num_workers <= 0) return DGNN_BAD_ARGUMENT;
@@ -453,10 +525,63 @@ int dgnn_pool_create(dgnn_batcher* batcher, int num_workers, dgnn_pool** out)
     std::unique_ptr<LeafPool> pool(new (std::nothrow) LeafPool());
     if (!pool) return DGNN_OUT_OF_MEMORY;
     pool->batcher = b;
-    LeafPool* raw = pool.get();
-    for (int i = 0; i < num_workers; ++i) pool->workers.emplace_back([raw] { raw->run(); });
-    *out = reinterpret_cast<dgnn_pool*>(pool.release());
-    return DGNN_OK;
+    pool->devices.assign(1, b->device);
+    pool->num_lanes = 1;
+    return start_pool(pool, num_workers, out);
+}
+
+int dgnn_pool_create_devices(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,
+                             int workers_per_device, dgnn_pool** out)
+{
+    if (!net || !out || max_batch_size <= 0 || batches_per_device <= 0 || workers_per_device <= 0) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    std::vector<int> lanes;
+    if (devices) {
+        if (num_devices <= 0) return DGNN_BAD_ARGUMENT;
+        lanes.assign(devices, devices + num_devices);
+    } else {                                                   // Device::all(), src/libdg_cuda/devices.rs:55-63
+        int count = 0;
+        const int status = dgnn_device_count(&count);
+        if (status != DGNN_OK) return status;
+        if (count <= 0) return DGNN_HIP_ERROR;
+        for (int d = 0; d < count; ++d) lanes.push_back(d);
+    }
+    int count = 0;
+    if (dgnn_device_count(&count) == DGNN_OK)
+        for (int d : lanes) if (d < 0 || d >= count) return DGNN_BAD_ARGUMENT;
+
+    dgnn_batcher* batcher = nullptr;                           // ONE queue for all devices like the reference's (batch.rs:60-73),
+    int status = dgnn_batcher_create(net, lanes[0], max_batch_size, batches_per_device * (int)lanes.size(), &batcher);   // 2 x devices alive (nn.rs:64-67)
+    if (status != DGNN_OK) return status;
+    std::unique_ptr<LeafPool> pool(new (std::nothrow) LeafPool());
+    if (!pool) { dgnn_batcher_destroy(batcher); return DGNN_OUT_OF_MEMORY; }
+    pool->batcher = reinterpret_cast<Batcher*>(batcher);
+    pool->owns_batcher = true;
+    pool->devices = lanes;
+    pool->num_lanes = (int)lanes.size();
+    status = start_pool(pool, workers_per_device, out);
+    if (status != DGNN_OK) dgnn_batcher_destroy(batcher);
+    return status;
+}
+
+int dgnn_pool_create_callbacks(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                               int workers_per_lane, dgnn_pool** out)
+{
+    if (!predict || !out || num_lanes <= 0 || max_batch_size <= 0 || batches_per_lane <= 0 || workers_per_lane <= 0) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    dgnn_batcher* batcher = nullptr;
+    int status = dgnn_batcher_create(nullptr, 0, max_batch_size, batches_per_lane * num_lanes, &batcher);
+    if (status != DGNN_OK) return status;
+    std::unique_ptr<LeafPool> pool(new (std::nothrow) LeafPool());
+    if (!pool) { dgnn_batcher_destroy(batcher); return DGNN_OUT_OF_MEMORY; }
+    pool->batcher = reinterpret_cast<Batcher*>(batcher);
+    pool->owns_batcher = true;
+    pool->callback = predict;
+    pool->callback_ctx = predict_ctx;
+    pool->num_lanes = num_lanes;
+    status = start_pool(pool, workers_per_lane, out);
+    if (status != DGNN_OK) dgnn_batcher_destroy(batcher);
+    return status;
 }
 
 void dgnn_pool_destroy(dgnn_pool* handle)
@@ -469,7 +594,26 @@ void dgnn_pool_destroy(dgnn_pool* handle)
     }
     pool->work.notify_all();
     for (std::thread& t : pool->workers) t.join();
+    Batcher* b = pool->batcher;
+    if (pool->owns_batcher) b->release();      // the handle dgnn_batcher_create returned
+    b->release();                              // the pool's own reference (start_pool)
     delete pool;
+}
+
+int dgnn_pool_stats(dgnn_pool* handle, int* num_lanes, uint64_t* calls, uint64_t* boards, uint64_t* batches,
+                    uint64_t* lane_boards, uint64_t* lane_batches, int lane_capacity)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    if (num_lanes) *num_lanes = pool->num_lanes;
+    if (calls) *calls = pool->calls.load();
+    if (boards) *boards = pool->batcher->boards_evaluated.load();
+    if (batches) *batches = pool->batcher->batches_evaluated.load();
+    for (int i = 0; i < pool->num_lanes && i < lane_capacity; ++i) {
+        if (lane_boards) lane_boards[i] = pool->lane_boards[i].load();
+        if (lane_batches) lane_batches[i] = pool->lane_batches[i].load();
+    }
+    return DGNN_OK;
 }
 
 int dgnn_pool_predict(dgnn_pool* handle, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out)
@@ -496,7 +640,7 @@ int dgnn_pool_predict(dgnn_pool* handle, const uint16_t* features, int batch_siz
         }
     }
     pool->calls.fetch_add(1, std::memory_order_relaxed);
-    pool->work.notify_one();
+    pool->wake();
     std::unique_lock<std::mutex> lock(request.mutex);
     request.done.wait(lock, [&] { return request.remaining == 0; });
     return request.status;

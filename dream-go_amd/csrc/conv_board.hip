@@ -520,6 +520,49 @@ void nhwc_to_board_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict_
     *reinterpret_cast<uint4*>(out + idx * 8) = v;
 }
 
+// Packed features (include/dgnn.h: DGNN_PACKED_WORDS words per board: 361 plane masks, then fp16(v1) << 16 | fp16(v0)) ->
+// the 32-channel input of the up-layer.  Channel c of a point is 0 where bit c of its mask is clear, else 1.0 -- except
+// channels 0 and 1, which carry the board-wide komi constant of features.rs:236-239 (v0 / v1).
+__device__ __forceinline__ uint4 expand_packed(unsigned mask, unsigned scalars, int slot)
+{
+    const unsigned bits = mask >> (slot * 8);
+    unsigned h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (bits >> e) & 1u ? 0x3c00u : 0u;
+    if (slot == 0) {
+        if (bits & 1u) h[0] = scalars & 0xffffu;
+        if (bits & 2u) h[1] = scalars >> 16;
+    }
+    return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+
+// -> [B][4][400][8] (padded slot-major; pad rows / columns zero): replaces the upload of 23 KB of fp16 per board AND nhwc_to_board_kernel
+__global__ __launch_bounds__(256)
+void packed_to_board_kernel(const uint32_t* __restrict__ packed, uint16_t* __restrict__ out, int batch)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * 4 * kRows) return;
+    const int row = (int)(idx % kRows);
+    const int slot = (int)((idx / kRows) % 4);
+    const long b = idx / (4 * kRows);
+    const int y = row / 20, x = row % 20;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (x < 19 && y < 19) v = expand_packed(packed[b * kPackedWords + y * 19 + x], packed[b * kPackedWords + 361], slot);
+    *reinterpret_cast<uint4*>(out + idx * 8) = v;
+}
+
+// -> [B][361][32] NHWC (the layout dgnn_forward takes), for the NHWC kernels
+__global__ __launch_bounds__(256)
+void packed_to_nhwc_kernel(const uint32_t* __restrict__ packed, uint16_t* __restrict__ out, int batch)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * 361 * 4) return;
+    const int slot = (int)(idx % 4);
+    const int pos = (int)((idx / 4) % 361);
+    const long b = idx / (4 * 361);
+    *reinterpret_cast<uint4*>(out + idx * 8) = expand_packed(packed[b * kPackedWords + pos], packed[b * kPackedWords + 361], slot);
+}
+
 // [B][C / 8][400][8] -> [B][361][C] NHWC
 __global__ __launch_bounds__(256)
 void board_to_nhwc_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int batch, int c)
@@ -572,17 +615,22 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
 
 // Slices per workgroup: the largest that divides C_out / 32, unless a smaller one is needed to put a workgroup on most
 // of the 256 CUs (a launch has batch * C_out / (32 * NS) workgroups).  DGNN_BOARD_NS=1|2|4|8 overrides.
-int conv_board_pick_ns(int batch, int cout)
+int conv_board_pick_ns(int batch, int cout, int forced_ns)
 {
     const int slices = cout / 32;
     int best = slices % 8 == 0 ? 8 : slices % 4 == 0 ? 4 : 2;
     while (best > 1 && (long)batch * (slices / best) < 192) best /= 2;
-    const char* const force = std::getenv("DGNN_BOARD_NS");
-    if (force) {
-        const int ns = std::atoi(force);
-        if ((ns == 1 || ns == 2 || ns == 4 || ns == 8) && slices % ns == 0) best = ns;
-    }
+    if ((forced_ns == 1 || forced_ns == 2 || forced_ns == 4 || forced_ns == 8) && slices % forced_ns == 0) best = forced_ns;
     return best;
+}
+
+BoardSwitches read_board_switches()
+{
+    BoardSwitches s;
+    if (const char* v = std::getenv("DGNN_BOARD_NS")) s.ns = std::atoi(v);
+    if (const char* v = std::getenv("DGNN_BOARD_SKIP")) s.epilogue_skip = std::atoi(v) == 1;   // =1: keep the skip in the epilogue (A/B, tests)
+    if (const char* v = std::getenv("DGNN_CONV_ABLATE")) s.ablate = std::atoi(v);
+    return s;
 }
 
 bool tower_board_supported(int batch, int channels)
@@ -606,18 +654,15 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
     return hipGetLastError();
 }
 
-hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream)
+hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches& env, hipStream_t stream)
 {
     if (args.batch <= 0) return hipSuccess;
     if (!conv_board_supported(args.cin, args.cout)) return hipErrorInvalidValue;
     const bool relu = args.relu != 0;
     // skip folded into the K loop needs two chunks to spread its row tiles over and a usable alpha2 / alpha1
-    const char* const mode = std::getenv("DGNN_BOARD_SKIP");        // =1: keep the skip in the epilogue (A/B, tests)
-    const bool epilogue_skip = mode && std::atoi(mode) == 1;
-    const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !epilogue_skip) ? 2 : 1;
-    const char* const abl = std::getenv("DGNN_CONV_ABLATE");
-    const int ablate = abl ? std::atoi(abl) : 0;
-    switch (conv_board_pick_ns(args.batch, args.cout)) {
+    const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !env.epilogue_skip) ? 2 : 1;
+    const int ablate = env.ablate;
+    switch (conv_board_pick_ns(args.batch, args.cout, env.ns)) {
         case 8: launch_board_variant<8>(args, skip, relu, ablate >= 1 && ablate <= 16 ? ablate : 0, stream); break;
         case 4: launch_board_variant<4>(args, skip, relu, 0, stream); break;
         case 2: launch_board_variant<2>(args, skip, relu, 0, stream); break;
@@ -631,6 +676,19 @@ hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, in
     if (batch <= 0) return hipSuccess;
     const long total = (long)batch * (channels / 8) * kRows;
     hipLaunchKernelGGL(nhwc_to_board_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, batch, channels);
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_features(const uint32_t* packed, uint16_t* out, int batch, bool board_layout, hipStream_t stream)
+{
+    if (batch <= 0) return hipSuccess;
+    if (board_layout) {
+        const long total = (long)batch * 4 * kRows;
+        hipLaunchKernelGGL(packed_to_board_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, packed, out, batch);
+    } else {
+        const long total = (long)batch * 361 * 4;
+        hipLaunchKernelGGL(packed_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, packed, out, batch);
+    }
     return hipGetLastError();
 }
 

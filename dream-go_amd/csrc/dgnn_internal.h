@@ -63,16 +63,20 @@ struct ConvParams {
     float alpha2 = 0.0f;     // scale of the skip input (0: skip is not read)
 };
 
+// filter layouts an image may carry (Topology::layouts, network.cpp: pack_layouts_from_env)
+constexpr unsigned kPackGeneric = 1, kPackTile = 2, kPackBoard = 4;
+
 struct Topology {
+    unsigned layouts = 0;        // kPack* bits of the image
     int num_blocks = 0;
     int num_channels = 0;
     int num_samples = 0;
     float softmax_temperature = 0.709888f;
+    bool gates_nonzero = true;   // no residual gate is 0 (alpha1 of every conv_2 != 0): what the one-launch tower needs
 
     ConvParams up;
     std::vector<ConvParams> res1, res2;
     ConvParams policy_conv, value_conv;
-    size_t policy_w_offset = 0;  // [361 * S][362] fp16 as stored ([in][out])
     size_t policy_b_offset = 0;  // [362] fp16, tau * b_l rounded to fp16
     size_t value_w_offset = 0;   // [722] fp16
     size_t value_b_offset = 0;   // [1] fp16
@@ -117,6 +121,14 @@ constexpr size_t kZeroPageBytes = 256;   // the image starts with a page of zero
 
 // Builds topo + image from tensors.  Returns a DGNN_* status.
 int build_network(Network& net);
+
+// Weight refresh: `image` (num_bytes == net.image.size()) was produced by build_network of a network with the same
+// architecture and packing -- checked against the header it carries -- possibly with other gates / temperature / weights.
+// Copies it over net.image and takes the launch scalars (alpha per block, tau) from its header.
+int adopt_image(Network& net, const uint8_t* image, size_t num_bytes);
+
+// dense.rs:182-189: a dense matrix stored [k_in][n_out] -> [n_out][k_pad] (dst zeroed by the caller, rows >= n_out stay zero)
+void pack_dense_transposed(const uint16_t* w_in_out, int k_in, int n_out, int k_pad, uint16_t* dst);
 
 // search.cpp: pool/policy_helper.rs:28-134 on the game callbacks
 void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, float* policy, int* indices);

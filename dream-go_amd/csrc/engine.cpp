@@ -44,6 +44,7 @@ struct Workspace {
 
     void* arena = nullptr;                  // one allocation, carved below
     uint16_t* d_features = nullptr;         // [batch][361][32]
+    uint32_t* d_packed = nullptr;           // [batch][DGNN_PACKED_WORDS]: packed features (dgnn_forward_packed)
     uint16_t* d_act[3] = {nullptr, nullptr, nullptr};   // rotating; [batch][361][C] NHWC, or [batch][C/8][400][8] on the board path
     uint16_t* d_features_board = nullptr;   // board path: features in padded slot-major layout [batch][4][400][8]
     uint16_t* d_tower_nhwc = nullptr;       // board path: tower output converted back to NHWC for the head kernels
@@ -55,6 +56,7 @@ struct Workspace {
 
     void* pinned = nullptr;                 // host staging, one allocation
     uint16_t* h_features = nullptr;
+    uint32_t* h_packed = nullptr;
     uint16_t* h_value = nullptr;
     uint16_t* h_policy = nullptr;
 
@@ -67,6 +69,7 @@ struct Workspace {
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
     int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
     int tile_variant = 2;                   // 1 = lock-step, 2 = staggered load|matrix phases, 3 = staggered balanced half-steps
+    BoardSwitches board_env;                // DGNN_BOARD_NS / DGNN_BOARD_SKIP / DGNN_CONV_ABLATE, read ONCE when the workspace is built
 
     ~Workspace();
 };
@@ -107,7 +110,7 @@ namespace {
 size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
 // Lazily creates the per-device state: weight image upload (tensor.rs:123-141 done once per device).
-int get_device_state(Network* net, int device, DeviceState** out)
+int get_device_state(Network* net, int device, DeviceState** out, bool upload = true)
 {
     auto it = net->devices.find(device);
     if (it != net->devices.end()) { *out = it->second.get(); return DGNN_OK; }
@@ -121,7 +124,7 @@ int get_device_state(Network* net, int device, DeviceState** out)
     if (!state) return DGNN_OUT_OF_MEMORY;
     state->device = device;
     DGNN_HIP(hipMalloc((void**)&state->d_image, net->image.size()));
-    DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
+    if (upload) DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
 
     *out = state.get();
     net->devices[device] = std::move(state);
@@ -179,6 +182,14 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         ws->use_tower = ws->use_board && !(tower && std::atoi(tower) == 0) && t.num_blocks > 0;
     }
 
+    ws->board_env = read_board_switches();
+    if (ws->use_board) {
+        if (t.head_w_board_offset == 0 && t.policy_conv.w_offset == 0) return DGNN_UNSUPPORTED;
+    } else {
+        // NHWC paths: the image must carry the generic layout (DGNN_CONV was different when the network was built)
+        if (t.up.w_offset == 0 || t.policy_conv.w_offset == 0) return DGNN_UNSUPPORTED;
+    }
+
     DGNN_HIP(hipSetDevice(dev->device));
     DGNN_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));   // stream.rs:55
     DGNN_HIP(hipEventCreate(&ws->ev_begin));
@@ -197,7 +208,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_value = align_up((size_t)batch * 2, 256);
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
     const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
-    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits;
+    const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
+    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed;
 
     DGNN_HIP(hipMalloc(&ws->arena, total));
     // board path: pad rows 384..399 of every k-slot are never written by the kernels and must read as zero
@@ -210,14 +222,16 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_value = (uint16_t*)p; p += sz_value;
     ws->d_policy = (uint16_t*)p; p += sz_policy;
     ws->d_logits = (uint16_t*)p; p += sz_logits;
+    ws->d_packed = (uint32_t*)p; p += sz_packed;
     if (ws->use_board) {
         ws->d_features_board = (uint16_t*)p; p += sz_fboard;
         ws->d_tower_nhwc = (uint16_t*)p;
     }
 
-    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_value + sz_policy, hipHostMallocDefault));
+    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_packed + sz_value + sz_policy, hipHostMallocDefault));
     uint8_t* h = (uint8_t*)ws->pinned;
     ws->h_features = (uint16_t*)h; h += sz_features;
+    ws->h_packed = (uint32_t*)h; h += sz_packed;
     ws->h_value = (uint16_t*)h; h += sz_value;
     ws->h_policy = (uint16_t*)h;
 
@@ -225,9 +239,16 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     return DGNN_OK;
 }
 
+// The tower as one launch: where a workgroup owns a whole board, and only with gates the in-loop skip can express
+// (it accumulates (alpha2 / alpha1) * z: a gate of 0 needs the epilogue form, which only the per-layer launcher has).
+bool tower_selected(const Workspace* ws)
+{
+    return ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero && tower_board_supported(ws->active, ws->net->topo.num_channels);
+}
+
 // Enqueues graph.rs:134-152 on the workspace's stream.  `tower_pair` (may be -1) selects the event pair that
 // brackets the residual convolutions.
-int enqueue_forward(Workspace* ws, int tower_pair)
+int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
 {
     const Topology& t = ws->net->topo;
     const uint8_t* image = ws->dev->d_image;
@@ -285,16 +306,19 @@ int enqueue_forward(Workspace* ws, int tower_pair)
         a.alpha1 = c.alpha1;
         a.alpha2 = c.alpha2;
         a.relu = 1;
-        return launch_conv3x3_board(a, ws->stream);
+        return launch_conv3x3_board(a, ws->board_env, ws->stream);
     };
 
     int cur = 0;
     const uint16_t* tower = nullptr;   // NHWC tower output for the heads
+    if (packed_input && !ws->use_board) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features, ws->active, false, ws->stream));
     if (ws->use_board) {
-        DGNN_HIP(launch_nhwc_to_board(ws->d_features, ws->d_features_board, ws->active, DGNN_NUM_FEATURES, ws->stream));
+        // features.rs:52-60 HWC fp16, or the packed form: either way the up-layer reads the padded slot-major layout
+        if (packed_input) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features_board, ws->active, true, ws->stream));
+        else DGNN_HIP(launch_nhwc_to_board(ws->d_features, ws->d_features_board, ws->active, DGNN_NUM_FEATURES, ws->stream));
         DGNN_HIP(conv_board(t.up, ws->d_features_board, nullptr, ws->d_act[cur]));
         if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair], ws->stream));
-        if (ws->use_tower && tower_board_supported(ws->active, t.num_channels)) {
+        if (tower_selected(ws)) {
             if (!ws->tower_layers_ready) {                     // the descriptors only hold addresses fixed for the workspace's life
                 std::vector<ConvBoardLaunch> layers;
                 int c = cur;
@@ -461,7 +485,8 @@ static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint
         if (ab && std::atoi(ab) == 1 && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess)
             a.timing = d_timing;
         const int reps = a.timing ? 3 : 1;   // the last repetition is reported (caches warm)
-        for (int r = 0; r < reps && err == hipSuccess; ++r) err = launch_conv3x3_board(a, nullptr);
+        const BoardSwitches env = read_board_switches();   // per call: the parity tests switch variants between calls
+        for (int r = 0; r < reps && err == hipSuccess; ++r) err = launch_conv3x3_board(a, env, nullptr);
         if (err == hipSuccess && d_timing && hipDeviceSynchronize() == hipSuccess) {
             std::vector<unsigned long long> t(num_wg * 8 * 4);
             if (hipMemcpy(t.data(), d_timing, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -508,6 +533,7 @@ const char* dgnn_status_string(int status)
         case DGNN_BAD_ARGUMENT: return "bad argument";
         case DGNN_OUT_OF_MEMORY: return "out of host memory";
         case DGNN_UNSUPPORTED: return "unsupported network architecture";
+        case DGNN_COMM_ERROR: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -724,6 +750,86 @@ int dgnn_forward(dgnn_workspace* ws, const uint16_t* features, size_t num_featur
     return dgnn_forward_wait(ws, value_out, policy_out);
 }
 
+// Packed features: 361 plane masks + the two komi constants per board (1 472 bytes instead of 23 104), expanded on the
+// device by the kernel that also produces the up-layer's input layout.  Same outputs, bit for bit, as dgnn_forward on the
+// fp16 features the words describe.
+int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, int count)
+{
+    if (!handle || !packed) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
+    if (ws->pending) return DGNN_BAD_ARGUMENT;
+    ws->active = count;
+    const size_t in_bytes = (size_t)count * DGNN_PACKED_WORDS * sizeof(uint32_t);
+
+    DGNN_HIP(hipSetDevice(ws->device));
+    if (packed != ws->h_packed) std::memcpy(ws->h_packed, packed, in_bytes);
+    DGNN_HIP(hipMemcpyAsync(ws->d_packed, ws->h_packed, in_bytes, hipMemcpyHostToDevice, ws->stream));
+
+    const int status = enqueue_forward(ws, -1, /*packed_input=*/true);
+    if (status != DGNN_OK) return status;
+
+    DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    ws->pending = true;
+    return DGNN_OK;
+}
+
+int dgnn_forward_packed(dgnn_workspace* ws, const uint32_t* packed, int count, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    const int status = dgnn_forward_submit_packed(ws, packed, count);
+    if (status != DGNN_OK) return status;
+    return dgnn_forward_wait(ws, value_out, policy_out);
+}
+
+int dgnn_workspace_packed_buffer(dgnn_workspace* ws, uint32_t** h_packed)
+{
+    if (!ws || !h_packed) return DGNN_BAD_ARGUMENT;
+    *h_packed = W(ws)->h_packed;
+    return DGNN_OK;
+}
+
+int dgnn_features_pack(const uint16_t* features, int count, uint32_t* packed)
+{
+    if (!features || !packed || count <= 0) return DGNN_BAD_ARGUMENT;
+    for (int b = 0; b < count; ++b) {
+        const uint16_t* f = features + (size_t)b * DGNN_FEATURE_SIZE;
+        uint32_t* out = packed + (size_t)b * DGNN_PACKED_WORDS;
+        uint16_t v[2] = {0, 0};
+        for (int pos = 0; pos < DGNN_NUM_POINTS; ++pos) {
+            uint32_t mask = 0;
+            for (int c = 0; c < DGNN_NUM_FEATURES; ++c) {
+                const uint16_t h = f[pos * DGNN_NUM_FEATURES + c];
+                if ((h & 0x7fff) == 0) continue;                      // +0 / -0
+                if (c < 2) {                                          // one constant per board (features.rs:236-239)
+                    if (v[c] == 0) v[c] = h;
+                    else if (v[c] != h) return DGNN_BAD_ARGUMENT;
+                } else if (h != 0x3c00) return DGNN_BAD_ARGUMENT;     // every other plane is 0 / 1
+                mask |= 1u << c;
+            }
+            out[pos] = mask;
+        }
+        out[DGNN_NUM_POINTS] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+        for (int i = DGNN_NUM_POINTS + 1; i < DGNN_PACKED_WORDS; ++i) out[i] = 0;
+    }
+    return DGNN_OK;
+}
+
+int dgnn_features_unpack(const uint32_t* packed, int count, uint16_t* features)
+{
+    if (!features || !packed || count <= 0) return DGNN_BAD_ARGUMENT;
+    for (int b = 0; b < count; ++b) {
+        const uint32_t* in = packed + (size_t)b * DGNN_PACKED_WORDS;
+        uint16_t* f = features + (size_t)b * DGNN_FEATURE_SIZE;
+        const uint16_t v[2] = {(uint16_t)(in[DGNN_NUM_POINTS] & 0xffff), (uint16_t)(in[DGNN_NUM_POINTS] >> 16)};
+        for (int pos = 0; pos < DGNN_NUM_POINTS; ++pos)
+            for (int c = 0; c < DGNN_NUM_FEATURES; ++c)
+                f[pos * DGNN_NUM_FEATURES + c] = !((in[pos] >> c) & 1u) ? 0 : c < 2 ? v[c] : 0x3c00;
+    }
+    return DGNN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- harness
 
 int dgnn_workspace_batch_size(const dgnn_workspace* ws, int* batch_size, int* device)
@@ -757,7 +863,7 @@ const char* dgnn_workspace_conv_kernel(const dgnn_workspace* handle)
     if (!handle) return "";
     const Workspace* ws = W(handle);
     const Topology& t = ws->net->topo;
-    if (ws->use_board && ws->use_tower && tower_board_supported(ws->active, t.num_channels)) return "tower_board_kernel";
+    if (tower_selected(ws)) return "tower_board_kernel";
     if (ws->use_board) return "conv3x3_board_kernel";
     if (ws->use_tile && conv_tile_supported(t.num_channels, t.num_channels)) {
         static const char* const names[3][3] = {
@@ -846,7 +952,7 @@ int dgnn_forward_timed(dgnn_workspace* handle, int steps, float* total_ms, float
         tower += t;
     }
     if (tower_ms) *tower_ms = tower;
-    const bool one_launch = ws->use_board && ws->use_tower && tower_board_supported(ws->active, ws->net->topo.num_channels);
+    const bool one_launch = tower_selected(ws);
     if (tower_launches) *tower_launches = one_launch ? steps : 2 * ws->net->topo.num_blocks * steps;
     return DGNN_OK;
 }
@@ -949,6 +1055,86 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
     return status;
 }
 
+int dgnn_layer_dense(int device, const uint16_t* x, int batch, int k_in, const uint16_t* w_in_out, const uint16_t* bias,
+                     int n_out, float alpha, int relu, uint16_t* y)
+{
+    if (!x || !w_in_out || !bias || !y || batch <= 0 || k_in <= 0 || n_out <= 0) return DGNN_BAD_ARGUMENT;
+    int count = 0;
+    DGNN_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP(hipSetDevice(device));
+
+    // what build_network does for linear_1: the stored [in][out] matrix transposed to [out][in], zero padded (dense.rs:182-189)
+    const int k_pad = (k_in + 63) / 64 * 64;
+    const int rows = (n_out + 31) / 32 * 32;
+    std::vector<uint16_t> wt((size_t)rows * k_pad, 0), bias_pad((size_t)rows, 0);
+    pack_dense_transposed(w_in_out, k_in, n_out, k_pad, wt.data());
+    std::memcpy(bias_pad.data(), bias, (size_t)n_out * 2);
+
+    const size_t sz_x = align_up((size_t)batch * k_in * 2 + 64, 256), sz_w = align_up(wt.size() * 2, 256);
+    const size_t sz_b = align_up(bias_pad.size() * 2, 256), sz_y = align_up((size_t)batch * n_out * 2, 256);
+    uint8_t* d = nullptr;
+    DGNN_HIP(hipMalloc((void**)&d, sz_x + sz_w + sz_b + sz_y));
+    int status = DGNN_OK;
+    hipError_t err = hipMemset(d, 0, sz_x);
+    if (err == hipSuccess) err = hipMemcpy(d, x, (size_t)batch * k_in * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + sz_x, wt.data(), wt.size() * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + sz_x + sz_w, bias_pad.data(), bias_pad.size() * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        PolicyGemmLaunch pg;
+        pg.features = (const uint16_t*)d;
+        pg.wt = (const uint16_t*)(d + sz_x);
+        pg.bias = (const uint16_t*)(d + sz_x + sz_w);
+        pg.logits = (uint16_t*)(d + sz_x + sz_w + sz_b);
+        pg.batch = batch; pg.k_in = k_in; pg.k_pad = k_pad; pg.tau = alpha;
+        pg.n_out = n_out; pg.ld_out = n_out; pg.relu = relu;
+        err = launch_policy_gemm(pg, nullptr);
+    }
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(y, d + sz_x + sz_w + sz_b, (size_t)batch * n_out * 2, hipMemcpyDeviceToHost);
+    if (err != hipSuccess) { set_last_hip_error((int)err); status = DGNN_HIP_ERROR; }
+    (void)hipFree(d);
+    return status;
+}
+
+int dgnn_layer_heads(int device, const uint16_t* logits, const uint16_t* value_features, int batch, const uint16_t* value_w,
+                     const uint16_t* value_b, uint16_t* policy_out, uint16_t* value_out)
+{
+    if (!logits || !value_features || !value_w || !value_b || !policy_out || !value_out || batch <= 0) return DGNN_BAD_ARGUMENT;
+    int count = 0;
+    DGNN_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP(hipSetDevice(device));
+    const size_t sz_l = align_up((size_t)batch * 384 * 2, 256), sz_vf = align_up((size_t)batch * 722 * 2, 256);
+    const size_t sz_w = align_up(722 * 2, 256), sz_b = 256, sz_p = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256), sz_v = align_up((size_t)batch * 2, 256);
+    std::vector<uint16_t> padded((size_t)batch * 384, 0);
+    for (int b = 0; b < batch; ++b) std::memcpy(padded.data() + (size_t)b * 384, logits + (size_t)b * DGNN_NUM_MOVES, DGNN_NUM_MOVES * 2);
+    uint8_t* d = nullptr;
+    DGNN_HIP(hipMalloc((void**)&d, sz_l + sz_vf + sz_w + sz_b + sz_p + sz_v));
+    int status = DGNN_OK;
+    hipError_t err = hipMemcpy(d, padded.data(), padded.size() * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + sz_l, value_features, (size_t)batch * 722 * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + sz_l + sz_vf, value_w, 722 * 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(d + sz_l + sz_vf + sz_w, value_b, 2, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        SoftmaxValueLaunch sv;
+        sv.logits = (const uint16_t*)d;
+        sv.value_features = (const uint16_t*)(d + sz_l);
+        sv.value_w = (const uint16_t*)(d + sz_l + sz_vf);
+        sv.value_b = (const uint16_t*)(d + sz_l + sz_vf + sz_w);
+        sv.policy_out = (uint16_t*)(d + sz_l + sz_vf + sz_w + sz_b);
+        sv.value_out = (uint16_t*)(d + sz_l + sz_vf + sz_w + sz_b + sz_p);
+        sv.batch = batch;
+        err = launch_softmax_value(sv, nullptr);
+    }
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(policy_out, d + sz_l + sz_vf + sz_w + sz_b, (size_t)batch * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost);
+    if (err == hipSuccess) err = hipMemcpy(value_out, d + sz_l + sz_vf + sz_w + sz_b + sz_p, (size_t)batch * 2, hipMemcpyDeviceToHost);
+    if (err != hipSuccess) { set_last_hip_error((int)err); status = DGNN_HIP_ERROR; }
+    (void)hipFree(d);
+    return status;
+}
+
 // ---------------------------------------------------------------------------------------------- multi-GPU
 
 int dgnn_network_weight_image(dgnn_network* net, int device, void** d_image, size_t* num_bytes)
@@ -958,6 +1144,19 @@ int dgnn_network_weight_image(dgnn_network* net, int device, void** d_image, siz
     std::lock_guard<std::mutex> lock(n->mutex);
     DeviceState* dev = nullptr;
     const int status = get_device_state(n, device, &dev);
+    if (status != DGNN_OK) return status;
+    if (d_image) *d_image = dev->d_image;
+    if (num_bytes) *num_bytes = n->image.size();
+    return DGNN_OK;
+}
+
+int dgnn_network_weight_image_reserve(dgnn_network* net, int device, void** d_image, size_t* num_bytes)
+{
+    if (!net) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+    DeviceState* dev = nullptr;
+    const int status = get_device_state(n, device, &dev, /*upload=*/false);
     if (status != DGNN_OK) return status;
     if (d_image) *d_image = dev->d_image;
     if (num_bytes) *num_bytes = n->image.size();
@@ -980,12 +1179,32 @@ int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src
     std::lock_guard<std::mutex> lock(n->mutex);
     if (num_bytes != n->image.size()) return DGNN_BAD_ARGUMENT;
     DeviceState* dev = nullptr;
-    const int status = get_device_state(n, device, &dev);
+    int status = get_device_state(n, device, &dev);
     if (status != DGNN_OK) return status;
-    DGNN_HIP(hipSetDevice(device));
-    DGNN_HIP(hipDeviceSynchronize());   // no forward may be reading the old image
-    if ((const void*)dev->d_image != src)
-        DGNN_HIP(hipMemcpy(dev->d_image, src, num_bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+
+    // the new image on the host first: its header is checked against this network (same architecture, same packing)
+    // BEFORE anything is overwritten, and it carries the launch scalars (gates, temperature) the kernels are started with
+    std::vector<uint8_t> incoming;
+    const uint8_t* host = (const uint8_t*)src;
+    if (src_on_device) {
+        incoming.resize(num_bytes);
+        DGNN_HIP(hipSetDevice(device));
+        DGNN_HIP(hipDeviceSynchronize());   // e.g. the collective that wrote it
+        DGNN_HIP(hipMemcpy(incoming.data(), src, num_bytes, hipMemcpyDeviceToHost));
+        host = incoming.data();
+    }
+    status = adopt_image(*n, host, num_bytes);   // net->image, alpha per block, tau; refuses a foreign image
+    if (status != DGNN_OK) return status;
+
+    // every device copy (devices first touched later upload net->image, which is now the new one)
+    for (auto& entry : n->devices) {
+        DeviceState* d = entry.second.get();
+        DGNN_HIP(hipSetDevice(d->device));
+        DGNN_HIP(hipDeviceSynchronize());   // no forward may be reading the old image
+        if (!(d == dev && (const void*)d->d_image == src))
+            DGNN_HIP(hipMemcpy(d->d_image, n->image.data(), num_bytes, hipMemcpyHostToDevice));
+        for (Workspace* ws : d->all) ws->tower_layers_ready = false;   // the cached descriptors hold the old gates
+    }
     return DGNN_OK;
 }
 

@@ -212,10 +212,11 @@ void policy_gemm_kernel(PolicyGemmLaunch a)
         const float sum = partial[0][r][lane] + partial[1][r][lane] + partial[2][r][lane] + partial[3][r][lane];
         const int bi = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int m = m0 + (lane & 31);
-        if (bi < a.batch && m < kMoves) {
+        if (bi < a.batch && m < a.n_out) {
             // dense.rs:197-220 with alpha1 = tau (policy_head.rs:54): fp16(tau * (w . x) + fp16(tau * b))
-            const float logit = __builtin_fmaf(a.tau, sum, half_bits_to_float(a.bias[m]));
-            a.logits[(long)bi * kMovesPad + m] = float_to_half_bits(logit);
+            float logit = __builtin_fmaf(a.tau, sum, half_bits_to_float(a.bias[m]));
+            if (a.relu) logit = __builtin_fmaxf(logit, 0.0f);
+            a.logits[(long)bi * a.ld_out + m] = float_to_half_bits(logit);
         }
     }
 }
@@ -289,7 +290,7 @@ hipError_t launch_head_conv_board(const HeadConvLaunch& args, hipStream_t stream
 hipError_t launch_policy_gemm(const PolicyGemmLaunch& args, hipStream_t stream)
 {
     if (args.batch <= 0) return hipSuccess;
-    hipLaunchKernelGGL(policy_gemm_kernel, dim3((args.batch + 31) / 32, kMovesPad / 32), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(policy_gemm_kernel, dim3((args.batch + 31) / 32, (args.n_out + 31) / 32), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ int conv_tile_pick_fm(int num_pos, int cout);
 // (conv3x3_tile2_kernel with SCHED = 2: load phase | matrix phase, SCHED = 3: balanced half-steps).
 hipError_t launch_conv3x3_tile(const ConvTileLaunch& args, int fm, int variant, hipStream_t stream);
 
+constexpr int kPackedWords = 368;   // == DGNN_PACKED_WORDS (include/dgnn.h)
 constexpr int kBoardRows = 400;   // padded slot-major layout: 20 rows x 20 columns per board, row 19 / column 19 zero
 
 struct ConvBoardLaunch {
@@ -74,10 +75,19 @@ struct ConvBoardLaunch {
     int relu;
 };
 
+// A/B switches of the board kernel, read from the environment ONCE per workspace (read_board_switches), never per launch:
+// DGNN_BOARD_NS=1|2|4|8 (slices per workgroup), DGNN_BOARD_SKIP=1 (skip added in the epilogue), DGNN_CONV_ABLATE (tools/ablate.sh).
+struct BoardSwitches {
+    int ns = 0;              // 0 = the launcher's own rule
+    int epilogue_skip = 0;
+    int ablate = 0;
+};
+BoardSwitches read_board_switches();
+
 // Residual-tower convolution on the padded slot-major layout, one board per workgroup (conv_board.hip).
 bool conv_board_supported(int cin, int cout);
-int conv_board_pick_ns(int batch, int cout);   // 32-channel slices per workgroup the launcher will use
-hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, hipStream_t stream);
+int conv_board_pick_ns(int batch, int cout, int forced_ns = 0);   // 32-channel slices per workgroup the launcher will use
+hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches& env, hipStream_t stream);
 // The residual tower as ONE launch, a workgroup per board walking all `count` layers (descriptors in HBM; conv_1 / conv_2 of
 // every block, relu, C -> C).  Only where a workgroup owns all channels of its board: conv_board_pick_ns(batch, C) == C / 32.
 bool tower_board_supported(int batch, int channels);
@@ -85,6 +95,8 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
 // Layout changes at the two ends of the tower: [B][361][C] NHWC <-> [B][C / 8][400][8].  C a multiple of 8.
 hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
 hipError_t launch_board_to_nhwc(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
+// Packed features [B][kPackedWords] -> the 32 input planes, either [B][4][400][8] (board_layout) or [B][361][32] NHWC.
+hipError_t launch_packed_features(const uint32_t* packed, uint16_t* out, int batch, bool board_layout, hipStream_t stream);
 
 struct HeadConvLaunch {
     const uint16_t* x;          // tower output [batch][cin / 8][400][8] fp16 (padded slot-major)
@@ -103,11 +115,14 @@ struct PolicyGemmLaunch {
     const uint16_t* features;   // [batch][k_in] fp16 (policy conv output, NHWC flattened: index S * pos + s)
     const uint16_t* wt;         // [384][k_pad] fp16: the dense matrix TRANSPOSED ([out][in]), zero padded
     const uint16_t* bias;       // [362] fp16, already multiplied by tau
-    uint16_t* logits;           // [batch][384] fp16
+    uint16_t* logits;           // [batch][ld_out] fp16
     int batch;
     int k_in;                   // 361 * S
     int k_pad;                  // k_in rounded up to a multiple of 64
     float tau;
+    int n_out = 362;            // outputs written per board (wt holds ceil(n_out / 32) * 32 rows)
+    int ld_out = 384;           // row stride of logits
+    int relu = 0;               // Dense with a ReLU (dense.rs:108-116); the heads use the identity
 };
 hipError_t launch_policy_gemm(const PolicyGemmLaunch& args, hipStream_t stream);
 

@@ -38,7 +38,7 @@ const HostTensor* find_half(const TensorMap& tensors, const std::string& name, s
 // Filter [cout][3][3][cin] (KRSC, conv2d.rs:111-117) -> [9 * cin / 32][cout_pad][32]:
 // k-step = tap * (cin / 32) + chunk; one k-step is one contiguous [cout_pad][32] slab.
 int pack_conv(const TensorMap& tensors, const std::string& name, int cout, int cin,
-              float alpha1, float alpha2, float bias_scale, std::vector<uint8_t>& image, ConvParams& out)
+              float alpha1, float alpha2, float bias_scale, unsigned layouts, std::vector<uint8_t>& image, ConvParams& out)
 {
     const HostTensor* w = find_half(tensors, name + ":0", (size_t)cout * 9 * cin);
     const HostTensor* b = find_half(tensors, name + "/offset:0", (size_t)cout);
@@ -52,15 +52,17 @@ int pack_conv(const TensorMap& tensors, const std::string& name, int cout, int c
     out.cout_pad = cout_pad;
     out.alpha1 = alpha1;
     out.alpha2 = alpha2;
-    out.w_offset = reserve(image, (size_t)9 * cin * cout_pad * sizeof(uint16_t));
-    pack_filter(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_offset));
-
-    if (cout % 256 == 0 && cin % 64 == 0) {
+    // only the layouts the selected kernels read (an offset of 0 = "not packed": offset 0 is the zero page)
+    out.w_offset = out.w_tile_offset = out.w_board_offset = 0;
+    if (layouts & kPackGeneric) {
+        out.w_offset = reserve(image, (size_t)9 * cin * cout_pad * sizeof(uint16_t));
+        pack_filter(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_offset));
+    }
+    if ((layouts & kPackTile) && cout % 256 == 0 && cin % 64 == 0) {
         out.w_tile_offset = reserve(image, (size_t)9 * cin * cout * sizeof(uint16_t));
         pack_filter_tile(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_tile_offset));
     }
-
-    if (cout % 64 == 0 && cin % 32 == 0) {
+    if ((layouts & kPackBoard) && cout % 64 == 0 && cin % 32 == 0) {
         out.w_board_offset = reserve(image, board_filter_elements(cout, cin) * sizeof(uint16_t));
         pack_filter_board(src, cout, cin, reinterpret_cast<uint16_t*>(image.data() + out.w_board_offset));
     }
@@ -139,6 +141,64 @@ std::string scope(int index, const char* suffix)
 
 }  // namespace
 
+// Which filter layouts the image carries: by default only what the kernels of the default path read -- the board layout
+// wherever the board kernel covers the network (C a multiple of 64), else the generic one.  DGNN_CONV=tile1|tile2|tile3|v1
+// (read when the network is built) selects the NHWC kernels and packs their layouts instead; DGNN_PACK=all packs all three
+// (A/B measurements that switch kernels per workspace).  20 x 256: 52 MB instead of 148 MB.
+unsigned pack_layouts_from_env(int channels)
+{
+    const char* all = std::getenv("DGNN_PACK");
+    if (all && std::strcmp(all, "all") == 0) return kPackGeneric | kPackTile | kPackBoard;
+    const char* impl = std::getenv("DGNN_CONV");
+    const bool board_ok = channels >= 64 && channels % 64 == 0;
+    if (impl && *impl && std::strcmp(impl, "board") != 0)
+        return std::strcmp(impl, "v1") == 0 ? kPackGeneric : (kPackGeneric | kPackTile);
+    return board_ok ? kPackBoard : kPackGeneric;
+}
+
+namespace {
+
+// Everything a forward pass needs besides tensors travels IN the image, so that a rank that receives it (RCCL broadcast,
+// weight refresh) launches with the sender's scalars: the residual gates, the soft-max temperature and the shape the
+// offsets were computed for.
+struct ImageHeader {
+    char magic[8];            // "DGNNIMG2"
+    uint32_t header_bytes;    // sizeof(ImageHeader) + 4 * num_blocks
+    uint32_t layouts;         // kPack* bits
+    uint64_t image_bytes;
+    int32_t num_blocks, num_channels, num_samples;
+    float softmax_temperature;
+    // float alpha[num_blocks] follows
+};
+constexpr char kMagic[8] = {'D', 'G', 'N', 'N', 'I', 'M', 'G', '2'};
+
+}  // namespace
+
+int adopt_image(Network& net, const uint8_t* image, size_t num_bytes)
+{
+    Topology& topo = net.topo;
+    if (num_bytes != net.image.size() || num_bytes < kZeroPageBytes + sizeof(ImageHeader)) return DGNN_BAD_ARGUMENT;
+    ImageHeader h;
+    std::memcpy(&h, image + kZeroPageBytes, sizeof(h));
+    if (std::memcmp(h.magic, kMagic, 8) != 0) return DGNN_MALFORMED_WEIGHTS;
+    // same architecture and same packing => same offsets; anything else cannot be launched with this network's descriptors
+    if (h.image_bytes != num_bytes || h.num_blocks != topo.num_blocks || h.num_channels != topo.num_channels ||
+        h.num_samples != topo.num_samples || h.layouts != topo.layouts ||
+        h.header_bytes != sizeof(ImageHeader) + 4u * (uint32_t)topo.num_blocks || !(h.softmax_temperature > 0.0f))
+        return DGNN_BAD_ARGUMENT;
+    for (int i = 0; i < topo.num_blocks; ++i) {
+        float alpha;
+        std::memcpy(&alpha, image + kZeroPageBytes + sizeof(ImageHeader) + 4 * (size_t)i, 4);
+        topo.res2[i].alpha1 = alpha;                 // residual_block.rs:57
+        topo.res2[i].alpha2 = 1.0f - alpha;
+    }
+    topo.softmax_temperature = h.softmax_temperature;
+    topo.gates_nonzero = true;
+    for (const ConvParams& p : topo.res2) topo.gates_nonzero = topo.gates_nonzero && p.alpha1 != 0.0f;
+    if (image != net.image.data()) std::memcpy(net.image.data(), image, num_bytes);
+    return DGNN_OK;
+}
+
 int build_network(Network& net)
 {
     const TensorMap& t = net.tensors;
@@ -158,18 +218,24 @@ int build_network(Network& net)
 
     reserve(image, kZeroPageBytes);   // offset 0: the zero page
 
+    // graph.rs:76-96: probe `{:02}_residual/conv_{1,2}:0` from 2 upwards until one is missing
+    int blocks = 0;
+    while (t.find(scope(2 + blocks, "_residual") + "/conv_1:0") != t.end() && t.find(scope(2 + blocks, "_residual") + "/conv_2:0") != t.end()) ++blocks;
+    const size_t header_offset = reserve(image, sizeof(ImageHeader) + 4 * (size_t)blocks);
+    std::vector<float> alphas;
+
+    const unsigned layouts = pack_layouts_from_env(c);
+    topo.layouts = layouts;
     topo.num_channels = c;
     topo.num_samples = s;
     topo.res1.clear();
     topo.res2.clear();
 
-    int status = pack_conv(t, "01_upsample/conv_1", c, DGNN_NUM_FEATURES, 1.0f, 0.0f, 1.0f, image, topo.up);
+    int status = pack_conv(t, "01_upsample/conv_1", c, DGNN_NUM_FEATURES, 1.0f, 0.0f, 1.0f, layouts, image, topo.up);
     if (status != DGNN_OK) return status;
 
-    // graph.rs:76-96: probe `{:02}_residual/conv_{1,2}:0` from 2 upwards until one is missing
-    for (int i = 2;; ++i) {
+    for (int i = 2; i < 2 + blocks; ++i) {
         const std::string base = scope(i, "_residual");
-        if (t.find(base + "/conv_1:0") == t.end() || t.find(base + "/conv_2:0") == t.end()) break;
 
         float alpha = 0.5f;   // residual_block.rs:50
         auto it = t.find(base + "/alpha:0");
@@ -177,26 +243,30 @@ int build_network(Network& net)
             if (it->second.bytes.size() < 4) return DGNN_MALFORMED_WEIGHTS;
             alpha = it->second.as_f32();
         }
+        alphas.push_back(alpha);
 
         ConvParams c1, c2;
-        status = pack_conv(t, base + "/conv_1", c, c, 1.0f, 0.0f, 1.0f, image, c1);
+        status = pack_conv(t, base + "/conv_1", c, c, 1.0f, 0.0f, 1.0f, layouts, image, c1);
         if (status != DGNN_OK) return status;
         // conv_2: alpha = [gate, 1 - gate] (residual_block.rs:57) and offset scaled by gate (:72-74)
-        status = pack_conv(t, base + "/conv_2", c, c, alpha, 1.0f - alpha, alpha, image, c2);
+        status = pack_conv(t, base + "/conv_2", c, c, alpha, 1.0f - alpha, alpha, layouts, image, c2);
         if (status != DGNN_OK) return status;
 
         topo.res1.push_back(c1);
         topo.res2.push_back(c2);
     }
     topo.num_blocks = (int)topo.res1.size();
+    topo.gates_nonzero = true;
+    for (const ConvParams& p : topo.res2) topo.gates_nonzero = topo.gates_nonzero && p.alpha1 != 0.0f;
 
     const int head = 2 + topo.num_blocks;   // graph.rs:54-55
     const std::string policy = scope(head, "p_policy");
     const std::string value = scope(head, "v_value");
 
-    status = pack_conv(t, policy + "/conv_1", s, c, 1.0f, 0.0f, 1.0f, image, topo.policy_conv);
+    // the head convolutions as separate generic-kernel launches: only on the NHWC paths (the board path fuses both, below)
+    status = pack_conv(t, policy + "/conv_1", s, c, 1.0f, 0.0f, 1.0f, layouts & kPackGeneric, image, topo.policy_conv);
     if (status != DGNN_OK) return status;
-    status = pack_conv(t, value + "/conv_1", 2, c, 1.0f, 0.0f, 1.0f, image, topo.value_conv);
+    status = pack_conv(t, value + "/conv_1", 2, c, 1.0f, 0.0f, 1.0f, layouts & kPackGeneric, image, topo.value_conv);
     if (status != DGNN_OK) return status;
 
     const float tau = 1.0f / topo.softmax_temperature;   // policy_head.rs:46
@@ -207,9 +277,6 @@ int build_network(Network& net)
     const HostTensor* vw = find_half(t, value + "/linear_2:0", (size_t)DGNN_NUM_POINTS * 2);
     const HostTensor* vb = find_half(t, value + "/linear_2/offset:0", 1);
     if (!pw || !pb || !vw || !vb) return DGNN_MALFORMED_WEIGHTS;
-
-    topo.policy_w_offset = reserve(image, policy_in * DGNN_NUM_MOVES * sizeof(uint16_t));
-    std::memcpy(image.data() + topo.policy_w_offset, pw->bytes.data(), policy_in * DGNN_NUM_MOVES * sizeof(uint16_t));
 
     topo.policy_b_offset = reserve(image, DGNN_NUM_MOVES * sizeof(uint16_t));
     {
@@ -227,17 +294,13 @@ int build_network(Network& net)
     // dense.rs:182-189: the policy matrix transposed to [out][in] for the MFMA GEMM (heads.hip), rows and columns zero padded
     topo.policy_k_pad = (int)((policy_in + 63) / 64 * 64);
     topo.policy_wt_offset = reserve(image, (size_t)384 * topo.policy_k_pad * sizeof(uint16_t));
-    {
-        uint16_t* dst = reinterpret_cast<uint16_t*>(image.data() + topo.policy_wt_offset);
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(pw->bytes.data());
-        for (size_t k = 0; k < policy_in; ++k)
-            for (int m = 0; m < DGNN_NUM_MOVES; ++m) dst[(size_t)m * topo.policy_k_pad + k] = src[k * DGNN_NUM_MOVES + m];
-    }
+    pack_dense_transposed(reinterpret_cast<const uint16_t*>(pw->bytes.data()), (int)policy_in, DGNN_NUM_MOVES, topo.policy_k_pad,
+                          reinterpret_cast<uint16_t*>(image.data() + topo.policy_wt_offset));
 
     // both head convolutions as one filter with 32 (zero padded) output rows, in the fragment order of
     // head_conv_board_kernel: [chunk][tap][k16][lane][8], lane l = row (l & 31), channels chunk*32 + k16*16 + (l>>5)*8 ..
     topo.head_w_board_offset = 0;
-    if (c % 32 == 0 && s + 2 <= 32) {
+    if ((layouts & kPackBoard) && c % 32 == 0 && s + 2 <= 32) {
         const HostTensor* pcw = find_half(t, policy + "/conv_1:0", (size_t)s * 9 * c);
         const HostTensor* pcb = find_half(t, policy + "/conv_1/offset:0", (size_t)s);
         const HostTensor* vcw = find_half(t, value + "/conv_1:0", (size_t)2 * 9 * c);
@@ -267,8 +330,28 @@ int build_network(Network& net)
 
     reserve(image, 0);
     image.resize((image.size() + kAlign - 1) / kAlign * kAlign, 0);
+
+    ImageHeader h;
+    std::memcpy(h.magic, kMagic, 8);
+    h.header_bytes = (uint32_t)(sizeof(ImageHeader) + 4 * alphas.size());
+    h.layouts = layouts;
+    h.image_bytes = image.size();
+    h.num_blocks = topo.num_blocks;
+    h.num_channels = c;
+    h.num_samples = s;
+    h.softmax_temperature = topo.softmax_temperature;
+    std::memcpy(image.data() + header_offset, &h, sizeof(h));
+    if (!alphas.empty()) std::memcpy(image.data() + header_offset + sizeof(h), alphas.data(), 4 * alphas.size());
+
     net.image.swap(image);
     return DGNN_OK;
+}
+
+// dense.rs:182-189: [in][out] as stored -> [out rounded up to 32 rows][k_pad] (the MFMA GEMM's A operand), zero padded
+void pack_dense_transposed(const uint16_t* w_in_out, int k_in, int n_out, int k_pad, uint16_t* dst)
+{
+    for (int k = 0; k < k_in; ++k)
+        for (int m = 0; m < n_out; ++m) dst[(size_t)m * k_pad + k] = w_in_out[(size_t)k * n_out + m];
 }
 
 }  // namespace dgnn

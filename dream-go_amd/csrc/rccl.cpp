@@ -1,0 +1,276 @@
+// The one collective of the path, inside the library: an RCCL broadcast of the packed weight image (include/dgnn.h,
+// "multi-GPU").  Replaces the per-device host upload of every tensor (src/libdg_nn/tensor.rs:123-141, run lazily by each
+// device's first forward) when weights are loaded or refreshed: the rank that read the file sends ONE contiguous image
+// over xGMI, the receivers take the launch scalars (gates, temperature) from the header it carries.
+//
+// librccl is opened at run time (dlopen), not linked: a host that never broadcasts -- the single-GPU engine, the CPU
+// tests -- loads libdgnn_hip.so with nothing but the HIP runtime, and a host that already has RCCL in the process (a
+// PyTorch harness, for one) shares that copy instead of loading a second one.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "dgnn_internal.h"
+
+namespace dgnn {
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+thread_local int g_last_rccl_error = 0;
+
+const Rccl* rccl()
+{
+    static Rccl lib;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy that is already in the process first (same soname: PyTorch-ROCm ships one), then the ROCm installation
+        const char* const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        void* h = nullptr;
+        for (const char* name : names) if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
+        if (!h) for (const char* name : names) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        Rccl r;
+        r.handle = h;
+#define DGNN_SYM(field, symbol) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, #symbol))
+        DGNN_SYM(get_unique_id, ncclGetUniqueId);
+        DGNN_SYM(comm_init_rank, ncclCommInitRank);
+        DGNN_SYM(comm_init_all, ncclCommInitAll);
+        DGNN_SYM(comm_destroy, ncclCommDestroy);
+        DGNN_SYM(comm_count, ncclCommCount);
+        DGNN_SYM(comm_user_rank, ncclCommUserRank);
+        DGNN_SYM(broadcast, ncclBroadcast);
+        DGNN_SYM(group_start, ncclGroupStart);
+        DGNN_SYM(group_end, ncclGroupEnd);
+        DGNN_SYM(error_string, ncclGetErrorString);
+#undef DGNN_SYM
+        if (r.get_unique_id && r.comm_init_rank && r.comm_init_all && r.comm_destroy && r.comm_count && r.comm_user_rank &&
+            r.broadcast && r.group_start && r.group_end && r.error_string)
+            lib = r;
+    });
+    return lib.handle ? &lib : nullptr;
+}
+
+#define DGNN_NCCL(expr)                                  \
+    do {                                                 \
+        const ncclResult_t nccl_status__ = (expr);       \
+        if (nccl_status__ != ncclSuccess) {              \
+            g_last_rccl_error = (int)nccl_status__;      \
+            return DGNN_COMM_ERROR;                      \
+        }                                                \
+    } while (0)
+
+#define DGNN_HIP_(expr)                                  \
+    do {                                                 \
+        const hipError_t hip_status__ = (expr);          \
+        if (hip_status__ != hipSuccess) {                \
+            set_last_hip_error((int)hip_status__);       \
+            return DGNN_HIP_ERROR;                       \
+        }                                                \
+    } while (0)
+
+}  // namespace
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int device = 0;
+    int rank = 0;
+    int num_ranks = 0;
+    bool owned = true;
+};
+
+}  // namespace dgnn
+
+using namespace dgnn;
+
+extern "C" {
+
+int dgnn_rccl_available(void) { return rccl() ? 1 : 0; }
+
+int dgnn_last_rccl_error(void) { return g_last_rccl_error; }
+
+const char* dgnn_rccl_error_string(int code)
+{
+    const Rccl* r = rccl();
+    return r ? r->error_string((ncclResult_t)code) : "librccl not found";
+}
+
+int dgnn_rccl_unique_id(uint8_t* id_out)
+{
+    if (!id_out) return DGNN_BAD_ARGUMENT;
+    const Rccl* r = rccl();
+    if (!r) return DGNN_COMM_ERROR;
+    static_assert(sizeof(ncclUniqueId) == DGNN_RCCL_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    DGNN_NCCL(r->get_unique_id(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return DGNN_OK;
+}
+
+int dgnn_rccl_comm_create(int device, int num_ranks, int rank, const uint8_t* id, dgnn_comm** out)
+{
+    if (!id || !out || num_ranks <= 0 || rank < 0 || rank >= num_ranks) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    const Rccl* r = rccl();
+    if (!r) return DGNN_COMM_ERROR;
+    int count = 0;
+    DGNN_HIP_(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP_(hipSetDevice(device));
+    Comm* c = new (std::nothrow) Comm();
+    if (!c) return DGNN_OUT_OF_MEMORY;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    const ncclResult_t status = r->comm_init_rank(&c->comm, num_ranks, uid, rank);
+    if (status != ncclSuccess) { g_last_rccl_error = (int)status; delete c; return DGNN_COMM_ERROR; }
+    c->device = device;
+    c->rank = rank;
+    c->num_ranks = num_ranks;
+    *out = reinterpret_cast<dgnn_comm*>(c);
+    return DGNN_OK;
+}
+
+int dgnn_rccl_comm_wrap(void* nccl_comm, int device, dgnn_comm** out)
+{
+    if (!nccl_comm || !out) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    const Rccl* r = rccl();
+    if (!r) return DGNN_COMM_ERROR;
+    Comm* c = new (std::nothrow) Comm();
+    if (!c) return DGNN_OUT_OF_MEMORY;
+    c->comm = (ncclComm_t)nccl_comm;
+    c->owned = false;
+    c->device = device;
+    ncclResult_t status = r->comm_count(c->comm, &c->num_ranks);
+    if (status == ncclSuccess) status = r->comm_user_rank(c->comm, &c->rank);
+    if (status != ncclSuccess) { g_last_rccl_error = (int)status; delete c; return DGNN_COMM_ERROR; }
+    *out = reinterpret_cast<dgnn_comm*>(c);
+    return DGNN_OK;
+}
+
+int dgnn_rccl_comm_info(const dgnn_comm* comm, int* num_ranks, int* rank, int* device)
+{
+    if (!comm) return DGNN_BAD_ARGUMENT;
+    const Comm* c = reinterpret_cast<const Comm*>(comm);
+    if (num_ranks) *num_ranks = c->num_ranks;
+    if (rank) *rank = c->rank;
+    if (device) *device = c->device;
+    return DGNN_OK;
+}
+
+void dgnn_rccl_comm_destroy(dgnn_comm* comm)
+{
+    if (!comm) return;
+    Comm* c = reinterpret_cast<Comm*>(comm);
+    const Rccl* r = rccl();
+    if (r && c->owned && c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)r->comm_destroy(c->comm);
+    }
+    delete c;
+}
+
+int dgnn_broadcast_weights(dgnn_network* net, dgnn_comm* comm, int root)
+{
+    if (!net || !comm) return DGNN_BAD_ARGUMENT;
+    Comm* c = reinterpret_cast<Comm*>(comm);
+    if (root < 0 || root >= c->num_ranks) return DGNN_BAD_ARGUMENT;
+    const Rccl* r = rccl();
+    if (!r) return DGNN_COMM_ERROR;
+
+    void* d_image = nullptr;
+    size_t num_bytes = 0;
+    // the root sends its image (uploaded on first use); a receiver that has not touched the device yet only reserves the range
+    int status = c->rank == root ? dgnn_network_weight_image(net, c->device, &d_image, &num_bytes)
+                                 : dgnn_network_weight_image_reserve(net, c->device, &d_image, &num_bytes);
+    if (status != DGNN_OK) return status;
+    DGNN_HIP_(hipSetDevice(c->device));
+    DGNN_HIP_(hipDeviceSynchronize());                   // no forward may be reading the image while it is replaced
+    hipStream_t stream = nullptr;
+    DGNN_HIP_(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const ncclResult_t sent = r->broadcast(d_image, d_image, num_bytes, ncclUint8, root, c->comm, stream);
+    const hipError_t waited = hipStreamSynchronize(stream);
+    (void)hipStreamDestroy(stream);
+    if (sent != ncclSuccess) { g_last_rccl_error = (int)sent; return DGNN_COMM_ERROR; }
+    if (waited != hipSuccess) { set_last_hip_error((int)waited); return DGNN_HIP_ERROR; }
+    // receivers: the image in place, now also on the host, with ITS header's gates and temperature (a no-op copy on the root)
+    return dgnn_network_set_weight_image(net, c->device, d_image, num_bytes, 1);
+}
+
+int dgnn_broadcast_weights_devices(dgnn_network* net, const int* devices, int num_devices)
+{
+    if (!net || num_devices <= 0) return DGNN_BAD_ARGUMENT;
+    std::vector<int> list;
+    if (devices) list.assign(devices, devices + num_devices);
+    else for (int d = 0; d < num_devices; ++d) list.push_back(d);
+    for (size_t i = 0; i < list.size(); ++i)
+        for (size_t j = 0; j < i; ++j) if (list[i] == list[j]) return DGNN_BAD_ARGUMENT;   // one rank per device
+
+    // the first device gets the host image over PCIe (if it does not hold it yet), the others only reserve the range and
+    // receive it over xGMI -- with one device that is all there is to do
+    std::vector<void*> images(list.size());
+    size_t num_bytes = 0;
+    for (size_t i = 0; i < list.size(); ++i) {
+        const int status = i == 0 ? dgnn_network_weight_image(net, list[i], &images[i], &num_bytes)
+                                  : dgnn_network_weight_image_reserve(net, list[i], &images[i], &num_bytes);
+        if (status != DGNN_OK) return status;
+    }
+    if (list.size() == 1) return DGNN_OK;
+
+    const Rccl* r = rccl();
+    if (!r) return DGNN_COMM_ERROR;
+    std::vector<ncclComm_t> comms(list.size(), nullptr);
+    DGNN_NCCL(r->comm_init_all(comms.data(), (int)list.size(), list.data()));
+    std::vector<hipStream_t> streams(list.size(), nullptr);
+    int status = DGNN_OK;
+    for (size_t i = 0; i < list.size() && status == DGNN_OK; ++i) {
+        if (hipSetDevice(list[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess)
+            status = DGNN_HIP_ERROR;
+    }
+    if (status == DGNN_OK) {
+        ncclResult_t st = r->group_start();                 // one thread, several ranks: the calls must be fused in a group
+        for (size_t i = 0; i < list.size() && st == ncclSuccess; ++i) {
+            (void)hipSetDevice(list[i]);
+            st = r->broadcast(images[i], images[i], num_bytes, ncclUint8, 0, comms[i], streams[i]);
+        }
+        const ncclResult_t ended = r->group_end();
+        if (st == ncclSuccess) st = ended;
+        if (st != ncclSuccess) { g_last_rccl_error = (int)st; status = DGNN_COMM_ERROR; }
+    }
+    for (size_t i = 0; i < list.size(); ++i) {
+        if (streams[i]) {
+            (void)hipSetDevice(list[i]);
+            if (hipStreamSynchronize(streams[i]) != hipSuccess && status == DGNN_OK) status = DGNN_HIP_ERROR;
+            (void)hipStreamDestroy(streams[i]);
+        }
+        if (comms[i]) (void)r->comm_destroy(comms[i]);
+    }
+    if (status != DGNN_OK) {
+        // the receivers' ranges may hold anything now: fall back to the reference's way, a host upload per device
+        const void* host = nullptr;
+        size_t n = 0;
+        if (dgnn_network_weight_image_host(net, &host, &n) == DGNN_OK) (void)dgnn_network_set_weight_image(net, list[0], host, n, 0);
+    }
+    return status;
+}
+
+}  // extern "C"

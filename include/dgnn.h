@@ -37,11 +37,13 @@ extern "C" {
 #define DGNN_BAD_ARGUMENT       -4  /* null pointer, batch <= 0, feature count != batch * 11552 (the debug_assert!s of graph.rs:124-125) */
 #define DGNN_OUT_OF_MEMORY      -5  /* host allocation failed */
 #define DGNN_UNSUPPORTED        -6  /* architecture outside what the kernels cover (num_channels not a multiple of 32, > 1024, ...) */
+#define DGNN_COMM_ERROR         -8  /* librccl missing or an RCCL call failed; see dgnn_last_rccl_error() (-7 is DGNN_PROBE_CONFLICT) */
 
 #define DGNN_NUM_FEATURES   32      /* features::V1::num_features(), src/libdg_go/utils/features.rs:88-90 */
 #define DGNN_NUM_POINTS     361     /* 19 x 19, src/libdg_nn/layers/conv2d.rs:50 */
 #define DGNN_FEATURE_SIZE   11552   /* features::V1::size() = 32 * 361, features.rs:94-96 */
 #define DGNN_NUM_MOVES      362     /* 361 points + pass, src/libdg_nn/layers/policy_head.rs:54 */
+#define DGNN_PACKED_WORDS   368     /* packed features of one board, 32-bit words: see dgnn_forward_packed */
 
 typedef struct dgnn_network dgnn_network;     /* replaces dg_nn::Network  (src/libdg_nn/network.rs:83-86)  */
 typedef struct dgnn_workspace dgnn_workspace; /* replaces dg_nn::Workspace (src/libdg_nn/graph.rs:99-113) */
@@ -125,6 +127,24 @@ int dgnn_forward_wait(dgnn_workspace* ws, uint16_t* value_out, uint16_t* policy_
 int dgnn_forward_n(dgnn_workspace* ws, const uint16_t* features, int count, uint16_t* value_out, uint16_t* policy_out);
 int dgnn_forward_submit_n(dgnn_workspace* ws, const uint16_t* features, int count);
 
+/* The same evaluation from PACKED features.  features::V1 (src/libdg_go/utils/features.rs:99-251) only ever produces, per
+ * board, 29 binary planes (channels 2..31, value 0 or 1) and two planes that are 0 or ONE board-wide constant (channels 0 / 1:
+ * the komi-scaled colour planes, features.rs:236-239).  Packed form of one board, DGNN_PACKED_WORDS 32-bit words:
+ *   words 0..360   bit c of word 19 * y + x is set  <=>  channel c of that point is non-zero
+ *   word  361      fp16 bits of the channel-0 constant | fp16 bits of the channel-1 constant << 16
+ *   words 362..367 zero (16-byte multiple)
+ * 1 472 bytes instead of 23 104 over PCIe and through the batcher; the device expands it directly into the up-layer's
+ * input layout.  Outputs are bit-identical to dgnn_forward on the fp16 tensor the words describe (dgnn_features_unpack). */
+int dgnn_forward_packed(dgnn_workspace* ws, const uint32_t* packed, int count, uint16_t* value_out, uint16_t* policy_out);
+int dgnn_forward_submit_packed(dgnn_workspace* ws, const uint32_t* packed, int count);   /* then dgnn_forward_wait */
+/* fp16 HWC features -> packed words (count boards).  DGNN_BAD_ARGUMENT when a board is not representable: a channel >= 2
+ * holding something other than 0 / 1, or channel 0 / 1 holding two different non-zero values. */
+int dgnn_features_pack(const uint16_t* features, int count, uint32_t* packed);
+int dgnn_features_unpack(const uint32_t* packed, int count, uint16_t* features);
+/* The workspace's pinned staging buffer for packed features (batch * DGNN_PACKED_WORDS words): a caller that assembles
+ * its batch there and passes the pointer skips the staging memcpy. */
+int dgnn_workspace_packed_buffer(dgnn_workspace* ws, uint32_t** h_packed);
+
 /* ---- device-resident variants (measurement harness; inputs already in HBM) ----------------- */
 
 int dgnn_workspace_batch_size(const dgnn_workspace* ws, int* batch_size, int* device);
@@ -176,6 +196,21 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
                        const uint16_t* w_krsc, const uint16_t* bias, int cout,
                        float alpha1, float alpha2, const uint16_t* z, int relu, uint16_t* y);
 
+/* One Dense::forward (src/libdg_nn/layers/dense.rs:173-220) on host buffers through the MFMA GEMM of the policy head
+ * (heads.hip: policy_gemm_kernel), for the layer-level tests that mirror the reference's own (dense.rs:243-299):
+ *   y[b][m] = act(fp16(alpha * sum_k x[b][k] * w[k][m] + bias[m]))      fp32 accumulate
+ *   x [batch][k_in] fp16, w [k_in][n_out] fp16 AS STORED in the weights file ([in][out]; the transpose of dense.rs:182-189
+ *   is done here), bias [n_out] fp16 (already scaled by the caller where the reference scales it), y [batch][n_out];
+ *   k_in a multiple of 8; relu != 0 selects ReLU (dense.rs:108-116), 0 the identity. */
+int dgnn_layer_dense(int device, const uint16_t* x, int batch, int k_in, const uint16_t* w_in_out, const uint16_t* bias,
+                     int n_out, float alpha, int relu, uint16_t* y);
+
+/* The tail of both heads (heads.hip: softmax_value_kernel) on host buffers: cudnnSoftmaxForward ACCURATE over the 362 logits
+ * of a board (src/libdg_cuda/cudnn/softmax.rs:58-79; policy_head.rs:98-100) and the value head's Dense 722 -> 1 followed by
+ * tanh (value_head.rs:80-81).  logits [batch][362], value_features [batch][722], value_w [722], value_b [1]. */
+int dgnn_layer_heads(int device, const uint16_t* logits, const uint16_t* value_features, int batch, const uint16_t* value_w,
+                     const uint16_t* value_b, uint16_t* policy_out, uint16_t* value_out);
+
 /* ---- multi-GPU: weight image for an RCCL broadcast ------------------------------------------ */
 
 /* The packed, kernel-native weight image of `net` on `device` (uploaded on first use) and its size.
@@ -186,10 +221,18 @@ int dgnn_network_weight_image(dgnn_network* net, int device, void** d_image, siz
 /* A 64-bit FNV-1a checksum of the host-side weight image, to verify a broadcast. */
 int dgnn_network_weight_checksum(const dgnn_network* net, uint64_t* checksum);
 
-/* Weight refresh: overwrite the image on `device` with `num_bytes` (== the image size) from `src`, which is a
- * device pointer on the same device when src_on_device != 0 (e.g. the buffer an RCCL broadcast landed in; pass
- * the pointer dgnn_network_weight_image returned to make it a no-op) or a host pointer otherwise.
- * Waits for the device to go idle first. */
+/* The same range without the upload when `device` is touched for the first time: what a RECEIVER of a broadcast needs
+ * (contents undefined until the collective has landed and dgnn_network_set_weight_image adopted it). */
+int dgnn_network_weight_image_reserve(dgnn_network* net, int device, void** d_image, size_t* num_bytes);
+
+/* Weight refresh.  `src` holds a whole image (`num_bytes` == the image size) produced by a network of the SAME architecture
+ * and packing -- the image starts with a header (architecture, packing, residual gates `NN_residual/alpha:0`, soft-max
+ * temperature) that is checked first: a foreign image is refused with DGNN_BAD_ARGUMENT / DGNN_MALFORMED_WEIGHTS and nothing is
+ * changed.  `src` is a device pointer on `device` when src_on_device != 0 (e.g. the buffer an RCCL broadcast landed in; the
+ * pointer dgnn_network_weight_image returned makes the device copy a no-op) or a host pointer otherwise.  Afterwards the
+ * network launches with the SENDER's gates and temperature, its host image (dgnn_network_weight_image_host / _checksum), every
+ * device copy and every cached launch descriptor are the new ones.  Waits for the devices to go idle first; no forward may be
+ * in flight. */
 int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src, size_t num_bytes, int src_on_device);
 
 /* FNV-1a checksum of the image as it currently sits in `device` memory (downloads it). */
@@ -197,6 +240,33 @@ int dgnn_network_weight_checksum_device(dgnn_network* net, int device, uint64_t*
 
 /* The host-side weight image itself (read-only, owned by the network). */
 int dgnn_network_weight_image_host(const dgnn_network* net, const void** image, size_t* num_bytes);
+
+/* ---- the collective itself: RCCL inside the library ------------------------------------------------------------
+ * librccl is opened with dlopen on first use (a copy already in the process is shared); a host that never calls these
+ * functions needs only the HIP runtime.  Replaces, at load / weight refresh, the host upload every device performs on its
+ * own in the reference (Tensor::copy_to_device, src/libdg_nn/tensor.rs:123-141, once per device and tensor). */
+#define DGNN_RCCL_UNIQUE_ID_BYTES 128
+typedef struct dgnn_comm dgnn_comm;
+int dgnn_rccl_available(void);                         /* 1 when librccl could be opened */
+int dgnn_last_rccl_error(void);                        /* the ncclResult_t of the most recent DGNN_COMM_ERROR on this thread */
+const char* dgnn_rccl_error_string(int nccl_result);
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks by whatever channel the host has (a file, a
+ * socket, MPI, a torch.distributed store). */
+int dgnn_rccl_unique_id(uint8_t* id_out /* DGNN_RCCL_UNIQUE_ID_BYTES */);
+/* ncclCommInitRank on `device`: collective over the num_ranks callers (one process per GPU, or one thread per GPU). */
+int dgnn_rccl_comm_create(int device, int num_ranks, int rank, const uint8_t* id, dgnn_comm** out);
+/* Use a communicator the host application already has (an ncclComm_t); not destroyed by dgnn_rccl_comm_destroy. */
+int dgnn_rccl_comm_wrap(void* nccl_comm, int device, dgnn_comm** out);
+int dgnn_rccl_comm_info(const dgnn_comm* comm, int* num_ranks, int* rank, int* device);
+void dgnn_rccl_comm_destroy(dgnn_comm* comm);
+/* ONE ncclBroadcast of the packed weight image from rank `root` into every rank's device copy, then
+ * dgnn_network_set_weight_image on what arrived (header check, gates / temperature adopted).  Collective: every rank of the
+ * communicator calls it with a network of the same architecture.  Blocking. */
+int dgnn_broadcast_weights(dgnn_network* net, dgnn_comm* comm, int root);
+/* The single-process form (the reference's own process model: one host process, all devices, predictors/nn.rs:84-108): the
+ * image is uploaded to devices[0] over PCIe and broadcast to the others over xGMI (ncclCommInitAll + one grouped
+ * ncclBroadcast).  devices == NULL: devices 0..num_devices-1. */
+int dgnn_broadcast_weights_devices(dgnn_network* net, const int* devices, int num_devices);
 
 /* ============================================================================================================
  * Host side of the boundary (scope row f-1): policy symmetries, transposition cache, many-game leaf batcher.
@@ -251,6 +321,8 @@ const uint16_t* dgnn_batch_features(const dgnn_batch* batch);
 /* Batch::forward (batch.rs:35-40): evaluates the batch on the batcher's device through a pooled workspace of
  * capacity max_batch_size; value_out[n], policy_out[n * 362] in tag order; the batch stops counting as alive. */
 int dgnn_batch_forward(dgnn_batch* batch, uint16_t* value_out, uint16_t* policy_out);
+/* The same on an explicit device (NnPredictor::predict picks one per call, predictors/nn.rs:87-89). */
+int dgnn_batch_forward_on(dgnn_batch* batch, int device, uint16_t* value_out, uint16_t* policy_out);
 void dgnn_batch_destroy(dgnn_batch* batch);
 
 /* Cross-caller coalescing (no reference counterpart: the reference sends the <= 8-board full_forward calls of its
@@ -259,9 +331,32 @@ void dgnn_batch_destroy(dgnn_batch* batch);
  * threads of the pool turn everything that has been pushed meanwhile into device batches (<= max_batch_size boards,
  * <= max_batches in flight). */
 typedef struct dgnn_pool dgnn_pool;
+/* Ownership: the pool holds a reference on the batcher until dgnn_pool_destroy has joined its workers, so the two may be
+ * destroyed in either order. */
 int dgnn_pool_create(dgnn_batcher* batcher, int num_workers, dgnn_pool** out);
 void dgnn_pool_destroy(dgnn_pool* pool);   /* every dgnn_pool_predict call must have returned */
 int dgnn_pool_predict(dgnn_pool* pool, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out);
+
+/* Predictor::predict as a C callback (src/libdg_mcts/predictor.rs:92): n boards of 11552 fp16 features -> value[n],
+ * policy[n * 362] fp16; returns a DGNN_* status. */
+typedef int (*dgnn_predict_fn)(void* ctx, const uint16_t* features, int n, uint16_t* value_out, uint16_t* policy_out);
+
+/* NnPredictor over SEVERAL devices in one process (src/libdg_mcts/predictors/nn.rs:46-108: one queue, `2 x devices` batches
+ * alive, every batch sent to the next device of Device::all()).  One queue shared by all devices; `workers_per_device`
+ * threads are bound to each device and a batch goes to whichever device has a worker free (the reference's round robin
+ * without its head-of-line blocking); `batches_per_device` x devices batches alive (the reference: 2).  devices == NULL: every
+ * visible device.  The pool owns its batcher.  dgnn_pool_predict / dgnn_pool_predictor() work on it unchanged, so one host
+ * process (dgnn_selfplay_go, a GTP engine) drives all GPUs of a node. */
+int dgnn_pool_create_devices(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,
+                             int workers_per_device, dgnn_pool** out);
+/* The same pool over `num_lanes` copies of a predictor callback instead of devices: the queueing, coalescing and lane logic
+ * without a GPU (CPU tests, dry runs of the harness). */
+int dgnn_pool_create_callbacks(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                               int workers_per_lane, dgnn_pool** out);
+/* Counters: dgnn_pool_predict calls, boards / device batches evaluated, and the same per lane (device) for the first
+ * lane_capacity lanes.  Any out pointer may be NULL. */
+int dgnn_pool_stats(dgnn_pool* pool, int* num_lanes, uint64_t* calls, uint64_t* boards, uint64_t* batches,
+                    uint64_t* lane_boards, uint64_t* lane_batches, int lane_capacity);
 
 /* ============================================================================================================
  * Formats either side of the path (scope row f-4), formats.cpp.
@@ -342,9 +437,7 @@ int dgnn_choose_f64(const double* items, int n, double cutoff_percentile, double
 
 /* ---- search driver (scope row f-2, second part), search.cpp ------------------------------------------------- */
 
-/* Predictor::predict (src/libdg_mcts/predictor.rs:92) as a C callback: n boards of 11552 fp16 features ->
- * value[n], policy[n * 362] fp16; returns a DGNN_* status. */
-typedef int (*dgnn_predict_fn)(void* ctx, const uint16_t* features, int n, uint16_t* value_out, uint16_t* policy_out);
+/* dgnn_predict_fn (declared with the leaf pool above) is the predictor behind a search. */
 dgnn_predict_fn dgnn_pool_predictor(void);    /* ctx = a dgnn_pool*: the HIP engine behind the cross-caller batcher */
 dgnn_predict_fn dgnn_hash_predictor(void);    /* ctx unused: deterministic CPU stand-in (role of predictors/{random,fake}.rs) */
 

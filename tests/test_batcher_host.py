@@ -192,3 +192,91 @@ def test_batcher_conserves_every_event_under_threads(api):
     [t.join() for t in workers]
     assert sorted(seen) == sorted(g * 1000 + i for g in range(8) for i in range(250))
     assert len(seen) == produced and b.pending() == (0, 0)
+
+
+# ---- round 2: the pool over lanes (devices in production, predictor callbacks here), NnPredictor's process model
+
+def test_pool_over_callback_lanes_coalesces_and_spreads(api):
+    """dgnn_pool_create_callbacks: the multi-device pool's queueing with the deterministic CPU predictor in place of the
+    devices.  Results equal direct predictor calls whatever lane evaluated them; every lane gets work under load; the
+    counters add up (predictors/nn.rs:84-108: one queue, batches spread over Device::all())."""
+    import ctypes
+    import threading
+    fn = api.lib.dgnn_hash_predictor()
+    lanes, callers, per_call, rounds = 3, 12, 5, 20
+    pool = api.LeafPool.over_callbacks(fn, None, num_lanes=lanes, max_batch_size=16, batches_per_lane=2, workers_per_lane=1)
+    rng = np.random.default_rng(5)
+    feats = (rng.random((callers, per_call, api.FEATURE_SIZE)) < 0.2).astype(np.float16)
+
+    # the predictor called directly
+    predict = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint16), ctypes.c_int,
+                               ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16))(fn)
+    want = []
+    for c in range(callers):
+        v = np.empty(per_call, np.uint16); p = np.empty(per_call * api.NUM_MOVES, np.uint16)
+        f = np.ascontiguousarray(feats[c]).view(np.uint16).reshape(-1)
+        assert predict(None, f.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), per_call, v.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                       p.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16))) == api.OK
+        want.append((v.copy(), p.copy()))
+
+    errors = []
+
+    def caller(c):
+        try:
+            for _ in range(rounds):
+                got = pool.predict(feats[c], per_call)
+                for i, pr in enumerate(got):
+                    assert np.asarray(pr._value).view(np.uint16) == want[c][0][i]
+                    assert np.array_equal(pr._policy.view(np.uint16), want[c][1][i * api.NUM_MOVES:(i + 1) * api.NUM_MOVES])
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=caller, args=(c,)) for c in range(callers)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors[0]
+    st = pool.stats()
+    assert st["lanes"] == lanes and st["calls"] == callers * rounds
+    assert st["boards"] == callers * rounds * per_call == sum(st["lane_boards"])
+    assert st["batches"] == sum(st["lane_batches"]) <= st["boards"]
+    assert st["batches"] < st["boards"]                      # boards of different callers shared device batches
+    assert all(n > 0 for n in st["lane_batches"])            # every lane took part
+    pool.close()
+
+
+def test_pool_outlives_its_batcher_handle(api):
+    """LeafPool held a raw Batcher*; destroying the batcher first left the workers polling freed memory.  The
+    pool now holds a reference: either order is fine (the old order, batcher first, runs under the sanitizers in
+    tools/sanitize_host.sh)."""
+    fn = api.lib.dgnn_hash_predictor()
+    pool = api.LeafPool.over_callbacks(fn, None, num_lanes=1, max_batch_size=4)
+    feats = np.zeros(api.FEATURE_SIZE, np.float16)
+    assert len(pool.predict(feats, 1)) == 1
+    pool.close()
+    pool.close()                                            # idempotent
+
+    with pytest.raises(api.Error) as e:
+        api.LeafPool.over_callbacks(None, None)
+    assert e.value.status == api.BAD_ARGUMENT
+    with pytest.raises(api.Error) as e:
+        api.LeafPool.over_callbacks(fn, None, num_lanes=0)
+    assert e.value.status == api.BAD_ARGUMENT
+
+
+def test_idle_pool_workers_sleep(api):
+    """idle workers woke every 200 us.  They now sleep on a condition variable until something is queued AND a
+    batch slot is free: an idle pool burns (almost) no CPU, and a request is still served at once."""
+    import time
+    fn = api.lib.dgnn_hash_predictor()
+    pool = api.LeafPool.over_callbacks(fn, None, num_lanes=2, max_batch_size=8, workers_per_lane=2)
+    feats = np.zeros(api.FEATURE_SIZE, np.float16)
+    pool.predict(feats, 1)
+    t0, c0 = time.perf_counter(), time.process_time()
+    time.sleep(0.5)
+    cpu = time.process_time() - c0
+    wall = time.perf_counter() - t0
+    assert cpu < 0.05 * wall, (cpu, wall)                    # four workers polling every 200 us cost about 10 % of a core each
+    t1 = time.perf_counter()
+    pool.predict(feats, 1)
+    assert time.perf_counter() - t1 < 0.015                  # woken by the push, not by the 20 ms safety timeout
+    pool.close()

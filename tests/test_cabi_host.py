@@ -112,11 +112,21 @@ def test_weight_image_layout_and_prescaling(api, synth, oracle):
     image = net.weight_image_host().copy()
     tensors, _ = oracle.load_weights(text)
 
-    # first tensor of the image: up-conv filter, [9 * cin / 32][cout_pad][32] from KRSC [cout][3][3][cin]
+    # the image starts with the zero page (off-board taps), then the header: everything a receiver of a broadcast needs to
+    # launch besides tensors -- architecture, packing, the residual gates and the temperature (network.cpp: ImageHeader)
+    assert not image[:256].any()
+    assert image[256:264].tobytes() == b"DGNNIMG2"
+    header_bytes, layouts = image[264:272].view(np.uint32)
+    assert image[272:280].view(np.uint64)[0] == image.size
+    assert tuple(image[280:292].view(np.int32)) == (blocks, c, s)
+    assert image[292:296].view(np.float32)[0] == np.float32(0.709888)
+    assert header_bytes == 40 + 4 * blocks and image[296:300].view(np.float32)[0] == np.float32(0.25)   # alpha of block 0
+    assert layouts == 1                                   # C = 32: only the generic layout exists for it
+
+    # first tensor behind the header: up-conv filter, [9 * cin / 32][cout_pad][32] from KRSC [cout][3][3][cin]
     w = tensors["01_upsample/conv_1:0"].view(np.uint16)[: c * 9 * 32].reshape(c, 9, 32)
     expect = np.transpose(w, (1, 0, 2)).reshape(-1)
-    assert not image[:256].any()                          # the image starts with the zero page (off-board taps)
-    got = image[256: 256 + expect.size * 2].view(np.uint16)
+    got = image[512: 512 + expect.size * 2].view(np.uint16)
     assert np.array_equal(got, expect)
 
     # alpha * b2 rounded to fp16 (residual_block.rs:72-74) and tau * b_l (policy_head.rs:87-89) appear in the image
@@ -136,8 +146,29 @@ def test_weight_image_layout_and_prescaling(api, synth, oracle):
     assert _find(net.weight_image_host().view(np.uint16), bl1) >= 0
 
 
-def test_tile_filter_layout(api, synth, oracle):
+def test_image_carries_only_the_layouts_its_kernels_read(api, synth, monkeypatch):
+    """the image held every filter three ways (148.5 MB for 20 x 256).  By default only the board layout is
+    packed where the board kernel covers the network; the NHWC layouts are packed when DGNN_CONV selects those kernels."""
+    blocks, c = 2, 256
+    text = synth.to_json(synth.make_tensors(blocks, c, seed=8))
+    filters = (2 * blocks * 9 * c * c + 9 * 32 * c) * 2                      # residual + up-layer filter bytes
+    monkeypatch.delenv("DGNN_CONV", raising=False)
+    monkeypatch.delenv("DGNN_PACK", raising=False)
+    board_only = api.Network.from_json(text).weight_image_host().size
+    assert filters < board_only < filters + 6_000_000                       # + heads (2 x 2.1 MB dense, 147 KB head filter), padding
+    monkeypatch.setenv("DGNN_CONV", "tile2")
+    nhwc = api.Network.from_json(text).weight_image_host().size
+    assert 2 * filters - 1_000_000 < nhwc < 2 * filters + 6_000_000          # generic + tile
+    monkeypatch.setenv("DGNN_CONV", "v1")
+    assert api.Network.from_json(text).weight_image_host().size < nhwc - filters + 1_000_000
+    monkeypatch.delenv("DGNN_CONV")
+    monkeypatch.setenv("DGNN_PACK", "all")
+    assert api.Network.from_json(text).weight_image_host().size > 3 * filters
+
+
+def test_tile_filter_layout(api, synth, oracle, monkeypatch):
     """conv_tile.hip consumes [cout/256][chunk * 9 + tap][256 rows][8 slots][8] with slot ^= (row >> 1) & 7."""
+    monkeypatch.setenv("DGNN_CONV", "tile2")               # the tile layout is packed when the tile kernel is selected
     c = 256
     text = synth.to_json(synth.make_tensors(1, c, num_samples=2, seed=6))
     net = api.Network.from_json(text)                      # keep alive: the image view borrows its memory
@@ -237,3 +268,66 @@ def test_selfplay_example_in_c(tmp_path):
     strip = lambda text: re.sub(r"DT\[[^\]]*\]", "", text)          # the date is the only thing that may differ between two runs
     assert strip(first.stdout) == strip(again.stdout)
     assert "2 games, 60 stones" in first.stderr
+
+
+# ---- round 2: packed features, RCCL entry points (status paths without a GPU)
+
+def test_packed_features_round_trip(api, synth):
+    """dgnn_features_pack / _unpack: 361 plane masks + the two komi constants describe a features::V1 tensor exactly."""
+    rng = np.random.default_rng(12)
+    count = 3
+    f = (rng.random((count, 361, 32)) < 0.2).astype(np.float16)
+    komi = np.float16(0.5 + 0.5 * 6.5 / 7.5)
+    f[0, :, 0] = komi; f[0, :, 1] = 0                        # black to move
+    f[1, :, 0] = 0; f[1, :, 1] = komi                        # white to move
+    f[2, :, 0] = 0; f[2, :, 1] = 0                           # komi -7.5 clamps to 0 (features.rs:236-239)
+    packed = api.features_pack(f, count)
+    assert packed.size == count * api.PACKED_WORDS
+    words = packed.reshape(count, api.PACKED_WORDS)
+    assert words[0, 361] == int(komi.view(np.uint16)) and words[1, 361] == int(komi.view(np.uint16)) << 16 and words[2, 361] == 0
+    assert not words[:, 362:].any()
+    for c in range(32):
+        assert np.array_equal(((words[:, :361] >> c) & 1).astype(bool), f[:, :, c] != 0)
+    back = api.features_unpack(packed, count)
+    assert np.array_equal(back.view(np.uint16), f.reshape(-1).view(np.uint16))
+
+    bad = f.copy(); bad[1, 5, 7] = 0.5                       # a binary plane holding something else
+    with pytest.raises(api.Error) as e:
+        api.features_pack(bad, count)
+    assert e.value.status == api.BAD_ARGUMENT
+    bad = f.copy(); bad[0, 9, 0] = 1.0                       # two different constants in channel 0
+    with pytest.raises(api.Error) as e:
+        api.features_pack(bad, count)
+    assert e.value.status == api.BAD_ARGUMENT
+
+
+def test_real_board_features_are_packable(api):
+    """Every tensor dgnn_go_features produces has the packed form (all 8 symmetries, komi planes, ko, ladders)."""
+    board = api.Board(komi=6.5)
+    moves = [(3, 3), (15, 15), (3, 15), (15, 3), (9, 9), (2, 5), (5, 2), (16, 13), (13, 16), (10, 10)]
+    for i, (x, y) in enumerate(moves):
+        board.place(i % 2, x, y)
+    for sym in range(8):
+        f = board.get_features(len(moves) % 2, sym)
+        back = api.features_unpack(api.features_pack(f, 1), 1)
+        assert np.array_equal(back.view(np.uint16), np.asarray(f).reshape(-1).view(np.uint16))
+
+
+def test_rccl_entry_points_without_a_gpu(api):
+    """The collective lives in the library (dgnn_broadcast_weights); librccl is opened on demand.  Argument and
+    status paths that need no device."""
+    import ctypes
+    assert api.lib.dgnn_rccl_available() in (0, 1)
+    assert api.lib.dgnn_rccl_unique_id(None) == api.BAD_ARGUMENT
+    out = ctypes.c_void_p()
+    ident = (ctypes.c_uint8 * api.RCCL_UNIQUE_ID_BYTES)()
+    assert api.lib.dgnn_rccl_comm_create(0, 0, 0, ident, ctypes.byref(out)) == api.BAD_ARGUMENT      # no ranks
+    assert api.lib.dgnn_rccl_comm_create(0, 2, 2, ident, ctypes.byref(out)) == api.BAD_ARGUMENT      # rank outside the job
+    assert api.lib.dgnn_rccl_comm_create(0, 2, 0, None, ctypes.byref(out)) == api.BAD_ARGUMENT
+    assert api.lib.dgnn_rccl_comm_wrap(None, 0, ctypes.byref(out)) == api.BAD_ARGUMENT
+    assert api.lib.dgnn_broadcast_weights(None, None, 0) == api.BAD_ARGUMENT
+    assert api.lib.dgnn_broadcast_weights_devices(None, None, 2) == api.BAD_ARGUMENT
+    assert api.lib.dgnn_rccl_comm_info(None, None, None, None) == api.BAD_ARGUMENT
+    api.lib.dgnn_rccl_comm_destroy(None)
+    assert api.lib.dgnn_status_string(api.COMM_ERROR) == b"RCCL error"
+    assert api.lib.dgnn_rccl_error_string(0)                                                         # never NULL
