@@ -3,20 +3,33 @@
 forward line, src/dg/bench/forward.rs:28-47, and of src/dg_tests/benches/batch_sizes.rs:41-68).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+
+`--gpus N` with N > 1 and no launcher in the environment SPAWNS the N ranks itself (one process per GPU under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started under a launcher
+(RANK / WORLD_SIZE set) it is one of the ranks.  It never prints an `n_gpus` other than the one asked for.
 
 One "step" = one pass of the hot path (dg_nn::forward's device work, graph.rs:134-152) over one batch of
 synthetic positions that is already resident in HBM.  Workload at every N: BASELINE.json configs[2] --
 19x19, 20-block / 256-filter network, batch 256 per GPU -- the configuration the metric's roofline target is
 quoted on.  Multi-GPU: independent replicas, one process per GPU, units sharded across ranks with no data-path
-collective ("weak" scaling); the only collective is one RCCL broadcast of the packed weight image at start-up.
+collective ("weak" scaling); the only collective is one RCCL broadcast of the packed weight image at start-up,
+issued by libdgnn_hip.so itself (dgnn_broadcast_weights): every rank but 0 starts from DIFFERENT weights of the
+same architecture, so checksum agreement afterwards proves that RCCL moved the image.
+
+Beside the engine number the line carries a bounded, MEASURED self-play leg (`selfplay`): real Go boards, the
+search, the leaf pool and the engine together, with the evaluations per move, cache-hit ratio and mean device batch
+it actually saw (BASELINE.json's metric is games/hour + evals/s; SURVEY.md 8d "reports the measured ratio").
+
+`--dry` runs the same control flow without a GPU (gloo, the deterministic CPU predictor behind the leaf pool): it
+exists so that the N > 1 path is covered by the CPU tests; its numbers mean nothing and the line says "dry": true.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +42,7 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides
 PEAK_HBM_GBS = 8000.0
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -38,37 +51,31 @@ def parse_args():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=256, help="boards the CPU oracle evaluates for cpu_baseline (0 = skip)")
+    ap.add_argument("--selfplay-games", type=int, default=256, help="games in flight PER GPU in the measured self-play leg (0 = skip the leg)")
+    ap.add_argument("--selfplay-moves", type=int, default=6, help="stones per game in the self-play leg (bounds its duration)")
+    ap.add_argument("--selfplay-rollouts", type=int, default=800, help="--num-rollout of the self-play leg (BASELINE.json: 800)")
+    ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
-    return ap.parse_args()
+    ap.add_argument("--dry", action="store_true", help="no GPU: gloo + the CPU hash predictor behind the leaf pool (CPU tests of the N > 1 path)")
+    return ap.parse_args(argv)
 
 
-class _DevicePointer:
-    """Lets torch wrap an HBM range owned by libdgnn_hip.so (zero-copy) through __cuda_array_interface__."""
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-
-def broadcast_weights(net, device, torch, dist, replicas):
-    """One RCCL broadcast of the packed weight image from rank 0 over xGMI, verified by checksum."""
-    ptr, nbytes = net.weight_image(device)
-    try:
-        image = torch.as_tensor(_DevicePointer(ptr, nbytes), device=f"cuda:{device}")
-        replicas.broadcast_image(dist, image, src=0)
-        torch.cuda.synchronize(device)
-        mode = "zero-copy"
-    except Exception:   # noqa: BLE001 -- fall back to a staging tensor + device-to-device copy
-        image = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{device}")
-        if dist.get_rank() == 0:
-            image.copy_(torch.from_numpy(net.weight_image_host().copy()))
-        replicas.broadcast_image(dist, image, src=0)
-        torch.cuda.synchronize(device)
-        net.set_weight_image(device, image.data_ptr(), nbytes, src_on_device=True)
-        mode = "staged"
-    if not replicas.all_agree(dist, torch, net.weight_checksum_device(device), device=f"cuda:{device}"):
-        raise RuntimeError("weight image differs across ranks after the broadcast")
-    return mode, nbytes
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  The reference needs none -- one process drives every
+    device (src/libdg_mcts/predictors/nn.rs:64-67,87-89) -- so a bare invocation must not silently measure one GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def effective_cpus():
@@ -102,89 +109,237 @@ def cpu_baseline(text, features, batch, sample):
     }, (value, policy)
 
 
+class Job:
+    """The ranks of this run: torch.distributed for the barrier / the max-over-ranks clock, nothing on the data path."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: refusing to report a different n_gpus")
+        self.dry = args.dry
+        self.dist = None
+        self.torch = None
+        self.device = self.local_rank
+        self.tensor_device = "cpu"
+
+    def start(self, force):
+        import torch   # device plumbing + torch.distributed only; imported before libdgnn_hip.so is loaded (one HIP runtime)
+        self.torch = torch
+        if not self.dry:
+            visible = torch.cuda.device_count()
+            if visible < self.world:
+                raise SystemExit(f"--gpus {self.world} but only {visible} GPU(s) visible")
+            self.tensor_device = f"cuda:{self.device}"
+        if self.world > 1 or force:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            import torch.distributed as dist
+            if self.dry:
+                dist.init_process_group(backend="gloo")
+            else:
+                torch.cuda.set_device(self.device)
+                dist.init_process_group(backend="nccl", device_id=torch.device(self.tensor_device))
+            self.dist = dist
+
+    def barrier(self, ws=None):
+        if self.dist is not None:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize(self.device)
+        if ws is not None:
+            ws.sync()
+
+    def gather_int(self, value):
+        if self.dist is None:
+            return [int(value)]
+        t = self.torch.tensor([int(value) & 0x7FFFFFFFFFFFFFFF], dtype=self.torch.int64, device=self.tensor_device)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [int(x.item()) for x in out]
+
+    def gather_float(self, value):
+        if self.dist is None:
+            return [float(value)]
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.tensor_device)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+
+    def broadcast_bytes(self, payload, size):
+        """rank 0's bytes to everybody (the RCCL unique id travels this way; any host channel would do)."""
+        if self.dist is None:
+            return bytes(payload)
+        t = self.torch.zeros(size, dtype=self.torch.uint8, device=self.tensor_device)
+        if self.rank == 0:
+            t.copy_(self.torch.frombuffer(bytearray(payload), dtype=self.torch.uint8))
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
+    def finish(self):
+        if self.dist is not None:
+            import ctypes
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)   # every rank empties its C stdio (RCCL's banner) BEFORE the barrier rank 0 prints after
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def broadcast_weights(job, api, net):
+    """ONE broadcast of the packed weight image from rank 0, by the library's own RCCL (dgnn_broadcast_weights); in a dry run a
+    gloo broadcast of the host image.  Every rank but 0 holds different weights before it."""
+    before = job.gather_int(net.weight_checksum())
+    t0 = time.perf_counter()
+    if job.dry:
+        image = job.torch.from_numpy(net.weight_image_host())      # view of the library's host image
+        job.dist.broadcast(image, src=0)
+        after = job.gather_int(net.weight_checksum())
+        backend, nbytes, comm_ranks = "gloo (dry run, host image)", int(image.numel()), job.world
+    else:
+        ident = job.broadcast_bytes(api.Comm.unique_id() if job.rank == 0 else b"", api.RCCL_UNIQUE_ID_BYTES)
+        comm = api.Comm.create(job.device, job.world, job.rank, ident)
+        comm_ranks = comm.info()["num_ranks"]
+        net.broadcast_weights(comm, root=0)
+        comm.destroy()
+        after = job.gather_int(net.weight_checksum_device(job.device))
+        host = job.gather_int(net.weight_checksum())
+        if len(set(host)) != 1 or host != after:
+            raise RuntimeError("host and device weight images disagree after the broadcast")
+        backend, nbytes = "rccl (libdgnn_hip.so: ncclBroadcast over a communicator built from a unique id)", net.weight_image(job.device)[1]
+    seconds = time.perf_counter() - t0
+    if len(set(after)) != 1 or after[0] != before[0]:
+        raise RuntimeError(f"weight image differs across ranks after the broadcast: {after} (rank 0 had {before[0]})")
+    return {"backend": backend, "bytes": nbytes, "ranks": comm_ranks, "checksums_agree": True,
+            "distinct_images_before": len(set(before)), "seconds_incl_comm_setup": seconds}
+
+
+def selfplay_leg(job, api, replicas, net, args):
+    """Whole pipeline, measured: Go boards -> feature planes -> search (1 thread x K leaves per game) -> transposition cache ->
+    leaf pool -> engine, `selfplay_games` games in flight per GPU for their first `selfplay_moves` stones
+    (self_play.rs:423-459; rollouts per move follow the win rate, :234-241).  Games are sharded `id mod world`."""
+    games = args.selfplay_games * job.world
+    cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
+    if job.dry:
+        pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
+    else:
+        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=2, workers_per_device=2)
+    out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=args.selfplay_moves,
+                                    num_rollouts=args.selfplay_rollouts, threads_per_search=1, seed=20260930, pool=pool, cache=cache,
+                                    device=job.tensor_device, leaves_per_thread=args.selfplay_leaves)
+    st = pool.stats()
+    boards = sum(job.gather_int(st["boards"]))
+    batches = sum(job.gather_int(st["batches"]))
+    pool.close()
+    j = out["job"]
+    sec = max(j["seconds"], 1e-9)
+    moves_per_sec = j["moves"] / sec
+    leg = {
+        "what": f"{args.selfplay_games} games in flight per GPU, first {args.selfplay_moves} stones of each, --num-rollout {args.selfplay_rollouts}, "
+                f"1 search thread x {args.selfplay_leaves} leaves per game, transposition cache 200001 x 8 shards, through the leaf pool "
+                "(PCIe-inclusive); random-init weights",
+        "seconds": sec, "games": j["games"], "moves": j["moves"],
+        "evals_per_sec": j["evals"] / sec,                          # predictor evaluations (cache misses) per second, whole job
+        "device_boards_per_sec": boards / sec,
+        "mean_device_batch": boards / max(batches, 1),
+        "evals_per_move": j["evals"] / max(j["moves"], 1),          # MEASURED: what one move costs the engine
+        "cache_hit_ratio": j["cache_hits"] / max(j["cache_hits"] + j["evals"], 1),
+        "probe_conflicts": j["conflicts"],
+        "moves_per_sec": moves_per_sec,
+        "assumed_stones_per_game": 250,
+        "games_per_hour": moves_per_sec * 3600.0 / 250.0,
+        "note": "games_per_hour = measured moves/s x 3600 / 250 stones (a trained net's game length; a random-init net plays to the "
+                "722-stone cap: whole games measured in profiles/, DESIGN.md section 8). Opening moves only: later moves see more cache hits "
+                "and narrower trees.",
+        "host_cpus": effective_cpus(),
+    }
+    return leg
+
+
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
 
-    import torch   # device plumbing + torch.distributed only; must be imported before libdgnn_hip.so is loaded
+    job = Job(args)
+    job.start(args.force_dist)
     import __graft_entry__ as graft
     graft.package()
     from dream_go_amd import api, replicas, synth
 
-    dist = None
-    if world > 1 or args.force_dist:
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    device = local_rank
+    rank, world, device = job.rank, job.world, job.device
 
-    # ---- synthetic network + inputs in the reference's formats (no network access for real weights)
-    text = synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1))
+    # ---- synthetic network + inputs in the reference's formats (no network access for real weights).  Rank r > 0 starts from
+    # DIFFERENT weights (seed 1 + r): only the broadcast can make the replicas agree
+    text = synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1 + (rank if job.dist is not None else 0)))
     net = api.Network.from_json(text)
     info = net.info()
     features = synth.make_features(args.batch, seed=replicas.rank_seed(synth.FEATURE_SEED, rank))
 
-    bcast = None
-    if dist is not None:
-        bcast = broadcast_weights(net, device, torch, dist, replicas)
+    bcast = broadcast_weights(job, api, net) if job.dist is not None else None
 
-    ws = net.get_workspace(args.batch, device=device)
-    ws.upload(features)                              # inputs resident in HBM before the timed region
+    ws = None
+    tower_ms, tower_launches, total_ms = 0.0, 0, 0.0
+    if job.dry:
+        pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
+        for _ in range(args.warmup):
+            pool.predict(features, args.batch)
+        job.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pool.predict(features, args.batch)
+        job.barrier()
+        elapsed = time.perf_counter() - t0
+        pool.close()
+    else:
+        ws = net.get_workspace(args.batch, device=device)
+        ws.upload(features)                              # inputs resident in HBM before the timed region
+        for _ in range(args.warmup):
+            ws.forward_resident()
+        job.barrier(ws)
+        t0 = time.perf_counter()
+        # K passes back to back on the workspace's stream; HIP events on that stream bracket the whole run and the
+        # residual-tower launches of every pass (include/dgnn.h: dgnn_forward_timed)
+        total_ms, tower_ms, tower_launches = ws.forward_timed(args.steps)
+        job.barrier(ws)
+        elapsed = time.perf_counter() - t0
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        ws.sync()
-
-    for _ in range(args.warmup):
-        ws.forward_resident()
-    barrier()
-
-    t0 = time.perf_counter()
-    # K passes back to back on the workspace's stream; HIP events on that stream bracket the whole run and the
-    # residual-tower launches of every pass (include/dgnn.h: dgnn_forward_timed)
-    total_ms, tower_ms, tower_launches = ws.forward_timed(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    if dist is not None:
-        elapsed = replicas.max_over_ranks(dist, torch, elapsed, device=f"cuda:{device}")
-
+    per_rank_elapsed = job.gather_float(elapsed)
+    elapsed = max(per_rank_elapsed)                      # the job's clock is the slowest rank's
     evals = world * args.batch * args.steps
     value = evals / elapsed
 
-    # ---- roofline of the dominant kernel: the C -> C residual convolution (2 per block)
     c = info["num_channels"]
-    conv_flops = 2.0 * 9 * c * c * 361 * args.batch            # algorithmic FLOPs per convolution
-    convs_per_launch = max(1, round(2 * info["num_blocks"] * args.steps / max(tower_launches, 1)))   # 1, or 2 * blocks (tower kernel)
-    launch_ms = tower_ms / max(tower_launches, 1)
-    achieved = conv_flops * convs_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-    roofline = {
-        "bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
-        "kernel": f"residual 3x3 convolution C->C ({ws.conv_kernel()})", "launch_us": launch_ms * 1e3,
-        "launches_timed": tower_launches, "convolutions_per_launch": convs_per_launch,
-        "flops_per_launch": conv_flops * convs_per_launch, "us_per_convolution": launch_ms * 1e3 / convs_per_launch,
-    }
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/profile.sh +
-    # tools/pmc_summary.py); only quoted when the profile was taken on this workload and this kernel
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file):
-        try:
-            t = json.load(open(traffic_file))
-            if t.get("batch") == args.batch and t.get("channels") == c and t.get("kernel", "") in roofline["kernel"]:
-                roofline["traffic"] = t["hbm_bytes_per_launch"]
-        except Exception:   # noqa: BLE001
-            pass
+    roofline = None
+    if not job.dry:
+        # ---- roofline of the dominant kernel: the C -> C residual convolution (2 per block)
+        conv_flops = 2.0 * 9 * c * c * 361 * args.batch            # algorithmic FLOPs per convolution
+        convs_per_launch = max(1, round(2 * info["num_blocks"] * args.steps / max(tower_launches, 1)))   # 1, or 2 * blocks (tower kernel)
+        launch_ms = tower_ms / max(tower_launches, 1)
+        achieved = conv_flops * convs_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+        roofline = {
+            "bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": None,
+            "kernel": f"residual 3x3 convolution C->C ({ws.conv_kernel()})", "launch_us": launch_ms * 1e3,
+            "launches_timed": tower_launches, "convolutions_per_launch": convs_per_launch,
+            "flops_per_launch": conv_flops * convs_per_launch, "us_per_convolution": launch_ms * 1e3 / convs_per_launch,
+        }
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/profile.sh +
+        # tools/pmc_summary.py); only quoted when the profile was taken on this workload and this kernel
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                t = json.load(open(traffic_file))
+                if t.get("batch") == args.batch and t.get("channels") == c and t.get("kernel", "") in roofline["kernel"]:
+                    roofline["traffic"] = t["hbm_bytes_per_launch"]
+            except Exception:   # noqa: BLE001
+                pass
+
+    selfplay = None
+    if args.selfplay_games > 0:
+        selfplay = selfplay_leg(job, api, replicas, net, args)
 
     out = None
     if rank == 0:
@@ -201,21 +356,28 @@ def main():
                 "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                 "parallelism": f"replicas x{world} (independent leaf batches, no data-path collective)",
             },
-            "roofline": roofline,
-            "whole_pass": {
+            "per_rank_evals_per_sec": [args.batch * args.steps / t for t in per_rank_elapsed],
+        }
+        if job.dry:
+            out["dry"] = True
+            out["config"]["workload"] += " -- DRY RUN: CPU hash predictor behind the leaf pool, numbers are not measurements"
+        else:
+            out["roofline"] = roofline
+            out["whole_pass"] = {
                 "tflops": flops_eval * args.batch * args.steps / (total_ms * 1e-3) / 1e12,
                 "frac_of_mfma_peak": flops_eval * args.batch * args.steps / (total_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                 "gpu_ms_per_step": total_ms / args.steps, "flops_per_eval": flops_eval,
-            },
-            "derived": {
-                "games_per_hour_est": value * 3600.0 / (250 * 800),
-                "assumption": "250 moves x 800 leaf evaluations per move, no cache hits, inputs resident; the measured "
-                              "figure through board + search + pool is tools/selfplay_go.py (DESIGN.md section 8)",
-            },
-        }
+            }
+        if selfplay is not None:
+            out["selfplay"] = selfplay
+            out["derived"] = {
+                "games_per_hour_upper_bound": value * 3600.0 / (250 * max(selfplay["evals_per_move"], 1e-9)),
+                "what": "engine evals/s (inputs resident) x 3600 / (250 stones x the MEASURED evals per move of the selfplay leg): what the "
+                        "engine alone would allow; the pipeline figure is selfplay.games_per_hour",
+            }
         # the reference's own harness style (`dream_go --bench`, src/dg/bench/forward.rs:28-47): one thread, one workspace,
         # synchronous forward() calls on host buffers -- PCIe-inclusive, reported beside `value`, never as `value`
-        if world == 1:
+        if world == 1 and not job.dry:
             reps = max(3, min(args.steps, 10))
             api.forward(ws, features)
             t1 = time.perf_counter()
@@ -224,13 +386,23 @@ def main():
             dt1 = time.perf_counter() - t1
             out["reference_style"] = {
                 "boards_per_sec": args.batch * reps / dt1, "calls": reps, "batch": args.batch,
-                "what": "synchronous dgnn_forward on host buffers (H2D + pass + D2H per call), single thread",
+                "what": "synchronous dgnn_forward on host buffers (H2D of 23 KB fp16 per board + pass + D2H per call), single thread",
             }
+            packed = api.features_pack(features, args.batch)
+            api.forward_packed(ws, packed, args.batch)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                api.forward_packed(ws, packed, args.batch)
+            dt2 = time.perf_counter() - t1
+            out["reference_style"]["packed_boards_per_sec"] = args.batch * reps / dt2
+            out["reference_style"]["packed"] = "synchronous dgnn_forward_packed (1.5 KB of plane masks per board, expanded on the device)"
         if bcast is not None:
-            out["weight_broadcast"] = {"mode": bcast[0], "bytes": bcast[1], "backend": "rccl"}
-        if world == 1 and args.cpu_sample > 0:
+            out["weight_broadcast"] = bcast
+        if world == 1 and args.cpu_sample > 0 and not job.dry:
             baseline, (ref_value, ref_policy) = cpu_baseline(text, features, args.batch, args.cpu_sample)
             out["cpu_baseline"] = baseline
+            ws.forward_resident()
+            ws.sync()
             got = ws.download()
             n = min(args.cpu_sample, args.batch)
             dv = float(np.abs(got.value.astype(np.float32)[:n] - ref_value.view(np.float16).astype(np.float32)).max())
@@ -240,14 +412,10 @@ def main():
     else:
         line = None
 
-    ws.release()
+    if ws is not None:
+        ws.release()
     net.destroy()
-    if dist is not None:
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)   # every rank empties its C stdio (RCCL's banner) BEFORE the barrier rank 0 prints after
-        dist.barrier()
-        dist.destroy_process_group()
+    job.finish()
     if line is not None:
         # RCCL prints a version banner through C stdio, which is block-buffered when stdout is a file and would otherwise
         # land AFTER this line at exit: flush the C streams first so that the JSON line is the last thing on stdout

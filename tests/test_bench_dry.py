@@ -1,0 +1,53 @@
+"""bench.py's N > 1 path without a GPU (VERDICT r01 "missing" #1): a bare `python bench.py --gpus 2` must produce two ranks by
+itself -- the reference needs no launcher, one process drives every device (src/libdg_mcts/predictors/nn.rs:64-67,87-89) -- and
+must never print an n_gpus other than the one asked for.  --dry swaps the GPU for gloo + the CPU hash predictor behind the leaf
+pool; everything else (self-spawn, rank bookkeeping, broadcast of the weight image with per-rank different weights, checksum
+agreement, sharded self-play leg, the one JSON line) is the code the GPU run executes."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+SMALL = ["--steps", "3", "--warmup", "1", "--blocks", "1", "--channels", "32", "--batch", "8",
+         "--selfplay-games", "2", "--selfplay-moves", "3", "--selfplay-rollouts", "16"]
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def test_bare_invocation_spawns_the_ranks_it_reports():
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", *SMALL],
+                         capture_output=True, text=True, timeout=600, env=_clean_env(), cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["dry"] is True and line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert len(line["per_rank_evals_per_sec"]) == 2 and all(v > 0 for v in line["per_rank_evals_per_sec"])
+    assert line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    b = line["weight_broadcast"]
+    assert b["ranks"] == 2 and b["checksums_agree"] is True and b["distinct_images_before"] == 2 and b["bytes"] > 0
+    s = line["selfplay"]
+    assert s["games"] == 4 and s["moves"] == 12 and s["evals_per_move"] > 0 and 0 <= s["cache_hit_ratio"] < 1
+    assert s["games_per_hour"] > 0 and line["derived"]["games_per_hour_upper_bound"] > 0
+    assert "roofline" not in line and "cpu_baseline" not in line      # a dry run measures nothing and claims nothing
+
+
+def test_refuses_a_world_that_is_not_the_one_asked_for():
+    env = _clean_env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", *SMALL],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert run.returncode != 0
+    assert "WORLD_SIZE=1" in run.stderr and '"n_gpus"' not in run.stdout
+
+
+def test_single_rank_dry_run_needs_no_process_group():
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry", *SMALL],
+                         capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and "weight_broadcast" not in line and line["selfplay"]["games"] == 2

@@ -546,7 +546,7 @@ def test_search_visit_counts_hip_vs_oracle(api, oracle, synth):
     moved = int(np.abs(hip_a - ref).sum()) // 2
     print(f"search 64 rollouts: {moved} of 64 visits differ between the HIP predictor and the oracle predictor")
     assert 0 < hip_a.sum() <= 64 and 0 < ref.sum() <= 64   # a search may end before its limit (EARLY-C, time_control/mod.rs:86-101)
-    assert moved <= 6                                      # fp16-rounding differences may flip a few near-tie selections
+    assert moved == 0                                      # north_star: bit-identical visit counts (more seeds: tests/test_round2_gpu.py)
 
 
 def test_synthetic_selfplay_through_the_pool(api, synth):
