@@ -203,8 +203,23 @@ def lib():
         L.dgo_num_threads.restype = ctypes.c_int
         L.dgo_set_num_threads.argtypes = [ctypes.c_int]
         L.dgo_set_num_threads.restype = None
+        # OpenMP's default is one thread per VISIBLE cpu; a GPU box of the pool shows 256 and grants 16 CPUs of time
+        # (cgroup quota): 256 spinning threads on 16 CPUs turn seconds into minutes
+        L.dgo_set_num_threads(effective_cpus())
         _lib = L
     return _lib
+
+
+def effective_cpus():
+    """The cores this process may really use: scheduler affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _u16(a):

@@ -42,7 +42,6 @@ def test_full_size_network_every_board(api, oracle, synth):
     with net.get_workspace(batch) as ws:
         assert ws.conv_kernel() == "tower_board_kernel"
         value, policy = api.forward(ws, features).unwrap()
-    oracle.lib().dgo_set_num_threads(max(1, len(os.sched_getaffinity(0))))
     rv, rp = _oracle_outputs(oracle, text, features, batch)
     gv, gp = value.astype(np.float32), policy.astype(np.float32).reshape(batch, 362)
     dv, dp, kl = np.abs(gv - rv), np.abs(gp - rp).max(axis=1), policy_kl(rp, gp)
