@@ -633,12 +633,21 @@ BoardSwitches read_board_switches()
     return s;
 }
 
+// smallest batch for which a workgroup per board is preferred at 128 / 256 channels (DGNN_TOWER_MIN_BATCH, read once)
+static int tower_min_batch()
+{
+    static const int v = [] { const char* e = std::getenv("DGNN_TOWER_MIN_BATCH"); return e && std::atoi(e) > 0 ? std::atoi(e) : 129; }();
+    return v;
+}
+
 bool tower_board_supported(int batch, int channels)
 {
     const int slices = channels / 32;
     // a workgroup per board: at 64 channels always (the layers are short, launches would dominate), at 128 / 256 channels
-    // once the boards alone fill most of the chip (below that the per-layer kernel splits a board over several workgroups)
-    return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || ((slices == 4 || slices == 8) && batch >= 192));
+    // from 129 boards on: a board split over two workgroups would need more workgroups than there are CUs (two rounds per
+    // layer), and a chip that is only half full clocks higher (power cap) -- measured 20x256, batch 144 / 160 / 176: 56.4 k /
+    // 60.2 k / 63.6 k evals/s against 43.5 k / 47.5 k / 50.9 k with one launch per layer (profiles/r02/sweep_*.jsonl)
+    return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || ((slices == 4 || slices == 8) && batch >= tower_min_batch()));
 }
 
 hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream)

@@ -66,6 +66,7 @@ struct Workspace {
     bool use_tower = false;                 // the residual tower as ONE launch where a workgroup owns a whole board (DGNN_TOWER)
     ConvBoardLaunch* d_tower_layers = nullptr;   // 2 * blocks descriptors for tower_board_kernel, filled on first use
     bool tower_layers_ready = false;
+    bool up_in_tower = true;                // the up-layer is the first layer of the tower launch (DGNN_TOWER_UP=0: a launch of its own)
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
     int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
     int tile_variant = 2;                   // 1 = lock-step, 2 = staggered load|matrix phases, 3 = staggered balanced half-steps
@@ -180,6 +181,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         // MI355X, 20x256 batch 256: 85.3 us per convolution against 91.3 with one launch per layer.  DGNN_TOWER=0: per layer.
         const char* tower = std::getenv("DGNN_TOWER");
         ws->use_tower = ws->use_board && !(tower && std::atoi(tower) == 0) && t.num_blocks > 0;
+        const char* up = std::getenv("DGNN_TOWER_UP");
+        ws->up_in_tower = !(up && std::atoi(up) == 0);
     }
 
     ws->board_env = read_board_switches();
@@ -316,7 +319,10 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
         // features.rs:52-60 HWC fp16, or the packed form: either way the up-layer reads the padded slot-major layout
         if (packed_input) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features_board, ws->active, true, ws->stream));
         else DGNN_HIP(launch_nhwc_to_board(ws->d_features, ws->d_features_board, ws->active, DGNN_NUM_FEATURES, ws->stream));
-        DGNN_HIP(conv_board(t.up, ws->d_features_board, nullptr, ws->d_act[cur]));
+        // the up-layer (C_in = 32: one chunk) is the tower launch's first layer where the tower is one launch: its output
+        // channels 0..31 stay in LDS for the first residual convolution like any other layer's (DGNN_TOWER_UP=0: own launch)
+        const bool up_in_tower = tower_selected(ws) && ws->up_in_tower;
+        if (!up_in_tower) DGNN_HIP(conv_board(t.up, ws->d_features_board, nullptr, ws->d_act[cur]));
         if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair], ws->stream));
         if (tower_selected(ws)) {
             if (!ws->tower_layers_ready) {                     // the descriptors only hold addresses fixed for the workspace's life
@@ -330,6 +336,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
                     a.w_next = nullptr; a.carry_in = 0;
                     layers.push_back(a);
                 };
+                if (up_in_tower) describe(t.up, ws->d_features_board, nullptr, ws->d_act[c]);
                 for (int i = 0; i < t.num_blocks; ++i) {
                     const int tmp = (c + 1) % 3, next = (c + 2) % 3;
                     describe(t.res1[i], ws->d_act[c], nullptr, ws->d_act[tmp]);
@@ -339,11 +346,11 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
                 const char* carry = std::getenv("DGNN_TOWER_CARRY");          // =0: no hand-over between the layers (A/B)
                 if (!(carry && std::atoi(carry) == 0))
                     for (size_t l = 0; l + 1 < layers.size(); ++l) { layers[l].w_next = layers[l + 1].w; layers[l + 1].carry_in = 1; }
-                if (!ws->d_tower_layers) DGNN_HIP(hipMalloc((void**)&ws->d_tower_layers, layers.size() * sizeof(ConvBoardLaunch)));
+                if (!ws->d_tower_layers) DGNN_HIP(hipMalloc((void**)&ws->d_tower_layers, (layers.size() + 1) * sizeof(ConvBoardLaunch)));
                 DGNN_HIP(hipMemcpy(ws->d_tower_layers, layers.data(), layers.size() * sizeof(ConvBoardLaunch), hipMemcpyHostToDevice));
                 ws->tower_layers_ready = true;
             }
-            DGNN_HIP(launch_tower_board(ws->d_tower_layers, 2 * t.num_blocks, ws->active, t.num_channels, ws->stream));
+            DGNN_HIP(launch_tower_board(ws->d_tower_layers, 2 * t.num_blocks + (up_in_tower ? 1 : 0), ws->active, t.num_channels, ws->stream));
             for (int i = 0; i < t.num_blocks; ++i) cur = (cur + 2) % 3;
         } else {
             for (int i = 0; i < t.num_blocks; ++i) {

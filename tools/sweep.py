@@ -24,9 +24,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--batches", type=str, default="1,2,4,8,16,32,64,128,256")
     args = ap.parse_args()
     net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
-    for batch in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+    for batch in [int(b) for b in args.batches.split(",")]:
         features = synth.make_features(batch, seed=batch)
         with net.get_workspace(batch) as ws:
             ws.upload(features)
