@@ -31,8 +31,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <type_traits>
 #include <utility>
 
@@ -142,6 +144,60 @@ struct Split {
 };
 static_assert(Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
 
+// A board split over G = C_out / (32 * NS) workgroups INSIDE one launch (tower_split_kernel): what a workgroup needs to
+// know about the others.  Every workgroup publishes "layer i of my channel block is in memory" by storing i + 1 into
+// done[board * G + nb] after its write-through stores have drained; a consumer polls the ONE word of the producer whose
+// channels it is about to fetch.  No grid-wide barrier, no fence: the payload is stored sc1 (write-through) and loaded sc1
+// (past the reader's L1), the recipe of the CDNA guide's inter-workgroup rule (Guideline 16, form "sc1 both sides").
+struct SplitSync {
+    unsigned* done;      // [board][G], zeroed by the launcher before every launch
+    unsigned* err;       // one word: set when a poll gave up (the host then repeats the pass with one launch per layer)
+    int epoch;           // layers of THIS launch that precede this one: 0 = the input comes from outside, nothing to wait for
+    int groups;          // G
+    unsigned long long* trace;   // measurement only (DGNN_SPLIT_TRACE=<file>): [layer][board][nb][4] s_memtime stamps of wave 0, or nullptr
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// one lane: wait until `flag` says the producer has published `epoch` layers.  Bounded: a launch whose workgroups are not
+// all resident (another process on the device) must not hang the queue.
+__device__ __forceinline__ void wait_published(unsigned* flag, unsigned epoch, unsigned* err)
+{
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch) return;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memtime() - t0 > (1ull << 31)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+}
+
+// 16-byte activation store / load.  SPLIT: write-through to memory (sc1) so that the other workgroups of the board see it
+// once this wave's vmcnt has drained, and loads that never look into this CU's L1.
+template <bool SPLIT>
+__device__ __forceinline__ void store_row(uint16_t* p, const uint4& v)
+{
+    if constexpr (SPLIT) {
+        const u32x4 t = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+template <bool SPLIT>
+__device__ __forceinline__ uint4 load_row(const uint16_t* p)
+{
+    if constexpr (SPLIT) {
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return make_uint4(t[0], t[1], t[2], t[3]);
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+
 // SKIP: 0 = no skip input, 1 = skip added in the epilogue (general), 2 = skip accumulated DURING the K loop (alpha1 != 0):
 // the row tiles of z are fetched one at a time while the memory system is otherwise idle and added to the fp32
 // accumulators as (alpha2 / alpha1) * z, so that the epilogue is store-only.  (With the skip read in the epilogue all
@@ -150,8 +206,12 @@ static_assert(Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
 // B-fragment reads, 8 the counted vmcnt waits of the k-steps (DMA still issued).
 // One convolution of one workgroup: board `b`, channel block `nb`.  A __device__ function so that the per-layer kernel
 // and the whole-tower kernel below share it; `lds` is the workgroup's S::LdsBytes of shared memory.
-template <int NS, int SKIP, bool RELU, int ABL>
-__device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb)
+// SPLIT: the board is shared with other workgroups of the same launch (SplitSync above); otherwise `sync` is not looked at.
+// Returns (SPLIT only) whether the NEXT layer's first input chunk is already on its way into LDS; the caller hands that back
+// as `x0_in_flight`.
+template <int NS, int SKIP, bool RELU, int ABL, bool SPLIT = false>
+__device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb,
+                                                const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, nullptr}, const bool x0_in_flight = false)
 {
     using S = Split<NS>;
     constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP;
@@ -165,7 +225,8 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     const int cout = a.cout;
     const int nchunks = cin / 32;
 
-    const unsigned long long t_start = a.timing ? __builtin_amdgcn_s_memtime() : 0;
+    const bool tracing = a.timing != nullptr || (SPLIT && sync.trace != nullptr);
+    const unsigned long long t_start = tracing ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- zero the halo rows of both activation buffers (never touched by the DMA) ----
     if (tid < 2 * 4 * kHalo) {
@@ -198,15 +259,21 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     // j-th (0..3) activation piece of this wave for `chunk` -> buffer `buf`.  28 pieces, 8 waves: waves 4..7 have
     // only three and repeat their third one (same bytes to the same place), so that every wave issues the same
     // number of DMA instructions and the vmcnt bookkeeping below is one set of constants.
-    auto issue_x = [&](int chunk, int buf, int j) {
+    auto issue_x_from = [&](const uint16_t* board, int chunk, int buf, int j) {
         int p = wave + S::WAVES * j;
         if (p >= 4 * kPieces) p -= S::WAVES;
         const int s = p / kPieces;
         const int i = p - s * kPieces;
-        const uint16_t* src = x_board + ((long)(chunk * 4 + s) * kRows + i * 64) * 8;
+        const uint16_t* src = board + ((long)(chunk * 4 + s) * kRows + i * 64) * 8;
         char* const dst = lds + buf * kXBufBytes + s * kSlotBytes + (kHalo + i * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, SPLIT ? 16 : 0);   // aux 16 = sc1
+    };
+    auto issue_x = [&](int chunk, int buf, int j) { issue_x_from(x_board, chunk, buf, j); };
+    // SPLIT: the flag of the workgroup that produces input chunk c (its channel block is c / NS)
+    unsigned* const done_board = SPLIT ? sync.done + (long)b * sync.groups : nullptr;
+    auto await_chunk = [&](int c) {       // lane 0 of wave 0 only; the caller's next barrier tells everybody
+        if (c / NS != nb) wait_published(done_board + c / NS, (unsigned)sync.epoch, sync.err);
     };
 
     // ---- fragment read addresses ----
@@ -240,7 +307,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
                                                       // the K loop (they would be spilled), one 64-bit add per load instead
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair)          // k-slot ct * 4 + pair * 2 (+ hi), row tile rt
-            zl[pair] = *reinterpret_cast<const uint4*>(p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
+            zl[pair] = load_row<SPLIT>(p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
     };
     const float zscale = SKIP == 2 ? a.alpha2 / a.alpha1 : 0.0f;
     auto add_z_unit = [&](auto rt_c, auto ct_c) {
@@ -260,15 +327,29 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     };
 
     // ---- prologue: chunk 0 and the first three filter slabs ----
-    if (!a.carry_in) {
+    if constexpr (SPLIT) {
+        // chunk 0 (and chunk 1, whose pieces go out during chunk 0) must have been published by their producers; the
+        // workgroup that produced chunk 0 itself found it in LDS (carry_in) and, unless NS == 1, owns chunk 1 too
+        const bool must_wait = sync.epoch > 0 && ((nb != 0 && !x0_in_flight) || (NS == 1 && nchunks > 1));
+        if (must_wait) {
+            if (tid == 0) {
+                await_chunk(0);
+                if (nchunks > 1) await_chunk(1);
+            }
+            __syncthreads();
+        }
+    }
+    if (!a.carry_in || (SPLIT && nb != 0 && !x0_in_flight)) {
 #pragma unroll
         for (int j = 0; j < XP; ++j) issue_x(0, 0, j);
+    }
+    if (!a.carry_in) {
 #pragma unroll
         for (int s = 0; s < kRing; ++s) issue_w(s, s);
     }
     wait_vmcnt<0>();
     __syncthreads();
-    const unsigned long long t_loop = a.timing ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_loop = tracing ? __builtin_amdgcn_s_memtime() : 0;
 
     // zc_c >= 0: this chunk also folds units 6 * zc_c .. 6 * zc_c + 5 of the skip input into the accumulators (SKIP == 2;
     // chunks 0 and 1 are peeled off the loop so that those VALU updates are unconditional straight-line code -- inside a
@@ -346,16 +427,27 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
             __builtin_amdgcn_sched_barrier(0);
             // skip input folded into the accumulators: row tile 6 * ZC + t is requested at the end of tap t of chunk ZC and
             // added at the end of tap t + 1
-            if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6 && ZC * 6 + TAP - 1 < RT) {
+            // WHEN a row tile's skip is added is part of the summation order, so it is fixed per BOARD row tile T = 0..11
+            // (chunk T / 6, end of tap T % 6 + 1) whatever the work split: the wave that owns T (T / RT == g) fetches the
+            // rows, every other wave adds zeros in that slot (x + 0 = x exactly; the accumulators never hold -0).
+            if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6 && ZC * 6 + TAP - 1 < 12) {
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
-                wait_vmcnt<W + (TAP < XP)>();
+                if (RT == 12 || (ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<W + (TAP < XP)>();     // (nothing was requested otherwise)
                 __builtin_amdgcn_sched_barrier(0);
-                add_z_unit(std::integral_constant<int, ZC * 6 + TAP - 1>(), std::integral_constant<int, 0>());
+                add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>(), std::integral_constant<int, 0>());
             }
             // extra memory operations only make the counted waits above more conservative (they require that many
             // more of the OLDER operations to have completed), never unsafe
-            if constexpr (ZC >= 0 && TAP <= 5 && ZC * 6 + TAP < RT) load_z_unit(ZC * 6 + TAP, 0);
+            if constexpr (ZC >= 0 && TAP <= 5 && ZC * 6 + TAP < 12) {
+                constexpr int T = ZC * 6 + TAP;
+                if constexpr (RT == 12) {
+                    load_z_unit(T, 0);
+                } else {
+                    if (T / RT == g) load_z_unit(T % RT, 0);
+                    else zl[0] = zl[1] = make_uint4(0, 0, 0, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>());
@@ -373,6 +465,10 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
         // the last one is younger than that wait covers: only the filter pieces of the steps after it may stay in flight.
         if constexpr (XP > 4) wait_vmcnt<W * (8 - (XP - 1))>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (SPLIT) {
+            // the pieces of chunk + 2 go out during chunk + 1: its producer must have published before this barrier opens
+            if (sync.epoch > 0 && tid == 0 && chunk + 2 < nchunks && (chunk + 2) % NS == 0) await_chunk(chunk + 2);
+        }
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -384,7 +480,27 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
     }
     for (int chunk = first_loop_chunk; chunk < nchunks; ++chunk) run_chunk(chunk, std::integral_constant<int, -1>());
 
-    const unsigned long long t_epilogue = a.timing ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long t_epilogue = tracing ? __builtin_amdgcn_s_memtime() : 0;
+
+    // SPLIT, a workgroup that does not produce channels 0..31 itself: if the one that does has ALREADY published this layer
+    // (it runs ahead: its first NS input chunks are its own), the next layer's first chunk is requested now and lands
+    // during the epilogue.  One look, no waiting; activation buffer 0 is free (nobody reads activations after the barrier
+    // that ended the last chunk, and every wave's DMA into buffer 0 had landed before it).
+    bool x0_next = false;
+    if constexpr (SPLIT) {
+        if (nb != 0 && a.w_next != nullptr) {
+            unsigned* const word = reinterpret_cast<unsigned*>(lds + S::LdsBytes);
+            if (tid == 0)
+                *word = __hip_atomic_load(done_board, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)sync.epoch + 1u ? 1u : 0u;
+            __syncthreads();
+            x0_next = *word != 0;
+            if (x0_next) {
+                const uint16_t* const y_board = a.y + (long)b * cout * kRows + lane * 8;
+#pragma unroll
+                for (int j = 0; j < XP; ++j) issue_x_from(y_board, 0, 0, j);
+            }
+        }
+    }
 
     // ---- epilogue ----
     // D[i][j]: j = lane & 31 = row within the tile, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = channel within the
@@ -412,7 +528,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
         if constexpr (SKIP == 1) {
 #pragma unroll
             for (int q = 0; q < CT * 2; ++q)          // q = ct * 2 + pair -> k-slot ct * 4 + pair * 2 (+ hi)
-                zq[rt & 1][q] = *reinterpret_cast<const uint4*>(zb + (((q >> 1) * 4 + (q & 1) * 2) * kRows + row_of(rt)) * 8);
+                zq[rt & 1][q] = load_row<SPLIT>(zb + (((q >> 1) * 4 + (q & 1) * 2) * kRows + row_of(rt)) * 8);
         }
     };
     load_z(0);
@@ -453,7 +569,7 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
             const auto sx = __builtin_amdgcn_permlane32_swap(out[0].x, out[1].x, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(out[0].y, out[1].y, false, false);
             const uint4 unit = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-            *reinterpret_cast<uint4*>(yb + ((ct * 4 + k0) * kRows + row) * 8) = unit;
+            store_row<SPLIT>(yb + ((ct * 4 + k0) * kRows + row) * 8, unit);
             // hand-over: channels 0..31 are the next layer's first input chunk; its place is activation buffer 0, which
             // nobody reads any more (the last chunk sits in buffer 1, and the barrier that ended it came after every
             // wave's last DMA into buffer 0 had landed)
@@ -471,6 +587,16 @@ __device__ __forceinline__ void conv_board_body(const ConvBoardLaunch& a, char* 
         }
     }
     wait_vmcnt<0>();        // the tail's surplus DMA (slabs past the last step) must not outlive the workgroup's LDS
+    if constexpr (SPLIT) {
+        // every wave's write-through stores have left (vmcnt counts stores): one lane says so to the rest of the board
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done_board + nb, (unsigned)sync.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sync.trace != nullptr && tid == 0) {
+            unsigned long long* out = sync.trace + (((long)sync.epoch * a.batch + b) * sync.groups + nb) * 4;
+            out[0] = t_start; out[1] = t_loop; out[2] = t_epilogue | (x0_next ? 1ull << 63 : 0ull); out[3] = __builtin_amdgcn_s_memtime();
+        }
+    }
+    return x0_next;
 }
 
 template <int NS, int SKIP, bool RELU, int ABL>
@@ -500,6 +626,31 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
         const ConvBoardLaunch a = layers[i];
         if (a.alpha2 != 0.0f) conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0);
         else conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0);
+    }
+}
+
+// The same walk with a board SPLIT over G = C / (32 * NS) workgroups (NS < C / 32): the batch is too small for a workgroup
+// per board to fill the chip.  Between two layers a workgroup needs the other channel blocks of its own board and nothing
+// else: per-board hand-offs (SplitSync) instead of 2 * blocks kernel boundaries, with the next layer's filter slabs already
+// in flight while the workgroup waits.  Placement: linear block id L runs on XCD L % 8 (observed, used for speed only --
+// the hand-off is agent-scope and does not depend on it), so the G workgroups of a board take ids that are congruent
+// mod 8 and share an L2.  All batch * G workgroups must be resident at once (the launcher keeps that <= the CU count).
+template <int NS>
+__global__ __launch_bounds__(Split<NS>::Threads)
+void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, int batch, int groups, unsigned* done, unsigned* err,
+                        unsigned long long* trace)
+{
+    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes + 16];    // + one word of workgroup-wide agreement
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nb = q % groups;
+    const int b = (q / groups) * 8 + xcd;
+    if (b >= batch) return;
+    bool x0_in_flight = false;
+    for (int i = 0; i < count; ++i) {
+        const ConvBoardLaunch a = layers[i];
+        const SplitSync sync{done, err, i, groups, trace};
+        if (a.alpha2 != 0.0f) x0_in_flight = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, sync, x0_in_flight);
+        else x0_in_flight = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, sync, x0_in_flight);
     }
 }
 
@@ -661,6 +812,61 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
         default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
     }
     return hipGetLastError();
+}
+
+// Slices per workgroup of the split tower, 0 = not applicable.  The rule of conv_board_pick_ns (fewest workgroups per board
+// that still put a workgroup on most CUs) under one more condition: every workgroup of the launch is resident at once.
+int tower_split_ns(int batch, int channels, int num_cus)
+{
+    if (!conv_board_supported(channels, channels) || batch <= 0) return 0;
+    const int slices = channels / 32;
+    if (slices != 2 && slices != 4 && slices != 8) return 0;
+    int ns = slices;
+    while (ns > 1 && (long)batch * (slices / ns) < 192 && (long)batch * (slices / ns) * 2 <= num_cus) ns /= 2;
+    return ns == slices ? 0 : ns;
+}
+
+hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
+                              unsigned* d_err, hipStream_t stream)
+{
+    if (batch <= 0 || count <= 0) return hipSuccess;
+    const int slices = channels / 32;
+    if (ns < 1 || ns >= slices || slices % ns != 0) return hipErrorInvalidValue;
+    const int groups = slices / ns;
+    const hipError_t st = hipMemsetAsync(d_done, 0, ((size_t)batch * groups + 1) * sizeof(unsigned), stream);   // + the err word behind it
+    if (st != hipSuccess) return st;
+    if (d_err != d_done + (size_t)batch * groups) {
+        const hipError_t st2 = hipMemsetAsync(d_err, 0, sizeof(unsigned), stream);
+        if (st2 != hipSuccess) return st2;
+    }
+    const dim3 grid((batch + 7) / 8 * 8 * groups);
+    // measurement only: DGNN_SPLIT_TRACE=<file> dumps wave 0's stamps of every (layer, board, channel block) of each launch
+    static const char* const trace_path = std::getenv("DGNN_SPLIT_TRACE");
+    unsigned long long* d_trace = nullptr;
+    const size_t trace_words = (size_t)count * batch * groups * 4;
+    if (trace_path && *trace_path) {
+        if (hipMalloc((void**)&d_trace, trace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
+    }
+    switch (ns) {
+        case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, d_done, d_err, d_trace); break;
+        case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, d_done, d_err, d_trace); break;
+        default: hipLaunchKernelGGL((tower_split_kernel<1>), grid, dim3(Split<1>::Threads), 0, stream, d_layers, count, batch, groups, d_done, d_err, d_trace); break;
+    }
+    const hipError_t launched = hipGetLastError();
+    if (d_trace) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(trace_words);
+        (void)hipMemcpy(h.data(), d_trace, trace_words * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_trace);
+        if (FILE* f = std::fopen(trace_path, "wb")) {
+            const int header[4] = {count, batch, groups, ns};
+            std::fwrite(header, sizeof(int), 4, f);
+            std::fwrite(h.data(), 8, trace_words, f);
+            std::fclose(f);
+        }
+    }
+    return launched;
 }
 
 hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches& env, hipStream_t stream)

@@ -67,6 +67,13 @@ struct Workspace {
     ConvBoardLaunch* d_tower_layers = nullptr;   // 2 * blocks descriptors for tower_board_kernel, filled on first use
     bool tower_layers_ready = false;
     bool up_in_tower = true;                // the up-layer is the first layer of the tower launch (DGNN_TOWER_UP=0: a launch of its own)
+    int split_pref = 1;                     // DGNN_TOWER_SPLIT: 0 = never split a board inside the tower launch, 1 = where a workgroup
+                                            // per board is not chosen, 2 = wherever a split is possible (A/B)
+    bool split_failed = false;              // a hand-off poll gave up once (not every workgroup was resident): per-layer launches from then on
+    unsigned* d_split_sync = nullptr;       // [batch * 8] layers published per (board, channel block) + the give-up word behind them
+    unsigned* h_split_err = nullptr;        // pinned copy of that word, fetched with the outputs
+    bool split_pending = false;             // the submission in flight used tower_split_kernel
+    bool pending_packed = false;            // ... and took packed features (what to repeat if it gave up)
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
     int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
     int tile_variant = 2;                   // 1 = lock-step, 2 = staggered load|matrix phases, 3 = staggered balanced half-steps
@@ -77,7 +84,13 @@ struct Workspace {
 
 struct DeviceState {
     int device = 0;
+    int num_cus = 0;
     uint8_t* d_image = nullptr;
+    // tower_split_kernel needs all its workgroups resident at once: two such launches on different streams could each hold
+    // CUs the other is waiting for.  They are chained on the device instead (each waits for the event behind the previous one).
+    std::mutex split_mutex;
+    hipEvent_t split_done = nullptr;
+    bool split_recorded = false;
     std::map<int, std::vector<Workspace*>> idle;   // batch size -> pooled workspaces
     std::vector<Workspace*> all;                   // ownership
 
@@ -101,6 +114,7 @@ DeviceState::~DeviceState()
 {
     for (Workspace* ws : all) delete ws;
     (void)hipSetDevice(device);
+    if (split_done) (void)hipEventDestroy(split_done);
     if (d_image) (void)hipFree(d_image);
 }
 
@@ -124,6 +138,8 @@ int get_device_state(Network* net, int device, DeviceState** out, bool upload = 
     std::unique_ptr<DeviceState> state(new (std::nothrow) DeviceState());
     if (!state) return DGNN_OUT_OF_MEMORY;
     state->device = device;
+    DGNN_HIP(hipDeviceGetAttribute(&state->num_cus, hipDeviceAttributeMultiprocessorCount, device));
+    DGNN_HIP(hipEventCreateWithFlags(&state->split_done, hipEventDisableTiming));
     DGNN_HIP(hipMalloc((void**)&state->d_image, net->image.size()));
     if (upload) DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
 
@@ -183,6 +199,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         ws->use_tower = ws->use_board && !(tower && std::atoi(tower) == 0) && t.num_blocks > 0;
         const char* up = std::getenv("DGNN_TOWER_UP");
         ws->up_in_tower = !(up && std::atoi(up) == 0);
+        const char* split = std::getenv("DGNN_TOWER_SPLIT");
+        if (split && *split) ws->split_pref = std::atoi(split);
     }
 
     ws->board_env = read_board_switches();
@@ -212,7 +230,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
     const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
     const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
-    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed;
+    const size_t sz_split = align_up(((size_t)batch * 8 + 1) * sizeof(unsigned), 256);
+    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split;
 
     DGNN_HIP(hipMalloc(&ws->arena, total));
     // board path: pad rows 384..399 of every k-slot are never written by the kernels and must read as zero
@@ -226,17 +245,20 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_policy = (uint16_t*)p; p += sz_policy;
     ws->d_logits = (uint16_t*)p; p += sz_logits;
     ws->d_packed = (uint32_t*)p; p += sz_packed;
+    ws->d_split_sync = (unsigned*)p; p += sz_split;
     if (ws->use_board) {
         ws->d_features_board = (uint16_t*)p; p += sz_fboard;
         ws->d_tower_nhwc = (uint16_t*)p;
     }
 
-    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_packed + sz_value + sz_policy, hipHostMallocDefault));
+    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_packed + sz_value + sz_policy + 256, hipHostMallocDefault));
     uint8_t* h = (uint8_t*)ws->pinned;
     ws->h_features = (uint16_t*)h; h += sz_features;
     ws->h_packed = (uint32_t*)h; h += sz_packed;
     ws->h_value = (uint16_t*)h; h += sz_value;
-    ws->h_policy = (uint16_t*)h;
+    ws->h_policy = (uint16_t*)h; h += sz_policy;
+    ws->h_split_err = (unsigned*)h;
+    *ws->h_split_err = 0;
 
     *out = ws.release();
     return DGNN_OK;
@@ -244,10 +266,22 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
 
 // The tower as one launch: where a workgroup owns a whole board, and only with gates the in-loop skip can express
 // (it accumulates (alpha2 / alpha1) * z: a gate of 0 needs the epilogue form, which only the per-layer launcher has).
-bool tower_selected(const Workspace* ws)
+// Two forms: a workgroup per board (tower_board_kernel), or -- batches too small for that to fill the chip -- a board split
+// over 2 / 4 / 8 workgroups that hand their channel blocks to each other inside the launch (tower_split_kernel).
+// Returns 0 = one launch per layer, -1 = a workgroup per board, n > 0 = split tower with n slices per workgroup.
+int tower_mode(const Workspace* ws)
 {
-    return ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero && tower_board_supported(ws->active, ws->net->topo.num_channels);
+    if (!(ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero)) return 0;
+    const int channels = ws->net->topo.num_channels;
+    const bool whole = tower_board_supported(ws->active, channels);
+    if (ws->split_pref != 0 && !ws->split_failed && (!whole || ws->split_pref == 2)) {
+        const int ns = tower_split_ns(ws->active, channels, ws->dev->num_cus);
+        if (ns > 0) return ns;
+    }
+    return whole ? -1 : 0;
 }
+
+bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
 
 // Enqueues graph.rs:134-152 on the workspace's stream.  `tower_pair` (may be -1) selects the event pair that
 // brackets the residual convolutions.
@@ -350,7 +384,19 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
                 DGNN_HIP(hipMemcpy(ws->d_tower_layers, layers.data(), layers.size() * sizeof(ConvBoardLaunch), hipMemcpyHostToDevice));
                 ws->tower_layers_ready = true;
             }
-            DGNN_HIP(launch_tower_board(ws->d_tower_layers, 2 * t.num_blocks + (up_in_tower ? 1 : 0), ws->active, t.num_channels, ws->stream));
+            const int layer_count = 2 * t.num_blocks + (up_in_tower ? 1 : 0);
+            const int mode = tower_mode(ws);
+            if (mode > 0) {
+                const int groups = t.num_channels / 32 / mode;
+                std::lock_guard<std::mutex> chain(ws->dev->split_mutex);
+                if (ws->dev->split_recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, ws->dev->split_done, 0));
+                DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
+                                            ws->d_split_sync + (size_t)ws->active * groups, ws->stream));
+                DGNN_HIP(hipEventRecord(ws->dev->split_done, ws->stream));
+                ws->dev->split_recorded = true;
+            } else {
+                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
+            }
             for (int i = 0; i < t.num_blocks; ++i) cur = (cur + 2) % 3;
         } else {
             for (int i = 0; i < t.num_blocks; ++i) {
@@ -415,6 +461,37 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
     sv.value_out = ws->d_value;
     sv.batch = ws->active;
     DGNN_HIP(launch_softmax_value(sv, ws->stream));
+    return DGNN_OK;
+}
+
+// After enqueue_forward: fetch the split tower's give-up word with the outputs.
+int enqueue_split_check(Workspace* ws, bool packed)
+{
+    const int mode = tower_mode(ws);
+    ws->split_pending = mode > 0;
+    ws->pending_packed = packed;
+    if (mode > 0) {
+        const int groups = ws->net->topo.num_channels / 32 / mode;
+        DGNN_HIP(hipMemcpyAsync(ws->h_split_err, ws->d_split_sync + (size_t)ws->active * groups, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream));
+    }
+    return DGNN_OK;
+}
+
+// After the stream has drained: a split tower whose workgroups were not all resident (the device is shared with another
+// process) gives up instead of hanging; its outputs are garbage.  Repeat the pass with one launch per layer and stay there.
+int resolve_split_failure(Workspace* ws)
+{
+    if (!ws->split_pending) return DGNN_OK;
+    ws->split_pending = false;
+    if (*ws->h_split_err == 0) return DGNN_OK;
+    *ws->h_split_err = 0;
+    ws->split_failed = true;
+    std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer from now on\n", ws->device);
+    const int status = enqueue_forward(ws, -1, ws->pending_packed);
+    if (status != DGNN_OK) return status;
+    DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipStreamSynchronize(ws->stream));
     return DGNN_OK;
 }
 
@@ -716,7 +793,9 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
     if (features != ws->h_features) std::memcpy(ws->h_features, features, in_bytes);
     DGNN_HIP(hipMemcpyAsync(ws->d_features, ws->h_features, in_bytes, hipMemcpyHostToDevice, ws->stream));   // graph.rs:130-131
 
-    const int status = enqueue_forward(ws, -1);
+    int status = enqueue_forward(ws, -1);
+    if (status != DGNN_OK) return status;
+    status = enqueue_split_check(ws, false);
     if (status != DGNN_OK) return status;
 
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
@@ -734,6 +813,8 @@ int dgnn_forward_wait(dgnn_workspace* handle, uint16_t* value_out, uint16_t* pol
     DGNN_HIP(hipSetDevice(ws->device));
     ws->pending = false;
     DGNN_HIP(hipStreamSynchronize(ws->stream));   // graph.rs:155-156 (to_vec + synchronize)
+    const int split_status = resolve_split_failure(ws);
+    if (split_status != DGNN_OK) { ws->active = ws->batch; return split_status; }
     if (value_out != ws->h_value) std::memcpy(value_out, ws->h_value, (size_t)ws->active * 2);
     if (policy_out != ws->h_policy) std::memcpy(policy_out, ws->h_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2);
     ws->active = ws->batch;
@@ -773,7 +854,9 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
     if (packed != ws->h_packed) std::memcpy(ws->h_packed, packed, in_bytes);
     DGNN_HIP(hipMemcpyAsync(ws->d_packed, ws->h_packed, in_bytes, hipMemcpyHostToDevice, ws->stream));
 
-    const int status = enqueue_forward(ws, -1, /*packed_input=*/true);
+    int status = enqueue_forward(ws, -1, /*packed_input=*/true);
+    if (status != DGNN_OK) return status;
+    status = enqueue_split_check(ws, true);
     if (status != DGNN_OK) return status;
 
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
@@ -870,6 +953,7 @@ const char* dgnn_workspace_conv_kernel(const dgnn_workspace* handle)
     if (!handle) return "";
     const Workspace* ws = W(handle);
     const Topology& t = ws->net->topo;
+    if (tower_mode(ws) > 0) return "tower_split_kernel";
     if (tower_selected(ws)) return "tower_board_kernel";
     if (ws->use_board) return "conv3x3_board_kernel";
     if (ws->use_tile && conv_tile_supported(t.num_channels, t.num_channels)) {

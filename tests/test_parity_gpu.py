@@ -431,7 +431,7 @@ def test_resident_and_timed_paths_match_host_path(api, synth):
         assert np.array_equal(out.policy.view(np.uint16), p0.view(np.uint16))
         total, tower, launches = ws.forward_timed(3)
         # one launch per pass where the whole tower is one kernel (64 channels: a workgroup owns a board), else one per convolution
-        assert launches == (3 if ws.conv_kernel() == "tower_board_kernel" else 2 * 2 * 3) and 0 < tower <= total
+        assert launches == (3 if ws.conv_kernel() in ("tower_board_kernel", "tower_split_kernel") else 2 * 2 * 3) and 0 < tower <= total
         out = ws.download()
         assert np.array_equal(out.policy.view(np.uint16), p0.view(np.uint16))
 
@@ -645,8 +645,60 @@ def test_tower_kernel_equals_one_launch_per_layer(api, synth, blocks, channels, 
     assert np.array_equal(outputs["1"][1][1].view(np.uint16), outputs["0"][1][1].view(np.uint16))
 
 
-def test_tower_kernel_is_not_used_when_a_board_is_split_over_workgroups(api, synth):
+def test_small_batches_split_a_board_inside_the_tower_launch(api, synth, monkeypatch):
     net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 256, seed=93)))
-    with net.get_workspace(8) as ws:                       # 8 boards of 256 channels: NS = 2, four workgroups per board
+    with net.get_workspace(8) as ws:                       # 8 boards of 256 channels: eight workgroups per board, ONE launch
+        assert ws.conv_kernel() == "tower_split_kernel"
+    with net.get_workspace(160) as ws:                     # a split would need more workgroups than CUs: a workgroup per board
+        assert ws.conv_kernel() == "tower_board_kernel"
+    net.destroy()
+    monkeypatch.setenv("DGNN_TOWER_SPLIT", "0")
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 256, seed=93)))
+    with net.get_workspace(8) as ws:
         assert ws.conv_kernel() == "conv3x3_board_kernel"
+    net.destroy()
+
+
+@pytest.mark.parametrize("blocks,channels,batch,split", [
+    (3, 256, 128, "1"), (3, 256, 100, "1"), (2, 256, 64, "1"), (2, 256, 37, "1"), (3, 256, 20, "1"), (2, 256, 1, "1"),
+    (4, 128, 128, "1"), (4, 128, 70, "1"), (3, 128, 40, "1"), (3, 128, 3, "1"), (3, 64, 50, "2"), (2, 64, 128, "2")])
+def test_split_tower_equals_one_launch_per_layer(api, synth, blocks, channels, batch, split, monkeypatch):
+    """tower_split_kernel: the workgroups of a board hand their channel blocks to each other inside one launch (per-board
+    flags, write-through stores, L1-bypassing loads).  Same per-layer code, same contraction order as conv3x3_board_kernel:
+    the outputs must be bit-identical to one launch per layer, pass after pass (a hand-off that let a workgroup read a
+    channel block too early would show up as a mismatch on some pass)."""
+    text = synth.to_json(synth.make_tensors(blocks, channels, seed=191))
+    monkeypatch.setenv("DGNN_TOWER", "0")
+    net = api.Network.from_json(text)
+    reference = []
+    with net.get_workspace(batch) as ws:
+        assert ws.conv_kernel() == "conv3x3_board_kernel"
+        for i in range(4):
+            reference.append(api.forward(ws, synth.make_features(batch, seed=300 + i)).unwrap())
+    net.destroy()
+    monkeypatch.setenv("DGNN_TOWER", "1")
+    monkeypatch.setenv("DGNN_TOWER_SPLIT", split)
+    net = api.Network.from_json(text)
+    with net.get_workspace(batch) as ws:
+        assert ws.conv_kernel() == "tower_split_kernel"
+        for rep in range(3):
+            for i in range(4):
+                value, policy = api.forward(ws, synth.make_features(batch, seed=300 + i)).unwrap()
+                assert np.array_equal(value.view(np.uint16), reference[i][0].view(np.uint16)), (rep, i)
+                assert np.array_equal(policy.view(np.uint16), reference[i][1].view(np.uint16)), (rep, i)
+    net.destroy()
+
+
+def test_one_workspace_serves_every_fill_level_with_the_same_bits(api, synth, monkeypatch):
+    """A workspace of capacity 256 is handed 256, 150, 100, 40 and 5 boards (dgnn_forward_n): a workgroup per board, then a
+    board over two, four and eight workgroups.  A board's outputs do not depend on which of these ran it."""
+    text = synth.to_json(synth.make_tensors(2, 256, seed=195))
+    features = synth.make_features(256, seed=196)
+    net = api.Network.from_json(text)
+    with net.get_workspace(256) as ws:
+        full_value, full_policy = api.forward(ws, features).unwrap()
+        for count in (150, 100, 40, 5):
+            value, policy = api.forward_n(ws, features[: count * 361 * 32], count).unwrap()
+            assert np.array_equal(value.view(np.uint16), full_value.view(np.uint16)[:count]), count
+            assert np.array_equal(policy.view(np.uint16).reshape(count, 362), full_policy.view(np.uint16).reshape(256, 362)[:count]), count
     net.destroy()

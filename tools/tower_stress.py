@@ -20,9 +20,15 @@ from dream_go_amd import api, synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
-    args = ap.parse_args()
     bad = 0
-    for blocks, channels, batch in ((20, 256, 256), (9, 128, 256), (6, 64, 77), (20, 256, 200)):
+    ap.add_argument("--split", action="store_true", help="the split tower (a board over several workgroups) instead")
+    args = ap.parse_args()
+    shapes = ((20, 256, 256), (9, 128, 256), (6, 64, 77), (20, 256, 200))
+    expect = "tower_board_kernel"
+    if args.split:
+        shapes = ((20, 256, 128), (20, 256, 64), (20, 256, 32), (20, 256, 90), (9, 128, 128), (9, 128, 32), (20, 256, 7))
+        expect = "tower_split_kernel"
+    for blocks, channels, batch in shapes:
         text = synth.to_json(synth.make_tensors(blocks, channels, seed=7))
         os.environ["DGNN_TOWER"] = "1"
         tower_net = api.Network.from_json(text)
@@ -30,7 +36,7 @@ def main():
         os.environ["DGNN_TOWER"] = "0"
         layer_net = api.Network.from_json(text)
         layers = layer_net.get_workspace(batch).__enter__()
-        assert tower.conv_kernel() == "tower_board_kernel" and layers.conv_kernel() == "conv3x3_board_kernel"
+        assert tower.conv_kernel() == expect and layers.conv_kernel() == "conv3x3_board_kernel"
         mismatches = 0
         for i in range(args.iters):
             features = synth.make_features(batch, seed=1000 + i)
