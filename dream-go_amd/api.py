@@ -26,7 +26,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdgnn_hip.so")
+# DGNN_LIBRARY=<path>: another build of the same library (A/B measurements of two builds on one box); default: the in-tree one
+LIB_PATH = os.environ.get("DGNN_LIBRARY") or os.path.join(_HERE, "lib", "libdgnn_hip.so")
 
 OK = 0
 MISSING_WEIGHTS = -1

@@ -85,6 +85,11 @@ __device__ __forceinline__ void wait_lgkm(half8& f0)
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f0) : "n"(N));
 }
 template <int N>
+__device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N));
+}
+template <int N>
 __device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2)
 {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f0), "+v"(f1), "+v"(f2) : "n"(N));
@@ -104,6 +109,52 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
     static_for_impl(f, std::make_integer_sequence<int, N>());
+}
+
+// Software-pipelined K loop: number of LDS reads issued AFTER the ones the MFMA of pair I needs and before that MFMA.
+// Program order of a step: [first step of a chunk: B reads of pairs 0..BD-2] then for every pair p: [p == AP: the two A reads
+// of the NEXT step] [the B read of sequence index p + BD - 1: this step's pair, or the next step's unless `last`] [MFMA p].
+// A position p < 0 is pair NP + p of the previous step (for a first step: the preload slot).
+template <int NP, int BD, int AP>
+constexpr int lds_younger(int I, bool first, bool last)
+{
+    const int pb = I - (BD - 1);                      // position whose B read MFMA I consumes
+    const int pa = first ? -1000 : AP - NP;           // position (previous step) that requested this step's A fragments
+    int n = 0;
+    for (int p = (pb > pa ? pb : pa); p <= I; ++p) {
+        const int q = p < 0 ? p + NP : p;
+        const bool in_prev = p < 0;
+        const bool has_a = q == AP && !(in_prev && first);
+        const int t = p + BD - 1;
+        const bool has_b = in_prev ? true : (t < NP || !last);
+        if (p == pb && p == pa) {}                                   // both needed reads sit here: nothing of it is younger
+        else if (p == pb) {}                                         // its B is the needed one; its A came before that
+        else if (p == pa) { if (has_b) n += 1; }                     // its A is the needed one; its B is younger
+        else { if (has_a) n += 2; if (has_b) n += 1; }
+    }
+    return n;
+}
+
+// The same count for the order [MFMA p] [p == AP: A reads of the next step] [B read of sequence index p + BD]: the read that
+// refills a register is issued right BEHIND the MFMA that consumed it (a read that has to queue for the LDS then never stands
+// between a wave and an MFMA whose operands are already there), and the rotation is BD deep instead of BD - 1.
+template <int NP, int BD, int AP>
+constexpr int lds_younger_mfma_first(int I, bool first, bool last)
+{
+    const int pb = I - BD;
+    const int pa = first ? -1000 : AP - NP;
+    int n = 0;
+    auto events = [&](int p, bool only_b) {
+        const int q = p < 0 ? p + NP : p;
+        const bool in_prev = p < 0;
+        const bool has_a = q == AP && !(in_prev && first);
+        const int t = p + BD;
+        const bool has_b = in_prev ? true : (t < NP || !last);
+        return (has_a && !only_b ? 2 : 0) + (has_b ? 1 : 0);
+    };
+    if (pa > pb) n += events(pa, true);                       // the needed A reads sit at pa; that position's B read is younger
+    for (int p = (pa > pb ? pa : pb) + 1; p <= I - 1; ++p) n += events(p, false);
+    return n;
 }
 
 // Work split of the 8 waves, template parameter NS = 32-channel slices per workgroup (a workgroup covers 32 * NS output
@@ -135,12 +186,14 @@ struct Split {
     static constexpr int RingBytes = kRing * SlabBytes;
     static constexpr int LdsBytes = kWBase + WAVES * RingBytes;
     static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step
-    static constexpr int BD = NS == 8 ? 5 : NS == 4 ? 4 : 3;   // B-fragment registers in rotation: BD - 1 pairs of read-ahead
+    static constexpr int BD = NS == 8 ? 5 : NS == 4 ? 4 : 5;   // B-fragment registers in rotation: BD - 1 pairs of read-ahead
     // byte offset of the B fragment of pair i = k16 * RT + row tile relative to the lane's base row
     static constexpr int b_offset(int i) { return (i / RT) * 2 * kSlotBytes + (i % RT) * 512; }
     // pair index behind which the j-th filter piece / the activation piece of the step is issued
-    static constexpr int w_pair(int j) { return NS == 8 ? 5 + 10 * j : NS == 4 ? 2 + 5 * j : 1 + 2 * j; }
-    static constexpr int x_pair() { return NS == 8 ? 20 : NS == 4 ? 10 : 5; }
+    static constexpr int w_pair(int j) { return NS == 8 ? 3 + 7 * j : NS == 4 ? 1 + 3 * j : j; }
+    static constexpr int x_pair() { return NS == 8 ? 14 : NS == 4 ? 6 : 2; }
+    // pair at which the NEXT step's A fragments are requested (behind this step's DMA instructions)
+    static constexpr int a_pair() { return NS == 8 ? 17 : NS == 4 ? 8 : 3; }
 };
 static_assert(Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
 
@@ -215,6 +268,9 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
 {
     using S = Split<NS>;
     constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP;
+    static_assert(CT == 1, "one 32-channel tile per wave");
+    constexpr bool PIPE = !(ABL & 32);               // ABL 32: the K loop without the software pipeline across steps (A/B)
+    constexpr int WI = (ABL & 64) ? 2 * W : W;       // ABL 64: every filter piece is requested TWICE (what does a DMA instruction cost?)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -354,6 +410,23 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
     // zc_c >= 0: this chunk also folds units 6 * zc_c .. 6 * zc_c + 5 of the skip input into the accumulators (SKIP == 2;
     // chunks 0 and 1 are peeled off the loop so that those VALU updates are unconditional straight-line code -- inside a
     // branch the register allocator copies whole 16-register accumulator tuples and spills)
+    //
+    // Software pipeline across the k-steps (PIPE): a step never starts with "wait for my slab, read A, read the first B
+    // fragments, wait for them" -- that bubble (an LDS round trip per step and wave) is what kept the MFMA pipe at 75 % of a
+    // step at NS = 4 and 88 % at NS = 8.  Instead
+    //   * the A fragments of step s + 1 are requested at pair AP of step s (behind all DMA instructions of step s, so the
+    //     counted vmcnt that guards slab s + 1 is the one the old code used at the start of step s + 1), into the other
+    //     half of af[2][2] (roles alternate with the tap's parity; tap 8 -> tap 0 needs one copy per chunk);
+    //   * the B-fragment rotation does not stop at the end of a step: the last BD - 1 pairs of step s request the first
+    //     BD - 1 pairs of step s + 1 (the next tap's immediate).  Only the chunk boundary (x buffer flips behind a barrier)
+    //     starts a fresh rotation.
+    // lds_younger() counts, for every MFMA, the LDS reads issued after the ones it needs (LDS returns in order).
+    half8 af[2][2];
+    half8 bf[BD];
+    if constexpr (PIPE) {
+        af[0][0] = lds_read<0>(w_addr);               // step 0 of the layer (slab 0 landed: the prologue waited for everything)
+        af[0][1] = lds_read<1024>(w_addr);
+    }
     auto run_chunk = [&](int chunk, auto zc_c) {
         constexpr int ZC = decltype(zc_c)::value;
         const int buf = chunk & 1;
@@ -365,55 +438,73 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
         auto step = [&](auto tap_c) {
             constexpr int TAP = decltype(tap_c)::value;
             constexpr int SHIFT = (TAP / 3 - 1) * 20 + (TAP % 3 - 1);
-            // DMA instructions issued after this step's slab: slab st is issued during step st - 3, the activation piece
-            // of a step (taps 0..3 only) after its filter pieces:
-            //     2 * W + |{TAP-3, TAP-2, TAP-1} mod 9  intersected with  {0,1,2,3}|
-            constexpr int N = 2 * W + ((TAP + 6) % 9 < XP) + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP);
-            if constexpr (!(ABL & 8)) wait_vmcnt<N>();
-
-            // Hand-placed LDS reads (inline asm, waits counted here: hipcc would otherwise serialise
-            // "read, s_waitcnt lgkmcnt(0), MFMAs" to save registers).  Issue order: the A fragments, B0 .. B(BD-2), then
-            // before the MFMAs of pair i = k16 * RT + row tile the B fragment of pair i + BD - 1 is requested and the
-            // wait leaves exactly the reads younger than B[i] outstanding.
+            constexpr int SHIFT_NEXT = ((TAP + 1) % 9 / 3 - 1) * 20 + ((TAP + 1) % 9 % 3 - 1);
+            // DMA instructions issued after slab st: slab st is issued during step st - 3, the activation piece of a step
+            // (taps 0..XP-1 only) after its filter pieces:
+            //     2 * W + |{TAP-3, TAP-2, TAP-1} mod 9  intersected with  {0..XP-1}|
+            constexpr int N = 2 * WI + ((TAP + 6) % 9 < XP) + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP);
+            // ... after slab st + 1, seen from pair AP of step st (all of this step's DMA instructions come before AP)
+            constexpr int N_NEXT = 2 * WI + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP) + (TAP < XP);
             constexpr int WOFF = (TAP % kRing) * S::SlabBytes;
+            constexpr int WOFF_NEXT = ((TAP + 1) % kRing) * S::SlabBytes;
             constexpr int XOFF = (kHalo + SHIFT) * 16;
-            half8 af[CT][2];                          // [channel tile][k16]
-            half8 bf[BD];
-            static_for<CT * 2>([&](auto fc) {
-                constexpr int F = decltype(fc)::value;
-                af[F / 2][F % 2] = lds_read<WOFF + F * 1024>(w_addr);
-            });
-            static_for<BD - 1>([&](auto ic) {
-                constexpr int I = decltype(ic)::value;
-                bf[I] = lds_read<XOFF + S::b_offset(I)>(x_addr);
-            });
+            constexpr int XOFF_NEXT = (kHalo + SHIFT_NEXT) * 16;
+            constexpr bool FIRST = TAP == 0, LAST = TAP == 8;
+            constexpr int P = PIPE ? (TAP & 1) : 0;
+            constexpr int PH = PIPE ? (TAP * NP) % BD : 0;        // where the rotation stands at the start of this step
+
+            if constexpr (!PIPE) {
+                if constexpr (!(ABL & 8)) wait_vmcnt<N>();
+                af[0][0] = lds_read<WOFF>(w_addr);
+                af[0][1] = lds_read<WOFF + 1024>(w_addr);
+            }
+            if constexpr (!PIPE || FIRST) {
+                static_for<(PIPE ? BD : BD - 1)>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value;
+                    bf[I] = lds_read<XOFF + S::b_offset(I)>(x_addr);
+                });
+            }
             static_for<NP>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 constexpr int K16 = I / RT, RTI = I % RT;
-                constexpr bool MORE = I + BD - 1 < NP && !(ABL & 4);
-                if constexpr (MORE) bf[(I + BD - 1) % BD] = lds_read<XOFF + S::b_offset(I + BD - 1)>(x_addr);
-                constexpr int YOUNGER = (ABL & 4) ? 0 : I + BD - 1 < NP ? BD - 1 : NP - 1 - I;
-                if constexpr (I == 0) {
-                    wait_lgkm<YOUNGER>(bf[0], af[0][0], af[0][1]);
+                if constexpr (PIPE) {
+                    constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair()>(I, FIRST, LAST);
+                    if constexpr (I == 0) wait_lgkm<YOUNGER>(bf[PH % BD], af[P][0], af[P][1]);
+                    else wait_lgkm<YOUNGER>(bf[(PH + I) % BD]);
                 } else {
-                    wait_lgkm<YOUNGER>(bf[I % BD]);
+                    constexpr bool MORE = I + BD - 1 < NP && !(ABL & 4);
+                    if constexpr (MORE) bf[(I + BD - 1) % BD] = lds_read<XOFF + S::b_offset(I + BD - 1)>(x_addr);
+                    constexpr int YOUNGER = (ABL & 4) ? 0 : I + BD - 1 < NP ? BD - 1 : NP - 1 - I;
+                    if constexpr (I == 0) wait_lgkm<YOUNGER>(bf[0], af[0][0], af[0][1]);
+                    else wait_lgkm<YOUNGER>(bf[I % BD]);
                 }
                 if constexpr (ABL & 1) {
-                    asm volatile("" ::"v"(af[0][K16]), "v"(bf[I % BD]));
+                    asm volatile("" ::"v"(af[P][K16]), "v"(bf[(PH + I) % BD]));
                 } else {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[ct][RTI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ct][K16], bf[I % BD], acc[ct][RTI], 0, 0, 0);
+                    acc[0][RTI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][K16], bf[(PH + I) % BD], acc[0][RTI], 0, 0, 0);
+                }
+                if constexpr (PIPE) {
+                    // keep the MFMA above the reads below: its result feeds an empty asm that the (volatile, ordered) reads follow
+                    // (not with four waves: their accumulators live in AGPRs and a "v" constraint would copy them back and forth)
+                    if constexpr (S::WAVES == 8) asm volatile("" : "+v"(acc[0][RTI]));
+                    if constexpr (I == S::a_pair()) {
+                        if constexpr (!(ABL & 8)) wait_vmcnt<N_NEXT>();
+                        af[P ^ 1][0] = lds_read<WOFF_NEXT>(w_addr);
+                        af[P ^ 1][1] = lds_read<WOFF_NEXT + 1024>(w_addr);
+                    }
+                    constexpr int T = I + BD;
+                    if constexpr (T < NP) bf[(PH + T) % BD] = lds_read<XOFF + S::b_offset(T)>(x_addr);
+                    else if constexpr (!LAST) bf[(PH + T) % BD] = lds_read<XOFF_NEXT + S::b_offset(T - NP)>(x_addr);
                 }
                 if constexpr (!(ABL & 2)) {
                     // The A fragments of this step are in registers since the first wait (I == 0): the slab may be
                     // refilled from now on.  The step's DMA instructions are spread over its MFMAs so that the wave has
                     // no separate, MFMA-free "issue phase".
-                    static_for<W>([&](auto jc) {
+                    static_for<WI>([&](auto jc) {
                         constexpr int J = decltype(jc)::value;
-                        if constexpr (I == S::w_pair(J)) {
+                        if constexpr (I == S::w_pair(J % W) + J / W) {
                             __builtin_amdgcn_sched_barrier(0);
-                            issue_w_piece(st0 + TAP + kRing, TAP % kRing, J);
+                            issue_w_piece(st0 + TAP + kRing, TAP % kRing, J % W);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     });
@@ -433,7 +524,7 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
             if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6 && ZC * 6 + TAP - 1 < 12) {
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
-                if (RT == 12 || (ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<W + (TAP < XP)>();     // (nothing was requested otherwise)
+                if (RT == 12 || (ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<WI + (TAP < XP)>();     // (nothing was requested otherwise)
                 __builtin_amdgcn_sched_barrier(0);
                 add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>(), std::integral_constant<int, 0>());
             }
@@ -463,8 +554,16 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
         // chunk boundary: this wave's pieces of the next chunk landed at tap 8's wait (issued at taps 0..3, at
         // least 5 slabs ago); its reads of this chunk retired with the MFMAs above.  With seven pieces per wave (taps 0..6)
         // the last one is younger than that wait covers: only the filter pieces of the steps after it may stay in flight.
-        if constexpr (XP > 4) wait_vmcnt<W * (8 - (XP - 1))>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (XP > 4) wait_vmcnt<WI * (8 - (XP - 1))>();
+        if constexpr (PIPE) {
+            // the only LDS reads still out are the A fragments of the next step (tap 8 requests no B read-ahead); tap 8
+            // left them in af[1], tap 0 of the next chunk looks in af[0]
+            wait_lgkm<0>(af[1][0], af[1][1]);
+            af[0][0] = af[1][0];
+            af[0][1] = af[1][1];
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if constexpr (SPLIT) {
             // the pieces of chunk + 2 go out during chunk + 1: its producer must have published before this barrier opens
             if (sync.epoch > 0 && tid == 0 && chunk + 2 < nchunks && (chunk + 2) % NS == 0) await_chunk(chunk + 2);
@@ -741,16 +840,20 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
 {
     const dim3 grid(args.batch, args.cout / (32 * NS));
 #define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(Split<NS>::Threads), 0, stream, args)
-    if constexpr (NS == 8) {
-        if (ablate != 0 && relu && skip != 1) {      // measurement only (tools/ablate.sh), residual shapes
+    if constexpr (NS == 8 || NS == 4) {
+        // measurement only (tools/ablate.sh), residual shapes: 1 = no MFMAs, 2 = no in-loop DMA, 3 = both, 32 = the K loop
+        // without the software pipeline across steps
+        if (ablate != 0 && relu && skip != 1) {
             if (skip == 2) {
                 switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 2: DGNN_BOARD(2, true, 2); break;
-                                  case 3: DGNN_BOARD(2, true, 3); break; case 4: DGNN_BOARD(2, true, 4); break;
-                                  case 16: DGNN_BOARD(2, true, 16); break; default: DGNN_BOARD(2, true, 8); break; }
+                                  case 3: DGNN_BOARD(2, true, 3); break; case 64: DGNN_BOARD(2, true, 64); break;
+                                  case 8: DGNN_BOARD(2, true, 8); break; case 16: DGNN_BOARD(2, true, 16); break; case 24: DGNN_BOARD(2, true, 24); break;
+                                  default: DGNN_BOARD(2, true, 32); break; }
             } else {
                 switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 2: DGNN_BOARD(0, true, 2); break;
-                                  case 3: DGNN_BOARD(0, true, 3); break; case 4: DGNN_BOARD(0, true, 4); break;
-                                  case 16: DGNN_BOARD(0, true, 16); break; default: DGNN_BOARD(0, true, 8); break; }
+                                  case 3: DGNN_BOARD(0, true, 3); break; case 64: DGNN_BOARD(0, true, 64); break;
+                                  case 8: DGNN_BOARD(0, true, 8); break; case 16: DGNN_BOARD(0, true, 16); break; case 24: DGNN_BOARD(0, true, 24); break;
+                                  default: DGNN_BOARD(0, true, 32); break; }
             }
             return;
         }
@@ -878,8 +981,8 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches
     const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !env.epilogue_skip) ? 2 : 1;
     const int ablate = env.ablate;
     switch (conv_board_pick_ns(args.batch, args.cout, env.ns)) {
-        case 8: launch_board_variant<8>(args, skip, relu, ablate >= 1 && ablate <= 16 ? ablate : 0, stream); break;
-        case 4: launch_board_variant<4>(args, skip, relu, 0, stream); break;
+        case 8: launch_board_variant<8>(args, skip, relu, ablate, stream); break;
+        case 4: launch_board_variant<4>(args, skip, relu, ablate, stream); break;
         case 2: launch_board_variant<2>(args, skip, relu, 0, stream); break;
         default: launch_board_variant<1>(args, skip, relu, 0, stream); break;
     }
