@@ -35,18 +35,34 @@ def needs_build():
     return False
 
 
+def _stale(src_path, obj):
+    """An object is rebuilt when its source, any header beside it or the public header is newer."""
+    if not os.path.exists(obj):
+        return True
+    built = os.path.getmtime(obj)
+    deps = [src_path] + [os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith(".h")]
+    inc = os.path.join(HERE, "..", "include")
+    deps += [os.path.join(inc, n) for n in os.listdir(inc)]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objects = []
+    objects, running = [], []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
+        objects.append(obj)
+        if not force and not _stale(os.path.join(CSRC, src), obj):
+            continue
         cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        objects.append(obj)
+        running.append((cmd, subprocess.Popen(cmd)))      # the translation units are independent: compile them side by side
+    for cmd, proc in running:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objects]
     if verbose:
         print(" ".join(cmd))

@@ -840,7 +840,7 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
 {
     const dim3 grid(args.batch, args.cout / (32 * NS));
 #define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(Split<NS>::Threads), 0, stream, args)
-    if constexpr (NS == 8 || NS == 4) {
+    if constexpr (NS == 8 || NS == 4 || NS == 1) {
         // measurement only (tools/ablate.sh), residual shapes: 1 = no MFMAs, 2 = no in-loop DMA, 3 = both, 32 = the K loop
         // without the software pipeline across steps
         if (ablate != 0 && relu && skip != 1) {
@@ -984,7 +984,7 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches
         case 8: launch_board_variant<8>(args, skip, relu, ablate, stream); break;
         case 4: launch_board_variant<4>(args, skip, relu, ablate, stream); break;
         case 2: launch_board_variant<2>(args, skip, relu, 0, stream); break;
-        default: launch_board_variant<1>(args, skip, relu, 0, stream); break;
+        default: launch_board_variant<1>(args, skip, relu, ablate, stream); break;
     }
     return hipGetLastError();
 }
