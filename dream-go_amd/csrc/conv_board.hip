@@ -138,7 +138,7 @@ constexpr int lds_younger(int I, bool first, bool last)
 // The same count for the order [MFMA p] [p == AP: A reads of the next step] [B read of sequence index p + BD]: the read that
 // refills a register is issued right BEHIND the MFMA that consumed it (a read that has to queue for the LDS then never stands
 // between a wave and an MFMA whose operands are already there), and the rotation is BD deep instead of BD - 1.
-template <int NP, int BD, int AP>
+template <int NP, int BD, int AP, bool A_NOT_AT_LAST = false>
 constexpr int lds_younger_mfma_first(int I, bool first, bool last)
 {
     const int pb = I - BD;
@@ -147,7 +147,7 @@ constexpr int lds_younger_mfma_first(int I, bool first, bool last)
     auto events = [&](int p, bool only_b) {
         const int q = p < 0 ? p + NP : p;
         const bool in_prev = p < 0;
-        const bool has_a = q == AP && !(in_prev && first);
+        const bool has_a = q == AP && !(in_prev && first) && !(A_NOT_AT_LAST && last && !in_prev);
         const int t = p + BD;
         const bool has_b = in_prev ? true : (t < NP || !last);
         return (has_a && !only_b ? 2 : 0) + (has_b ? 1 : 0);
@@ -171,12 +171,20 @@ constexpr int lds_younger_mfma_first(int I, bool first, bool last)
 // with the B-fragment reads ablated) -- saved cycles come back as a lower clock unless bytes moved per MFMA go down too.
 // Filter packing (host, pack_filter_board): [k-step][C_out / 32 slices][k16][64 lanes][8 halfs], k-step = chunk * 9 + tap,
 // lane l holds w[co = slice * 32 + (l & 31)][tap][ci = chunk * 32 + k16 * 16 + (l >> 5) * 8 .. + 8].
-//   NS = 1   1 slice x 4 row groups of 96 rows (3 row tiles per wave), FOUR waves: one wave per SIMD, half the MFMAs per
-//            SIMD and k-step of NS = 2 -- the latency variant for the smallest batches (twice the workgroups per board)
+//   NS = 1   1 slice x 12 row groups of 32 rows (one row tile per wave), TWELVE waves, three per SIMD: the latency variant for
+//            the smallest batches (twice the workgroups per board).  [Round 1 / early round 2: four waves x 3 row tiles, one
+//            per SIMD -- a lone wave issues its 6 MFMAs, 8 LDS reads and 3 DMA instructions of a k-step one after the
+//            other: 400..460 cycles per k-step for 192 cycles of MFMA.]
+// NS <= 2 are CHUNKED: the waves of such a workgroup share few slices, so a wave-private filter ring fetches every byte 4
+// (NS = 2) or 12 times.  Instead the workgroup's filter rows of one 32-channel chunk (9 taps x NS slices x 2 KiB) sit next to
+// the chunk's activations in the SAME double buffer, fetched once by all waves together and published by the chunk barrier
+// that is there anyway: no counted vmcnt per k-step, 4 (NS = 1) or 8 (NS = 2) DMA instructions per wave and chunk instead of
+// 25 / 22.
 template <int NS>
 struct Split {
     static constexpr int CT = 1;                       // 32-channel MFMA tiles per wave
-    static constexpr int WAVES = NS == 1 ? 4 : 8;
+    static constexpr bool Chunked = NS <= 2;
+    static constexpr int WAVES = NS == 1 ? 12 : 8;
     static constexpr int Threads = WAVES * 64;
     static constexpr int XP = (4 * kPieces + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
     static constexpr int RG = WAVES / NS;              // row groups
@@ -184,18 +192,28 @@ struct Split {
     static constexpr int W = 2;                        // DMA instructions (1 KiB fragments) per filter slab: k16 = 0, 1
     static constexpr int SlabBytes = W * 1024;
     static constexpr int RingBytes = kRing * SlabBytes;
-    static constexpr int LdsBytes = kWBase + WAVES * RingBytes;
+    static constexpr int FChunkBytes = 9 * NS * 2048;  // Chunked: the workgroup's filter rows of one chunk, [tap][slice][k16][lane][8]
+    static constexpr int BufStride = Chunked ? kXBufBytes + FChunkBytes : kXBufBytes;   // one of the two chunk buffers
+    static constexpr int LdsBytes = Chunked ? 2 * BufStride : kWBase + WAVES * RingBytes;
+    static constexpr int Pieces = 4 * kPieces + 18 * NS;            // Chunked: DMA instructions per chunk, activations then filter
+    static constexpr int PPW = (Pieces + WAVES - 1) / WAVES;        // ... per wave (4 at NS = 1, 8 at NS = 2; surplus ones repeat)
+    // Chunked: piece j of a wave goes out behind the MFMA of pair piece_pair(j) of tap piece_tap(j) (early in the chunk: it
+    // has to land before the chunk barrier)
+    static constexpr int piece_tap(int j) { return NS == 1 ? j : j / 2; }
+    static constexpr int piece_pair(int j) { return NS == 1 ? 1 : (j % 2 ? 4 : 1); }
+    static constexpr int pieces_in_tap(int tap) { int n = 0; for (int j = 0; j < PPW; ++j) n += piece_tap(j) == tap ? 1 : 0; return n; }
     static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step
-    static constexpr int BD = NS == 8 ? 5 : NS == 4 ? 4 : 5;   // B-fragment registers in rotation: BD - 1 pairs of read-ahead
+    static constexpr int BD = NS == 8 ? 5 : NS == 4 ? 4 : NS == 2 ? 5 : 2;   // B-fragment registers in rotation = pairs of read-ahead (<= NP)
     // byte offset of the B fragment of pair i = k16 * RT + row tile relative to the lane's base row
     static constexpr int b_offset(int i) { return (i / RT) * 2 * kSlotBytes + (i % RT) * 512; }
     // pair index behind which the j-th filter piece / the activation piece of the step is issued
     static constexpr int w_pair(int j) { return NS == 8 ? 3 + 7 * j : NS == 4 ? 1 + 3 * j : j; }
     static constexpr int x_pair() { return NS == 8 ? 14 : NS == 4 ? 6 : 2; }
     // pair at which the NEXT step's A fragments are requested (behind this step's DMA instructions)
-    static constexpr int a_pair() { return NS == 8 ? 17 : NS == 4 ? 8 : 3; }
+    static constexpr int a_pair() { return NS == 8 ? 17 : NS == 4 ? 8 : NS == 2 ? 3 : 0; }
 };
-static_assert(Split<8>::LdsBytes <= 160 * 1024, "LDS budget");
+static_assert(Split<8>::LdsBytes <= 160 * 1024 && Split<4>::LdsBytes <= 160 * 1024 && Split<2>::LdsBytes <= 160 * 1024, "LDS budget");
+static_assert(Split<1>::BD <= Split<1>::NP && Split<2>::BD <= Split<2>::NP, "the B rotation reaches one step ahead at most");
 
 // A board split over G = C_out / (32 * NS) workgroups INSIDE one launch (tower_split_kernel): what a workgroup needs to
 // know about the others.  Every workgroup publishes "layer i of my channel block is in memory" by storing i + 1 into
@@ -260,14 +278,23 @@ __device__ __forceinline__ uint4 load_row(const uint16_t* p)
 // One convolution of one workgroup: board `b`, channel block `nb`.  A __device__ function so that the per-layer kernel
 // and the whole-tower kernel below share it; `lds` is the workgroup's S::LdsBytes of shared memory.
 // SPLIT: the board is shared with other workgroups of the same launch (SplitSync above); otherwise `sync` is not looked at.
-// Returns (SPLIT only) whether the NEXT layer's first input chunk is already on its way into LDS; the caller hands that back
-// as `x0_in_flight`.
+// `carry` / return value: what a layer of a tower launch leaves behind for the next one, bit kHandedOver = its last steps
+// fetched the next layer's first filter slabs (chunk) and -- channel block 0 -- its epilogue left the next layer's first input
+// chunk in LDS, bit kX0InFlight (SPLIT) = the next layer's first input chunk is already on its way into LDS, bit kChained = an
+// earlier layer of this launch wrote this layer's input (set by the tower kernels from their second layer on), bit kStartBuffer
+// (chunked kernels) = the chunk buffer the next layer starts in (the one its predecessor's last chunk did not use).
+constexpr int kHandedOver = 2, kX0InFlight = 1, kChained = 4, kStartBuffer = 8;
 template <int NS, int SKIP, bool RELU, int ABL, bool SPLIT = false>
-__device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb,
-                                                const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, nullptr}, const bool x0_in_flight = false)
+__device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb,
+                                               const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, nullptr}, const int carry = 0)
 {
     using S = Split<NS>;
     constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP;
+    constexpr bool CHUNKED = S::Chunked;
+    constexpr int BUF = S::BufStride;
+    static_assert(!CHUNKED || !(ABL & ~1), "the chunked kernels know ablation 1 (no MFMAs) only");
+    const bool x0_in_flight = (carry & kX0InFlight) != 0;
+    const bool carry_in = a.carry_in != 0 && (carry & kHandedOver) != 0;
     static_assert(CT == 1, "one 32-channel tile per wave");
     constexpr bool PIPE = !(ABL & 32);               // ABL 32: the K loop without the software pipeline across steps (A/B)
     constexpr int WI = (ABL & 64) ? 2 * W : W;       // ABL 64: every filter piece is requested TWICE (what does a DMA instruction cost?)
@@ -280,6 +307,11 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
     const int cin = a.cin;
     const int cout = a.cout;
     const int nchunks = cin / 32;
+    // Hand-over to the next layer of a tower launch.  Chunked: the next layer's first filter chunk is fetched into the buffer
+    // the last chunk does NOT use, so that is where the next layer starts (and where its first input chunk is left).
+    const bool hand_over = a.w_next != nullptr;
+    const int buf0 = CHUNKED && (carry & kStartBuffer) ? 1 : 0;      // chunk c of this layer lives in buffer (buf0 + c) & 1
+    const int buf_next = CHUNKED ? (buf0 + nchunks) & 1 : 0;
 
     const bool tracing = a.timing != nullptr || (SPLIT && sync.trace != nullptr);
     const unsigned long long t_start = tracing ? __builtin_amdgcn_s_memtime() : 0;
@@ -290,7 +322,7 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
         const int rem = tid - buf * (4 * kHalo);
         const int slot = rem / kHalo;
         const int row = rem - slot * kHalo;
-        *reinterpret_cast<uint4*>(lds + buf * kXBufBytes + slot * kSlotBytes + row * 16) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(lds + buf * BUF + slot * kSlotBytes + row * 16) = make_uint4(0, 0, 0, 0);
     }
 
     const uint16_t* const x_board = a.x + (long)b * cin * kRows + lane * 8;
@@ -321,22 +353,56 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
         const int s = p / kPieces;
         const int i = p - s * kPieces;
         const uint16_t* src = board + ((long)(chunk * 4 + s) * kRows + i * 64) * 8;
-        char* const dst = lds + buf * kXBufBytes + s * kSlotBytes + (kHalo + i * 64) * 16;
+        char* const dst = lds + buf * BUF + s * kSlotBytes + (kHalo + i * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, SPLIT ? 16 : 0);   // aux 16 = sc1
     };
     auto issue_x = [&](int chunk, int buf, int j) { issue_x_from(x_board, chunk, buf, j); };
+    // Chunked: piece q (0 .. 18 * NS - 1 = [tap][slice][k16]) of the workgroup's filter rows of `chunk` -> buffer `buf`.  Chunks
+    // past the last one belong to the next layer when there is one to hand over to.
+    const uint16_t* const w_group = a.w + (long)(nb * NS) * 1024 + lane * 8;
+    const uint16_t* const w_next_group = a.w_next ? a.w_next + (long)(nb * NS) * 1024 + lane * 8 - (long)nsteps_total * step_halfs : w_group;
+    auto issue_f = [&](int chunk, int buf, int q) {
+        const int tap = q / (2 * NS), rest = q - tap * (2 * NS);
+        const int st = chunk * 9 + tap;
+        const uint16_t* src = (st >= nsteps_total ? w_next_group : w_group) + (long)st * step_halfs + rest * 512;
+        char* const dst = lds + buf * BUF + kXBufBytes + q * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    // Chunked: j-th DMA instruction of this wave for `chunk` (activations: the first 28 pieces, then the filter) -> buffer `buf`
+    auto issue_piece = [&](int x_chunk, int f_chunk, int buf, int j) {
+        int p = wave + S::WAVES * j;
+        if (p >= S::Pieces) p -= S::WAVES;            // a surplus instruction repeats the wave's previous piece
+        if (p < 4 * kPieces) {
+            const int sl = p / kPieces;
+            const int i = p - sl * kPieces;
+            const uint16_t* src = x_board + ((long)(x_chunk * 4 + sl) * kRows + i * 64) * 8;
+            char* const dst = lds + buf * BUF + sl * kSlotBytes + (kHalo + i * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, SPLIT ? 16 : 0);
+        } else {
+            issue_f(f_chunk, buf, p - 4 * kPieces);
+        }
+    };
     // SPLIT: the flag of the workgroup that produces input chunk c (its channel block is c / NS)
     unsigned* const done_board = SPLIT ? sync.done + (long)b * sync.groups : nullptr;
     auto await_chunk = [&](int c) {       // lane 0 of wave 0 only; the caller's next barrier tells everybody
         if (c / NS != nb) wait_published(done_board + c / NS, (unsigned)sync.epoch, sync.err);
+    };
+    // A look at a producer's flag costs a round trip to the L2 (some 600 cycles): it is requested EARLY -- a plain load that
+    // completes while the waves compute -- and only a flag that was not up yet is polled where the data is needed.
+    auto peek_chunk = [&](int c) -> unsigned {          // wave 0: the flag of chunk c's producer now (own chunks: "published")
+        if (c / NS == nb) return ~0u;
+        return __hip_atomic_load(done_board + c / NS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // ---- fragment read addresses ----
     // B (rows): lane l reads row tile * 32 + (l & 31), k-slot k16 * 2 + (l >> 5); tap shift is an immediate.
     const int x_lane = (lane >> 5) * kSlotBytes + (g * (RT * 32) + (lane & 31)) * 16;
     // A (filter): fragment ct * 2 + k16, lane-linear.
-    const int w_lane = kWBase + wave * S::RingBytes + lane * 16;
+    // A (filter): fragment k16, lane-linear: in the wave's ring, or (Chunked) in the chunk buffer behind the activations
+    const int w_lane = CHUNKED ? kXBufBytes + wn * 2048 + lane * 16 : kWBase + wave * S::RingBytes + lane * 16;
     const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)lds;
     const unsigned w_addr = lds_base + w_lane;
 
@@ -387,21 +453,31 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
         // chunk 0 (and chunk 1, whose pieces go out during chunk 0) must have been published by their producers; the
         // workgroup that produced chunk 0 itself found it in LDS (carry_in) and, unless NS == 1, owns chunk 1 too
         const bool must_wait = sync.epoch > 0 && ((nb != 0 && !x0_in_flight) || (NS == 1 && nchunks > 1));
+        // (channel block 0 without a hand-over reads back its own output: no flag to wait for)
         if (must_wait) {
             if (tid == 0) {
-                await_chunk(0);
-                if (nchunks > 1) await_chunk(1);
+                const unsigned f0 = peek_chunk(0);        // both requests go out before either answer is looked at
+                const unsigned f1 = nchunks > 1 ? peek_chunk(1) : ~0u;
+                if (f0 < (unsigned)sync.epoch) await_chunk(0);
+                if (f1 < (unsigned)sync.epoch) await_chunk(1);
             }
             __syncthreads();
         }
     }
-    if (!a.carry_in || (SPLIT && nb != 0 && !x0_in_flight)) {
+    // a chained layer without a hand-over fetches chunk 0 -- rows that OTHER waves of this workgroup stored a moment ago (each
+    // wave has waited for its own stores only): meet them first
+    if ((carry & kChained) != 0 && !carry_in) __syncthreads();
+    if (!carry_in || (SPLIT && nb != 0 && !x0_in_flight)) {
 #pragma unroll
-        for (int j = 0; j < XP; ++j) issue_x(0, 0, j);
+        for (int j = 0; j < XP; ++j) issue_x(0, buf0, j);
     }
-    if (!a.carry_in) {
+    if (!carry_in) {
+        if constexpr (CHUNKED) {
+            for (int q = wave; q < 18 * NS; q += S::WAVES) issue_f(0, buf0, q);
+        } else {
 #pragma unroll
-        for (int s = 0; s < kRing; ++s) issue_w(s, s);
+            for (int s = 0; s < kRing; ++s) issue_w(s, s);
+        }
     }
     wait_vmcnt<0>();
     __syncthreads();
@@ -421,18 +497,30 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
     //     BD - 1 pairs of step s + 1 (the next tap's immediate).  Only the chunk boundary (x buffer flips behind a barrier)
     //     starts a fresh rotation.
     // lds_younger() counts, for every MFMA, the LDS reads issued after the ones it needs (LDS returns in order).
+    // Chunked kernels: the A fragments come out of the chunk buffer (tap-major), so tap 8 cannot request its successor's
+    // (other buffer, published by the chunk barrier): tap 0 requests its own in front of its first B fragments.
     half8 af[2][2];
     half8 bf[BD];
-    if constexpr (PIPE) {
+    if constexpr (PIPE && !CHUNKED) {
         af[0][0] = lds_read<0>(w_addr);               // step 0 of the layer (slab 0 landed: the prologue waited for everything)
         af[0][1] = lds_read<1024>(w_addr);
     }
     auto run_chunk = [&](int chunk, auto zc_c) {
         constexpr int ZC = decltype(zc_c)::value;
-        const int buf = chunk & 1;
+        const int buf = (chunk + buf0) & 1;
         const int next_chunk = chunk + 1 < nchunks ? chunk + 1 : 0;    // the last chunk re-fetches chunk 0 (unused):
                                                                        // keeps the DMA count per step constant
-        const unsigned x_addr = lds_base + buf * kXBufBytes + x_lane;
+        // SPLIT: the pieces of chunk + 2 go out during chunk + 1: its producer must have published before the barrier at the
+        // end of this chunk opens.  The flag is requested now and looked at there.
+        unsigned flag_ahead = ~0u;
+        const bool needs_flag = SPLIT && sync.epoch > 0 && chunk + 2 < nchunks && (chunk + 2) % NS == 0;
+        if constexpr (SPLIT && CHUNKED) {     // (NS = 4: measured 1..3 % slower with the early look -- the extra load sits among wave 0's counted waits)
+            if (needs_flag && wave == 0) flag_ahead = peek_chunk(chunk + 2);
+        } else if constexpr (SPLIT) {
+            flag_ahead = 0;
+        }
+        const unsigned x_addr = lds_base + buf * BUF + x_lane;
+        const unsigned w_addr_c = CHUNKED ? w_addr + buf * BUF : w_addr;
         const int st0 = chunk * 9;
 
         auto step = [&](auto tap_c) {
@@ -445,8 +533,8 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
             constexpr int N = 2 * WI + ((TAP + 6) % 9 < XP) + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP);
             // ... after slab st + 1, seen from pair AP of step st (all of this step's DMA instructions come before AP)
             constexpr int N_NEXT = 2 * WI + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP) + (TAP < XP);
-            constexpr int WOFF = (TAP % kRing) * S::SlabBytes;
-            constexpr int WOFF_NEXT = ((TAP + 1) % kRing) * S::SlabBytes;
+            constexpr int WOFF = CHUNKED ? TAP * NS * 2048 : (TAP % kRing) * S::SlabBytes;
+            constexpr int WOFF_NEXT = CHUNKED ? (TAP + 1) % 9 * NS * 2048 : ((TAP + 1) % kRing) * S::SlabBytes;
             constexpr int XOFF = (kHalo + SHIFT) * 16;
             constexpr int XOFF_NEXT = (kHalo + SHIFT_NEXT) * 16;
             constexpr bool FIRST = TAP == 0, LAST = TAP == 8;
@@ -458,6 +546,10 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
                 af[0][0] = lds_read<WOFF>(w_addr);
                 af[0][1] = lds_read<WOFF + 1024>(w_addr);
             }
+            if constexpr (CHUNKED && FIRST) {
+                af[0][0] = lds_read<WOFF>(w_addr_c);
+                af[0][1] = lds_read<WOFF + 1024>(w_addr_c);
+            }
             if constexpr (!PIPE || FIRST) {
                 static_for<(PIPE ? BD : BD - 1)>([&](auto ic) {
                     constexpr int I = decltype(ic)::value;
@@ -468,7 +560,7 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
                 constexpr int I = decltype(ic)::value;
                 constexpr int K16 = I / RT, RTI = I % RT;
                 if constexpr (PIPE) {
-                    constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair()>(I, FIRST, LAST);
+                    constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair(), CHUNKED>(I, FIRST, LAST);
                     if constexpr (I == 0) wait_lgkm<YOUNGER>(bf[PH % BD], af[P][0], af[P][1]);
                     else wait_lgkm<YOUNGER>(bf[(PH + I) % BD]);
                 } else {
@@ -487,7 +579,12 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
                     // keep the MFMA above the reads below: its result feeds an empty asm that the (volatile, ordered) reads follow
                     // (not with four waves: their accumulators live in AGPRs and a "v" constraint would copy them back and forth)
                     if constexpr (S::WAVES == 8) asm volatile("" : "+v"(acc[0][RTI]));
-                    if constexpr (I == S::a_pair()) {
+                    if constexpr (I == S::a_pair() && CHUNKED) {
+                        if constexpr (!LAST) {
+                            af[P ^ 1][0] = lds_read<WOFF_NEXT>(w_addr_c);
+                            af[P ^ 1][1] = lds_read<WOFF_NEXT + 1024>(w_addr_c);
+                        }
+                    } else if constexpr (I == S::a_pair()) {
                         if constexpr (!(ABL & 8)) wait_vmcnt<N_NEXT>();
                         af[P ^ 1][0] = lds_read<WOFF_NEXT>(w_addr);
                         af[P ^ 1][1] = lds_read<WOFF_NEXT + 1024>(w_addr);
@@ -496,7 +593,17 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
                     if constexpr (T < NP) bf[(PH + T) % BD] = lds_read<XOFF + S::b_offset(T)>(x_addr);
                     else if constexpr (!LAST) bf[(PH + T) % BD] = lds_read<XOFF_NEXT + S::b_offset(T - NP)>(x_addr);
                 }
-                if constexpr (!(ABL & 2)) {
+                if constexpr (CHUNKED) {
+                    // this wave's share of the NEXT chunk's activations and filter rows -> the other buffer
+                    static_for<S::PPW>([&](auto jc) {
+                        constexpr int J = decltype(jc)::value;
+                        if constexpr (S::piece_tap(J) == TAP && S::piece_pair(J) == I) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(next_chunk, chunk + 1, buf ^ 1, J);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                } else if constexpr (!(ABL & 2)) {
                     // The A fragments of this step are in registers since the first wait (I == 0): the slab may be
                     // refilled from now on.  The step's DMA instructions are spread over its MFMAs so that the wave has
                     // no separate, MFMA-free "issue phase".
@@ -524,7 +631,7 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
             if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6 && ZC * 6 + TAP - 1 < 12) {
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
-                if (RT == 12 || (ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<WI + (TAP < XP)>();     // (nothing was requested otherwise)
+                if (RT == 12 || (ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<(CHUNKED ? S::pieces_in_tap(TAP) : WI + (TAP < XP))>();     // (nothing was requested otherwise)
                 __builtin_amdgcn_sched_barrier(0);
                 add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>(), std::integral_constant<int, 0>());
             }
@@ -554,8 +661,15 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
         // chunk boundary: this wave's pieces of the next chunk landed at tap 8's wait (issued at taps 0..3, at
         // least 5 slabs ago); its reads of this chunk retired with the MFMAs above.  With seven pieces per wave (taps 0..6)
         // the last one is younger than that wait covers: only the filter pieces of the steps after it may stay in flight.
-        if constexpr (XP > 4) wait_vmcnt<WI * (8 - (XP - 1))>();
-        if constexpr (PIPE) {
+        if constexpr (CHUNKED) {
+            // every piece of the next chunk this wave asked for has landed (tap 8 left no LDS read in flight); the barrier
+            // below publishes all of them
+            wait_vmcnt<0>();
+        } else if constexpr (XP > 4) {
+            wait_vmcnt<WI * (8 - (XP - 1))>();
+        }
+        if constexpr (CHUNKED) {
+        } else if constexpr (PIPE) {
             // the only LDS reads still out are the A fragments of the next step (tap 8 requests no B read-ahead); tap 8
             // left them in af[1], tap 0 of the next chunk looks in af[0]
             wait_lgkm<0>(af[1][0], af[1][1]);
@@ -565,8 +679,7 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if constexpr (SPLIT) {
-            // the pieces of chunk + 2 go out during chunk + 1: its producer must have published before this barrier opens
-            if (sync.epoch > 0 && tid == 0 && chunk + 2 < nchunks && (chunk + 2) % NS == 0) await_chunk(chunk + 2);
+            if (needs_flag && tid == 0 && flag_ahead < (unsigned)sync.epoch) await_chunk(chunk + 2);
         }
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -582,22 +695,28 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
     const unsigned long long t_epilogue = tracing ? __builtin_amdgcn_s_memtime() : 0;
 
     // SPLIT, a workgroup that does not produce channels 0..31 itself: if the one that does has ALREADY published this layer
-    // (it runs ahead: its first NS input chunks are its own), the next layer's first chunk is requested now and lands
-    // during the epilogue.  One look, no waiting; activation buffer 0 is free (nobody reads activations after the barrier
-    // that ended the last chunk, and every wave's DMA into buffer 0 had landed before it).
+    // (it runs ahead: its first NS input chunks are its own), the next layer's first chunk is requested at the END of the
+    // epilogue and lands while the stores drain and the next prologue runs.  One look, no waiting, and the look itself (a round
+    // trip to the L2) is requested here and read behind the stores.  Activation buffer 0 is free: nobody reads activations
+    // after the barrier that ended the last chunk, and every wave's DMA into buffer 0 had landed before it.
     bool x0_next = false;
-    if constexpr (SPLIT) {
-        if (nb != 0 && a.w_next != nullptr) {
-            unsigned* const word = reinterpret_cast<unsigned*>(lds + S::LdsBytes);
-            if (tid == 0)
-                *word = __hip_atomic_load(done_board, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)sync.epoch + 1u ? 1u : 0u;
-            __syncthreads();
-            x0_next = *word != 0;
-            if (x0_next) {
-                const uint16_t* const y_board = a.y + (long)b * cout * kRows + lane * 8;
+    unsigned flag_x0 = 0;
+    const bool may_prefetch_x0 = SPLIT && nb != 0 && hand_over;
+    auto prefetch_x0 = [&] {
+        unsigned* const word = reinterpret_cast<unsigned*>(lds + S::LdsBytes);
+        if (tid == 0) *word = flag_x0 >= (unsigned)sync.epoch + 1u ? 1u : 0u;
+        __syncthreads();
+        x0_next = *word != 0;
+        if (x0_next) {
+            const uint16_t* const y_board = a.y + (long)b * cout * kRows + lane * 8;
 #pragma unroll
-                for (int j = 0; j < XP; ++j) issue_x_from(y_board, 0, 0, j);
-            }
+            for (int j = 0; j < XP; ++j) issue_x_from(y_board, 0, buf_next, j);
+        }
+    };
+    if constexpr (SPLIT) {
+        if (may_prefetch_x0 && wave == 0) flag_x0 = __hip_atomic_load(done_board, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (!CHUNKED) {             // NS = 4: look and request now, in front of the epilogue (the longer epilogue covers it)
+            if (may_prefetch_x0) prefetch_x0();
         }
     }
 
@@ -672,20 +791,26 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
             // hand-over: channels 0..31 are the next layer's first input chunk; its place is activation buffer 0, which
             // nobody reads any more (the last chunk sits in buffer 1, and the barrier that ended it came after every
             // wave's last DMA into buffer 0 had landed)
-            if (ct == 0 && wn == 0 && nb == 0 && a.w_next != nullptr)
-                *reinterpret_cast<uint4*>(lds + (k0 + hi) * kSlotBytes + (kHalo + row) * 16) = unit;
+            if (ct == 0 && wn == 0 && nb == 0 && hand_over)
+                *reinterpret_cast<uint4*>(lds + buf_next * BUF + (k0 + hi) * kSlotBytes + (kHalo + row) * 16) = unit;
         }
         if (rt + 2 < RT) load_z(rt + 2);
     }
     if (a.timing) {
         wait_vmcnt<0>();
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        if (lane == 0) {
+        if (lane == 0 && wave < 8) {
             unsigned long long* out = a.timing + ((long)(nb * gridDim.x + b) * 8 + wave) * 4;
             out[0] = t_start; out[1] = t_loop; out[2] = t_epilogue; out[3] = t_end;
         }
     }
-    wait_vmcnt<0>();        // the tail's surplus DMA (slabs past the last step) must not outlive the workgroup's LDS
+    if constexpr (SPLIT && CHUNKED) {
+        if (may_prefetch_x0) prefetch_x0();
+    }
+    // the tail's surplus DMA (slabs past the last step) must not outlive the workgroup's LDS; pieces requested just now are
+    // the next prologue's to wait for (they are this wave's youngest XP operations)
+    if (CHUNKED && x0_next) wait_vmcnt<XP>();
+    else wait_vmcnt<0>();
     if constexpr (SPLIT) {
         // every wave's write-through stores have left (vmcnt counts stores): one lane says so to the rest of the board
         __syncthreads();
@@ -695,7 +820,7 @@ __device__ __forceinline__ bool conv_board_body(const ConvBoardLaunch& a, char* 
             out[0] = t_start; out[1] = t_loop; out[2] = t_epilogue | (x0_next ? 1ull << 63 : 0ull); out[3] = __builtin_amdgcn_s_memtime();
         }
     }
-    return x0_next;
+    return (x0_next ? kX0InFlight : 0) | (hand_over ? kHandedOver : 0) | (buf_next ? kStartBuffer : 0);
 }
 
 template <int NS, int SKIP, bool RELU, int ABL>
@@ -714,17 +839,20 @@ void conv3x3_board_kernel(ConvBoardLaunch a)
 // `layers` = 2 * blocks descriptors in HBM (conv_1 / conv_2 of every block: alpha2 == 0 / != 0), all with relu and
 // cin = cout = 32 * NS.
 template <int NS>
-__global__ __launch_bounds__(kThreads)
+__global__ __launch_bounds__(Split<NS>::Threads)
 void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
+    int carry = 0;
     for (int i = 0; i < count; ++i) {
         // the descriptors carry the hand-over fields (w_next, carry_in); a layer ends with its own loads and stores waited
         // for, and the next one starts with a barrier behind workgroup-scope fences (__syncthreads): this board's y is
         // visible to this workgroup's loads
         const ConvBoardLaunch a = layers[i];
-        if (a.alpha2 != 0.0f) conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0);
-        else conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0);
+        const SplitSync none{nullptr, nullptr, 0, 1, nullptr};
+        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0, none, carry);
+        else carry = conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0, none, carry);
+        carry |= kChained;
     }
 }
 
@@ -744,12 +872,13 @@ void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, i
     const int nb = q % groups;
     const int b = (q / groups) * 8 + xcd;
     if (b >= batch) return;
-    bool x0_in_flight = false;
+    int carry = 0;
     for (int i = 0; i < count; ++i) {
         const ConvBoardLaunch a = layers[i];
         const SplitSync sync{done, err, i, groups, trace};
-        if (a.alpha2 != 0.0f) x0_in_flight = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, sync, x0_in_flight);
-        else x0_in_flight = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, sync, x0_in_flight);
+        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, sync, carry);
+        else carry = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, sync, carry);
+        carry |= kChained;
     }
 }
 
@@ -840,7 +969,13 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
 {
     const dim3 grid(args.batch, args.cout / (32 * NS));
 #define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(Split<NS>::Threads), 0, stream, args)
-    if constexpr (NS == 8 || NS == 4 || NS == 1) {
+    if constexpr (NS == 1) {
+        if (ablate == 1 && relu && skip != 1) {      // timing only: the chunked kernel without its MFMAs
+            if (skip == 2) DGNN_BOARD(2, true, 1); else DGNN_BOARD(0, true, 1);
+            return;
+        }
+    }
+    if constexpr (NS == 8 || NS == 4) {
         // measurement only (tools/ablate.sh), residual shapes: 1 = no MFMAs, 2 = no in-loop DMA, 3 = both, 32 = the K loop
         // without the software pipeline across steps
         if (ablate != 0 && relu && skip != 1) {
@@ -912,7 +1047,7 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
     switch (channels / 32) {
         case 8: hipLaunchKernelGGL((tower_board_kernel<8>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
         case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
-        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count); break;
     }
     return hipGetLastError();
 }

@@ -113,7 +113,7 @@ void pack_filter_tile(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
 // Filter KRSC -> the per-wave MFMA fragment stream of conv3x3_board_kernel (conv_board.hip):
 // [9 * cin / 32 k-steps][cout / 32 slices][2 k16][64 lanes][8 halfs], k-step = chunk * 9 + tap, lane l holds
 // w[co = slice * 32 + (l & 31)][tap][ci = chunk * 32 + k16 * 16 + (l >> 5) * 8 .. + 8].  Requires cout % 64 == 0 and
-// cin % 32 == 0.  dst holds board_filter_elements(cout, cin) halfs: the kernel reads (never uses) up to 3 k-steps past the end.
+// cin % 32 == 0.  dst holds board_filter_elements(cout, cin) halfs: the kernel reads (never uses) up to 9 k-steps (one chunk) past the end.
 void pack_filter_board(const uint16_t* krsc, int cout, int cin, uint16_t* dst);
 size_t board_filter_elements(int cout, int cin);
 

@@ -111,7 +111,7 @@ void pack_filter_tile(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
 
 size_t board_filter_elements(int cout, int cin)
 {
-    return (size_t)9 * cin * cout + (size_t)3 * (cout / 32) * 1024;   // + 3 k-steps (read ahead by the kernel, never used)
+    return (size_t)9 * cin * cout + (size_t)9 * (cout / 32) * 1024;   // + 9 k-steps (one chunk: read ahead by the kernel, never used)
 }
 
 void pack_filter_board(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
