@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-moves", type=int, default=6, help="stones per game in the self-play leg (bounds its duration)")
     ap.add_argument("--selfplay-rollouts", type=int, default=800, help="--num-rollout of the self-play leg (BASELINE.json: 800)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
+    ap.add_argument("--selfplay-batches", type=int, default=2, help="device batches the leaf pool keeps alive per GPU (nn.rs:64-67: 2 per device)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
     ap.add_argument("--dry", action="store_true", help="no GPU: gloo + the CPU hash predictor behind the leaf pool (CPU tests of the N > 1 path)")
@@ -225,7 +226,8 @@ def selfplay_leg(job, api, replicas, net, args):
     if job.dry:
         pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
     else:
-        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=2, workers_per_device=2)
+        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
+                                        workers_per_device=args.selfplay_batches)
     out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=args.selfplay_moves,
                                     num_rollouts=args.selfplay_rollouts, threads_per_search=1, seed=20260930, pool=pool, cache=cache,
                                     device=job.tensor_device, leaves_per_thread=args.selfplay_leaves)

@@ -221,10 +221,12 @@ static_assert(Split<1>::BD <= Split<1>::NP && Split<2>::BD <= Split<2>::NP, "the
 // channels it is about to fetch.  No grid-wide barrier, no fence: the payload is stored sc1 (write-through) and loaded sc1
 // (past the reader's L1), the recipe of the CDNA guide's inter-workgroup rule (Guideline 16, form "sc1 both sides").
 struct SplitSync {
-    unsigned* done;      // [board][G], zeroed by the launcher before every launch
+    unsigned* done;      // [board][G]: `base` + layers published.  Never reset: every launch gets a `base` above anything an
+                         // earlier launch stored (two fill kernels per pass were 9 us of a 230 us pass at 9x128, batch 32)
     unsigned* err;       // one word: set when a poll gave up (the host then repeats the pass with one launch per layer)
     int epoch;           // layers of THIS launch that precede this one: 0 = the input comes from outside, nothing to wait for
     int groups;          // G
+    unsigned base;       // what the flags of this launch count from
     unsigned long long* trace;   // measurement only (DGNN_SPLIT_TRACE=<file>): [layer][board][nb][4] s_memtime stamps of wave 0, or nullptr
 };
 
@@ -286,7 +288,7 @@ __device__ __forceinline__ uint4 load_row(const uint16_t* p)
 constexpr int kHandedOver = 2, kX0InFlight = 1, kChained = 4, kStartBuffer = 8;
 template <int NS, int SKIP, bool RELU, int ABL, bool SPLIT = false>
 __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb,
-                                               const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, nullptr}, const int carry = 0)
+                                               const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, 0, nullptr}, const int carry = 0)
 {
     using S = Split<NS>;
     constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP;
@@ -388,7 +390,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     // SPLIT: the flag of the workgroup that produces input chunk c (its channel block is c / NS)
     unsigned* const done_board = SPLIT ? sync.done + (long)b * sync.groups : nullptr;
     auto await_chunk = [&](int c) {       // lane 0 of wave 0 only; the caller's next barrier tells everybody
-        if (c / NS != nb) wait_published(done_board + c / NS, (unsigned)sync.epoch, sync.err);
+        if (c / NS != nb) wait_published(done_board + c / NS, sync.base + (unsigned)sync.epoch, sync.err);
     };
     // A look at a producer's flag costs a round trip to the L2 (some 600 cycles): it is requested EARLY -- a plain load that
     // completes while the waves compute -- and only a flag that was not up yet is polled where the data is needed.
@@ -458,8 +460,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             if (tid == 0) {
                 const unsigned f0 = peek_chunk(0);        // both requests go out before either answer is looked at
                 const unsigned f1 = nchunks > 1 ? peek_chunk(1) : ~0u;
-                if (f0 < (unsigned)sync.epoch) await_chunk(0);
-                if (f1 < (unsigned)sync.epoch) await_chunk(1);
+                if (f0 < sync.base + (unsigned)sync.epoch) await_chunk(0);
+                if (f1 < sync.base + (unsigned)sync.epoch) await_chunk(1);
             }
             __syncthreads();
         }
@@ -679,7 +681,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if constexpr (SPLIT) {
-            if (needs_flag && tid == 0 && flag_ahead < (unsigned)sync.epoch) await_chunk(chunk + 2);
+            if (needs_flag && tid == 0 && flag_ahead < sync.base + (unsigned)sync.epoch) await_chunk(chunk + 2);
         }
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -704,7 +706,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     const bool may_prefetch_x0 = SPLIT && nb != 0 && hand_over;
     auto prefetch_x0 = [&] {
         unsigned* const word = reinterpret_cast<unsigned*>(lds + S::LdsBytes);
-        if (tid == 0) *word = flag_x0 >= (unsigned)sync.epoch + 1u ? 1u : 0u;
+        if (tid == 0) *word = flag_x0 >= sync.base + (unsigned)sync.epoch + 1u ? 1u : 0u;
         __syncthreads();
         x0_next = *word != 0;
         if (x0_next) {
@@ -814,7 +816,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     if constexpr (SPLIT) {
         // every wave's write-through stores have left (vmcnt counts stores): one lane says so to the rest of the board
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(done_board + nb, (unsigned)sync.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(done_board + nb, sync.base + (unsigned)sync.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sync.trace != nullptr && tid == 0) {
             unsigned long long* out = sync.trace + (((long)sync.epoch * a.batch + b) * sync.groups + nb) * 4;
             out[0] = t_start; out[1] = t_loop; out[2] = t_epilogue | (x0_next ? 1ull << 63 : 0ull); out[3] = __builtin_amdgcn_s_memtime();
@@ -849,7 +851,7 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
         // for, and the next one starts with a barrier behind workgroup-scope fences (__syncthreads): this board's y is
         // visible to this workgroup's loads
         const ConvBoardLaunch a = layers[i];
-        const SplitSync none{nullptr, nullptr, 0, 1, nullptr};
+        const SplitSync none{nullptr, nullptr, 0, 1, 0, nullptr};
         if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0, none, carry);
         else carry = conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0, none, carry);
         carry |= kChained;
@@ -864,8 +866,8 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 // mod 8 and share an L2.  All batch * G workgroups must be resident at once (the launcher keeps that <= the CU count).
 template <int NS>
 __global__ __launch_bounds__(Split<NS>::Threads)
-void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, int batch, int groups, unsigned* done, unsigned* err,
-                        unsigned long long* trace)
+void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, int batch, int groups, unsigned base, unsigned* done,
+                        unsigned* err, unsigned long long* trace)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes + 16];    // + one word of workgroup-wide agreement
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -875,7 +877,7 @@ void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, i
     int carry = 0;
     for (int i = 0; i < count; ++i) {
         const ConvBoardLaunch a = layers[i];
-        const SplitSync sync{done, err, i, groups, trace};
+        const SplitSync sync{done, err, i, groups, base, trace};
         if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, sync, carry);
         else carry = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, sync, carry);
         carry |= kChained;
@@ -1065,18 +1067,23 @@ int tower_split_ns(int batch, int channels, int num_cus)
 }
 
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
-                              unsigned* d_err, hipStream_t stream)
+                              size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     const int slices = channels / 32;
     if (ns < 1 || ns >= slices || slices % ns != 0) return hipErrorInvalidValue;
     const int groups = slices / ns;
-    const hipError_t st = hipMemsetAsync(d_done, 0, ((size_t)batch * groups + 1) * sizeof(unsigned), stream);   // + the err word behind it
-    if (st != hipSuccess) return st;
-    if (d_err != d_done + (size_t)batch * groups) {
-        const hipError_t st2 = hipMemsetAsync(d_err, 0, sizeof(unsigned), stream);
-        if (st2 != hipSuccess) return st2;
+    if ((size_t)batch * groups > done_words) return hipErrorInvalidValue;
+    // The flags are never reset between launches: a launch publishes *base + 1 .. *base + count, the next one counts from
+    // above that (whatever batch size or split it uses: every stale word is below its base).  Only a counter about to wrap
+    // costs a fill.
+    if (*base > 0xf0000000u) {
+        const hipError_t st = hipMemsetAsync(d_done, 0, done_words * sizeof(unsigned), stream);
+        if (st != hipSuccess) return st;
+        *base = 0;
     }
+    const unsigned launch_base = *base;
+    *base += (unsigned)count + 1u;
     const dim3 grid((batch + 7) / 8 * 8 * groups);
     // measurement only: DGNN_SPLIT_TRACE=<file> dumps wave 0's stamps of every (layer, board, channel block) of each launch
     static const char* const trace_path = std::getenv("DGNN_SPLIT_TRACE");
@@ -1087,9 +1094,9 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
         (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
     }
     switch (ns) {
-        case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, d_done, d_err, d_trace); break;
-        case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, d_done, d_err, d_trace); break;
-        default: hipLaunchKernelGGL((tower_split_kernel<1>), grid, dim3(Split<1>::Threads), 0, stream, d_layers, count, batch, groups, d_done, d_err, d_trace); break;
+        case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
+        case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
+        default: hipLaunchKernelGGL((tower_split_kernel<1>), grid, dim3(Split<1>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
     }
     const hipError_t launched = hipGetLastError();
     if (d_trace) {

@@ -70,7 +70,8 @@ struct Workspace {
     int split_pref = 1;                     // DGNN_TOWER_SPLIT: 0 = never split a board inside the tower launch, 1 = where a workgroup
                                             // per board is not chosen, 2 = wherever a split is possible (A/B)
     bool split_failed = false;              // a hand-off poll gave up once (not every workgroup was resident): per-layer launches from then on
-    unsigned* d_split_sync = nullptr;       // [batch * 8] layers published per (board, channel block) + the give-up word behind them
+    unsigned* d_split_sync = nullptr;       // [batch * 8] layers published per (board, channel block), then the give-up word
+    unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
     unsigned* h_split_err = nullptr;        // pinned copy of that word, fetched with the outputs
     bool split_pending = false;             // the submission in flight used tower_split_kernel
     bool pending_packed = false;            // ... and took packed features (what to repeat if it gave up)
@@ -390,8 +391,9 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
                 const int groups = t.num_channels / 32 / mode;
                 std::lock_guard<std::mutex> chain(ws->dev->split_mutex);
                 if (ws->dev->split_recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, ws->dev->split_done, 0));
+                (void)groups;
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
-                                            ws->d_split_sync + (size_t)ws->active * groups, ws->stream));
+                                            (size_t)ws->batch * 8, ws->d_split_sync + (size_t)ws->batch * 8, &ws->split_base, ws->stream));
                 DGNN_HIP(hipEventRecord(ws->dev->split_done, ws->stream));
                 ws->dev->split_recorded = true;
             } else {
@@ -471,8 +473,7 @@ int enqueue_split_check(Workspace* ws, bool packed)
     ws->split_pending = mode > 0;
     ws->pending_packed = packed;
     if (mode > 0) {
-        const int groups = ws->net->topo.num_channels / 32 / mode;
-        DGNN_HIP(hipMemcpyAsync(ws->h_split_err, ws->d_split_sync + (size_t)ws->active * groups, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream));
+        DGNN_HIP(hipMemcpyAsync(ws->h_split_err, ws->d_split_sync + (size_t)ws->batch * 8, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream));
     }
     return DGNN_OK;
 }

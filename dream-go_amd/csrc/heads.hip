@@ -147,11 +147,15 @@ void head_conv_board_kernel(HeadConvLaunch a)
     }
 }
 
-// C[b][m] = sum_k P[b][k] * Wt[m][k];  one 32 x 32 tile per workgroup, the 4 waves split K (k16 step s goes to wave s & 3).
-__global__ __launch_bounds__(256)
+// C[b][m] = sum_k P[b][k] * Wt[m][k];  one 32 x 32 tile per workgroup, the waves split K (k16 step s goes to wave s % kGemmWaves).
+// Operands come straight from memory, so a wave's share is a chain of round trips: sixteen waves (round 1: four, 13-14 us
+// whatever the batch -- as long as the whole 9x128 tower at batch 8) make the chain a quarter as long.
+constexpr int kGemmWaves = 16;
+__global__ __launch_bounds__(kGemmWaves * 64)
 void policy_gemm_kernel(PolicyGemmLaunch a)
 {
-    __shared__ float partial[4][16][64];
+    constexpr int WV = kGemmWaves;
+    __shared__ float partial[WV][16][64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -174,11 +178,11 @@ void policy_gemm_kernel(PolicyGemmLaunch a)
     const int nmain = k_in / 16;        // k16 steps that lie completely inside the input row
     const int nsteps = kp / 16;
     int s = wave;
-    for (; s + 12 < nmain; s += 16) {   // four steps of this wave per trip: eight loads in flight, two MFMA chains
+    for (; s + 3 * WV < nmain; s += 4 * WV) {   // four steps of this wave per trip: eight loads in flight, two MFMA chains
         half8 af[4], bf[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = (s + 4 * u) * 16 + kl;
+            const int k = (s + WV * u) * 16 + kl;
             af[u] = *reinterpret_cast<const half8*>(prow + k);
             bf[u] = *reinterpret_cast<const half8*>(wrow + k);
         }
@@ -187,13 +191,13 @@ void policy_gemm_kernel(PolicyGemmLaunch a)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2], bf[2], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[3], bf[3], acc2, 0, 0, 0);
     }
-    for (; s < nmain; s += 4) {
+    for (; s < nmain; s += WV) {
         const int k = s * 16 + kl;
         const half8 af = *reinterpret_cast<const half8*>(prow + k);
         const half8 bf = *reinterpret_cast<const half8*>(wrow + k);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
     }
-    for (; s < nsteps; s += 4) {        // the ragged end of the row: element-wise, zero beyond k_in
+    for (; s < nsteps; s += WV) {       // the ragged end of the row: element-wise, zero beyond k_in
         const int k = s * 16 + kl;
         half8 af;
 #pragma unroll
@@ -205,11 +209,15 @@ void policy_gemm_kernel(PolicyGemmLaunch a)
     for (int r = 0; r < 16; ++r) partial[wave][r][lane] = acc[r] + acc2[r];
     __syncthreads();
 
-    // D[i][j]: i = board row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = move = lane & 31.  256 threads x 4 elements.
+    // D[i][j]: i = board row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = move = lane & 31.  1024 elements over the threads.
+    constexpr int PER = 16 / WV > 0 ? 16 / WV : 1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = wave * 4 + q;
-        const float sum = partial[0][r][lane] + partial[1][r][lane] + partial[2][r][lane] + partial[3][r][lane];
+    for (int q = 0; q < PER; ++q) {
+        const int r = wave * PER + q;
+        if (r >= 16) break;
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WV; ++w) sum += partial[w][r][lane];
         const int bi = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int m = m0 + (lane & 31);
         if (bi < a.batch && m < a.n_out) {
@@ -290,7 +298,7 @@ hipError_t launch_head_conv_board(const HeadConvLaunch& args, hipStream_t stream
 hipError_t launch_policy_gemm(const PolicyGemmLaunch& args, hipStream_t stream)
 {
     if (args.batch <= 0) return hipSuccess;
-    hipLaunchKernelGGL(policy_gemm_kernel, dim3((args.batch + 31) / 32, (args.n_out + 31) / 32), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(policy_gemm_kernel, dim3((args.batch + 31) / 32, (args.n_out + 31) / 32), dim3(kGemmWaves * 64), 0, stream, args);
     return hipGetLastError();
 }
 
