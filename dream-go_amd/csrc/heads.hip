@@ -147,74 +147,132 @@ void head_conv_board_kernel(HeadConvLaunch a)
     }
 }
 
-// C[b][m] = sum_k P[b][k] * Wt[m][k];  one 32 x 32 tile per workgroup, the waves split K (k16 step s goes to wave s % kGemmWaves).
-// Operands come straight from memory, so a wave's share is a chain of round trips: sixteen waves (round 1: four, 13-14 us
-// whatever the batch -- as long as the whole 9x128 tower at batch 8) make the chain a quarter as long.
-constexpr int kGemmWaves = 16;
+// C[b][m] = sum_k P[b][k] * Wt[m][k];  one 32 x 32 tile per workgroup, the eight waves split K in pieces of 64.
+//
+// A fragment read straight from memory is 64 lanes x 16 bytes out of 32 different rows: 64 cache-line requests per
+// instruction, and the vector memory path of the ONE CU a workgroup runs on serves about one per cycle -- 2 x 181 such
+// instructions made the kernel 13-14 us at ANY batch size (as long as the whole 9x128 tower at batch 8; more waves changed
+// nothing).  So the operands are staged: an LDS-DMA instruction whose lanes cover 8 rows x 128 contiguous bytes (8 line
+// requests) drops a 32-row x 64-k tile into LDS, 16-byte segments XOR-swizzled by the row so that the fragment reads
+// (32 rows at a 128-byte stride) are two-way conflicts at worst.  Double buffered per wave.  Rows whose length is not a
+// multiple of 8 (dgnn_layer_dense with arbitrary shapes) and the ragged last piece take the element-wise path.
+constexpr int kGemmWaves = 8;
+constexpr int kGemmTileBytes = 32 * 128;      // 32 rows x 64 halfs
 __global__ __launch_bounds__(kGemmWaves * 64)
 void policy_gemm_kernel(PolicyGemmLaunch a)
 {
     constexpr int WV = kGemmWaves;
-    __shared__ float partial[WV][16][64];
+    __shared__ __attribute__((aligned(16))) char stage[WV][2][2][kGemmTileBytes];     // [wave][buffer][P / Wt][tile]: 128 KiB
+    float (*const partial)[16][64] = reinterpret_cast<float (*)[16][64]>(&stage[0][0][0][0]);   // reused behind a barrier: [WV][16][64]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * 32;
     const int m0 = blockIdx.y * 32;
     const int k_in = a.k_in;            // 361 * S
     const int kp = a.k_pad;             // k_in rounded up to a multiple of 64; Wt rows are zero beyond k_in
 
-    // rows past the batch read board 0 instead (their results are never stored)
-    const int brow = b0 + (lane & 31);
-    const uint16_t* const prow = a.features + (long)(brow < a.batch ? brow : 0) * k_in;
-    const uint16_t* const wrow = a.wt + (long)(m0 + (lane & 31)) * kp;
-    const int kl = (lane >> 5) * 8;
-
     floatx16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
 
-    const int nmain = k_in / 16;        // k16 steps that lie completely inside the input row
     const int nsteps = kp / 16;
-    int s = wave;
-    for (; s + 3 * WV < nmain; s += 4 * WV) {   // four steps of this wave per trip: eight loads in flight, two MFMA chains
-        half8 af[4], bf[4];
+    const bool staged = (k_in & 7) == 0;                  // 16-byte aligned rows
+    const int nfull = staged ? k_in / 64 : 0;             // pieces of 64 that lie completely inside an input row
+
+    // ---- staged pieces: piece p = wave, wave + WV, ...
+    {
+        // DMA: instruction j of a tile covers rows 8 j .. 8 j + 7; this lane fetches segment (lane & 7) ^ (row & 7) of its row
+        const int drow = lane >> 3;                       // row within the group of 8 (== row & 7)
+        const int dseg = (lane & 7) ^ drow;
+        const uint16_t* prow_j[4];
+        const uint16_t* wrow_j[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = (s + WV * u) * 16 + kl;
-            af[u] = *reinterpret_cast<const half8*>(prow + k);
-            bf[u] = *reinterpret_cast<const half8*>(wrow + k);
+        for (int j = 0; j < 4; ++j) {
+            const int br = b0 + 8 * j + drow;             // rows past the batch read board 0 instead (never stored)
+            prow_j[j] = a.features + (long)(br < a.batch ? br : 0) * k_in + dseg * 8;
+            wrow_j[j] = a.wt + (long)(m0 + 8 * j + drow) * kp + dseg * 8;
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2], bf[2], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[3], bf[3], acc2, 0, 0, 0);
-    }
-    for (; s < nmain; s += WV) {
-        const int k = s * 16 + kl;
-        const half8 af = *reinterpret_cast<const half8*>(prow + k);
-        const half8 bf = *reinterpret_cast<const half8*>(wrow + k);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
-    }
-    for (; s < nsteps; s += WV) {       // the ragged end of the row: element-wise, zero beyond k_in
-        const int k = s * 16 + kl;
-        half8 af;
+        auto issue = [&](int piece, int buf) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) af[e] = (k + e < k_in) ? __builtin_bit_cast(_Float16, prow[k + e]) : (_Float16)0.0f;
-        const half8 bf = *reinterpret_cast<const half8*>(wrow + k);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(prow_j[j] + piece * 64),
+                                                 (__attribute__((address_space(3))) void*)(&stage[wave][buf][0][j * 1024]), 16, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow_j[j] + piece * 64),
+                                                 (__attribute__((address_space(3))) void*)(&stage[wave][buf][1][j * 1024]), 16, 0, 0);
+        };
+        // fragment of k16 step t: row lane & 31, segment t * 2 + (lane >> 5), where the swizzle put it
+        const int frow = lane & 31;
+        int foff[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) foff[t] = frow * 128 + (((t * 2 + (lane >> 5)) ^ (frow & 7)) * 16);
+
+        int piece = wave, buf = 0;
+        if (piece < nfull) issue(piece, 0);
+        for (; piece < nfull; piece += WV, buf ^= 1) {
+            if (piece + WV < nfull) {
+                issue(piece + WV, buf ^ 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // this piece landed; the next one may stay in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const char* const pa = &stage[wave][buf][0][0];
+            const char* const pw = &stage[wave][buf][1][0];
+            half8 af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *reinterpret_cast<const half8*>(pa + foff[t]);
+                bf[t] = *reinterpret_cast<const half8*>(pw + foff[t]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2], bf[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[3], bf[3], acc2, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the fragments are in registers before the buffer is refilled
+        }
     }
+
+    // ---- what is left (everything, for unaligned rows): k16 steps straight from memory, element-wise at the ragged end
+    {
+        const int brow = b0 + (lane & 31);
+        const uint16_t* const prow = a.features + (long)(brow < a.batch ? brow : 0) * k_in;
+        const uint16_t* const wrow = a.wt + (long)(m0 + (lane & 31)) * kp;
+        const int kl = (lane >> 5) * 8;
+        const int nmain = k_in / 16;    // k16 steps that lie completely inside the input row
+        int s = nfull * 4 + wave;
+        if (staged) {
+            for (; s < nmain; s += WV) {
+                const int k = s * 16 + kl;
+                const half8 af = *reinterpret_cast<const half8*>(prow + k);
+                const half8 bf = *reinterpret_cast<const half8*>(wrow + k);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+            }
+        }
+        for (; s < nsteps; s += WV) {   // element-wise, zero beyond k_in
+            const int k = s * 16 + kl;
+            half8 af;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[e] = (k + e < k_in) ? __builtin_bit_cast(_Float16, prow[k + e]) : (_Float16)0.0f;
+            half8 bf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bf[e] = __builtin_bit_cast(_Float16, wrow[k + e]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+        }
+    }
+
+    __syncthreads();                    // every wave is done with its staging buffers: they become the partial sums
 #pragma unroll
     for (int r = 0; r < 16; ++r) partial[wave][r][lane] = acc[r] + acc2[r];
     __syncthreads();
 
     // D[i][j]: i = board row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = move = lane & 31.  1024 elements over the threads.
-    constexpr int PER = 16 / WV > 0 ? 16 / WV : 1;
+    constexpr int PER = 16 / WV;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const int r = wave * PER + q;
-        if (r >= 16) break;
         float sum = 0.0f;
 #pragma unroll
         for (int w = 0; w < WV; ++w) sum += partial[w][r][lane];

@@ -12,7 +12,7 @@ python tools/sweep.py --blocks 9 --channels 128 --batches 1,8,16,32,64,96,128,19
 python tools/sweep.py --blocks 6 --channels 64 --batches 1,8,16,64,256 > $out/batch_sweep_6x64.jsonl 2>/dev/null
 python bench.py > $out/bench.json 2> $out/bench.err
 bash tools/profile.sh $tag > /dev/null 2>&1
-python tools/pmc_summary.py gpurun_out/prof_$tag $out/pmc tower_board_kernel > $out/pmc/traffic_line.txt 2>&1
+mkdir -p $out/pmc; python tools/pmc_summary.py gpurun_out/prof_$tag $out/pmc tower_board_kernel > $out/pmc/traffic_line.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 for cfg in "20 256 128" "9 128 32" "20 256 16"; do
   set -- $cfg
