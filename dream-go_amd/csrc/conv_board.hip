@@ -55,10 +55,20 @@ constexpr int kRing = 3;                               // filter slabs per wave 
 constexpr int kWBase = 2 * kXBufBytes;
 constexpr int kThreads = 512;
 
-__device__ __forceinline__ _Float16 round_to_half(float t)
+// two fp32 -> packed fp16 (round to nearest even, like v_cvt_f16_f32) and max(packed fp16, 0): the epilogue's arithmetic at
+// a third of the instructions.  As asm so that the fp32 fma in front stays a separate instruction with its own rounding
+// (the oracle rounds twice; hipcc would otherwise fuse fma + cvt into v_fma_mixlo_f16).
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi)
 {
-    asm volatile("" : "+v"(t));          // keep fma and cvt separate: two roundings, like the oracle (see kernels.hip)
-    return (_Float16)t;
+    unsigned r;
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_relu_f16(unsigned v)
+{
+    unsigned r;
+    asm volatile("v_pk_max_f16 %0, %1, 0" : "=v"(r) : "v"(v));
+    return r;
 }
 
 template <int N>
@@ -93,6 +103,11 @@ template <int N>
 __device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2)
 {
     asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f0), "+v"(f1), "+v"(f2) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2, half8& f3)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2, half8& f3, half8& f4)
@@ -138,7 +153,7 @@ constexpr int lds_younger(int I, bool first, bool last)
 // The same count for the order [MFMA p] [p == AP: A reads of the next step] [B read of sequence index p + BD]: the read that
 // refills a register is issued right BEHIND the MFMA that consumed it (a read that has to queue for the LDS then never stands
 // between a wave and an MFMA whose operands are already there), and the rotation is BD deep instead of BD - 1.
-template <int NP, int BD, int AP, bool A_NOT_AT_LAST = false>
+template <int NP, int BD, int AP, bool A_NOT_AT_LAST = false, int NA = 2>
 constexpr int lds_younger_mfma_first(int I, bool first, bool last)
 {
     const int pb = I - BD;
@@ -150,11 +165,30 @@ constexpr int lds_younger_mfma_first(int I, bool first, bool last)
         const bool has_a = q == AP && !(in_prev && first) && !(A_NOT_AT_LAST && last && !in_prev);
         const int t = p + BD;
         const bool has_b = in_prev ? true : (t < NP || !last);
-        return (has_a && !only_b ? 2 : 0) + (has_b ? 1 : 0);
+        return (has_a && !only_b ? NA : 0) + (has_b ? 1 : 0);
     };
     if (pa > pb) n += events(pa, true);                       // the needed A reads sit at pa; that position's B read is younger
     for (int p = (pa > pb ? pa : pb) + 1; p <= I - 1; ++p) n += events(p, false);
     return n;
+}
+
+// v_mfma_f32_32x32x16_f16 with the accumulator's register file chosen by the caller (AGPR: "a" / VGPR: "v").  For the wide
+// variant only (Split<16>): hipcc neither schedules nor pads what is inside -- the callers keep the rules of the CDNA guide's
+// inline-asm section: operands come from LDS reads behind their own s_waitcnt; consecutive MFMAs on one accumulator are an
+// accumulate chain (no wait states); any OTHER reader or writer of an accumulator goes through mfma_fence() first.
+template <bool AGPR>
+__device__ __forceinline__ void mfma_asm(floatx16& c, const half8& a, const half8& b)
+{
+    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// 8-pass MFMA result -> any reader but the next MFMA of the chain: 12 wait states; VALU write -> MFMA operand: 2.  One
+// statement in front of (BEFORE = true) or behind the VALU code that touches the tile, tied to it through the operand.
+template <bool AGPR, bool BEFORE>
+__device__ __forceinline__ void mfma_fence(floatx16& c)
+{
+    if constexpr (AGPR) { if constexpr (BEFORE) asm volatile("s_nop 11" : "+a"(c)); else asm volatile("s_nop 1" : "+a"(c)); }
+    else { if constexpr (BEFORE) asm volatile("s_nop 11" : "+v"(c)); else asm volatile("s_nop 1" : "+v"(c)); }
 }
 
 // Work split of the 8 waves, template parameter NS = 32-channel slices per workgroup (a workgroup covers 32 * NS output
@@ -180,16 +214,24 @@ constexpr int lds_younger_mfma_first(int I, bool first, bool last)
 // the chunk's activations in the SAME double buffer, fetched once by all waves together and published by the chunk barrier
 // that is there anyway: no counted vmcnt per k-step, 4 (NS = 1) or 8 (NS = 2) DMA instructions per wave and chunk instead of
 // 25 / 22.
+//   NS = 16  ("wide") the 8 slices of NS = 8 on FOUR waves x TWO channel tiles x 12 row tiles: a B fragment feeds two MFMAs, so the
+//            workgroup reads half the activation bytes from LDS per FLOP and still fetches every filter byte once.  384
+//            accumulator registers per wave (one wave per SIMD, 512 registers): hipcc cannot place them by itself (it puts every
+//            MFMA accumulator of a function in AGPRs, 256 at most, and spills the rest by the thousand), so this variant issues
+//            its MFMAs from inline asm with the accumulator's register file spelled out: row tiles 0..7 in AGPRs, 8..11 in VGPRs.
 template <int NS>
 struct Split {
-    static constexpr int CT = 1;                       // 32-channel MFMA tiles per wave
+    static constexpr int SL = NS == 16 ? 8 : NS;       // 32-channel slices per workgroup
+    static constexpr int CT = NS == 16 ? 2 : 1;        // 32-channel MFMA tiles per wave
+    static constexpr int CW = SL / CT;                 // waves along the channels
     static constexpr bool Chunked = NS <= 2;
-    static constexpr int WAVES = NS == 1 ? 12 : 8;
+    static constexpr bool AsmMfma = NS == 16;
+    static constexpr int WAVES = NS == 1 ? 12 : NS == 16 ? 4 : 8;
     static constexpr int Threads = WAVES * 64;
     static constexpr int XP = (4 * kPieces + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
-    static constexpr int RG = WAVES / NS;              // row groups
+    static constexpr int RG = WAVES / CW;              // row groups
     static constexpr int RT = 12 / RG;                 // 32-row MFMA tiles per wave
-    static constexpr int W = 2;                        // DMA instructions (1 KiB fragments) per filter slab: k16 = 0, 1
+    static constexpr int W = 2 * CT;                   // DMA instructions (1 KiB fragments) per filter slab: (tile, k16)
     static constexpr int SlabBytes = W * 1024;
     static constexpr int RingBytes = kRing * SlabBytes;
     static constexpr int FChunkBytes = 9 * NS * 2048;  // Chunked: the workgroup's filter rows of one chunk, [tap][slice][k16][lane][8]
@@ -202,17 +244,18 @@ struct Split {
     static constexpr int piece_tap(int j) { return NS == 1 ? j : j / 2; }
     static constexpr int piece_pair(int j) { return NS == 1 ? 1 : (j % 2 ? 4 : 1); }
     static constexpr int pieces_in_tap(int tap) { int n = 0; for (int j = 0; j < PPW; ++j) n += piece_tap(j) == tap ? 1 : 0; return n; }
-    static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step
-    static constexpr int BD = NS == 8 ? 5 : NS == 4 ? 4 : NS == 2 ? 5 : 2;   // B-fragment registers in rotation = pairs of read-ahead (<= NP)
+    static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step, CT MFMAs each
+    static constexpr int BD = NS == 16 ? 3 : NS == 8 ? 5 : NS == 4 ? 4 : NS == 2 ? 5 : 2;   // B-fragment registers in rotation = pairs of read-ahead (<= NP)
     // byte offset of the B fragment of pair i = k16 * RT + row tile relative to the lane's base row
     static constexpr int b_offset(int i) { return (i / RT) * 2 * kSlotBytes + (i % RT) * 512; }
     // pair index behind which the j-th filter piece / the activation piece of the step is issued
-    static constexpr int w_pair(int j) { return NS == 8 ? 3 + 7 * j : NS == 4 ? 1 + 3 * j : j; }
-    static constexpr int x_pair() { return NS == 8 ? 14 : NS == 4 ? 6 : 2; }
+    static constexpr int w_pair(int j) { return NS == 16 ? 2 + 4 * j : NS == 8 ? 3 + 7 * j : NS == 4 ? 1 + 3 * j : j; }
+    static constexpr int x_pair() { return NS == 16 ? 17 : NS == 8 ? 14 : NS == 4 ? 6 : 2; }
     // pair at which the NEXT step's A fragments are requested (behind this step's DMA instructions)
-    static constexpr int a_pair() { return NS == 8 ? 17 : NS == 4 ? 8 : NS == 2 ? 3 : 0; }
+    static constexpr int a_pair() { return NS == 16 ? 19 : NS == 8 ? 17 : NS == 4 ? 8 : NS == 2 ? 3 : 0; }
 };
-static_assert(Split<8>::LdsBytes <= 160 * 1024 && Split<4>::LdsBytes <= 160 * 1024 && Split<2>::LdsBytes <= 160 * 1024, "LDS budget");
+static_assert(Split<8>::LdsBytes <= 160 * 1024 && Split<4>::LdsBytes <= 160 * 1024 && Split<2>::LdsBytes <= 160 * 1024 &&
+              Split<16>::LdsBytes <= 160 * 1024, "LDS budget");
 static_assert(Split<1>::BD <= Split<1>::NP && Split<2>::BD <= Split<2>::NP, "the B rotation reaches one step ahead at most");
 
 // A board split over G = C_out / (32 * NS) workgroups INSIDE one launch (tower_split_kernel): what a workgroup needs to
@@ -257,18 +300,40 @@ __device__ __forceinline__ void store_row(uint16_t* p, const uint4& v)
         const u32x4 t = {v.x, v.y, v.z, v.w};
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
     } else {
-        *reinterpret_cast<uint4*>(p) = v;
+        // spelled as a GLOBAL store: a pointer that came out of a descriptor in memory (tower kernels) or through an opaque
+        // asm is generic to hipcc, and a flat_store / flat_load counts in vmcnt AND lgkmcnt -- hipcc then waits for a flat
+        // load with "vmcnt(0) lgkmcnt(0)", i.e. for every DMA piece in flight and every LDS read of the software pipeline
+        const u32x4 t = {v.x, v.y, v.z, v.w};
+        *reinterpret_cast<__attribute__((address_space(1))) u32x4*>((__UINTPTR_TYPE__)p) = t;
     }
 }
 template <bool SPLIT>
 __device__ __forceinline__ uint4 load_row(const uint16_t* p)
 {
-    if constexpr (SPLIT) {
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-        return make_uint4(t[0], t[1], t[2], t[3]);
-    } else {
-        return *reinterpret_cast<const uint4*>(p);
-    }
+    const auto* const g = reinterpret_cast<const __attribute__((address_space(1))) u32x4*>((__UINTPTR_TYPE__)p);   // global, not flat (store_row)
+    const u32x4 t = SPLIT ? __builtin_nontemporal_load(g) : *g;
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
+
+// The skip rows folded in during the K loop are requested from inline asm: a load hipcc tracks is waited for with the
+// vmcnt it can prove -- with LDS-DMA instructions in the stream that is vmcnt(0), i.e. every filter slab and activation piece
+// in flight, twelve times per skip layer.  As asm the load is waited for by the kernel's own counted vmcnt (wait_z below, which
+// names the destinations so that no consumer moves above it).
+template <bool SPLIT>
+__device__ __forceinline__ void load_row_asm(u32x4& dst, const uint16_t* p)
+{
+    if constexpr (SPLIT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_z(u32x4& z0, u32x4& z1)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(z0), "+v"(z1) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_z(u32x4& z0, u32x4& z1, u32x4& z2, u32x4& z3)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3) : "n"(N) : "memory");
 }
 
 // SKIP: 0 = no skip input, 1 = skip added in the epilogue (general), 2 = skip accumulated DURING the K loop (alpha1 != 0):
@@ -291,21 +356,22 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                                                const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, 0, nullptr}, const int carry = 0)
 {
     using S = Split<NS>;
-    constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP;
+    constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP, SL = S::SL;
     constexpr bool CHUNKED = S::Chunked;
+    constexpr bool ASM = S::AsmMfma;                 // MFMAs from inline asm, accumulators of row tiles 0..7 in AGPRs (Split<16>)
+    static_assert(!ASM || ABL == 0, "no ablations of the asm variant");
     constexpr int BUF = S::BufStride;
     static_assert(!CHUNKED || !(ABL & ~1), "the chunked kernels know ablation 1 (no MFMAs) only");
     const bool x0_in_flight = (carry & kX0InFlight) != 0;
     const bool carry_in = a.carry_in != 0 && (carry & kHandedOver) != 0;
-    static_assert(CT == 1, "one 32-channel tile per wave");
     constexpr bool PIPE = !(ABL & 32);               // ABL 32: the K loop without the software pipeline across steps (A/B)
     constexpr int WI = (ABL & 64) ? 2 * W : W;       // ABL 64: every filter piece is requested TWICE (what does a DMA instruction cost?)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % NS;                        // channel slice
-    const int g = wave / NS;                         // row group
+    const int wn = wave % S::CW;                     // channel position: slices wn * CT .. wn * CT + CT - 1 of the workgroup's SL
+    const int g = wave / S::CW;                      // row group
     const int cin = a.cin;
     const int cout = a.cout;
     const int nchunks = cin / 32;
@@ -330,12 +396,12 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     const uint16_t* const x_board = a.x + (long)b * cin * kRows + lane * 8;
     // one k-step of one 256-channel block is 8192 halfs; this wave's slab starts wn * W fragments of 512 halfs into it
     const int step_halfs = (cout / 32) * 1024;       // one k-step of the packed filter
-    const uint16_t* const w_wave = a.w + (long)(nb * NS + wn) * 1024 + lane * 8;
+    const uint16_t* const w_wave = a.w + (long)(nb * SL + wn * CT) * 1024 + lane * 8;
 
     // fragment f of k-step `st` of this wave's filter slice -> ring slot `slot`
     // steps past the last one belong to the next layer when there is one to hand over to (tower_board_kernel)
     const int nsteps_total = nchunks * 9;
-    const uint16_t* const w_next_wave = a.w_next ? a.w_next + (long)(nb * NS + wn) * 1024 + lane * 8 - (long)nsteps_total * step_halfs : w_wave;
+    const uint16_t* const w_next_wave = a.w_next ? a.w_next + (long)(nb * SL + wn * CT) * 1024 + lane * 8 - (long)nsteps_total * step_halfs : w_wave;
     auto issue_w_piece = [&](int st, int slot, int f) {
         const uint16_t* src = (st >= nsteps_total ? w_next_wave : w_wave) + (long)st * step_halfs;
         char* const dst = lds + kWBase + wave * S::RingBytes + slot * S::SlabBytes;
@@ -390,13 +456,13 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     // SPLIT: the flag of the workgroup that produces input chunk c (its channel block is c / NS)
     unsigned* const done_board = SPLIT ? sync.done + (long)b * sync.groups : nullptr;
     auto await_chunk = [&](int c) {       // lane 0 of wave 0 only; the caller's next barrier tells everybody
-        if (c / NS != nb) wait_published(done_board + c / NS, sync.base + (unsigned)sync.epoch, sync.err);
+        if (c / SL != nb) wait_published(done_board + c / SL, sync.base + (unsigned)sync.epoch, sync.err);
     };
     // A look at a producer's flag costs a round trip to the L2 (some 600 cycles): it is requested EARLY -- a plain load that
     // completes while the waves compute -- and only a flag that was not up yet is polled where the data is needed.
     auto peek_chunk = [&](int c) -> unsigned {          // wave 0: the flag of chunk c's producer now (own chunks: "published")
-        if (c / NS == nb) return ~0u;
-        return __hip_atomic_load(done_board + c / NS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c / SL == nb) return ~0u;
+        return __hip_atomic_load(done_board + c / SL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     // ---- fragment read addresses ----
@@ -415,31 +481,51 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][rt][r] = 0.0f;
+    if constexpr (ASM) {
+        // hipcc materialises these zeros lazily -- a v_accvgpr_mov / v_mov of the tuple straight in front of the tile's first
+        // MFMA, which as an asm statement gets no hazard padding (VALU write -> MFMA operand: two wait states; found by
+        // tools/asm_lint.py as one stale accumulator register).  A statement per tile pins the zeros in their registers here.
+        static_for<RT>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            mfma_fence<(R < 8), false>(acc[0][R]);
+            if constexpr (CT == 2) mfma_fence<(R < 8), false>(acc[CT - 1][R]);
+        });
+    }
 
     // ---- skip input, 16-byte accesses: lanes 0..31 read the whole 16-byte row of k-slot k, lanes 32..63 that of
     // k-slot k + 1; one v_permlane32_swap per dword then gives every lane its 4 channels of both k-slots ----
     const int hi = lane >> 5;
-    const int co_base = (nb * NS + wn) * 32;
+    const int co_base = (nb * SL + wn * CT) * 32;
     // element offset of (this wave's k-slot 0 (+1 for the upper half-wave), row 0); k-slot stride = 400 rows * 8
     const long ep_base = (((long)b * (cout / 8) + co_base / 8 + hi) * kRows) * 8;
     auto row_of = [&](int rt) { return g * (RT * 32) + rt * 32 + (lane & 31); };
-    uint4 zl[2];                                      // one (row tile, channel tile) unit of z in flight: two k-slot pairs
+    u32x4 zl[CT][2];                                  // one row tile of z in flight: per channel tile two k-slot pairs
     const uint16_t* const z_lane = a.z + ep_base + row_of(0) * 8;
-    auto load_z_unit = [&](int rt, int ct) {
+    auto load_z_unit = [&](int rt) {
         const uint16_t* p = z_lane;
         asm volatile("" : "+v"(p));                   // opaque per use: keeps the 24 addresses from being hoisted out of
                                                       // the K loop (they would be spilled), one 64-bit add per load instead
 #pragma unroll
-        for (int pair = 0; pair < 2; ++pair)          // k-slot ct * 4 + pair * 2 (+ hi), row tile rt
-            zl[pair] = load_row<SPLIT>(p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pair = 0; pair < 2; ++pair)      // k-slot ct * 4 + pair * 2 (+ hi), row tile rt
+                if constexpr (RT == 12) {
+                    load_row_asm<SPLIT>(zl[ct][pair], p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
+                } else {
+                    // a wave that owns only some row tiles loads under a branch: at the join hipcc copies the destination
+                    // registers -- of an asm load, before the data is there (tools/asm_lint.py).  These variants keep loads hipcc tracks.
+                    const uint4 v = load_row<SPLIT>(p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
+                    zl[ct][pair] = u32x4{v.x, v.y, v.z, v.w};
+                }
     };
     const float zscale = SKIP == 2 ? a.alpha2 / a.alpha1 : 0.0f;
-    auto add_z_unit = [&](auto rt_c, auto ct_c) {
+    auto add_z_tile = [&](auto rt_c, auto ct_c) {
         constexpr int RTI = decltype(rt_c)::value, CTI = decltype(ct_c)::value;
+        if constexpr (ASM) mfma_fence<(RTI < 8), true>(acc[CTI][RTI]);      // the tile's last MFMA may be the step's last
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {
-            const auto sx = __builtin_amdgcn_permlane32_swap(zl[pair].x, zl[pair].z, false, false);
-            const auto sy = __builtin_amdgcn_permlane32_swap(zl[pair].y, zl[pair].w, false, false);
+            const auto sx = __builtin_amdgcn_permlane32_swap(zl[CTI][pair][0], zl[CTI][pair][2], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(zl[CTI][pair][1], zl[CTI][pair][3], false, false);
             const half4 z0 = __builtin_bit_cast(half4, make_uint2(sx[0], sy[0]));   // k-slot pair * 2
             const half4 z1 = __builtin_bit_cast(half4, make_uint2(sx[1], sy[1]));   // k-slot pair * 2 + 1
 #pragma unroll
@@ -448,13 +534,18 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 acc[CTI][RTI][pair * 8 + 4 + jj] = __builtin_fmaf(zscale, (float)z1[jj], acc[CTI][RTI][pair * 8 + 4 + jj]);
             }
         }
+        if constexpr (ASM) mfma_fence<(RTI < 8), false>(acc[CTI][RTI]);
+    };
+    auto add_z_unit = [&](auto rt_c) {
+        add_z_tile(rt_c, std::integral_constant<int, 0>());
+        if constexpr (CT == 2) add_z_tile(rt_c, std::integral_constant<int, 1>());
     };
 
     // ---- prologue: chunk 0 and the first three filter slabs ----
     if constexpr (SPLIT) {
         // chunk 0 (and chunk 1, whose pieces go out during chunk 0) must have been published by their producers; the
         // workgroup that produced chunk 0 itself found it in LDS (carry_in) and, unless NS == 1, owns chunk 1 too
-        const bool must_wait = sync.epoch > 0 && ((nb != 0 && !x0_in_flight) || (NS == 1 && nchunks > 1));
+        const bool must_wait = sync.epoch > 0 && ((nb != 0 && !x0_in_flight) || (SL == 1 && nchunks > 1));
         // (channel block 0 without a hand-over reads back its own output: no flag to wait for)
         if (must_wait) {
             if (tid == 0) {
@@ -501,12 +592,22 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     // lds_younger() counts, for every MFMA, the LDS reads issued after the ones it needs (LDS returns in order).
     // Chunked kernels: the A fragments come out of the chunk buffer (tap-major), so tap 8 cannot request its successor's
     // (other buffer, published by the chunk barrier): tap 0 requests its own in front of its first B fragments.
-    half8 af[2][2];
+    half8 af[2][CT][2];                               // [step parity][channel tile][k16]
     half8 bf[BD];
-    if constexpr (PIPE && !CHUNKED) {
-        af[0][0] = lds_read<0>(w_addr);               // step 0 of the layer (slab 0 landed: the prologue waited for everything)
-        af[0][1] = lds_read<1024>(w_addr);
-    }
+    auto read_a = [&](auto par_c, auto off_c, unsigned addr) {       // the W fragments (tile, k16) of the slab at ring offset OFF
+        constexpr int PAR = decltype(par_c)::value, OFF = decltype(off_c)::value;
+        static_for<W>([&](auto fc) {
+            constexpr int F = decltype(fc)::value;
+            af[PAR][F / 2][F % 2] = lds_read<OFF + F * 1024>(addr);
+        });
+    };
+    auto wait_first = [&](auto younger_c, auto par_c, half8& b0) {    // the wait in front of a step's first MFMA: B0 and all of A
+        constexpr int Y = decltype(younger_c)::value, PAR = decltype(par_c)::value;
+        if constexpr (CT == 1) wait_lgkm<Y>(b0, af[PAR][0][0], af[PAR][0][1]);
+        else wait_lgkm<Y>(b0, af[PAR][0][0], af[PAR][0][1], af[PAR][1][0], af[PAR][1][1]);
+    };
+    // step 0 of the layer (slab 0 landed: the prologue waited for everything)
+    if constexpr (PIPE && !CHUNKED) read_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), w_addr);
     auto run_chunk = [&](int chunk, auto zc_c) {
         constexpr int ZC = decltype(zc_c)::value;
         const int buf = (chunk + buf0) & 1;
@@ -515,7 +616,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         // SPLIT: the pieces of chunk + 2 go out during chunk + 1: its producer must have published before the barrier at the
         // end of this chunk opens.  The flag is requested now and looked at there.
         unsigned flag_ahead = ~0u;
-        const bool needs_flag = SPLIT && sync.epoch > 0 && chunk + 2 < nchunks && (chunk + 2) % NS == 0;
+        const bool needs_flag = SPLIT && sync.epoch > 0 && chunk + 2 < nchunks && (chunk + 2) % SL == 0;
         if constexpr (SPLIT && CHUNKED) {     // (NS = 4: measured 1..3 % slower with the early look -- the extra load sits among wave 0's counted waits)
             if (needs_flag && wave == 0) flag_ahead = peek_chunk(chunk + 2);
         } else if constexpr (SPLIT) {
@@ -545,13 +646,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
 
             if constexpr (!PIPE) {
                 if constexpr (!(ABL & 8)) wait_vmcnt<N>();
-                af[0][0] = lds_read<WOFF>(w_addr);
-                af[0][1] = lds_read<WOFF + 1024>(w_addr);
+                read_a(std::integral_constant<int, 0>(), std::integral_constant<int, WOFF>(), w_addr);
             }
-            if constexpr (CHUNKED && FIRST) {
-                af[0][0] = lds_read<WOFF>(w_addr_c);
-                af[0][1] = lds_read<WOFF + 1024>(w_addr_c);
-            }
+            if constexpr (CHUNKED && FIRST) read_a(std::integral_constant<int, 0>(), std::integral_constant<int, WOFF>(), w_addr_c);
             if constexpr (!PIPE || FIRST) {
                 static_for<(PIPE ? BD : BD - 1)>([&](auto ic) {
                     constexpr int I = decltype(ic)::value;
@@ -562,34 +659,35 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 constexpr int I = decltype(ic)::value;
                 constexpr int K16 = I / RT, RTI = I % RT;
                 if constexpr (PIPE) {
-                    constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair(), CHUNKED>(I, FIRST, LAST);
-                    if constexpr (I == 0) wait_lgkm<YOUNGER>(bf[PH % BD], af[P][0], af[P][1]);
+                    constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair(), CHUNKED, W>(I, FIRST, LAST);
+                    if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, P>(), bf[PH % BD]);
                     else wait_lgkm<YOUNGER>(bf[(PH + I) % BD]);
                 } else {
                     constexpr bool MORE = I + BD - 1 < NP && !(ABL & 4);
                     if constexpr (MORE) bf[(I + BD - 1) % BD] = lds_read<XOFF + S::b_offset(I + BD - 1)>(x_addr);
                     constexpr int YOUNGER = (ABL & 4) ? 0 : I + BD - 1 < NP ? BD - 1 : NP - 1 - I;
-                    if constexpr (I == 0) wait_lgkm<YOUNGER>(bf[0], af[0][0], af[0][1]);
+                    if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, 0>(), bf[0]);
                     else wait_lgkm<YOUNGER>(bf[I % BD]);
                 }
-                if constexpr (ABL & 1) {
-                    asm volatile("" ::"v"(af[P][K16]), "v"(bf[(PH + I) % BD]));
-                } else {
-                    acc[0][RTI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][K16], bf[(PH + I) % BD], acc[0][RTI], 0, 0, 0);
-                }
-                if constexpr (PIPE) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if constexpr (ABL & 1) {
+                        asm volatile("" ::"v"(af[P][ct][K16]), "v"(bf[(PH + I) % BD]));
+                    } else if constexpr (ASM) {
+                        mfma_asm<(RTI < 8)>(acc[ct][RTI], af[P][ct][K16], bf[(PH + I) % BD]);     // volatile asm: stays in program order
+                    } else {
+                        acc[ct][RTI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][ct][K16], bf[(PH + I) % BD], acc[ct][RTI], 0, 0, 0);
+                    }
                     // keep the MFMA above the reads below: its result feeds an empty asm that the (volatile, ordered) reads follow
                     // (not with four waves: their accumulators live in AGPRs and a "v" constraint would copy them back and forth)
-                    if constexpr (S::WAVES == 8) asm volatile("" : "+v"(acc[0][RTI]));
+                    if constexpr (PIPE && S::WAVES == 8) asm volatile("" : "+v"(acc[ct][RTI]));
+                }
+                if constexpr (PIPE) {
                     if constexpr (I == S::a_pair() && CHUNKED) {
-                        if constexpr (!LAST) {
-                            af[P ^ 1][0] = lds_read<WOFF_NEXT>(w_addr_c);
-                            af[P ^ 1][1] = lds_read<WOFF_NEXT + 1024>(w_addr_c);
-                        }
+                        if constexpr (!LAST) read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr_c);
                     } else if constexpr (I == S::a_pair()) {
                         if constexpr (!(ABL & 8)) wait_vmcnt<N_NEXT>();
-                        af[P ^ 1][0] = lds_read<WOFF_NEXT>(w_addr);
-                        af[P ^ 1][1] = lds_read<WOFF_NEXT + 1024>(w_addr);
+                        read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr);
                     }
                     constexpr int T = I + BD;
                     if constexpr (T < NP) bf[(PH + T) % BD] = lds_read<XOFF + S::b_offset(T)>(x_addr);
@@ -633,19 +731,28 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             if constexpr (ZC >= 0 && TAP >= 1 && TAP <= 6 && ZC * 6 + TAP - 1 < 12) {
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
-                if (RT == 12 || (ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<(CHUNKED ? S::pieces_in_tap(TAP) : WI + (TAP < XP))>();     // (nothing was requested otherwise)
+                constexpr int YOUNGER_VM = CHUNKED ? S::pieces_in_tap(TAP) : WI + (TAP < XP);
+                if constexpr (RT == 12) {
+                    if constexpr (CT == 1) wait_z<YOUNGER_VM>(zl[0][0], zl[0][1]);
+                    else wait_z<YOUNGER_VM>(zl[0][0], zl[0][1], zl[CT - 1][0], zl[CT - 1][1]);
+                } else {
+                    if ((ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<YOUNGER_VM>();               // (nothing was requested otherwise)
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>(), std::integral_constant<int, 0>());
+                add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>());
             }
             // extra memory operations only make the counted waits above more conservative (they require that many
             // more of the OLDER operations to have completed), never unsafe
             if constexpr (ZC >= 0 && TAP <= 5 && ZC * 6 + TAP < 12) {
                 constexpr int T = ZC * 6 + TAP;
                 if constexpr (RT == 12) {
-                    load_z_unit(T, 0);
+                    load_z_unit(T);
                 } else {
-                    if (T / RT == g) load_z_unit(T % RT, 0);
-                    else zl[0] = zl[1] = make_uint4(0, 0, 0, 0);
+                    if (T / RT == g) load_z_unit(T % RT);
+                    else {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) zl[ct][0] = zl[ct][1] = u32x4{0, 0, 0, 0};
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -674,9 +781,13 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         } else if constexpr (PIPE) {
             // the only LDS reads still out are the A fragments of the next step (tap 8 requests no B read-ahead); tap 8
             // left them in af[1], tap 0 of the next chunk looks in af[0]
-            wait_lgkm<0>(af[1][0], af[1][1]);
-            af[0][0] = af[1][0];
-            af[0][1] = af[1][1];
+            if constexpr (CT == 1) wait_lgkm<0>(af[1][0][0], af[1][0][1]);
+            else wait_lgkm<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                af[0][ct][0] = af[1][ct][0];
+                af[0][ct][1] = af[1][ct][1];
+            }
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -731,7 +842,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const half4 b4 = *reinterpret_cast<const half4*>(a.bias + co_base + ct * 32 + k * 8 + hi * 4);
+            const half4 b4 = *reinterpret_cast<const __attribute__((address_space(1))) half4*>((__UINTPTR_TYPE__)(a.bias + co_base + ct * 32 + k * 8 + hi * 4));
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) bias[ct][k][jj] = (float)b4[jj];
         }
@@ -753,6 +864,14 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     };
     load_z(0);
     load_z(1);
+    if constexpr (ASM) {
+        // the K loop's last MFMAs are a few instructions back: one fence per accumulator tile before anything reads it
+        static_for<RT>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            mfma_fence<(R < 8), true>(acc[0][R]);
+            if constexpr (CT == 2) mfma_fence<(R < 8), true>(acc[CT - 1][R]);
+        });
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int row = row_of(rt);
@@ -774,17 +893,16 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             for (int kk = 0; kk < 2; ++kk) {
                 const int k = k0 + kk;
                 const half4 z4 = __builtin_bit_cast(half4, kk == 0 ? za : zb2);
-                half4 y4;
+                float t[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    float t = __builtin_fmaf(a.alpha1, acc[ct][rt][k * 4 + jj], bias[ct][k][jj]);
-                    if constexpr (SKIP == 1) t = __builtin_fmaf(a.alpha2, (float)z4[jj], t);
-                    if constexpr (RELU) t = __builtin_fmaxf(t, 0.0f);
-                    y4[jj] = round_to_half(t);
+                    t[jj] = __builtin_fmaf(a.alpha1, acc[ct][rt][k * 4 + jj], bias[ct][k][jj]);
+                    if constexpr (SKIP == 1) t[jj] = __builtin_fmaf(a.alpha2, (float)z4[jj], t[jj]);
                 }
-                out[kk] = __builtin_bit_cast(uint2, y4);
-                out[kk].x &= live;
-                out[kk].y &= live;
+                // relu behind the conversion: the same bits as max(t, 0) in fp32 first (rounding is monotone, 0 is exact, a NaN gives 0 either way)
+                unsigned y01 = cvt_pk_f16(t[0], t[1]), y23 = cvt_pk_f16(t[2], t[3]);
+                if constexpr (RELU) { y01 = pk_relu_f16(y01); y23 = pk_relu_f16(y23); }
+                out[kk] = make_uint2(y01 & live, y23 & live);
             }
             const auto sx = __builtin_amdgcn_permlane32_swap(out[0].x, out[1].x, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(out[0].y, out[1].y, false, false);
@@ -969,7 +1087,7 @@ bool conv_board_supported(int cin, int cout)
 template <int NS>
 static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool relu, int ablate, hipStream_t stream)
 {
-    const dim3 grid(args.batch, args.cout / (32 * NS));
+    const dim3 grid(args.batch, args.cout / (32 * Split<NS>::SL));
 #define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(Split<NS>::Threads), 0, stream, args)
     if constexpr (NS == 1) {
         if (ablate == 1 && relu && skip != 1) {      // timing only: the chunked kernel without its MFMAs
@@ -1012,6 +1130,7 @@ int conv_board_pick_ns(int batch, int cout, int forced_ns)
     int best = slices % 8 == 0 ? 8 : slices % 4 == 0 ? 4 : 2;
     while (best > 1 && (long)batch * (slices / best) < 192) best /= 2;
     if ((forced_ns == 1 || forced_ns == 2 || forced_ns == 4 || forced_ns == 8) && slices % forced_ns == 0) best = forced_ns;
+    if (forced_ns == 16 && slices % 8 == 0) best = 16;          // the wide variant of NS = 8 (Split<16>)
     return best;
 }
 
@@ -1046,6 +1165,13 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
     if (batch <= 0 || count <= 0) return hipSuccess;
     if (!tower_board_supported(batch, channels)) return hipErrorInvalidValue;
     const dim3 grid(batch, 1);
+    // A 256-channel tower walks with the wide work split (Split<16>: four waves, two channel tiles each; bit-identical to
+    // Split<8>, half its LDS reads, +2.7 % at batch 256).  DGNN_TOWER_WIDE=0: the eight-wave split (A/B, tests).
+    static const int wide = [] { const char* e = std::getenv("DGNN_TOWER_WIDE"); return e ? std::atoi(e) : 1; }();
+    if (channels == 256 && wide == 1) {
+        hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count);
+        return hipGetLastError();
+    }
     switch (channels / 32) {
         case 8: hipLaunchKernelGGL((tower_board_kernel<8>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
         case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
@@ -1123,6 +1249,7 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches
     const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !env.epilogue_skip) ? 2 : 1;
     const int ablate = env.ablate;
     switch (conv_board_pick_ns(args.batch, args.cout, env.ns)) {
+        case 16: launch_board_variant<16>(args, skip, relu, 0, stream); break;
         case 8: launch_board_variant<8>(args, skip, relu, ablate, stream); break;
         case 4: launch_board_variant<4>(args, skip, relu, ablate, stream); break;
         case 2: launch_board_variant<2>(args, skip, relu, 0, stream); break;

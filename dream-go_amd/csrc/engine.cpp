@@ -567,8 +567,10 @@ static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint
         const char* ab = std::getenv("DGNN_CONV_TIMING");
         const size_t num_wg = (size_t)batch * (cout / 256);
         unsigned long long* d_timing = nullptr;
-        if (ab && std::atoi(ab) == 1 && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess)
+        if (ab && std::atoi(ab) == 1 && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemset(d_timing, 0, num_wg * 8 * 4 * sizeof(unsigned long long));    // variants with fewer than 8 waves leave slots empty
             a.timing = d_timing;
+        }
         const int reps = a.timing ? 3 : 1;   // the last repetition is reported (caches warm)
         const BoardSwitches env = read_board_switches();   // per call: the parity tests switch variants between calls
         for (int r = 0; r < reps && err == hipSuccess; ++r) err = launch_conv3x3_board(a, env, nullptr);
@@ -577,7 +579,10 @@ static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint
             if (hipMemcpy(t.data(), d_timing, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                 double pro = 0, loop = 0, epi = 0;
                 unsigned long long first = ~0ull, last = 0, first_end = ~0ull;
+                size_t waves = 0;
                 for (size_t i = 0; i < num_wg * 8; ++i) {
+                    if (t[i * 4] == 0) continue;
+                    ++waves;
                     pro += (double)(t[i * 4 + 1] - t[i * 4 + 0]);
                     loop += (double)(t[i * 4 + 2] - t[i * 4 + 1]);
                     epi += (double)(t[i * 4 + 3] - t[i * 4 + 2]);
@@ -585,7 +590,7 @@ static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint
                     if (t[i * 4 + 3] > last) last = t[i * 4 + 3];
                     if (t[i * 4 + 3] < first_end) first_end = t[i * 4 + 3];
                 }
-                const double n = (double)num_wg * 8;
+                const double n = (double)(waves ? waves : 1);
                 std::fprintf(stderr, "[dgnn timing] board kernel, %zu workgroups: mean cycles per wave  prologue %.0f  k-loop %.0f (%.0f per k-step)  "
                              "epilogue %.0f | first start -> last end %llu, first end at %llu (s_memtime ticks)\n",
                              num_wg, pro / n, loop / n, loop / n / (9.0 * cin / 32), epi / n, last - first, first_end - first);
