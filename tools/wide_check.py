@@ -18,14 +18,16 @@ def child(path):
     graft.package()
     from dream_go_amd import api, synth
     out = {}
-    for blocks, batch in ((20, 256), (3, 200), (20, 131)):
-        net = api.Network.from_json(synth.to_json(synth.make_tensors(blocks, 256, seed=5 + blocks)))
+    # 256 channels: whole boards (batch > 128: Split<16> / Split<8>) and boards split in two (batch 65..128: Split<20> / Split<4>);
+    # 128 channels: whole boards (batch > 128: Split<20> / Split<4>)
+    for blocks, channels, batch in ((20, 256, 256), (3, 256, 200), (20, 256, 131), (20, 256, 128), (4, 256, 77), (9, 128, 256), (9, 128, 150)):
+        net = api.Network.from_json(synth.to_json(synth.make_tensors(blocks, channels, seed=5 + blocks)))
         with net.get_workspace(batch) as ws:
             for rep in range(3):
-                features = synth.make_features(batch, seed=100 * blocks + rep)
+                features = synth.make_features(batch, seed=100 * blocks + channels + rep)
                 value, policy = api.forward(ws, features).unwrap()
-                out[f"v{blocks}_{batch}_{rep}"] = value.view(np.uint16).copy()
-                out[f"p{blocks}_{batch}_{rep}"] = policy.view(np.uint16).copy()
+                out[f"v{blocks}x{channels}_{batch}_{rep}"] = value.view(np.uint16).copy()
+                out[f"p{blocks}x{channels}_{batch}_{rep}"] = policy.view(np.uint16).copy()
         net.destroy()
     np.savez(path, **out)
 
