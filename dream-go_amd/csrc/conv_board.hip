@@ -1089,6 +1089,10 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
 {
     const dim3 grid(args.batch, args.cout / (32 * Split<NS>::SL));
 #define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(Split<NS>::Threads), 0, stream, args)
+    // The ablated kernels (tools/ablate.sh, tools/ablate2.sh: timing only, garbage results) are 34 more instantiations of the
+    // body -- half the compile time of this file.  They are built only with -DDGNN_ABLATIONS (DGNN_ABLATIONS=1 python
+    // dream-go_amd/build.py); a library without them ignores DGNN_CONV_ABLATE.
+#ifdef DGNN_ABLATIONS
     if constexpr (NS == 1) {
         if (ablate == 1 && relu && skip != 1) {      // timing only: the chunked kernel without its MFMAs
             if (skip == 2) DGNN_BOARD(2, true, 1); else DGNN_BOARD(0, true, 1);
@@ -1113,6 +1117,9 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
             return;
         }
     }
+#else
+    (void)ablate;
+#endif
     if (skip == 2 && relu) DGNN_BOARD(2, true, 0);
     else if (skip == 2) DGNN_BOARD(2, false, 0);
     else if (skip == 1 && relu) DGNN_BOARD(1, true, 0);

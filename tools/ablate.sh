@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a library built with the ablated kernels:  DGNN_ABLATIONS=1 python dream-go_amd/build.py --force
 # Component pricing of the residual convolution (results of ablated runs are garbage; only the timing matters).
 #   1 = no MFMA, 2 = no in-loop DMA, 4 = no in-loop B-fragment reads, 3 = neither MFMA nor DMA, 8 = DMA issued but never waited for,
 #   16 = no barrier at the chunk boundaries (what a barrier-free K loop could gain at most)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs a library built with the ablated kernels:  DGNN_ABLATIONS=1 python dream-go_amd/build.py --force
 # Component pricing of the per-layer board kernel at a given batch (results of ablated runs are garbage; only the timing matters):
 #   0 = shipped, 32 = K loop without the software pipeline, 1 = no MFMA, 2 = no in-loop DMA, 3 = neither
 #   tools/ablate2.sh <batch> [blocks channels]

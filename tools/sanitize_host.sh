@@ -22,6 +22,7 @@ int dgnn_forward_n(dgnn_workspace*, const uint16_t* features, int n, uint16_t* v
     return dgnn_hash_predictor()(nullptr, features, n, value, policy);
 }
 void dgnn_workspace_release(dgnn_workspace*) {}
+int dgnn_device_count(int* count) { *count = 1; return DGNN_OK; }
 }
 STUBS
 FILES="$SRC/go.cpp $SRC/batcher.cpp $SRC/formats.cpp $SRC/tree.cpp $SRC/search.cpp $SRC/loader.cpp $TMP/stubs.cpp $ROOT/tools/sanitize_host.cpp"
