@@ -228,9 +228,11 @@ def selfplay_leg(job, api, replicas, net, args):
     else:
         pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
                                         workers_per_device=args.selfplay_batches)
+    cpu0, wall0 = time.process_time(), time.perf_counter()
     out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=args.selfplay_moves,
                                     num_rollouts=args.selfplay_rollouts, threads_per_search=1, seed=20260930, pool=pool, cache=cache,
                                     device=job.tensor_device, leaves_per_thread=args.selfplay_leaves)
+    cpu_cores_busy = (time.process_time() - cpu0) / max(time.perf_counter() - wall0, 1e-9)    # this rank's threads, user + system
     st = pool.stats()
     boards = sum(job.gather_int(st["boards"]))
     batches = sum(job.gather_int(st["batches"]))
@@ -256,6 +258,9 @@ def selfplay_leg(job, api, replicas, net, args):
                 "722-stone cap: whole games measured in profiles/, DESIGN.md section 8). Opening moves only: later moves see more cache hits "
                 "and narrower trees.",
         "host_cpus": effective_cpus(),
+        "host_cpu_affinity": f"{min(os.sched_getaffinity(0))}-{max(os.sched_getaffinity(0))} ({len(os.sched_getaffinity(0))} CPUs)",
+        "host_cpus_busy": cpu_cores_busy,          # CPU time of rank 0's process over the leg / its wall time: cores kept busy
+        "rollouts_per_sec": (j["evals"] + j["cache_hits"]) / sec,
     }
     return leg
 
@@ -266,10 +271,12 @@ def main():
         raise SystemExit(spawn_ranks(args))
 
     job = Job(args)
-    job.start(args.force_dist)
     import __graft_entry__ as graft
     graft.package()
-    from dream_go_amd import api, replicas, synth
+    from dream_go_amd import replicas           # (numpy only: libdgnn_hip.so is loaded behind torch, below)
+    replicas.pin_to_compact_cpus(job.local_rank)   # before any thread exists: they all inherit the mask
+    job.start(args.force_dist)
+    from dream_go_amd import api, synth
 
     rank, world, device = job.rank, job.world, job.device
 

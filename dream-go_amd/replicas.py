@@ -95,3 +95,34 @@ def selfplay_sharded(api, dist, torch, num_games, num_moves, num_rollouts, threa
     job["world"] = world
     out["job"] = job
     return out
+
+
+def pin_to_compact_cpus(local_rank=0, quota=None):
+    """Keeps this process's threads on a compact set of CPUs, as many as its CPU-time quota pays for.
+
+    The GPU boxes of the pool show 256 logical CPUs (2 sockets x 64 cores x 2) and grant a container 16 CPUs of TIME
+    (cgroup cpu.max): unpinned, the 256 game threads of a self-play job roam over every core of both sockets, run with cold
+    caches after every wait and are throttled in bursts -- measured on the bench's self-play leg: 13.3 cores of CPU time for
+    143 k rollouts/s unpinned, 6.0 cores for 195 k rollouts/s on CPUs 0-15 (tools/affinity_probe.sh).  Rank r of a node takes
+    the r-th slice of the allowed CPUs (in their numeric order: on these boxes the first half is socket 0, where GPUs 0-3
+    hang, and a slice of 16 is 16 physical cores of two neighbouring CCDs).  Returns the chosen CPUs, or None when the process
+    is not oversubscribed (quota >= allowed CPUs) or the platform has no affinity call.  DGNN_PIN_CPUS=0 switches it off."""
+    import os
+    if os.environ.get("DGNN_PIN_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    if quota is None:
+        quota = len(allowed)
+        try:
+            q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = max(1, int(int(q) / int(period)))
+        except (OSError, ValueError):
+            pass
+    if quota >= len(allowed):
+        return None
+    slices = max(1, len(allowed) // quota)
+    start = (local_rank % slices) * quota
+    chosen = allowed[start:start + quota]
+    os.sched_setaffinity(0, chosen)
+    return chosen

@@ -116,3 +116,22 @@ def test_games_sharded_over_two_ranks_are_the_games_one_rank_plays():
     assert r0["job"] == r1["job"] and r0["job"]["games"] == 5 and r0["job"]["moves"] == 30 and r0["job"]["world"] == 2
     assert r0["job"]["evals"] == r0["evals"] + r1["evals"] == alone["job"]["evals"]
     assert [replicas.games_of_rank(5, 8, r)[0] for r in range(8)] == [1, 1, 1, 1, 1, 0, 0, 0]
+
+
+def test_pin_to_compact_cpus_takes_a_slice_per_rank(monkeypatch):
+    """replicas.pin_to_compact_cpus: a process whose CPU-time quota is smaller than the CPUs it may run on is pinned to `quota`
+    neighbouring CPUs, rank r of a node to the r-th slice; nothing happens when it is not oversubscribed or when switched off."""
+    import os
+    from dream_go_amd import replicas
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no scheduler affinity on this platform")
+    allowed = list(range(64))
+    chosen = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(allowed))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: chosen.__setitem__("cpus", list(cpus)))
+    assert replicas.pin_to_compact_cpus(0, quota=16) == list(range(16)) and chosen["cpus"] == list(range(16))
+    assert replicas.pin_to_compact_cpus(3, quota=16) == list(range(48, 64))
+    assert replicas.pin_to_compact_cpus(5, quota=16) == list(range(16, 32))          # more ranks than slices: wrap around
+    assert replicas.pin_to_compact_cpus(0, quota=64) is None                           # not oversubscribed
+    monkeypatch.setenv("DGNN_PIN_CPUS", "0")
+    assert replicas.pin_to_compact_cpus(0, quota=16) is None

@@ -48,10 +48,12 @@ def main():
 
     before = batcher.stats()
     threads = [threading.Thread(target=game) for _ in range(args.threads)]
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     [t.start() for t in threads]
     [t.join() for t in threads]
     dt = time.perf_counter() - t0
+    cpu = time.process_time() - cpu0
     after = batcher.stats()
     boards = after["boards"] - before["boards"]
     batches = after["batches"] - before["batches"]
@@ -61,6 +63,7 @@ def main():
         "callers": args.threads, "boards_per_call": args.boards, "calls": args.threads * args.calls,
         "device_batches": batches, "mean_batch": boards / max(batches, 1), "max_batch": args.max_batch,
         "max_batches_in_flight": args.max_batches, "net": f"{args.blocks}x{args.channels}",
+        "cpu_cores_busy": cpu / dt,        # the whole process: callers (Python threads), pool workers, HIP runtime threads
     }))
 
 

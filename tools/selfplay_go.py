@@ -19,7 +19,9 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 graft.package()
-from dream_go_amd import api, replicas, synth  # noqa: E402
+from dream_go_amd import replicas
+replicas.pin_to_compact_cpus(int(os.environ.get("LOCAL_RANK", "0")))   # before any thread exists
+from dream_go_amd import api, synth  # noqa: E402
 
 
 def main():
