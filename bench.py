@@ -274,7 +274,8 @@ def main():
     import __graft_entry__ as graft
     graft.package()
     from dream_go_amd import replicas           # (numpy only: libdgnn_hip.so is loaded behind torch, below)
-    replicas.pin_to_compact_cpus(job.local_rank)   # before any thread exists: they all inherit the mask
+    unpinned = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pinned = replicas.pin_to_compact_cpus(job.local_rank)   # before any thread exists: they all inherit the mask
     job.start(args.force_dist)
     from dream_go_amd import api, synth
 
@@ -408,7 +409,13 @@ def main():
         if bcast is not None:
             out["weight_broadcast"] = bcast
         if world == 1 and args.cpu_sample > 0 and not job.dry:
+            # the CPU baseline runs as an unpinned process would (its OpenMP team is created here and inherits this mask): the
+            # pinning is the GPU pipeline's business, and neighbours on the box may sit on the same low-numbered cores
+            if pinned is not None:
+                os.sched_setaffinity(0, unpinned)
             baseline, (ref_value, ref_policy) = cpu_baseline(text, features, args.batch, args.cpu_sample)
+            if pinned is not None:
+                os.sched_setaffinity(0, pinned)
             out["cpu_baseline"] = baseline
             ws.forward_resident()
             ws.sync()

@@ -122,7 +122,40 @@ def pin_to_compact_cpus(local_rank=0, quota=None):
     if quota >= len(allowed):
         return None
     slices = max(1, len(allowed) // quota)
-    start = (local_rank % slices) * quota
-    chosen = allowed[start:start + quota]
+    index = local_rank % slices
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # alone on (a share of) the machine: other tenants may already sit on the low-numbered cores -- take the idlest slice
+        busy = _cpu_busy_fractions()
+        if busy:
+            load = [sum(busy.get(c, 0.0) for c in allowed[i * quota:(i + 1) * quota]) for i in range(slices)]
+            index = min(range(slices), key=lambda i: (round(load[i], 1), i))
+    chosen = allowed[index * quota:(index + 1) * quota]
     os.sched_setaffinity(0, chosen)
     return chosen
+
+
+def _cpu_busy_fractions(interval=0.05):
+    """Busy fraction per logical CPU over a short interval, from /proc/stat ({} where there is none)."""
+    import time
+
+    def snapshot():
+        out = {}
+        try:
+            for line in open("/proc/stat"):
+                if line.startswith("cpu") and line[3].isdigit():
+                    f = line.split()
+                    v = [int(x) for x in f[1:9]]
+                    out[int(f[0][3:])] = (sum(v), v[3] + v[4])          # total, idle + iowait
+        except (OSError, ValueError, IndexError):
+            return {}
+        return out
+    a = snapshot()
+    if not a:
+        return {}
+    time.sleep(interval)
+    b = snapshot()
+    busy = {}
+    for cpu, (total, idle) in b.items():
+        if cpu in a and total > a[cpu][0]:
+            busy[cpu] = 1.0 - (idle - a[cpu][1]) / (total - a[cpu][0])
+    return busy

@@ -129,9 +129,14 @@ def test_pin_to_compact_cpus_takes_a_slice_per_rank(monkeypatch):
     chosen = {}
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(allowed))
     monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: chosen.__setitem__("cpus", list(cpus)))
+    monkeypatch.setenv("WORLD_SIZE", "8")
     assert replicas.pin_to_compact_cpus(0, quota=16) == list(range(16)) and chosen["cpus"] == list(range(16))
     assert replicas.pin_to_compact_cpus(3, quota=16) == list(range(48, 64))
     assert replicas.pin_to_compact_cpus(5, quota=16) == list(range(16, 32))          # more ranks than slices: wrap around
     assert replicas.pin_to_compact_cpus(0, quota=64) is None                           # not oversubscribed
+    # a single-rank job takes the idlest slice: here somebody else keeps CPUs 0..19 busy
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(replicas, "_cpu_busy_fractions", lambda interval=0.05: {c: (0.9 if c < 20 else 0.0) for c in allowed})
+    assert replicas.pin_to_compact_cpus(0, quota=16) == list(range(32, 48))
     monkeypatch.setenv("DGNN_PIN_CPUS", "0")
     assert replicas.pin_to_compact_cpus(0, quota=16) is None
