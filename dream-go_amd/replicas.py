@@ -119,6 +119,7 @@ def pin_to_compact_cpus(local_rank=0, quota=None):
                 quota = max(1, int(int(q) / int(period)))
         except (OSError, ValueError):
             pass
+        quota = max(1, quota // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))     # the node's ranks share the container's quota
     if quota >= len(allowed):
         return None
     slices = max(1, len(allowed) // quota)
