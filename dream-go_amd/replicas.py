@@ -129,7 +129,8 @@ def pin_to_compact_cpus(local_rank=0, quota=None):
         busy = _cpu_busy_fractions()
         if busy:
             load = [sum(busy.get(c, 0.0) for c in allowed[i * quota:(i + 1) * quota]) for i in range(slices)]
-            index = min(range(slices), key=lambda i: (round(load[i], 1), i))
+            quiet = [i for i in range(slices) if load[i] < 0.1 * quota]          # less than a tenth of the slice in use
+            index = quiet[0] if quiet else min(range(slices), key=lambda i: load[i])   # the first quiet one: near GPU 0's socket
     chosen = allowed[index * quota:(index + 1) * quota]
     os.sched_setaffinity(0, chosen)
     return chosen
