@@ -501,22 +501,19 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     auto row_of = [&](int rt) { return g * (RT * 32) + rt * 32 + (lane & 31); };
     u32x4 zl[CT][2];                                  // one row tile of z in flight: per channel tile two k-slot pairs
     const uint16_t* const z_lane = a.z + ep_base + row_of(0) * 8;
-    auto load_z_unit = [&](int rt) {
-        const uint16_t* p = z_lane;
+    // Row tile `rt` of this wave -- or, for a wave that does not own board row tile T (`mine` false), ZEROS: the same k-slots'
+    // pad rows 384..399, which no kernel ever writes.  A load either way, never a branch: at the join of a branch hipcc copies
+    // the destination registers -- of an asm load, before the data is there (tools/asm_lint.py).
+    const long z_pad_rows = (long)(384 + (lane & 15) - row_of(0)) * 8;          // from z_lane's row to a pad row of the k-slot
+    auto load_z_unit = [&](int rt, bool mine) {
+        const uint16_t* p = z_lane + (mine ? (long)rt * 32 * 8 : z_pad_rows);
         asm volatile("" : "+v"(p));                   // opaque per use: keeps the 24 addresses from being hoisted out of
                                                       // the K loop (they would be spilled), one 64-bit add per load instead
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int pair = 0; pair < 2; ++pair)      // k-slot ct * 4 + pair * 2 (+ hi), row tile rt
-                if constexpr (RT == 12) {
-                    load_row_asm<SPLIT>(zl[ct][pair], p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
-                } else {
-                    // a wave that owns only some row tiles loads under a branch: at the join hipcc copies the destination
-                    // registers -- of an asm load, before the data is there (tools/asm_lint.py).  These variants keep loads hipcc tracks.
-                    const uint4 v = load_row<SPLIT>(p + ((ct * 4 + pair * 2) * kRows + rt * 32) * 8);
-                    zl[ct][pair] = u32x4{v.x, v.y, v.z, v.w};
-                }
+            for (int pair = 0; pair < 2; ++pair)      // k-slot ct * 4 + pair * 2 (+ hi)
+                load_row_asm<SPLIT>(zl[ct][pair], p + ((ct * 4 + pair * 2) * kRows) * 8);
     };
     const float zscale = SKIP == 2 ? a.alpha2 / a.alpha1 : 0.0f;
     auto add_z_tile = [&](auto rt_c, auto ct_c) {
@@ -732,12 +729,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
                 constexpr int YOUNGER_VM = CHUNKED ? S::pieces_in_tap(TAP) : WI + (TAP < XP);
-                if constexpr (RT == 12) {
-                    if constexpr (CT == 1) wait_z<YOUNGER_VM>(zl[0][0], zl[0][1]);
-                    else wait_z<YOUNGER_VM>(zl[0][0], zl[0][1], zl[CT - 1][0], zl[CT - 1][1]);
-                } else {
-                    if ((ZC * 6 + TAP - 1) / RT == g) wait_vmcnt<YOUNGER_VM>();               // (nothing was requested otherwise)
-                }
+                if constexpr (CT == 1) wait_z<YOUNGER_VM>(zl[0][0], zl[0][1]);
+                else wait_z<YOUNGER_VM>(zl[0][0], zl[0][1], zl[CT - 1][0], zl[CT - 1][1]);
                 __builtin_amdgcn_sched_barrier(0);
                 add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>());
             }
@@ -745,15 +738,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             // more of the OLDER operations to have completed), never unsafe
             if constexpr (ZC >= 0 && TAP <= 5 && ZC * 6 + TAP < 12) {
                 constexpr int T = ZC * 6 + TAP;
-                if constexpr (RT == 12) {
-                    load_z_unit(T);
-                } else {
-                    if (T / RT == g) load_z_unit(T % RT);
-                    else {
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) zl[ct][0] = zl[ct][1] = u32x4{0, 0, 0, 0};
-                    }
-                }
+                load_z_unit(T % RT, RT == 12 || T / RT == g);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
