@@ -18,7 +18,10 @@ same architecture, so checksum agreement afterwards proves that RCCL moved the i
 
 Beside the engine number the line carries a bounded, MEASURED self-play leg (`selfplay`): real Go boards, the
 search, the leaf pool and the engine together, with the evaluations per move, cache-hit ratio and mean device batch
-it actually saw (BASELINE.json's metric is games/hour + evals/s; SURVEY.md 8d "reports the measured ratio").
+it actually saw (BASELINE.json's metric is games/hour + evals/s; SURVEY.md 8d "reports the measured ratio"), the rollouts per
+second and the CPU cores the process kept busy.  The process pins itself to as many neighbouring CPUs as its cgroup quota
+pays for before any thread exists (replicas.pin_to_compact_cpus; DGNN_PIN_CPUS=0 switches it off); the
+CPU baseline runs unpinned.
 
 `--dry` runs the same control flow without a GPU (gloo, the deterministic CPU predictor behind the leaf pool): it
 exists so that the N > 1 path is covered by the CPU tests; its numbers mean nothing and the line says "dry": true.
