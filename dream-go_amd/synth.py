@@ -87,6 +87,22 @@ def make_tensors(num_blocks, num_channels, num_samples=8, seed=1, alpha=0.5):
     return out
 
 
+def make_sharp_tensors(num_blocks, num_channels, num_samples=8, seed=1, alpha=0.1, policy_gain=24.0, value_gain=16.0):
+    """A random-init network whose OUTPUTS discriminate between positions: the plain He-init net of
+    make_tensors with alpha = 0.5 forgets its input over 20 blocks (policy maxima 0.013-0.03 on every board, boards of a batch 1e-4
+    apart), so a kernel that mixed up boards or lost accuracy on peaked soft-maxes / saturated tanh would pass a 1e-3 test.  Here
+    the residual gate is small (the skip path carries the input through the tower) and the two dense layers are scaled
+    (`p_policy/linear_1` by policy_gain, `v_value/linear_2` by value_gain): on real positions the policy maximum then spans
+    about 0.05 ... 0.99 with many different arg-maxima and the value reaches both ends of tanh (measured with the oracle:
+    20x256 with (24, 16), 9x128 with (32, 6))."""
+    out = make_tensors(num_blocks, num_channels, num_samples, seed, alpha)
+    head = 2 + num_blocks
+    for name, gain in ((f"{head:02d}p_policy/linear_1:0", policy_gain), (f"{head:02d}v_value/linear_2:0", value_gain)):
+        array, tag = out[name]
+        out[name] = (array * gain, tag)
+    return out
+
+
 def to_json(tensors, model_name="synthetic"):
     doc = {name: _entry(array, tag) for name, (array, tag) in tensors.items()}
     doc["model_name:0"] = model_name     # string-valued entry, ignored by the loader (loader.rs:47)
