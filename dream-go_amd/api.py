@@ -43,6 +43,7 @@ NUM_POINTS = 361
 FEATURE_SIZE = 11552
 NUM_MOVES = 362
 PACKED_WORDS = 368
+BOARD_RECORD_BYTES = 896
 RCCL_UNIQUE_ID_BYTES = 128
 
 # every symbol include/dgnn.h declares: (name, restype, argtypes)
@@ -209,6 +210,13 @@ SYMBOLS = [
     ("dgnn_pool_create_devices", ctypes.c_int, [_vp, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
     ("dgnn_pool_create_callbacks", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
     ("dgnn_pool_stats", ctypes.c_int, [_vp, _ip, _u64p, _u64p, _u64p, _u64p, _u64p, ctypes.c_int]),
+    # round 3: compact board records (the feature planes are built on the device)
+    ("dgnn_forward_boards", ctypes.c_int, [_vp, _u8p, ctypes.c_int, _u16p, _u16p]),
+    ("dgnn_forward_submit_boards", ctypes.c_int, [_vp, _u8p, ctypes.c_int]),
+    ("dgnn_workspace_records_buffer", ctypes.c_int, [_vp, ctypes.POINTER(_u8p)]),
+    ("dgnn_board_records_to_packed", ctypes.c_int, [_u8p, ctypes.c_int, _u32p]),
+    ("dgnn_board_records_to_packed_device", ctypes.c_int, [ctypes.c_int, _u8p, ctypes.c_int, _u32p]),
+    ("dgnn_go_board_record", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u8p]),
 ]
 
 
@@ -539,6 +547,35 @@ def forward_packed(workspace, packed, count):
     _check(lib.dgnn_forward_packed(workspace.handle, p.ctypes.data_as(_u32p), int(count),
                                    value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "forward_packed")
     return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+
+def _as_records(records, count):
+    r = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1)
+    if r.size != count * BOARD_RECORD_BYTES:
+        raise Error(BAD_ARGUMENT, "board records")
+    return r
+
+
+def forward_boards(workspace, records, count):
+    """dg_nn::forward from compact board records (include/dgnn.h: dgnn_forward_boards): the planes are built on the device."""
+    r = _as_records(records, count)
+    value = np.empty(count, dtype=np.uint16)
+    policy = np.empty(count * NUM_MOVES, dtype=np.uint16)
+    _check(lib.dgnn_forward_boards(workspace.handle, r.ctypes.data_as(_u8p), int(count), value.ctypes.data_as(_u16p),
+                                   policy.ctypes.data_as(_u16p)), "forward_boards")
+    return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+
+def board_records_to_packed(records, count, device=None):
+    """Records -> packed plane words [count * 368]: the host statement (device=None) or what the DEVICE kernel builds."""
+    r = _as_records(records, count)
+    out = np.empty(count * PACKED_WORDS, dtype=np.uint32)
+    if device is None:
+        _check(lib.dgnn_board_records_to_packed(r.ctypes.data_as(_u8p), int(count), out.ctypes.data_as(_u32p)), "board_records_to_packed")
+    else:
+        _check(lib.dgnn_board_records_to_packed_device(int(device), r.ctypes.data_as(_u8p), int(count), out.ctypes.data_as(_u32p)),
+               "board_records_to_packed_device")
+    return out
 
 
 def layer_dense(x, batch, k_in, w_in_out, bias, n_out, alpha=1.0, relu=False, device=0):
@@ -1223,6 +1260,12 @@ class Board:
         winner, territory = ctypes.create_string_buffer(32), ctypes.create_string_buffer(4 * 361 + 8)
         _check(lib.dgnn_go_result_sgf(self._handle, winner, len(winner), territory, len(territory)), "Board.result_sgf")
         return winner.value.decode("ascii"), territory.value.decode("ascii")
+
+    def record(self, to_move, symmetry=0):
+        """The compact record of the position for forward_boards (include/dgnn.h) -> uint8 [896]."""
+        out = np.empty(BOARD_RECORD_BYTES, dtype=np.uint8)
+        _check(lib.dgnn_go_board_record(self._handle, int(to_move), int(symmetry), out.ctypes.data_as(_u8p)), "Board.record")
+        return out
 
     def get_features(self, to_move, symmetry=0):
         """features::V1::get_features::<HWC, f16> -> float16 [361, 32]."""

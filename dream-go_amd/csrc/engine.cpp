@@ -45,6 +45,7 @@ struct Workspace {
     void* arena = nullptr;                  // one allocation, carved below
     uint16_t* d_features = nullptr;         // [batch][361][32]
     uint32_t* d_packed = nullptr;           // [batch][DGNN_PACKED_WORDS]: packed features (dgnn_forward_packed)
+    uint8_t* d_records = nullptr;           // [batch][DGNN_BOARD_RECORD_BYTES]: compact board records (dgnn_forward_boards)
     uint16_t* d_act[3] = {nullptr, nullptr, nullptr};   // rotating; [batch][361][C] NHWC, or [batch][C/8][400][8] on the board path
     uint16_t* d_features_board = nullptr;   // board path: features in padded slot-major layout [batch][4][400][8]
     uint16_t* d_tower_nhwc = nullptr;       // board path: tower output converted back to NHWC for the head kernels
@@ -57,6 +58,7 @@ struct Workspace {
     void* pinned = nullptr;                 // host staging, one allocation
     uint16_t* h_features = nullptr;
     uint32_t* h_packed = nullptr;
+    uint8_t* h_records = nullptr;
     uint16_t* h_value = nullptr;
     uint16_t* h_policy = nullptr;
 
@@ -74,7 +76,7 @@ struct Workspace {
     unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
     unsigned* h_split_err = nullptr;        // pinned copy of that word, fetched with the outputs
     bool split_pending = false;             // the submission in flight used tower_split_kernel
-    bool pending_packed = false;            // ... and took packed features (what to repeat if it gave up)
+    int pending_form = 0;                   // ... and took this input form (what to repeat if it gave up)
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
     int tile_fm = 8;                        // position-tile height of the tile kernel for this batch size
     int tile_variant = 2;                   // 1 = lock-step, 2 = staggered load|matrix phases, 3 = staggered balanced half-steps
@@ -232,7 +234,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
     const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
     const size_t sz_split = align_up(((size_t)batch * 8 + 1) * sizeof(unsigned), 256);
-    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split;
+    const size_t sz_records = align_up((size_t)batch * DGNN_BOARD_RECORD_BYTES, 256);
+    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split + sz_records;
 
     DGNN_HIP(hipMalloc(&ws->arena, total));
     // board path: pad rows 384..399 of every k-slot are never written by the kernels and must read as zero
@@ -247,15 +250,17 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_logits = (uint16_t*)p; p += sz_logits;
     ws->d_packed = (uint32_t*)p; p += sz_packed;
     ws->d_split_sync = (unsigned*)p; p += sz_split;
+    ws->d_records = p; p += sz_records;
     if (ws->use_board) {
         ws->d_features_board = (uint16_t*)p; p += sz_fboard;
         ws->d_tower_nhwc = (uint16_t*)p;
     }
 
-    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_packed + sz_value + sz_policy + 256, hipHostMallocDefault));
+    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_packed + sz_records + sz_value + sz_policy + 256, hipHostMallocDefault));
     uint8_t* h = (uint8_t*)ws->pinned;
     ws->h_features = (uint16_t*)h; h += sz_features;
     ws->h_packed = (uint32_t*)h; h += sz_packed;
+    ws->h_records = h; h += sz_records;
     ws->h_value = (uint16_t*)h; h += sz_value;
     ws->h_policy = (uint16_t*)h; h += sz_policy;
     ws->h_split_err = (unsigned*)h;
@@ -286,8 +291,11 @@ bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
 
 // Enqueues graph.rs:134-152 on the workspace's stream.  `tower_pair` (may be -1) selects the event pair that
 // brackets the residual convolutions.
-int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
+enum InputForm { kInputFeatures = 0, kInputPacked = 1, kInputRecords = 2 };   // d_features / d_packed / d_records hold the batch
+
+int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatures)
 {
+    const bool packed_input = input_form == kInputPacked;
     const Topology& t = ws->net->topo;
     const uint8_t* image = ws->dev->d_image;
     const int num_pos = ws->active * DGNN_NUM_POINTS;
@@ -349,10 +357,13 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
 
     int cur = 0;
     const uint16_t* tower = nullptr;   // NHWC tower output for the heads
-    if (packed_input && !ws->use_board) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features, ws->active, false, ws->stream));
+    // compact board records: the planes are built on the device (features.hip), straight into the up-layer's input on the board path
+    if (input_form == kInputRecords) DGNN_HIP(launch_board_records(ws->d_records, ws->d_packed, ws->use_board ? ws->d_features_board : nullptr, ws->active, ws->stream));
+    if ((packed_input || input_form == kInputRecords) && !ws->use_board) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features, ws->active, false, ws->stream));
     if (ws->use_board) {
         // features.rs:52-60 HWC fp16, or the packed form: either way the up-layer reads the padded slot-major layout
-        if (packed_input) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features_board, ws->active, true, ws->stream));
+        if (input_form == kInputRecords) {}
+        else if (packed_input) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features_board, ws->active, true, ws->stream));
         else DGNN_HIP(launch_nhwc_to_board(ws->d_features, ws->d_features_board, ws->active, DGNN_NUM_FEATURES, ws->stream));
         // the up-layer (C_in = 32: one chunk) is the tower launch's first layer where the tower is one launch: its output
         // channels 0..31 stay in LDS for the first residual convolution like any other layer's (DGNN_TOWER_UP=0: own launch)
@@ -467,11 +478,11 @@ int enqueue_forward(Workspace* ws, int tower_pair, bool packed_input = false)
 }
 
 // After enqueue_forward: fetch the split tower's give-up word with the outputs.
-int enqueue_split_check(Workspace* ws, bool packed)
+int enqueue_split_check(Workspace* ws, int input_form)
 {
     const int mode = tower_mode(ws);
     ws->split_pending = mode > 0;
-    ws->pending_packed = packed;
+    ws->pending_form = input_form;
     if (mode > 0) {
         DGNN_HIP(hipMemcpyAsync(ws->h_split_err, ws->d_split_sync + (size_t)ws->batch * 8, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream));
     }
@@ -488,7 +499,7 @@ int resolve_split_failure(Workspace* ws)
     *ws->h_split_err = 0;
     ws->split_failed = true;
     std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer from now on\n", ws->device);
-    const int status = enqueue_forward(ws, -1, ws->pending_packed);
+    const int status = enqueue_forward(ws, -1, ws->pending_form);
     if (status != DGNN_OK) return status;
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
@@ -801,7 +812,7 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
 
     int status = enqueue_forward(ws, -1);
     if (status != DGNN_OK) return status;
-    status = enqueue_split_check(ws, false);
+    status = enqueue_split_check(ws, kInputFeatures);
     if (status != DGNN_OK) return status;
 
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
@@ -860,9 +871,9 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
     if (packed != ws->h_packed) std::memcpy(ws->h_packed, packed, in_bytes);
     DGNN_HIP(hipMemcpyAsync(ws->d_packed, ws->h_packed, in_bytes, hipMemcpyHostToDevice, ws->stream));
 
-    int status = enqueue_forward(ws, -1, /*packed_input=*/true);
+    int status = enqueue_forward(ws, -1, kInputPacked);
     if (status != DGNN_OK) return status;
-    status = enqueue_split_check(ws, true);
+    status = enqueue_split_check(ws, kInputPacked);
     if (status != DGNN_OK) return status;
 
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
@@ -877,6 +888,66 @@ int dgnn_forward_packed(dgnn_workspace* ws, const uint32_t* packed, int count, u
     const int status = dgnn_forward_submit_packed(ws, packed, count);
     if (status != DGNN_OK) return status;
     return dgnn_forward_wait(ws, value_out, policy_out);
+}
+
+// Compact board records: 896 bytes of board state per position; the feature planes are built on the device (features.hip).
+int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, int count)
+{
+    if (!handle || !records) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
+    if (ws->pending) return DGNN_BAD_ARGUMENT;
+    ws->active = count;
+    const size_t in_bytes = (size_t)count * DGNN_BOARD_RECORD_BYTES;
+
+    DGNN_HIP(hipSetDevice(ws->device));
+    if (records != ws->h_records) std::memcpy(ws->h_records, records, in_bytes);
+    DGNN_HIP(hipMemcpyAsync(ws->d_records, ws->h_records, in_bytes, hipMemcpyHostToDevice, ws->stream));
+
+    int status = enqueue_forward(ws, -1, kInputRecords);
+    if (status != DGNN_OK) return status;
+    status = enqueue_split_check(ws, kInputRecords);
+    if (status != DGNN_OK) return status;
+
+    DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    ws->pending = true;
+    return DGNN_OK;
+}
+
+int dgnn_forward_boards(dgnn_workspace* ws, const uint8_t* records, int count, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    const int status = dgnn_forward_submit_boards(ws, records, count);
+    if (status != DGNN_OK) return status;
+    return dgnn_forward_wait(ws, value_out, policy_out);
+}
+
+int dgnn_workspace_records_buffer(dgnn_workspace* ws, uint8_t** h_records)
+{
+    if (!ws || !h_records) return DGNN_BAD_ARGUMENT;
+    *h_records = W(ws)->h_records;
+    return DGNN_OK;
+}
+
+int dgnn_board_records_to_packed_device(int device, const uint8_t* records, int count, uint32_t* packed)
+{
+    if (!records || !packed || count <= 0) return DGNN_BAD_ARGUMENT;
+    int devices = 0;
+    DGNN_HIP(hipGetDeviceCount(&devices));
+    if (device < 0 || device >= devices) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP(hipSetDevice(device));
+    const size_t sz_r = align_up((size_t)count * DGNN_BOARD_RECORD_BYTES, 256), sz_p = (size_t)count * DGNN_PACKED_WORDS * 4;
+    uint8_t* d = nullptr;
+    DGNN_HIP(hipMalloc((void**)&d, sz_r + sz_p));
+    int status = DGNN_OK;
+    hipError_t err = hipMemcpy(d, records, (size_t)count * DGNN_BOARD_RECORD_BYTES, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = launch_board_records(d, (uint32_t*)(d + sz_r), nullptr, count, nullptr);
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(packed, d + sz_r, sz_p, hipMemcpyDeviceToHost);
+    if (err != hipSuccess) { set_last_hip_error((int)err); status = DGNN_HIP_ERROR; }
+    (void)hipFree(d);
+    return status;
 }
 
 int dgnn_workspace_packed_buffer(dgnn_workspace* ws, uint32_t** h_packed)

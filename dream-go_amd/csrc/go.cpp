@@ -457,6 +457,145 @@ void features_v1(const GoBoard& b, int to_move, int symmetry, uint16_t* out)
 }
 
 
+// ---- the compact board record (dgnn_forward_boards): what the DEVICE needs to build the 32 planes itself ----
+//
+// features_v1 above costs 10-45 us of host time per leaf and ships 23 KB; the record costs well under a microsecond and 896
+// bytes.  It holds what the host keeps incrementally anyway -- stones and block ids -- plus the three planes whose definition
+// needs history or look-ahead (super-ko against the hash ring, the two ladder readers), restricted to the few points where they
+// can be set at all.  Liberty counts, liberties-after-move, validity, the move history planes and the constant planes are
+// computed from it on the device (csrc/features.hip), bit-identical to features_v1 (tests/test_features_gpu.py), and on the
+// host by record_to_packed below (the statement of the same algorithm the CPU tests check against features_v1).
+struct BoardRecord {
+    uint16_t cell[368];            // bits 0-1: 0 empty / 1 black / 2 white; bits 2-10: block id (a point of the block); 361..367 zero
+    uint32_t ko[12];               // bit p: p is empty, not suicide for to_move, and playing there repeats a position (board.rs:120-130)
+    uint32_t ladder_capture[12];   // bit p: ... and it captures in a ladder (utils/ladder.rs:124-136)
+    uint32_t ladder_escape[12];    // bit p: ... and it escapes a ladder (utils/ladder.rs:138-170)
+    uint8_t to_move, symmetry;
+    uint16_t komi;                 // fp16 bits of clamp(0.5 + 0.5 * komi / 7.5, 0, 1) (features.rs:236-239)
+    int16_t last[2];               // the two most recent moves, -1 = none / pass
+    uint8_t reserved[8];
+};
+static_assert(sizeof(BoardRecord) == DGNN_BOARD_RECORD_BYTES, "BoardRecord layout");
+
+void board_record(const GoBoard& b, int to_move, int symmetry, BoardRecord* out)
+{
+    const Fast& f = b.inner;
+    std::memset(out, 0, sizeof(*out));
+    for (int p = 0; p < kPoints; ++p) out->cell[p] = (uint16_t)(f.stone[p] | (f.stone[p] != kEmpty ? f.head[p] << 2 : 0));
+    out->to_move = (uint8_t)to_move;
+    out->symmetry = (uint8_t)symmetry;
+    out->komi = float_to_half(std::max(0.0f, std::min(1.0f, 0.5f + (0.5f * b.komi) / 7.5f)));
+    for (int i = 0; i < 2; ++i) out->last[i] = (int16_t)((b.history[i] >= 0 && b.history[i] < kPoints) ? b.history[i] : -1);
+
+    auto set = [](uint32_t* mask, int p) { mask[p >> 5] |= 1u << (p & 31); };
+    // super-ko can only strike on a point that has held a stone (board.rs:121)
+    for (int p = 0; p < kPoints; ++p)
+        if (f.visited[p] && f.stone[p] == kEmpty && f.is_valid(to_move, p) && b.is_ko(to_move, p)) set(out->ko, p);
+    // the ladder readers answer "no" unless an opponent block with exactly two liberties (capture, may_start_ladder) or an own
+    // block with fewer than two (escape, ladder.rs:146-151) is adjacent: only the liberties of such blocks are ever read out
+    const unsigned char mine = (unsigned char)(to_move + 1), theirs = (unsigned char)(2 - to_move);
+    for (int h = 0; h < kPoints; ++h) {
+        if (f.stone[h] == kEmpty || f.head[h] != h) continue;
+        const bool capture = f.stone[h] == theirs && f.libs[h] == 2, escape = f.stone[h] == mine && f.libs[h] < 2;
+        if (!capture && !escape) continue;
+        int s = h;
+        do {
+            for (int d = 0; d < 4; ++d) {
+                const int q = neighbour(s, d);
+                if (q < 0 || f.stone[q] != kEmpty) continue;
+                if (capture && !((out->ladder_capture[q >> 5] >> (q & 31)) & 1u) && f.is_valid(to_move, q) && ladder_capture(f, to_move, q)) set(out->ladder_capture, q);
+                if (escape && !((out->ladder_escape[q >> 5] >> (q & 31)) & 1u) && f.is_valid(to_move, q) && ladder_escape(f, to_move, q)) set(out->ladder_escape, q);
+            }
+            s = f.next[s];
+        } while (s != h);
+    }
+}
+
+// The planes from a record alone: the host statement of csrc/features.hip (same steps, same order), producing the packed
+// form of dgnn_forward_packed (361 plane masks + the komi word).  Used by the CPU tests (against features_v1 on every position of
+// the committed games) and by leaf pools whose lanes are predictor CALLBACKS (dry runs, the oracle as the predictor); a pool over
+// devices never calls it.
+void record_to_packed(const BoardRecord& r, uint32_t* out /* DGNN_PACKED_WORDS */)
+{
+    struct Set { uint32_t w[12]; };
+    static thread_local Set nb[kPoints], st[kPoints];      // per block id: every neighbour of its stones / its stones
+    unsigned char stone[kPoints];
+    short head[kPoints], libs[kPoints];
+    Set empty;
+    std::memset(&empty, 0, sizeof(empty));
+    for (int p = 0; p < kPoints; ++p) {
+        stone[p] = (unsigned char)(r.cell[p] & 3);
+        head[p] = (short)(r.cell[p] >> 2);
+        if (stone[p] == kEmpty) empty.w[p >> 5] |= 1u << (p & 31);
+        else if (head[p] == p) { std::memset(&nb[p], 0, sizeof(Set)); std::memset(&st[p], 0, sizeof(Set)); }
+    }
+    for (int p = 0; p < kPoints; ++p) {
+        if (stone[p] == kEmpty) continue;
+        const int h = head[p];
+        st[h].w[p >> 5] |= 1u << (p & 31);
+        for (int d = 0; d < 4; ++d) { const int q = neighbour(p, d); if (q >= 0) nb[h].w[q >> 5] |= 1u << (q & 31); }
+    }
+    for (int p = 0; p < kPoints; ++p) {
+        if (stone[p] == kEmpty || head[p] != p) continue;
+        int n = 0;
+        for (int i = 0; i < 12; ++i) n += __builtin_popcount(nb[p].w[i] & empty.w[i]);
+        libs[p] = (short)n;
+    }
+    auto valid = [&](int color, int p) {
+        for (int d = 0; d < 4; ++d) {
+            const int q = neighbour(p, d);
+            if (q < 0) continue;
+            if (stone[q] == kEmpty) return true;
+            if ((stone[q] == color + 1) == (libs[head[q]] >= 2)) return true;
+        }
+        return false;
+    };
+    auto liberties_if = [&](int color, int p) {
+        Set reach, count_in = empty;                         // reach: N(p) + the neighbourhoods of the own blocks p joins
+        std::memset(&reach, 0, sizeof(reach));
+        for (int d = 0; d < 4; ++d) {
+            const int q = neighbour(p, d);
+            if (q < 0) continue;
+            reach.w[q >> 5] |= 1u << (q & 31);
+            if (stone[q] == color + 1) for (int i = 0; i < 12; ++i) reach.w[i] |= nb[head[q]].w[i];
+            else if (stone[q] == 2 - color && libs[head[q]] == 1) for (int i = 0; i < 12; ++i) count_in.w[i] |= st[head[q]].w[i];   // lifted
+        }
+        reach.w[p >> 5] &= ~(1u << (p & 31));
+        int n = 0;
+        for (int i = 0; i < 12; ++i) n += __builtin_popcount(reach.w[i] & count_in.w[i]);
+        return n;
+    };
+
+    const int to_move = r.to_move, opponent = 1 - to_move;
+    const uint16_t* map = symmetry_map(r.symmetry);
+    uint32_t word[kPoints];
+    bool any_ko = false;
+    for (int p = 0; p < kPoints; ++p) {
+        uint32_t m = 0;
+        if (stone[p] != kEmpty) {
+            const int start = stone[p] == to_move + 1 ? 5 : 17;
+            const int n = std::min((int)libs[head[p]], 6);
+            m |= ((1u << n) - 1u) << start;
+        } else {
+            const bool ok = valid(to_move, p);
+            if (ok) m |= ((1u << std::min(liberties_if(to_move, p), 6)) - 1u) << 11;
+            if (valid(opponent, p)) m |= ((1u << std::min(liberties_if(opponent, p), 6)) - 1u) << 23;
+            const uint32_t bit = 1u << (p & 31);
+            if (ok && (r.ko[p >> 5] & bit)) { m |= 1u << 29; any_ko = true; }
+            if (ok && (r.ladder_capture[p >> 5] & bit)) m |= 1u << 30;
+            if (ok && (r.ladder_escape[p >> 5] & bit)) m |= 1u << 31;
+        }
+        if (r.last[0] == p) m |= 1u << 3;
+        if (r.last[1] == p) m |= 1u << 4;
+        word[p] = m;
+    }
+    const bool komi_set = (r.komi & 0x7fff) != 0;
+    const uint32_t global = (komi_set ? 1u << to_move : 0u) | (any_ko ? 4u : 0u);
+    for (int p = 0; p < kPoints; ++p) out[map[p]] = word[p] | global;
+    out[kPoints] = komi_set ? (uint32_t)r.komi << (16 * to_move) : 0u;
+    for (int i = kPoints + 1; i < DGNN_PACKED_WORDS; ++i) out[i] = 0;
+}
+
 // ---- Benson's unconditional life, Tromp-Taylor score, stone status (utils/benson.rs, utils/score.rs) ----
 enum : unsigned char { kStatusNone = 0, kStatusBlock = 1, kStatusRegion = 2 };      // benson.rs:48-53
 
@@ -699,6 +838,7 @@ int go_is_symmetric(void* b, int symmetry)                                    //
     return 1;
 }
 uint64_t go_hash(void* b) { return static_cast<GoBoard*>(b)->hash; }      // BoardTuple, predictors/nn.rs:31-45
+void go_record(void* b, int to_move, int symmetry, uint8_t* out) { board_record(*static_cast<GoBoard*>(b), to_move, symmetry, reinterpret_cast<BoardRecord*>(out)); }
 void go_candidates_scoring(void* b, int to_move, unsigned char* out)          // ScoringPolicyChecker, options.rs:110-139
 {
     const GoBoard* g = static_cast<GoBoard*>(b);
@@ -709,8 +849,8 @@ void go_candidates_scoring(void* b, int to_move, unsigned char* out)          //
         out[p] = black[p] != kStatusRegion && white[p] != kStatusRegion && g->is_valid(to_move, p) && !is_simple_eye(g->inner, to_move, p);
     out[kPass] = 0;
 }
-const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric, go_hash};
-const dgnn_game_ops kGoScoringOps = {go_clone, go_destroy, go_place, go_features, go_candidates_scoring, go_is_symmetric, go_hash};
+const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric, go_hash, go_record};
+const dgnn_game_ops kGoScoringOps = {go_clone, go_destroy, go_place, go_features, go_candidates_scoring, go_is_symmetric, go_hash, go_record};
 
 struct Rng2 {
     uint64_t state;
@@ -765,6 +905,26 @@ int dgnn_go_features(const dgnn_go_board* b, int to_move, int symmetry, uint16_t
 {
     if (!b || !out || (to_move != 0 && to_move != 1) || symmetry < 0 || symmetry >= 8) return DGNN_BAD_ARGUMENT;
     features_v1(*CGO(b), to_move, symmetry, out);
+    return DGNN_OK;
+}
+int dgnn_go_board_record(const dgnn_go_board* b, int to_move, int symmetry, uint8_t* out)
+{
+    if (!b || !out || (to_move != 0 && to_move != 1) || symmetry < 0 || symmetry >= 8) return DGNN_BAD_ARGUMENT;
+    BoardRecord r;                                       // (the caller's buffer need not be aligned)
+    board_record(*CGO(b), to_move, symmetry, &r);
+    std::memcpy(out, &r, sizeof(r));
+    return DGNN_OK;
+}
+int dgnn_board_records_to_packed(const uint8_t* records, int count, uint32_t* packed)
+{
+    if (!records || !packed || count <= 0) return DGNN_BAD_ARGUMENT;
+    for (int i = 0; i < count; ++i) {
+        BoardRecord r;
+        std::memcpy(&r, records + (size_t)i * DGNN_BOARD_RECORD_BYTES, sizeof(r));
+        if (r.to_move > 1 || r.symmetry > 7) return DGNN_BAD_ARGUMENT;
+        for (int p = 0; p < kPoints; ++p) if ((r.cell[p] & 3) == 3 || (r.cell[p] >> 2) >= kPoints) return DGNN_BAD_ARGUMENT;
+        record_to_packed(r, packed + (size_t)i * DGNN_PACKED_WORDS);
+    }
     return DGNN_OK;
 }
 int dgnn_go_is_symmetric(const dgnn_go_board* b, int symmetry) { return (b && symmetry >= 0 && symmetry < 8) ? go_is_symmetric((void*)b, symmetry) : 0; }

@@ -105,6 +105,9 @@ hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, in
 hipError_t launch_board_to_nhwc(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
 // Packed features [B][kPackedWords] -> the 32 input planes, either [B][4][400][8] (board_layout) or [B][361][32] NHWC.
 hipError_t launch_packed_features(const uint32_t* packed, uint16_t* out, int batch, bool board_layout, hipStream_t stream);
+// Compact board records [B][DGNN_BOARD_RECORD_BYTES] -> the planes (features.hip): always the packed words [B][kPackedWords], and --
+// planes_board != nullptr -- the up-layer's input [B][4][400][8] as well.
+hipError_t launch_board_records(const uint8_t* records, uint32_t* packed, uint16_t* planes_board, int batch, hipStream_t stream);
 
 struct HeadConvLaunch {
     const uint16_t* x;          // tower output [batch][cin / 8][400][8] fp16 (padded slot-major)

@@ -44,6 +44,7 @@ extern "C" {
 #define DGNN_FEATURE_SIZE   11552   /* features::V1::size() = 32 * 361, features.rs:94-96 */
 #define DGNN_NUM_MOVES      362     /* 361 points + pass, src/libdg_nn/layers/policy_head.rs:54 */
 #define DGNN_PACKED_WORDS   368     /* packed features of one board, 32-bit words: see dgnn_forward_packed */
+#define DGNN_BOARD_RECORD_BYTES 896 /* compact board record of one position: see dgnn_forward_boards */
 
 typedef struct dgnn_network dgnn_network;     /* replaces dg_nn::Network  (src/libdg_nn/network.rs:83-86)  */
 typedef struct dgnn_workspace dgnn_workspace; /* replaces dg_nn::Workspace (src/libdg_nn/graph.rs:99-113) */
@@ -144,6 +145,32 @@ int dgnn_features_unpack(const uint32_t* packed, int count, uint16_t* features);
 /* The workspace's pinned staging buffer for packed features (batch * DGNN_PACKED_WORDS words): a caller that assembles
  * its batch there and passes the pointer skips the staging memcpy. */
 int dgnn_workspace_packed_buffer(dgnn_workspace* ws, uint32_t** h_packed);
+
+/* The same evaluation from COMPACT BOARD RECORDS: the feature planes themselves are built on the device.
+ * features::V1::get_features (src/libdg_go/utils/features.rs:99-251) runs on the CPU of the reference, once per leaf, on the
+ * search worker's thread (src/libdg_mcts/pool/event.rs:46-59): 10-45 us and 23 KB per leaf.  Here the host hands over what it
+ * keeps incrementally anyway and the device computes liberties (features.rs:130-140), liberties-after-move and validity for
+ * both colours (:141-158), the move-history, colour / komi and any-ko planes (:103-128, :236-250) -- bit-identical planes, so
+ * bit-identical outputs to dgnn_forward on dgnn_go_features of the same position.  One record, DGNN_BOARD_RECORD_BYTES, little endian:
+ *   u16 cell[368]            per point 19 * y + x (identity orientation): bits 0-1 = 0 empty / 1 black / 2 white, bits 2-10 = block id
+ *                            (the index of any one point of the block; every stone of a block carries the same id); 361..367 zero
+ *   u32 ko[12]               bit p set: p is empty, not suicide for the side to move, and playing there repeats one of the last positions
+ *                            (Board::_is_ko, src/libdg_go/board.rs:120-130 -- needs the hash ring, so it stays on the host)
+ *   u32 ladder_capture[12]   bit p set: ... and the stone captures in a ladder (src/libdg_go/utils/ladder.rs:124-136)
+ *   u32 ladder_escape[12]    bit p set: ... and the stone escapes a ladder    (ladder.rs:138-170)
+ *   u8 to_move, u8 symmetry  colour to move (0 black / 1 white), symmetry 0..7 applied to the OUTPUT planes (symmetry::ALL order)
+ *   u16 komi                 fp16 bits of clamp(0.5 + 0.5 * komi / 7.5, 0, 1) (features.rs:236-239)
+ *   i16 last[2]              the two most recent moves as points, -1 = none / pass (features.rs:103-110)
+ *   u8 reserved[8]           zero
+ * dgnn_go_board_record fills one from a dgnn_go_board; dgnn_board_records_to_packed is the HOST statement of the device algorithm
+ * (records -> the packed form of dgnn_forward_packed), what the CPU tests compare with dgnn_go_features. */
+int dgnn_forward_boards(dgnn_workspace* ws, const uint8_t* records, int count, uint16_t* value_out, uint16_t* policy_out);
+int dgnn_forward_submit_boards(dgnn_workspace* ws, const uint8_t* records, int count);   /* then dgnn_forward_wait */
+/* The workspace's pinned staging buffer for records (batch * DGNN_BOARD_RECORD_BYTES): assembling the batch there skips a memcpy. */
+int dgnn_workspace_records_buffer(dgnn_workspace* ws, uint8_t** h_records);
+int dgnn_board_records_to_packed(const uint8_t* records, int count, uint32_t* packed /* count * DGNN_PACKED_WORDS */);
+/* Test hook: the planes the DEVICE builds from `count` records, downloaded in packed form (allocates, runs, frees; blocking). */
+int dgnn_board_records_to_packed_device(int device, const uint8_t* records, int count, uint32_t* packed);
 
 /* ---- device-resident variants (measurement harness; inputs already in HBM) ----------------- */
 
@@ -451,6 +478,7 @@ typedef struct dgnn_game_ops {
     void (*candidates)(void* board, int to_move, unsigned char* out /* 362: 1 = may be searched */);
     int (*is_symmetric)(void* board, int symmetry);                                /* may be NULL: no elimination */
     uint64_t (*hash)(void* board);                                                 /* may be NULL: no transposition cache */
+    void (*record)(void* board, int to_move, int symmetry, uint8_t* out /* DGNN_BOARD_RECORD_BYTES */);   /* may be NULL: only fp16 features */
 } dgnn_game_ops;
 
 /* One search on `root` from `board` (not modified): rollouts until root.total_count >= num_rollouts
@@ -515,6 +543,8 @@ int dgnn_go_is_symmetric(const dgnn_go_board* board, int symmetry);          /* 
 /* features::V1::get_features::<HWC, f16> (src/libdg_go/utils/features.rs:99-251): 361 * 32 fp16, the `features` argument of
  * dgnn_forward for one board. */
 int dgnn_go_features(const dgnn_go_board* board, int to_move, int symmetry, uint16_t* out);
+/* The compact record of the position for dgnn_forward_boards (layout there). */
+int dgnn_go_board_record(const dgnn_go_board* board, int to_move, int symmetry, uint8_t* out /* DGNN_BOARD_RECORD_BYTES */);
 /* The board as the game behind dgnn_search_run (a dgnn_go_board* is the `board` argument). */
 const dgnn_game_ops* dgnn_go_game_ops(void);        /* StandardSearch: every legal move and pass (options.rs:44-82) */
 const dgnn_game_ops* dgnn_go_scoring_ops(void);     /* ScoringSearch: no pass, no point inside a Benson eye of either colour, no filling of

@@ -1,0 +1,105 @@
+"""CPU tests of the compact board record (include/dgnn.h: dgnn_forward_boards): the record of a position, expanded by the HOST
+statement of the device algorithm (go.cpp: record_to_packed), gives exactly the planes of features::V1
+(src/libdg_go/utils/features.rs:99-251 as go.cpp's features_v1 states it) -- on every position of the three committed
+reference games (tests/golden/real_games.json; src/dg_tests/tests/real_games.rs), all eight symmetries, both colours to move, and
+on dense random positions with many captures, ataris and kos.  The -m gpu twin (tests/test_features_gpu.py) checks the DEVICE kernel
+the same way."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def game_positions(api, stride=1):
+    for game in json.load(open(os.path.join(GOLDEN, "real_games.json")))["games"]:
+        board = api.Board(7.5)
+        for n, (color, vertex) in enumerate(re.findall(r";([BW])\[([a-s]{2})\]", game["moves"])):
+            board.place(0 if color == "B" else 1, ord(vertex[0]) - 97, ord(vertex[1]) - 97)
+            if n % stride == 0:
+                yield board
+
+
+def random_positions(api, seed, games, stones, komi=0.5):
+    """Dense random legal play: captures, ataris, snapbacks and kos in quantity (the three professional games hold few)."""
+    rng = np.random.default_rng(seed)
+    for _ in range(games):
+        board, color = api.Board(komi), 0
+        for _ in range(stones):
+            for index in rng.permutation(361)[:60]:
+                if board.is_valid(color, int(index % 19), int(index // 19)):
+                    board.place(color, int(index % 19), int(index // 19))
+                    break
+            color ^= 1
+            yield board
+
+
+def expected_and_records(api, boards):
+    features, records = [], []
+    for board in boards:
+        for color in (0, 1):
+            for symmetry in range(8):
+                features.append(board.get_features(color, symmetry).reshape(-1).view(np.uint16))
+                records.append(board.record(color, symmetry))
+    n = len(records)
+    return api.features_pack(np.concatenate(features), n).reshape(n, api.PACKED_WORDS), np.concatenate(records), n
+
+
+def describe_mismatch(expected, got):
+    bad = np.argwhere(expected != got)
+    i, w = bad[0]
+    return (f"{len(bad)} words differ; first: variant {i} (colour {(i // 8) % 2}, symmetry {i % 8}) word {w}: "
+            f"expected {expected[i, w]:#010x} got {got[i, w]:#010x} (planes {[b for b in range(32) if ((expected[i, w] ^ got[i, w]) >> b) & 1]})")
+
+
+def test_record_planes_equal_features_v1_on_the_reference_games(api):
+    total = 0
+    for board in game_positions(api):
+        expected, records, n = expected_and_records(api, [board])
+        got = api.board_records_to_packed(records, n).reshape(n, api.PACKED_WORDS)
+        assert np.array_equal(expected, got), f"after {board.count()} stones: " + describe_mismatch(expected, got)
+        total += n
+    assert total == 648 * 16
+
+
+@pytest.mark.parametrize("komi", [0.5, 7.5, -7.5, -20.0])
+def test_record_planes_equal_features_v1_on_dense_random_positions(api, komi):
+    """komi -7.5 and below clamp the colour plane's constant to 0 (features.rs:236-239): plane 0 / 1 is then all zero."""
+    total, with_ko, with_ladder = 0, 0, 0
+    for board in random_positions(api, seed=int(abs(komi) * 10) + 3, games=2, stones=330, komi=komi):
+        if board.count() % 3:
+            continue
+        expected, records, n = expected_and_records(api, [board])
+        got = api.board_records_to_packed(records, n).reshape(n, api.PACKED_WORDS)
+        assert np.array_equal(expected, got), f"after {board.count()} stones: " + describe_mismatch(expected, got)
+        with_ko += int(((expected[:, :361] >> 29) & 1).any())
+        with_ladder += int(((expected[:, :361] >> 30) & 3).any())
+        total += n
+    print(f"komi {komi}: {total} variants, {with_ko} positions with a ko plane, {with_ladder} with a ladder plane")
+    assert total > 2000 and with_ladder > 0
+
+
+def test_record_layout_and_argument_checks(api):
+    board = api.Board(6.5)
+    board.place(0, 3, 3)
+    board.place(1, 15, 15)
+    board.place(0, 3, 4)
+    r = board.record(1, 5)
+    assert r.size == api.BOARD_RECORD_BYTES == 896
+    cell = r[:736].view(np.uint16)
+    assert cell[3 * 19 + 3] & 3 == 1 and cell[15 * 19 + 15] & 3 == 2 and cell[0] == 0
+    assert cell[3 * 19 + 3] >> 2 == cell[4 * 19 + 3] >> 2                     # one block, one id
+    assert r[880] == 1 and r[881] == 5                                        # to_move, symmetry
+    assert r[884:888].view(np.int16).tolist() == [4 * 19 + 3, 15 * 19 + 15]   # the two most recent moves
+    assert np.all(r[888:] == 0)
+    bad = r.copy()
+    bad[880] = 2
+    with pytest.raises(api.Error):
+        api.board_records_to_packed(bad, 1)
+    bad = r.copy()
+    bad[0] = 3                                                                # a cell that is neither empty, black nor white
+    with pytest.raises(api.Error):
+        api.board_records_to_packed(bad, 1)
