@@ -59,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-rollouts", type=int, default=800, help="--num-rollout of the self-play leg (BASELINE.json: 800)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
     ap.add_argument("--selfplay-batches", type=int, default=2, help="device batches the leaf pool keeps alive per GPU (nn.rs:64-67: 2 per device)")
+    ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
+                    help="where the 32 feature planes are built: on the device from 896-byte board records (default), or on the host like the reference")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
     ap.add_argument("--dry", action="store_true", help="no GPU: gloo + the CPU hash predictor behind the leaf pool (CPU tests of the N > 1 path)")
@@ -226,16 +228,19 @@ def selfplay_leg(job, api, replicas, net, args):
     (self_play.rs:423-459; rollouts per move follow the win rate, :234-241).  Games are sharded `id mod world`."""
     games = args.selfplay_games * job.world
     cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
+    boards = args.selfplay_planes == "device"
     if job.dry:
-        pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
+        pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch, boards=boards)
     else:
         pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
-                                        workers_per_device=args.selfplay_batches)
+                                        workers_per_device=args.selfplay_batches, boards=boards)
     cpu0, wall0 = time.process_time(), time.perf_counter()
     out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=args.selfplay_moves,
                                     num_rollouts=args.selfplay_rollouts, threads_per_search=1, seed=20260930, pool=pool, cache=cache,
                                     device=job.tensor_device, leaves_per_thread=args.selfplay_leaves)
-    cpu_cores_busy = (time.process_time() - cpu0) / max(time.perf_counter() - wall0, 1e-9)    # this rank's threads, user + system
+    cpu_seconds = time.process_time() - cpu0                                                  # this rank's threads, user + system
+    cpu_cores_busy = cpu_seconds / max(time.perf_counter() - wall0, 1e-9)
+    rank_rollouts = out["evals"] + out["cache_hits"]                                          # this rank's own games
     st = pool.stats()
     boards = sum(job.gather_int(st["boards"]))
     batches = sum(job.gather_int(st["batches"]))
@@ -246,7 +251,8 @@ def selfplay_leg(job, api, replicas, net, args):
     leg = {
         "what": f"{args.selfplay_games} games in flight per GPU, first {args.selfplay_moves} stones of each, --num-rollout {args.selfplay_rollouts}, "
                 f"1 search thread x {args.selfplay_leaves} leaves per game, transposition cache 200001 x 8 shards, through the leaf pool "
-                "(PCIe-inclusive); random-init weights",
+                "(PCIe-inclusive); random-init weights; feature planes built on the " +
+                ("DEVICE from 896-byte board records (dgnn_forward_boards)" if boards else "HOST (features::V1, 23 KB of fp16 per leaf)"),
         "seconds": sec, "games": j["games"], "moves": j["moves"],
         "evals_per_sec": j["evals"] / sec,                          # predictor evaluations (cache misses) per second, whole job
         "device_boards_per_sec": boards / sec,
@@ -264,7 +270,12 @@ def selfplay_leg(job, api, replicas, net, args):
         "host_cpu_affinity": f"{min(os.sched_getaffinity(0))}-{max(os.sched_getaffinity(0))} ({len(os.sched_getaffinity(0))} CPUs)",
         "host_cpus_busy": cpu_cores_busy,          # CPU time of rank 0's process over the leg / its wall time: cores kept busy
         "rollouts_per_sec": (j["evals"] + j["cache_hits"]) / sec,
+        # what one rollout (probe, board, record, cache, prior, insert, queueing) costs this rank's host: CPU seconds / rollouts
+        "host_us_per_rollout": 1e6 * cpu_seconds / max(rank_rollouts, 1),
+        "host_us_per_eval": 1e6 * cpu_seconds / max(out["evals"], 1),
     }
+    # how many GPUs running THIS leg the box's CPU quota could feed: quota cores / cores one GPU's leg kept busy
+    leg["gpus_feedable_at_quota"] = leg["host_cpus"] / max(cpu_cores_busy, 1e-9)
     return leg
 
 

@@ -217,6 +217,18 @@ SYMBOLS = [
     ("dgnn_board_records_to_packed", ctypes.c_int, [_u8p, ctypes.c_int, _u32p]),
     ("dgnn_board_records_to_packed_device", ctypes.c_int, [ctypes.c_int, _u8p, ctypes.c_int, _u32p]),
     ("dgnn_go_board_record", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u8p]),
+    ("dgnn_batcher_create_boards", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_batcher_push_board", ctypes.c_int, [_vp, _u8p, ctypes.c_uint64]),
+    ("dgnn_batch_records", _u8p, [_vp]),
+    ("dgnn_pool_create_devices_boards", ctypes.c_int, [_vp, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_pool_create_callbacks_boards", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_pool_predict_boards", ctypes.c_int, [_vp, _u8p, ctypes.c_int, _u16p, _u16p]),
+    ("dgnn_pool_takes_boards", ctypes.c_int, [_vp]),
+    ("dgnn_pool_boards_predictor", _vp, []),
+    ("dgnn_search_run_boards", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("dgnn_full_forward_boards", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _fp, _fp]),
+    ("dgnn_selfplay_go_boards", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _ip, ctypes.c_char_p, ctypes.c_size_t]),
 ]
 
 
@@ -816,22 +828,39 @@ class LeafPool:
         self._handle = out
 
     @classmethod
-    def over_devices(cls, network, devices=None, max_batch_size=256, batches_per_device=2, workers_per_device=2):
+    def over_devices(cls, network, devices=None, max_batch_size=256, batches_per_device=2, workers_per_device=2, boards=False):
         """NnPredictor over several devices in ONE process (predictors/nn.rs:46-108): one queue, a batch goes to whichever
-        device has a worker free.  devices=None: Device.all()."""
+        device has a worker free.  devices=None: Device.all().  boards=True: the queue holds compact board records and the
+        feature planes are built on the device (include/dgnn.h: dgnn_forward_boards)."""
         out = ctypes.c_void_p()
         arr, n = (None, 0) if devices is None else ((ctypes.c_int * len(devices))(*[int(d) for d in devices]), len(devices))
-        _check(lib.dgnn_pool_create_devices(network.handle, arr, n, int(max_batch_size), int(batches_per_device),
-                                            int(workers_per_device), ctypes.byref(out)), "LeafPool.over_devices")
+        create = lib.dgnn_pool_create_devices_boards if boards else lib.dgnn_pool_create_devices
+        _check(create(network.handle, arr, n, int(max_batch_size), int(batches_per_device), int(workers_per_device), ctypes.byref(out)),
+               "LeafPool.over_devices")
         return cls(None, _handle=out, _keep=network)
 
     @classmethod
-    def over_callbacks(cls, predict_fn, predict_ctx=None, num_lanes=1, max_batch_size=256, batches_per_lane=2, workers_per_lane=1):
-        """The same pool over copies of a dgnn_predict_fn (e.g. lib.dgnn_hash_predictor()): no GPU needed."""
+    def over_callbacks(cls, predict_fn, predict_ctx=None, num_lanes=1, max_batch_size=256, batches_per_lane=2, workers_per_lane=1, boards=False):
+        """The same pool over copies of a dgnn_predict_fn (e.g. lib.dgnn_hash_predictor()): no GPU needed.  boards=True: the queue
+        holds board records, expanded for the callback by the host statement of the device kernel."""
         out = ctypes.c_void_p()
-        _check(lib.dgnn_pool_create_callbacks(predict_fn, predict_ctx, int(num_lanes), int(max_batch_size), int(batches_per_lane),
-                                              int(workers_per_lane), ctypes.byref(out)), "LeafPool.over_callbacks")
+        create = lib.dgnn_pool_create_callbacks_boards if boards else lib.dgnn_pool_create_callbacks
+        _check(create(predict_fn, predict_ctx, int(num_lanes), int(max_batch_size), int(batches_per_lane), int(workers_per_lane), ctypes.byref(out)),
+               "LeafPool.over_callbacks")
         return cls(None, _handle=out, _keep=(predict_fn, predict_ctx))
+
+    @property
+    def takes_boards(self):
+        return bool(lib.dgnn_pool_takes_boards(self._handle))
+
+    def predict_boards(self, records, batch_size):
+        r = _as_records(records, batch_size)
+        value = np.empty(batch_size, dtype=np.uint16)
+        policy = np.empty(batch_size * NUM_MOVES, dtype=np.uint16)
+        _check(lib.dgnn_pool_predict_boards(self._handle, r.ctypes.data_as(_u8p), int(batch_size), value.ctypes.data_as(_u16p),
+                                            policy.ctypes.data_as(_u16p)), "LeafPool.predict_boards")
+        v, p = value.view(np.float16), policy.view(np.float16).reshape(batch_size, NUM_MOVES)
+        return [Prediction(v[i], p[i]) for i in range(batch_size)]
 
     def stats(self):
         n, calls, boards, batches = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
@@ -1134,7 +1163,13 @@ def _predictor(pool):
         return lib.dgnn_hash_predictor(), None
     if isinstance(pool, PREDICT_FN):
         return ctypes.cast(pool, ctypes.c_void_p), None
+    if pool.takes_boards:
+        return lib.dgnn_pool_boards_predictor(), pool._handle
     return lib.dgnn_pool_predictor(), pool._handle
+
+
+def _takes_boards(pool):
+    return isinstance(pool, LeafPool) and pool.takes_boards
 
 
 def _game_ops(board, scoring=False):
@@ -1149,9 +1184,10 @@ def search_run(root, board, num_rollouts, num_threads=1, seed=0, pool=None, cach
     scoring=True searches a Board as a ScoringSearch (options.rs:141-163) instead of a StandardSearch."""
     fn, ctx = _predictor(pool)
     evals, conflicts, hits = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-    _check(lib.dgnn_search_run_batched(root._handle, _game_ops(board, scoring), board._handle, fn, ctx,
-                                       cache._handle if cache is not None else None, int(num_rollouts), int(num_threads), int(leaves_per_thread),
-                                       int(seed), ctypes.byref(evals), ctypes.byref(conflicts), ctypes.byref(hits)), "search_run")
+    run = lib.dgnn_search_run_boards if _takes_boards(pool) else lib.dgnn_search_run_batched
+    _check(run(root._handle, _game_ops(board, scoring), board._handle, fn, ctx,
+               cache._handle if cache is not None else None, int(num_rollouts), int(num_threads), int(leaves_per_thread),
+               int(seed), ctypes.byref(evals), ctypes.byref(conflicts), ctypes.byref(hits)), "search_run")
     return (evals.value, conflicts.value) if cache is None else (evals.value, conflicts.value, hits.value)
 
 
@@ -1160,8 +1196,9 @@ def full_forward(board, to_move, pool=None, cache=None, scoring=False):
     fn, ctx = _predictor(pool)
     value = ctypes.c_float()
     policy = np.empty(368, dtype=np.float32)
-    n = lib.dgnn_full_forward(_game_ops(board, scoring), board._handle, int(to_move), fn, ctx, cache._handle if cache is not None else None,
-                              ctypes.byref(value), policy.ctypes.data_as(_fp))
+    call = lib.dgnn_full_forward_boards if _takes_boards(pool) else lib.dgnn_full_forward
+    n = call(_game_ops(board, scoring), board._handle, int(to_move), fn, ctx, cache._handle if cache is not None else None,
+             ctypes.byref(value), policy.ctypes.data_as(_fp))
     if n < 0:
         raise Error(n, "full_forward")
     return value.value, policy[:NUM_MOVES].copy(), n
@@ -1309,9 +1346,9 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
     params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
                             int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed))
-    _check(lib.dgnn_selfplay_go(fn, ctx, cache._handle if cache is not None else None, ctypes.byref(params), ctypes.byref(stats),
-                                moves.ctypes.data_as(_ip) if moves is not None else None, sgf, len(sgf) if sgf is not None else 0),
-           "selfplay_go")
+    play = lib.dgnn_selfplay_go_boards if _takes_boards(pool) else lib.dgnn_selfplay_go
+    _check(play(fn, ctx, cache._handle if cache is not None else None, ctypes.byref(params), ctypes.byref(stats),
+                moves.ctypes.data_as(_ip) if moves is not None else None, sgf, len(sgf) if sgf is not None else 0), "selfplay_go")
     out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts,
            "cache_hits": stats.cache_hits, "games_ended": stats.games_ended, "ex_it_searches": stats.ex_it_searches}
     if return_moves:

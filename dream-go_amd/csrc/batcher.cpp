@@ -126,6 +126,10 @@ struct Batcher {
     int device = 0;
     int max_batch_size = 0;
     int max_batches = 0;
+    // What one queued position is: 11552 fp16 feature values (the reference's form) or a compact board record of
+    // DGNN_BOARD_RECORD_BYTES (dgnn_forward_boards: the planes are built on the device).  Stored in units of uint16_t either way.
+    bool records = false;
+    size_t item = DGNN_FEATURE_SIZE;
 
     std::mutex mutex;               // batch.rs:60-73: the list lock
     std::vector<uint16_t> features;
@@ -331,7 +335,7 @@ int dgnn_cache_stats(dgnn_cache* cache, uint64_t* entries, uint64_t* hits, uint6
 
 // ---- batcher
 
-int dgnn_batcher_create(dgnn_network* net, int device, int max_batch_size, int max_batches, dgnn_batcher** out)
+static int batcher_create(dgnn_network* net, int device, int max_batch_size, int max_batches, bool records, dgnn_batcher** out)
 {
     if (!out || max_batch_size <= 0 || max_batches <= 0) return DGNN_BAD_ARGUMENT;
     *out = nullptr;
@@ -341,23 +345,45 @@ int dgnn_batcher_create(dgnn_network* net, int device, int max_batch_size, int m
     b->device = device;
     b->max_batch_size = max_batch_size;
     b->max_batches = max_batches;
-    b->features.reserve((size_t)2 * max_batch_size * DGNN_FEATURE_SIZE);        // batch.rs:51-56
+    b->records = records;
+    b->item = records ? DGNN_BOARD_RECORD_BYTES / sizeof(uint16_t) : DGNN_FEATURE_SIZE;
+    b->features.reserve((size_t)2 * max_batch_size * b->item);                  // batch.rs:51-56
     b->tags.reserve((size_t)2 * max_batch_size);
     *out = reinterpret_cast<dgnn_batcher*>(b.release());
     return DGNN_OK;
 }
 
+int dgnn_batcher_create(dgnn_network* net, int device, int max_batch_size, int max_batches, dgnn_batcher** out)
+{
+    return batcher_create(net, device, max_batch_size, max_batches, false, out);
+}
+
+int dgnn_batcher_create_boards(dgnn_network* net, int device, int max_batch_size, int max_batches, dgnn_batcher** out)
+{
+    return batcher_create(net, device, max_batch_size, max_batches, true, out);
+}
+
 void dgnn_batcher_destroy(dgnn_batcher* batcher) { if (batcher) reinterpret_cast<Batcher*>(batcher)->release(); }
 
-int dgnn_batcher_push(dgnn_batcher* batcher, const uint16_t* features, uint64_t tag)
+static int batcher_push(Batcher* b, const uint16_t* item, uint64_t tag)
 {
-    if (!batcher || !features) return DGNN_BAD_ARGUMENT;
-    Batcher* b = reinterpret_cast<Batcher*>(batcher);
     std::lock_guard<std::mutex> lock(b->mutex);                                 // batch.rs:80-84
-    b->features.insert(b->features.end(), features, features + DGNN_FEATURE_SIZE);
+    b->features.insert(b->features.end(), item, item + b->item);
     b->tags.push_back(tag);
     b->queued.store((int)b->tags.size(), std::memory_order_release);
     return DGNN_OK;
+}
+
+int dgnn_batcher_push(dgnn_batcher* batcher, const uint16_t* features, uint64_t tag)
+{
+    if (!batcher || !features || reinterpret_cast<Batcher*>(batcher)->records) return DGNN_BAD_ARGUMENT;
+    return batcher_push(reinterpret_cast<Batcher*>(batcher), features, tag);
+}
+
+int dgnn_batcher_push_board(dgnn_batcher* batcher, const uint8_t* record, uint64_t tag)
+{
+    if (!batcher || !record || !reinterpret_cast<Batcher*>(batcher)->records) return DGNN_BAD_ARGUMENT;
+    return batcher_push(reinterpret_cast<Batcher*>(batcher), reinterpret_cast<const uint16_t*>(record), tag);
 }
 
 int dgnn_batcher_pending(dgnn_batcher* batcher, int* queued, int* batches_alive)
@@ -395,9 +421,9 @@ int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch
         if (!b->spare_features.empty()) { b->features.swap(b->spare_features.back()); b->spare_features.pop_back(); }
         if (!b->spare_tags.empty()) { b->tags.swap(b->spare_tags.back()); b->spare_tags.pop_back(); }
     } else {
-        batch->features.assign(b->features.begin() + split * DGNN_FEATURE_SIZE, b->features.end());   // split_off: the NEWEST entries
+        batch->features.assign(b->features.begin() + split * b->item, b->features.end());   // split_off: the NEWEST entries
         batch->tags.assign(b->tags.begin() + split, b->tags.end());
-        b->features.resize(split * DGNN_FEATURE_SIZE);
+        b->features.resize(split * b->item);
         b->tags.resize(split);
     }
     b->queued.store((int)b->tags.size(), std::memory_order_release);
@@ -422,7 +448,14 @@ int dgnn_batch_tags(const dgnn_batch* batch, uint64_t* tags_out)
     return DGNN_OK;
 }
 
-const uint16_t* dgnn_batch_features(const dgnn_batch* batch) { return batch ? reinterpret_cast<const Batch*>(batch)->features.data() : nullptr; }
+const uint16_t* dgnn_batch_features(const dgnn_batch* batch)
+{
+    return (batch && !reinterpret_cast<const Batch*>(batch)->owner->records) ? reinterpret_cast<const Batch*>(batch)->features.data() : nullptr;
+}
+const uint8_t* dgnn_batch_records(const dgnn_batch* batch)
+{
+    return (batch && reinterpret_cast<const Batch*>(batch)->owner->records) ? reinterpret_cast<const uint8_t*>(reinterpret_cast<const Batch*>(batch)->features.data()) : nullptr;
+}
 
 static void retire(Batch* bt)
 {
@@ -449,7 +482,8 @@ int dgnn_batch_forward_on(dgnn_batch* batch, int device, uint16_t* value_out, ui
     dgnn_workspace* ws = nullptr;
     int status = dgnn_network_get_workspace(b->net, device, b->max_batch_size, &ws);
     if (status == DGNN_OK) {
-        status = dgnn_forward_n(ws, bt->features.data(), n, value_out, policy_out);   // batch.rs:36 -> nn.rs:84-108
+        status = b->records ? dgnn_forward_boards(ws, reinterpret_cast<const uint8_t*>(bt->features.data()), n, value_out, policy_out)
+                            : dgnn_forward_n(ws, bt->features.data(), n, value_out, policy_out);   // batch.rs:36 -> nn.rs:84-108
         dgnn_workspace_release(ws);
     }
     retire(bt);
@@ -485,6 +519,15 @@ int LeafPool::evaluate(int lane, dgnn_batch* batch, int n, uint16_t* value, uint
 {
     int status;
     if (callback) {
+        if (batcher->records) {
+            // lanes that are predictor CALLBACKS (dry runs, the oracle as the predictor in the tests) take fp16 planes: the host
+            // statement of the device kernel expands the records (go.cpp: record_to_packed).  A pool over devices never gets here.
+            std::vector<uint32_t> packed((size_t)n * DGNN_PACKED_WORDS);
+            std::vector<uint16_t> planes((size_t)n * DGNN_FEATURE_SIZE);
+            status = dgnn_board_records_to_packed(dgnn_batch_records(batch), n, packed.data());
+            if (status == DGNN_OK) status = dgnn_features_unpack(packed.data(), n, planes.data());
+            if (status == DGNN_OK) status = callback(callback_ctx, planes.data(), n, value, policy);
+        } else
         status = callback(callback_ctx, dgnn_batch_features(batch), n, value, policy);
         if (status == DGNN_OK) {
             batcher->boards_evaluated.fetch_add((uint64_t)n, std::memory_order_relaxed);
@@ -530,8 +573,23 @@ int dgnn_pool_create(dgnn_batcher* batcher, int num_workers, dgnn_pool** out)
     return start_pool(pool, num_workers, out);
 }
 
+static int pool_create_devices(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,
+                               int workers_per_device, bool records, dgnn_pool** out);
+
 int dgnn_pool_create_devices(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,
                              int workers_per_device, dgnn_pool** out)
+{
+    return pool_create_devices(net, devices, num_devices, max_batch_size, batches_per_device, workers_per_device, false, out);
+}
+
+int dgnn_pool_create_devices_boards(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,
+                                    int workers_per_device, dgnn_pool** out)
+{
+    return pool_create_devices(net, devices, num_devices, max_batch_size, batches_per_device, workers_per_device, true, out);
+}
+
+static int pool_create_devices(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,
+                               int workers_per_device, bool records, dgnn_pool** out)
 {
     if (!net || !out || max_batch_size <= 0 || batches_per_device <= 0 || workers_per_device <= 0) return DGNN_BAD_ARGUMENT;
     *out = nullptr;
@@ -551,7 +609,7 @@ int dgnn_pool_create_devices(dgnn_network* net, const int* devices, int num_devi
         for (int d : lanes) if (d < 0 || d >= count) return DGNN_BAD_ARGUMENT;
 
     dgnn_batcher* batcher = nullptr;                           // ONE queue for all devices like the reference's (batch.rs:60-73),
-    int status = dgnn_batcher_create(net, lanes[0], max_batch_size, batches_per_device * (int)lanes.size(), &batcher);   // 2 x devices alive (nn.rs:64-67)
+    int status = batcher_create(net, lanes[0], max_batch_size, batches_per_device * (int)lanes.size(), records, &batcher);   // 2 x devices alive (nn.rs:64-67)
     if (status != DGNN_OK) return status;
     std::unique_ptr<LeafPool> pool(new (std::nothrow) LeafPool());
     if (!pool) { dgnn_batcher_destroy(batcher); return DGNN_OUT_OF_MEMORY; }
@@ -564,13 +622,28 @@ int dgnn_pool_create_devices(dgnn_network* net, const int* devices, int num_devi
     return status;
 }
 
+static int pool_create_callbacks(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                                 int workers_per_lane, bool records, dgnn_pool** out);
+
 int dgnn_pool_create_callbacks(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
                                int workers_per_lane, dgnn_pool** out)
+{
+    return pool_create_callbacks(predict, predict_ctx, num_lanes, max_batch_size, batches_per_lane, workers_per_lane, false, out);
+}
+
+int dgnn_pool_create_callbacks_boards(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                                      int workers_per_lane, dgnn_pool** out)
+{
+    return pool_create_callbacks(predict, predict_ctx, num_lanes, max_batch_size, batches_per_lane, workers_per_lane, true, out);
+}
+
+static int pool_create_callbacks(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                                 int workers_per_lane, bool records, dgnn_pool** out)
 {
     if (!predict || !out || num_lanes <= 0 || max_batch_size <= 0 || batches_per_lane <= 0 || workers_per_lane <= 0) return DGNN_BAD_ARGUMENT;
     *out = nullptr;
     dgnn_batcher* batcher = nullptr;
-    int status = dgnn_batcher_create(nullptr, 0, max_batch_size, batches_per_lane * num_lanes, &batcher);
+    int status = batcher_create(nullptr, 0, max_batch_size, batches_per_lane * num_lanes, records, &batcher);
     if (status != DGNN_OK) return status;
     std::unique_ptr<LeafPool> pool(new (std::nothrow) LeafPool());
     if (!pool) { dgnn_batcher_destroy(batcher); return DGNN_OUT_OF_MEMORY; }
@@ -616,10 +689,28 @@ int dgnn_pool_stats(dgnn_pool* handle, int* num_lanes, uint64_t* calls, uint64_t
     return DGNN_OK;
 }
 
+static int pool_predict(LeafPool* pool, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out);
+
 int dgnn_pool_predict(dgnn_pool* handle, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out)
 {
     if (!handle || !features || !value_out || !policy_out || batch_size <= 0) return DGNN_BAD_ARGUMENT;
     LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    if (pool->batcher->records) return DGNN_BAD_ARGUMENT;      // this pool queues board records: dgnn_pool_predict_boards
+    return pool_predict(pool, features, batch_size, value_out, policy_out);
+}
+
+int dgnn_pool_predict_boards(dgnn_pool* handle, const uint8_t* records, int batch_size, uint16_t* value_out, uint16_t* policy_out)
+{
+    if (!handle || !records || !value_out || !policy_out || batch_size <= 0) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    if (!pool->batcher->records) return DGNN_BAD_ARGUMENT;
+    return pool_predict(pool, reinterpret_cast<const uint16_t*>(records), batch_size, value_out, policy_out);
+}
+
+int dgnn_pool_takes_boards(const dgnn_pool* handle) { return handle && reinterpret_cast<const LeafPool*>(handle)->batcher->records ? 1 : 0; }
+
+static int pool_predict(LeafPool* pool, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out)
+{
     LeafRequest request;
     request.value_out = value_out;
     request.policy_out = policy_out;
@@ -629,8 +720,7 @@ int dgnn_pool_predict(dgnn_pool* handle, const uint16_t* features, int batch_siz
     for (int i = 0; i < batch_size; ++i) {
         slots[i].request = &request;
         slots[i].index = i;
-        const int status = dgnn_batcher_push(reinterpret_cast<dgnn_batcher*>(pool->batcher), features + (size_t)i * DGNN_FEATURE_SIZE,
-                                             (uint64_t)(uintptr_t)&slots[i]);
+        const int status = batcher_push(pool->batcher, features + (size_t)i * pool->batcher->item, (uint64_t)(uintptr_t)&slots[i]);
         if (status != DGNN_OK) {       // cannot happen after the argument checks above; the pushed part still completes
             std::unique_lock<std::mutex> lock(request.mutex);
             request.remaining -= batch_size - i;

@@ -130,6 +130,35 @@ int adopt_image(Network& net, const uint8_t* image, size_t num_bytes);
 // dense.rs:182-189: a dense matrix stored [k_in][n_out] -> [n_out][k_pad] (dst zeroed by the caller, rows >= n_out stay zero)
 void pack_dense_transposed(const uint16_t* w_in_out, int k_in, int n_out, int k_pad, uint16_t* dst);
 
+// The network behind a search: Predictor::predict (src/libdg_mcts/predictor.rs:92) on fp16 feature planes, or -- `boards` set --
+// on compact board records (the planes are then built on the device, dgnn_forward_boards) and the game's `record` callback is
+// used instead of `features`.
+struct Predictor {
+    dgnn_predict_fn features = nullptr;
+    dgnn_predict_boards_fn boards = nullptr;
+    void* ctx = nullptr;
+
+    bool takes_records() const { return boards != nullptr; }
+    size_t item_bytes() const { return takes_records() ? (size_t)DGNN_BOARD_RECORD_BYTES : (size_t)DGNN_FEATURE_SIZE * sizeof(uint16_t); }
+    // one position of `board` into slot `index` of `buffer` (item_bytes() per slot)
+    void encode(const dgnn_game_ops* ops, void* board, int to_move, int symmetry, uint8_t* buffer, size_t index) const
+    {
+        if (takes_records()) ops->record(board, to_move, symmetry, buffer + index * DGNN_BOARD_RECORD_BYTES);
+        else ops->features(board, to_move, symmetry, reinterpret_cast<uint16_t*>(buffer) + index * DGNN_FEATURE_SIZE);
+    }
+    int predict(const uint8_t* buffer, int n, uint16_t* value, uint16_t* policy) const
+    {
+        return takes_records() ? boards(ctx, buffer, n, value, policy) : features(ctx, reinterpret_cast<const uint16_t*>(buffer), n, value, policy);
+    }
+    bool usable_with(const dgnn_game_ops* ops) const { return takes_records() ? ops->record != nullptr : (features != nullptr && ops->features != nullptr); }
+};
+
+int search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, const Predictor& predictor, dgnn_cache* cache, int num_rollouts,
+               int num_threads, int leaves_per_thread, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out);
+int full_forward(const dgnn_game_ops* ops, void* board, int to_move, const Predictor& predictor, dgnn_cache* cache, float* value_out, float* policy_out);
+int selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, const dgnn_selfplay_params* params, dgnn_selfplay_stats* stats,
+                int* moves_out, char* sgf_out, size_t sgf_capacity);
+
 // search.cpp: pool/policy_helper.rs:28-134 on the game callbacks
 void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, float* policy, int* indices);
 void add_valid_candidates(float* dst, const uint16_t* src_f16, const int* indices, int transform);

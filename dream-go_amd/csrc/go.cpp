@@ -988,7 +988,30 @@ int dgnn_go_result_sgf(const dgnn_go_board* b, char* winner_out, size_t winner_c
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* shared_cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
 {
-    if (!predict || !params || !stats) return DGNN_BAD_ARGUMENT;
+    if (!predict) return DGNN_BAD_ARGUMENT;
+    Predictor predictor;
+    predictor.features = predict;
+    predictor.ctx = predict_ctx;
+    return selfplay_go(predictor, shared_cache, params, stats, moves_out, sgf_out, sgf_capacity);
+}
+
+// The same with the network taking compact board records (dgnn_forward_boards): the feature planes are built on the device.
+int dgnn_selfplay_go_boards(dgnn_predict_boards_fn predict, void* predict_ctx, dgnn_cache* shared_cache, const dgnn_selfplay_params* params,
+                            dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity)
+{
+    if (!predict) return DGNN_BAD_ARGUMENT;
+    Predictor predictor;
+    predictor.boards = predict;
+    predictor.ctx = predict_ctx;
+    return selfplay_go(predictor, shared_cache, params, stats, moves_out, sgf_out, sgf_capacity);
+}
+
+}  // extern "C"
+
+int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, const dgnn_selfplay_params* params, dgnn_selfplay_stats* stats,
+                      int* moves_out, char* sgf_out, size_t sgf_capacity)
+{
+    if (!params || !stats) return DGNN_BAD_ARGUMENT;
     const int num_games = params->num_games, first_game = params->first_game, game_stride = params->game_stride > 0 ? params->game_stride : 1;
     const int num_rollouts = params->num_rollouts, num_ex_it_rollouts = params->num_ex_it_rollouts;
     const int threads_per_search = params->threads_per_search > 0 ? params->threads_per_search : 1;
@@ -1038,7 +1061,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* sha
                 float value = 0.0f, prior[368];
                 *value_out = std::numeric_limits<float>::quiet_NaN();
                 *index_out = kPass;
-                int st = dgnn_full_forward(ops, &board, me, predict, predict_ctx, cache, &value, prior);   // lib.rs:154-159
+                int st = full_forward(ops, &board, me, predictor, cache, &value, prior);   // lib.rs:154-159
                 if (st < 0) { status.store(st); dgnn_tree_node_free(start); return nullptr; }
                 evals.fetch_add((uint64_t)st);
                 bool any = false;
@@ -1049,7 +1072,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* sha
                 if (root) { if (!allow_pass) dgnn_tree_node_disqualify(root, kPass); dgnn_tree_node_set_prior(root, prior); }   // lib.rs:170-181
                 else root = dgnn_tree_node_new(me, value, prior);
                 uint64_t e = 0, c = 0, h = 0;
-                st = dgnn_search_run_batched(root, ops, &board, predict, predict_ctx, cache, rollouts, threads_per_search, leaves_per_thread, rng.next(), &e, &c, &h);
+                st = search_run(root, ops, &board, predictor, cache, rollouts, threads_per_search, leaves_per_thread, rng.next(), &e, &c, &h);
                 evals.fetch_add(e);
                 conflicts.fetch_add(c);
                 hits.fetch_add(h);
@@ -1104,7 +1127,7 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* sha
                 }
             } else {                                                           // policy play, self_play.rs:369-405
                 float value = 0.0f, prior[368];
-                const int st = dgnn_full_forward(ops, &board, me, predict, predict_ctx, cache, &value, prior);
+                const int st = full_forward(ops, &board, me, predictor, cache, &value, prior);
                 if (st < 0) { status.store(st); break; }
                 evals.fetch_add((uint64_t)st);
                 if (!allow_pass) prior[kPass] = -std::numeric_limits<float>::infinity();
@@ -1169,5 +1192,3 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* sha
     }
     return status.load();
 }
-
-}  // extern "C"

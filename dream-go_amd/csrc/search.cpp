@@ -90,8 +90,7 @@ struct SearchShared {
     dgnn_tree_node* root;
     const dgnn_game_ops* ops;
     void* board;
-    dgnn_predict_fn predict;
-    void* predict_ctx;
+    Predictor predictor;
     dgnn_cache* cache = nullptr;        // transposition table (needs ops->hash), may be NULL
     int limit;
     int leaves_per_thread = 1;
@@ -109,7 +108,9 @@ void search_worker(SearchShared* s, uint64_t seed)
     struct Leaf { void* board; dgnn_trace* trace; int to_move; int transform; uint64_t key; };
     const int capacity = std::max(1, s->leaves_per_thread);
     Rng rng{seed};
-    std::vector<uint16_t> features((size_t)capacity * DGNN_FEATURE_SIZE), policy((size_t)capacity * DGNN_NUM_MOVES), value((size_t)capacity);
+    std::vector<uint16_t> policy((size_t)capacity * DGNN_NUM_MOVES), value((size_t)capacity);
+    std::vector<uint64_t> encoded(((size_t)capacity * s->predictor.item_bytes() + 7) / 8);      // fp16 planes or board records, 8-byte aligned
+    uint8_t* const features = reinterpret_cast<uint8_t*>(encoded.data());
     std::vector<Leaf> leaves;
     leaves.reserve((size_t)capacity);
     float prior[368];
@@ -156,7 +157,7 @@ void search_worker(SearchShared* s, uint64_t seed)
                 finish(leaf, v, policy.data());
                 continue;
             }
-            s->ops->features(board, leaf.to_move, leaf.transform, features.data() + leaves.size() * DGNN_FEATURE_SIZE);
+            s->predictor.encode(s->ops, board, leaf.to_move, leaf.transform, features, leaves.size());
             leaves.push_back(leaf);
         }
 
@@ -172,7 +173,7 @@ void search_worker(SearchShared* s, uint64_t seed)
         idle_conflicts = 0;
 
         const int n = (int)leaves.size();
-        const int status = s->predict(s->predict_ctx, features.data(), n, value.data(), policy.data());
+        const int status = s->predictor.predict(features, n, value.data(), policy.data());
         if (status != DGNN_OK) {
             for (const Leaf& leaf : leaves) {
                 dgnn_tree_undo(leaf.trace, 1);
@@ -236,6 +237,10 @@ int pool_predict(void* ctx, const uint16_t* features, int n, uint16_t* value, ui
 {
     return dgnn_pool_predict(static_cast<dgnn_pool*>(ctx), features, n, value, policy);
 }
+int pool_predict_boards(void* ctx, const uint8_t* records, int n, uint16_t* value, uint16_t* policy)
+{
+    return dgnn_pool_predict_boards(static_cast<dgnn_pool*>(ctx), records, n, value, policy);
+}
 
 // A deterministic CPU stand-in for the network (the role of the reference's Random / FakePredictor,
 // src/libdg_mcts/predictors/{random,fake}.rs): policy and value are a hash of the feature bits.
@@ -277,6 +282,7 @@ void dgnn_synthetic_board_free(void* board) { syn_destroy(board); }
 
 dgnn_predict_fn dgnn_hash_predictor(void) { return hash_predict; }
 dgnn_predict_fn dgnn_pool_predictor(void) { return pool_predict; }
+dgnn_predict_boards_fn dgnn_pool_boards_predictor(void) { return pool_predict_boards; }
 
 int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
                     int num_rollouts, int num_threads, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out)
@@ -290,7 +296,28 @@ int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board,
 int dgnn_full_forward(const dgnn_game_ops* ops, void* board, int to_move, dgnn_predict_fn predict, void* predict_ctx,
                       dgnn_cache* cache, float* value_out, float* policy_out /* 368 */)
 {
-    if (!ops || !ops->features || !ops->candidates || !predict || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
+    Predictor predictor;
+    predictor.features = predict;
+    predictor.ctx = predict_ctx;
+    return full_forward(ops, board, to_move, predictor, cache, value_out, policy_out);
+}
+
+int dgnn_full_forward_boards(const dgnn_game_ops* ops, void* board, int to_move, dgnn_predict_boards_fn predict, void* predict_ctx,
+                             dgnn_cache* cache, float* value_out, float* policy_out /* 368 */)
+{
+    if (!predict) return DGNN_BAD_ARGUMENT;
+    Predictor predictor;
+    predictor.boards = predict;
+    predictor.ctx = predict_ctx;
+    return full_forward(ops, board, to_move, predictor, cache, value_out, policy_out);
+}
+
+}  // extern "C"
+
+int dgnn::full_forward(const dgnn_game_ops* ops, void* board, int to_move, const Predictor& predictor, dgnn_cache* cache, float* value_out,
+                       float* policy_out /* 368 */)
+{
+    if (!ops || !ops->candidates || !predictor.usable_with(ops) || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
     float initial[368];
     int indices[DGNN_NUM_MOVES];
     create_initial_policy(ops, board, to_move, initial, indices);
@@ -299,7 +326,8 @@ int dgnn_full_forward(const dgnn_game_ops* ops, void* board, int to_move, dgnn_p
     const bool cached = cache && ops->hash;
     const uint64_t key = cached ? ops->hash(board) : 0;
 
-    std::vector<uint16_t> features, values(8), policies(8 * DGNN_NUM_MOVES);
+    std::vector<uint16_t> values(8), policies(8 * DGNN_NUM_MOVES);
+    std::vector<uint64_t> encoded;
     int missing[8], num_missing = 0;
     auto accumulate = [&](int t, uint16_t v, const uint16_t* p) {
         float one[368];
@@ -312,12 +340,12 @@ int dgnn_full_forward(const dgnn_game_ops* ops, void* board, int to_move, dgnn_p
     for (int t = 0; t < 8; ++t) {
         uint16_t v = 0, p[DGNN_NUM_MOVES];
         if (cached && dgnn_cache_fetch(cache, key, to_move, t, &v, p) == 1) { accumulate(t, v, p); continue; }
-        features.resize((size_t)(num_missing + 1) * DGNN_FEATURE_SIZE);
-        ops->features(board, to_move, t, features.data() + (size_t)num_missing * DGNN_FEATURE_SIZE);
+        if (encoded.empty()) encoded.resize((8 * predictor.item_bytes() + 7) / 8);
+        predictor.encode(ops, board, to_move, t, reinterpret_cast<uint8_t*>(encoded.data()), (size_t)num_missing);
         missing[num_missing++] = t;
     }
     if (num_missing > 0) {
-        const int status = predict(predict_ctx, features.data(), num_missing, values.data(), policies.data());
+        const int status = predictor.predict(reinterpret_cast<const uint8_t*>(encoded.data()), num_missing, values.data(), policies.data());
         if (status != DGNN_OK) return status;
         for (int k = 0; k < num_missing; ++k) {
             accumulate(missing[k], values[k], policies.data() + (size_t)k * DGNN_NUM_MOVES);
@@ -327,6 +355,8 @@ int dgnn_full_forward(const dgnn_game_ops* ops, void* board, int to_move, dgnn_p
     *value_out = value;
     return num_missing;       // >= 0: how many symmetries had to be evaluated
 }
+
+extern "C" {
 
 // dirichlet::add_ex (dirichlet.rs:40-70): x <- (1 - beta) x + beta Dirichlet(shape) over the finite entries; gamma variates by
 // Marsaglia-Tsang with the shape < 1 boost, from a seeded generator instead of thread_rng().
@@ -371,15 +401,36 @@ int dgnn_search_run_batched(dgnn_tree_node* root, const dgnn_game_ops* ops, void
                             dgnn_cache* cache, int num_rollouts, int num_threads, int leaves_per_thread, uint64_t seed,
                             uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out)
 {
-    if (!root || !ops || !ops->clone || !ops->destroy || !ops->place || !ops->features || !ops->candidates || !predict ||
+    Predictor predictor;
+    predictor.features = predict;
+    predictor.ctx = predict_ctx;
+    return search_run(root, ops, board, predictor, cache, num_rollouts, num_threads, leaves_per_thread, seed, evals_out, conflicts_out, cache_hits_out);
+}
+
+int dgnn_search_run_boards(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_boards_fn predict, void* predict_ctx,
+                           dgnn_cache* cache, int num_rollouts, int num_threads, int leaves_per_thread, uint64_t seed,
+                           uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out)
+{
+    if (!predict) return DGNN_BAD_ARGUMENT;
+    Predictor predictor;
+    predictor.boards = predict;
+    predictor.ctx = predict_ctx;
+    return search_run(root, ops, board, predictor, cache, num_rollouts, num_threads, leaves_per_thread, seed, evals_out, conflicts_out, cache_hits_out);
+}
+
+}  // extern "C"
+
+int dgnn::search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, const Predictor& predictor, dgnn_cache* cache, int num_rollouts,
+                     int num_threads, int leaves_per_thread, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out)
+{
+    if (!root || !ops || !ops->clone || !ops->destroy || !ops->place || !ops->candidates || !predictor.usable_with(ops) ||
         num_rollouts <= 0 || num_threads <= 0 || leaves_per_thread <= 0 || leaves_per_thread > 64)
         return DGNN_BAD_ARGUMENT;
     SearchShared shared;
     shared.root = root;
     shared.ops = ops;
     shared.board = board;
-    shared.predict = predict;
-    shared.predict_ctx = predict_ctx;
+    shared.predictor = predictor;
     shared.cache = cache;
     shared.limit = num_rollouts;
     shared.leaves_per_thread = leaves_per_thread;
@@ -396,6 +447,8 @@ int dgnn_search_run_batched(dgnn_tree_node* root, const dgnn_game_ops* ops, void
     if (cache_hits_out) *cache_hits_out = shared.cache_hits.load();
     return shared.status.load();
 }
+
+extern "C" {
 
 // Synthetic self-play: `num_games` games in parallel (one thread each + `threads_per_search` search threads per move),
 // `num_moves` moves per game, `num_rollouts` rollouts per move on a fresh tree, every network call through `predict`.

@@ -368,6 +368,10 @@ int dgnn_pool_predict(dgnn_pool* pool, const uint16_t* features, int batch_size,
  * policy[n * 362] fp16; returns a DGNN_* status. */
 typedef int (*dgnn_predict_fn)(void* ctx, const uint16_t* features, int n, uint16_t* value_out, uint16_t* policy_out);
 
+/* The same signature over compact board records (n * DGNN_BOARD_RECORD_BYTES, 2-byte aligned): what a pool of board records and
+ * dgnn_forward_boards take. */
+typedef int (*dgnn_predict_boards_fn)(void* ctx, const uint8_t* records, int n, uint16_t* value_out, uint16_t* policy_out);
+
 /* NnPredictor over SEVERAL devices in one process (src/libdg_mcts/predictors/nn.rs:46-108: one queue, `2 x devices` batches
  * alive, every batch sent to the next device of Device::all()).  One queue shared by all devices; `workers_per_device`
  * threads are bound to each device and a batch goes to whichever device has a worker free (the reference's round robin
@@ -380,6 +384,21 @@ int dgnn_pool_create_devices(dgnn_network* net, const int* devices, int num_devi
  * without a GPU (CPU tests, dry runs of the harness). */
 int dgnn_pool_create_callbacks(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
                                int workers_per_lane, dgnn_pool** out);
+/* The same batcher and pools queueing COMPACT BOARD RECORDS instead of fp16 planes (dgnn_forward_boards): 896 instead of 23 104
+ * bytes per position through the queue and over PCIe, and no feature extraction on the host.  A record pool is fed with
+ * dgnn_pool_predict_boards / dgnn_pool_boards_predictor(); dgnn_pool_predict on it (and vice versa) is DGNN_BAD_ARGUMENT.  The
+ * callback form takes an fp16-plane predictor (dgnn_predict_fn): its lanes expand the records with the host statement of the device
+ * kernel (dgnn_board_records_to_packed) -- for dry runs and for tests with the CPU oracle as the predictor. */
+int dgnn_batcher_create_boards(dgnn_network* net, int device, int max_batch_size, int max_batches, dgnn_batcher** out);
+int dgnn_batcher_push_board(dgnn_batcher* batcher, const uint8_t* record /* DGNN_BOARD_RECORD_BYTES */, uint64_t tag);
+const uint8_t* dgnn_batch_records(const dgnn_batch* batch);       /* NULL for a batch of fp16 planes (and dgnn_batch_features vice versa) */
+int dgnn_pool_create_devices_boards(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,
+                                    int workers_per_device, dgnn_pool** out);
+int dgnn_pool_create_callbacks_boards(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                                      int workers_per_lane, dgnn_pool** out);
+int dgnn_pool_predict_boards(dgnn_pool* pool, const uint8_t* records, int batch_size, uint16_t* value_out, uint16_t* policy_out);
+int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool of board records */
+
 /* Counters: dgnn_pool_predict calls, boards / device batches evaluated, and the same per lane (device) for the first
  * lane_capacity lanes.  Any out pointer may be NULL. */
 int dgnn_pool_stats(dgnn_pool* pool, int* num_lanes, uint64_t* calls, uint64_t* boards, uint64_t* batches,
@@ -467,6 +486,7 @@ int dgnn_choose_f64(const double* items, int n, double cutoff_percentile, double
 /* dgnn_predict_fn (declared with the leaf pool above) is the predictor behind a search. */
 dgnn_predict_fn dgnn_pool_predictor(void);    /* ctx = a dgnn_pool*: the HIP engine behind the cross-caller batcher */
 dgnn_predict_fn dgnn_hash_predictor(void);    /* ctx unused: deterministic CPU stand-in (role of predictors/{random,fake}.rs) */
+dgnn_predict_boards_fn dgnn_pool_boards_predictor(void);   /* ctx = a dgnn_pool* of board records */
 
 /* The game behind the search: what libdg_go provides in the reference (Board::clone / place,
  * features::V1::get_features, the policy checker of pool/policy_helper.rs:36-48, symmetry::is_symmetric). */
@@ -499,6 +519,13 @@ int dgnn_search_run_cached(dgnn_tree_node* root, const dgnn_game_ops* ops, void*
 int dgnn_search_run_batched(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
                             dgnn_cache* cache, int num_rollouts, int num_threads, int leaves_per_thread, uint64_t seed,
                             uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out);
+/* dgnn_search_run_batched / dgnn_full_forward / dgnn_selfplay_go behind a predictor of board records: the game's `record` callback
+ * is used instead of `features` (pool/event.rs:54 without the feature extraction), everything else is the same code. */
+int dgnn_search_run_boards(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_boards_fn predict, void* predict_ctx,
+                           dgnn_cache* cache, int num_rollouts, int num_threads, int leaves_per_thread, uint64_t seed,
+                           uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out);
+int dgnn_full_forward_boards(const dgnn_game_ops* ops, void* board, int to_move, dgnn_predict_boards_fn predict, void* predict_ctx,
+                             dgnn_cache* cache, float* value_out, float* policy_out);
 /* full_forward (src/libdg_mcts/lib.rs:83-130): win rate and prior (368 floats, -inf = not a candidate) of a position as the
  * average over the eight symmetries, the uncached ones evaluated as ONE batch.  Returns the number of symmetries evaluated
  * (>= 0) or a negative status. */
@@ -598,6 +625,9 @@ typedef struct dgnn_selfplay_params {
 } dgnn_selfplay_params;
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
+
+int dgnn_selfplay_go_boards(dgnn_predict_boards_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
+                            dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
 
 /* Library version / build info string (static). */
 const char* dgnn_version(void);

@@ -103,3 +103,42 @@ def test_record_layout_and_argument_checks(api):
     bad[0] = 3                                                                # a cell that is neither empty, black nor white
     with pytest.raises(api.Error):
         api.board_records_to_packed(bad, 1)
+
+
+def test_selfplay_through_a_pool_of_board_records_plays_the_same_games(api):
+    """The search worker hands the pool 896-byte records instead of 23 KB of planes (search.cpp: Predictor::encode); a pool whose
+    lanes are callbacks expands them with the host statement of the device kernel.  One search thread and a transposition table per
+    game make a game a function of (seed, network outputs): the records pool must reproduce the games of the planes pool, move
+    for move and record for record."""
+    kw = dict(num_games=4, num_moves=14, num_rollouts=60, threads_per_search=1, leaves_per_thread=4, seed=77, cache_per_game=4096,
+              return_moves=True, return_sgf=True)
+    out = {}
+    for boards in (False, True):
+        pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=32, boards=boards)
+        assert pool.takes_boards == boards
+        out[boards] = api.selfplay_go(pool=pool, **kw)
+        stats = pool.stats()
+        pool.close()
+        assert stats["boards"] == out[boards]["evals"] > 0
+    assert np.array_equal(out[False]["record"], out[True]["record"])
+    strip = lambda sgf: re.sub(r"DT\[[^\]]*\]", "", sgf)          # the date stamp is the wall clock
+    assert [strip(g) for g in out[False]["sgf"]] == [strip(g) for g in out[True]["sgf"]]
+
+
+def test_pools_refuse_the_other_input_form(api):
+    planes = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=8)
+    records = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=8, boards=True)
+    board = api.Board(7.5)
+    board.place(0, 3, 3)
+    with pytest.raises(api.Error):
+        planes.predict_boards(board.record(1), 1)
+    with pytest.raises(api.Error):
+        records.predict(board.get_features(1).reshape(-1), 1)
+    a = planes.predict(board.get_features(1, 3).reshape(-1), 1)[0]
+    b = records.predict_boards(board.record(1, 3), 1)[0]
+    assert a.value() == b.value() and np.array_equal(a.policy(), b.policy())
+    value, prior, n = api.full_forward(board, 1, pool=records)
+    value2, prior2, n2 = api.full_forward(board, 1, pool=planes)
+    assert n == n2 == 8 and value == value2 and np.array_equal(prior, prior2)
+    planes.close()
+    records.close()
