@@ -217,6 +217,8 @@ SYMBOLS = [
     ("dgnn_board_records_to_packed", ctypes.c_int, [_u8p, ctypes.c_int, _u32p]),
     ("dgnn_board_records_to_packed_device", ctypes.c_int, [ctypes.c_int, _u8p, ctypes.c_int, _u32p]),
     ("dgnn_go_board_record", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u8p]),
+    ("dgnn_go_benson_flood", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
+    ("dgnn_go_candidates", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_batcher_create_boards", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
     ("dgnn_batcher_push_board", ctypes.c_int, [_vp, _u8p, ctypes.c_uint64]),
     ("dgnn_batch_records", _u8p, [_vp]),
@@ -1273,6 +1275,18 @@ class Board:
         out = np.empty(NUM_POINTS, dtype=np.uint8)
         _check(lib.dgnn_go_benson(self._handle, int(color), out.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))), "Board.benson")
         return out.reshape(19, 19)
+
+    def benson_flood(self, color):
+        """The same by the reference's own flood-fill steps (the checker of the bit-board form)."""
+        out = np.empty(NUM_POINTS, dtype=np.uint8)
+        _check(lib.dgnn_go_benson_flood(self._handle, int(color), out.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))), "Board.benson_flood")
+        return out.reshape(19, 19)
+
+    def candidates(self, to_move, scoring=False):
+        """The candidate moves of a StandardSearch / ScoringSearch (options.rs:44-214) -> bool [362], index 361 = pass."""
+        out = np.empty(NUM_MOVES, dtype=np.uint8)
+        _check(lib.dgnn_go_candidates(self._handle, int(to_move), int(bool(scoring)), out.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))), "Board.candidates")
+        return out.astype(bool)
 
     def is_scorable(self):
         return bool(lib.dgnn_go_is_scorable(self._handle))

@@ -601,11 +601,13 @@ enum : unsigned char { kStatusNone = 0, kStatusBlock = 1, kStatusRegion = 2 };  
 
 struct Bits { uint64_t w[6]; void set(int i) { w[i >> 6] |= 1ull << (i & 63); } bool get(int i) const { return (w[i >> 6] >> (i & 63)) & 1; } };
 
+// (This flood-fill form follows the reference step by step; since round 3 it is the CHECKER of the bit-board form below, which
+// is what the search calls: dgnn_go_benson_flood, tests/test_go_host.py.)
 // Benson::new (benson.rs:62-78) over AllBlocksImpl / AllRegionsImpl (:231-253, :300-333).  The reference's variant of the
 // algorithm, kept as it is: a region is every point reachable from an EMPTY point without crossing a stone of `color`
 // (so it holds the opponent's stones too); it is vital to a block when EVERY one of its points -- stones included -- is
 // adjacent to the block (is_vital :207-209 over adjacencies_of, board_fast.rs:154-159).
-void benson(const Fast& b, int color, unsigned char* status)
+void benson_flood(const Fast& b, int color, unsigned char* status)
 {
     const unsigned char mine = (unsigned char)(color + 1);
     struct Group { short first, count; bool live; };
@@ -716,18 +718,158 @@ void benson(const Fast& b, int color, unsigned char* status)
     }
 }
 
+// ---- bit boards: 361 bits, point p = 19 y + x in bit p ----
+struct BB {
+    uint64_t w[6];
+    bool any() const { return (w[0] | w[1] | w[2] | w[3] | w[4] | w[5]) != 0; }
+    bool get(int i) const { return (w[i >> 6] >> (i & 63)) & 1; }
+    void set(int i) { w[i >> 6] |= 1ull << (i & 63); }
+    int lowest() const { for (int i = 0; i < 6; ++i) if (w[i]) return i * 64 + __builtin_ctzll(w[i]); return -1; }
+    bool operator==(const BB& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+};
+inline BB operator&(const BB& a, const BB& b) { BB r; for (int i = 0; i < 6; ++i) r.w[i] = a.w[i] & b.w[i]; return r; }
+inline BB operator|(const BB& a, const BB& b) { BB r; for (int i = 0; i < 6; ++i) r.w[i] = a.w[i] | b.w[i]; return r; }
+inline BB andnot(const BB& a, const BB& b) { BB r; for (int i = 0; i < 6; ++i) r.w[i] = a.w[i] & ~b.w[i]; return r; }   // a & ~b
+template <int K> inline BB shift_up(const BB& a)        // towards higher points
+{
+    BB r;
+    r.w[0] = a.w[0] << K;
+    for (int i = 1; i < 6; ++i) r.w[i] = (a.w[i] << K) | (a.w[i - 1] >> (64 - K));
+    return r;
+}
+template <int K> inline BB shift_down(const BB& a)
+{
+    BB r;
+    for (int i = 0; i < 5; ++i) r.w[i] = (a.w[i] >> K) | (a.w[i + 1] << (64 - K));
+    r.w[5] = a.w[5] >> K;
+    return r;
+}
+struct BoardMasks {
+    BB board, not_col0, not_col18;
+    BoardMasks()
+    {
+        std::memset(this, 0, sizeof(*this));
+        for (int p = 0; p < kPoints; ++p) { board.set(p); if (p % kN != 0) not_col0.set(p); if (p % kN != kN - 1) not_col18.set(p); }
+    }
+};
+const BoardMasks kMasks;
+// the four neighbours of every point of x (x itself not included unless it neighbours another of its points)
+inline BB neighbours_of(const BB& x)
+{
+    return (shift_up<1>(x & kMasks.not_col18) | shift_down<1>(x & kMasks.not_col0) | shift_up<kN>(x) | shift_down<kN>(x)) & kMasks.board;
+}
+inline BB dilate(const BB& x) { return x | neighbours_of(x); }
+inline BB flood(BB seed, const BB& within)                 // everything of `within` connected to the seed
+{
+    for (;;) {
+        const BB next = dilate(seed) & within;
+        if (next == seed) return seed;
+        seed = next;
+    }
+}
+struct StoneSets { BB stones[2], empty; };
+inline StoneSets stone_sets(const Fast& b)
+{
+    StoneSets s;
+    for (int i = 0; i < 6; ++i) {
+        uint64_t black = 0, white = 0;
+        const int first = i * 64, last = std::min(first + 64, kPoints);
+        for (int p = first; p < last; ++p) { black |= (uint64_t)(b.stone[p] == 1) << (p - first); white |= (uint64_t)(b.stone[p] == 2) << (p - first); }
+        s.stones[0].w[i] = black;
+        s.stones[1].w[i] = white;
+    }
+    s.empty = andnot(kMasks.board, s.stones[0] | s.stones[1]);
+    return s;
+}
+inline BB block_stones(const Fast& b, int q) { BB r; std::memset(&r, 0, sizeof(r)); int s = q; do { r.set(s); s = b.next[s]; } while (s != q); return r; }
+
+// Benson's unconditional life (utils/benson.rs:62-190), same result as benson_flood above, on bit boards.
+// A region can only be vital to a block when EVERY one of its points is adjacent to that block (is_vital, benson.rs:207-209), and
+// regions without a vital block are dropped before the iteration starts (:136-152).  So a region that holds a point with no
+// stone of `color` next to it never matters: flooding from those "open" points through the non-`color` points removes, in a few
+// bit-parallel steps, every such region -- on most positions all of them, and the answer is "nothing is alive" without a single
+// per-point loop.  What is left are the few small enclosed regions; they are walked in the reference's order (a region is found
+// from its lowest EMPTY point, and only blocks next to that point can be its vital blocks, :300-333).  The removal iteration
+// (:73-132) is monotone, so its fixed point does not depend on the order of removals.
+void benson_sets(const Fast& b, const StoneSets& sets, int color, BB* alive, BB* eyes)
+{
+    std::memset(alive, 0, sizeof(*alive));
+    std::memset(eyes, 0, sizeof(*eyes));
+    const BB& mine = sets.stones[color];
+    if (!mine.any()) return;
+    const BB others = andnot(kMasks.board, mine);                       // what a region is made of: empty points and opponent stones
+    const BB open = andnot(others, neighbours_of(mine));
+    const BB enclosed = open.any() ? andnot(others, flood(open, others)) : others;
+    BB seeds = enclosed & sets.empty;
+    if (!seeds.any()) return;
+
+    struct Region { BB points, border; short vital[4]; int num_vital; bool live; };
+    struct Block { short id; BB stones; bool live; int healthy; };
+    static thread_local Region regions[192];
+    static thread_local Block blocks[192];
+    int num_regions = 0, num_blocks = 0;
+    while (seeds.any() && num_regions < 192) {
+        const int p0 = seeds.lowest();
+        BB start;
+        std::memset(&start, 0, sizeof(start));
+        start.set(p0);
+        Region& r = regions[num_regions];
+        r.points = flood(start, enclosed);
+        seeds = andnot(seeds, r.points);
+        r.border = neighbours_of(r.points) & mine;
+        r.num_vital = 0;
+        short seen[4]; int n_seen = 0;
+        for (int d = 0; d < 4; ++d) {
+            const int q = neighbour(p0, d);
+            if (q < 0 || b.stone[q] != color + 1) continue;
+            const short id = b.head[q];
+            if (std::find(seen, seen + n_seen, id) != seen + n_seen) continue;
+            seen[n_seen++] = id;
+            int k = 0;
+            while (k < num_blocks && blocks[k].id != id) ++k;
+            if (k == num_blocks) {
+                if (num_blocks == 192) continue;
+                blocks[num_blocks++] = Block{id, block_stones(b, q), true, 0};
+            }
+            if (!andnot(r.points, dilate(blocks[k].stones)).any()) r.vital[r.num_vital++] = (short)k;    // is_vital, benson.rs:207-209
+        }
+        r.live = r.num_vital > 0;                                       // remove_non_vital_regions, :136-152
+        if (r.live) ++num_regions;
+    }
+    if (num_regions == 0) return;
+
+    for (bool changed = true; changed;) {                               // :73-75
+        changed = false;
+        for (int k = 0; k < num_blocks; ++k) blocks[k].healthy = 0;     // remove_non_alive_blocks, :95-112
+        for (int r = 0; r < num_regions; ++r) if (regions[r].live) for (int i = 0; i < regions[r].num_vital; ++i) ++blocks[regions[r].vital[i]].healthy;
+        BB living;
+        std::memset(&living, 0, sizeof(living));
+        for (int k = 0; k < num_blocks; ++k) {
+            if (blocks[k].live && blocks[k].healthy < 2) { blocks[k].live = false; changed = true; }
+            if (blocks[k].live) living = living | blocks[k].stones;
+        }
+        for (int r = 0; r < num_regions; ++r)                           // remove_non_surrounded_regions, :116-132
+            if (regions[r].live && andnot(regions[r].border, living).any()) { regions[r].live = false; changed = true; }
+    }
+    for (int k = 0; k < num_blocks; ++k) if (blocks[k].live) *alive = *alive | blocks[k].stones;
+    for (int r = 0; r < num_regions; ++r) if (regions[r].live) *eyes = *eyes | regions[r].points;
+}
+
+void benson(const Fast& b, int color, unsigned char* status)
+{
+    BB alive, eyes;
+    benson_sets(b, stone_sets(b), color, &alive, &eyes);
+    for (int p = 0; p < kPoints; ++p) status[p] = alive.get(p) ? kStatusBlock : eyes.get(p) ? kStatusRegion : kStatusNone;
+}
+
 bool is_scorable(const Fast& b)                                               // score.rs:105-117
 {
-    unsigned char black[kPoints], white[kPoints];
-    benson(b, 0, black);
-    benson(b, 1, white);
-    for (int p = 0; p < kPoints; ++p) {
-        const bool ok = b.stone[p] == kEmpty ? (black[p] == kStatusRegion || white[p] == kStatusRegion)
-                      : b.stone[p] == 1      ? (black[p] == kStatusBlock || white[p] == kStatusRegion)
-                                             : (white[p] == kStatusBlock || black[p] == kStatusRegion);
-        if (!ok) return false;
-    }
-    return true;
+    const StoneSets sets = stone_sets(b);
+    BB alive[2], eyes[2];
+    benson_sets(b, sets, 0, &alive[0], &eyes[0]);
+    benson_sets(b, sets, 1, &alive[1], &eyes[1]);
+    const BB both = eyes[0] | eyes[1];
+    return !andnot(sets.empty, both).any() && !andnot(sets.stones[0], alive[0] | eyes[1]).any() && !andnot(sets.stones[1], alive[1] | eyes[0]).any();
 }
 
 // get_territory_distance (score.rs:248-283): 0 on a stone of `color`, the distance through empty points elsewhere, 0xff if unreachable
@@ -824,10 +966,36 @@ void* go_clone(void* b) { return new GoBoard(*static_cast<GoBoard*>(b)); }
 void go_destroy(void* b) { delete static_cast<GoBoard*>(b); }
 void go_place(void* b, int color, int index) { if (index >= 0 && index < kPoints) static_cast<GoBoard*>(b)->place(color, index); }
 void go_features(void* b, int to_move, int symmetry, uint16_t* out) { features_v1(*static_cast<GoBoard*>(b), to_move, symmetry, out); }
+// Board::is_valid for every point at once (board_fast.rs:213-241 + board.rs:120-145): an empty point next to an empty point, to
+// an own block with at least two liberties or to an opponent block with fewer than two; minus the super-ko points, which can only
+// be points that have held a stone.
+BB valid_moves(const GoBoard& g, const StoneSets& sets, int to_move)
+{
+    const Fast& f = g.inner;
+    BB weak[2];                                                          // stones of blocks with fewer than two liberties
+    std::memset(weak, 0, sizeof(weak));
+    for (int p = 0; p < kPoints; ++p)
+        if (f.stone[p] != kEmpty && f.head[p] == p && f.libs[p] < 2) weak[f.stone[p] - 1] = weak[f.stone[p] - 1] | block_stones(f, p);
+    const BB support = sets.empty | andnot(sets.stones[to_move], weak[to_move]) | weak[1 - to_move];
+    BB valid = sets.empty & neighbours_of(support);
+    for (int i = 0; i < 6; ++i) {                                        // super-ko: rare
+        const int first = i * 64, last = std::min(first + 64, kPoints);
+        for (int p = first; p < last; ++p)
+            if (f.visited[p] && valid.get(p) && g.is_ko(to_move, p)) valid.w[i] &= ~(1ull << (p - first));
+    }
+    return valid;
+}
+void write_candidates(const BB& set, unsigned char* out)
+{
+    for (int i = 0; i < 6; ++i) {
+        const int first = i * 64, last = std::min(first + 64, kPoints);
+        for (int p = first; p < last; ++p) out[p] = (unsigned char)((set.w[i] >> (p - first)) & 1);
+    }
+}
 void go_candidates(void* b, int to_move, unsigned char* out)                  // options.rs:44-48
 {
     const GoBoard* g = static_cast<GoBoard*>(b);
-    for (int p = 0; p < kPoints; ++p) out[p] = g->is_valid(to_move, p);
+    write_candidates(valid_moves(*g, stone_sets(g->inner), to_move), out);
     out[kPass] = 1;
 }
 int go_is_symmetric(void* b, int symmetry)                                    // symmetry.rs:136-144
@@ -842,11 +1010,19 @@ void go_record(void* b, int to_move, int symmetry, uint8_t* out) { board_record(
 void go_candidates_scoring(void* b, int to_move, unsigned char* out)          // ScoringPolicyChecker, options.rs:110-139
 {
     const GoBoard* g = static_cast<GoBoard*>(b);
-    unsigned char black[kPoints], white[kPoints];
-    benson(g->inner, 0, black);
-    benson(g->inner, 1, white);
-    for (int p = 0; p < kPoints; ++p)
-        out[p] = black[p] != kStatusRegion && white[p] != kStatusRegion && g->is_valid(to_move, p) && !is_simple_eye(g->inner, to_move, p);
+    const StoneSets sets = stone_sets(g->inner);
+    BB alive, eyes[2];
+    benson_sets(g->inner, sets, 0, &alive, &eyes[0]);
+    benson_sets(g->inner, sets, 1, &alive, &eyes[1]);
+    BB candidates = andnot(valid_moves(*g, sets, to_move), eyes[0] | eyes[1]);
+    // one's own simple eye (options.rs:192-213) needs every on-board cross neighbour to be one's own stone: look only there
+    BB closed = andnot(candidates, neighbours_of(andnot(kMasks.board, sets.stones[to_move])));
+    while (closed.any()) {
+        const int p = closed.lowest();
+        closed.w[p >> 6] &= ~(1ull << (p & 63));
+        if (is_simple_eye(g->inner, to_move, p)) candidates.w[p >> 6] &= ~(1ull << (p & 63));
+    }
+    write_candidates(candidates, out);
     out[kPass] = 0;
 }
 const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric, go_hash, go_record};
@@ -936,6 +1112,18 @@ int dgnn_go_benson(const dgnn_go_board* b, int color, unsigned char* status_out)
 {
     if (!b || !status_out || (color != 0 && color != 1)) return DGNN_BAD_ARGUMENT;
     benson(CGO(b)->inner, color, status_out);
+    return DGNN_OK;
+}
+int dgnn_go_benson_flood(const dgnn_go_board* b, int color, unsigned char* status_out)
+{
+    if (!b || !status_out || (color != 0 && color != 1)) return DGNN_BAD_ARGUMENT;
+    benson_flood(CGO(b)->inner, color, status_out);
+    return DGNN_OK;
+}
+int dgnn_go_candidates(const dgnn_go_board* b, int to_move, int scoring, unsigned char* out)
+{
+    if (!b || !out || (to_move != 0 && to_move != 1)) return DGNN_BAD_ARGUMENT;
+    (scoring ? go_candidates_scoring : go_candidates)((void*)b, to_move, out);
     return DGNN_OK;
 }
 int dgnn_go_check(const dgnn_go_board* b) { return b && CGO(b)->inner.consistent() ? 1 : 0; }

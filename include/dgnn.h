@@ -580,6 +580,11 @@ const dgnn_game_ops* dgnn_go_scoring_ops(void);     /* ScoringSearch: no pass, n
 /* Benson's unconditional life as the reference computes it (src/libdg_go/utils/benson.rs:62-190): per point 0 = neither,
  * 1 = stone of an unconditionally alive block of `color` (is_alive), 2 = point of a region vital to one (is_eye). */
 int dgnn_go_benson(const dgnn_go_board* board, int color, unsigned char* status_out /* 361 */);
+/* The same by the reference's own steps (flood fills over points): the checker of the bit-board form dgnn_go_benson runs. */
+int dgnn_go_benson_flood(const dgnn_go_board* board, int color, unsigned char* status_out /* 361 */);
+/* The candidate moves of a search as the game callbacks give them (pool/policy_helper.rs:36-48): scoring == 0 the
+ * StandardSearch rule (any valid move, and pass), else the ScoringSearch rule (options.rs:110-214).  out: 362 flags. */
+int dgnn_go_candidates(const dgnn_go_board* board, int to_move, int scoring, unsigned char* out);
 /* 1 when the incremental block / liberty bookkeeping equals a from-scratch flood fill of the position (a self-test hook). */
 int dgnn_go_check(const dgnn_go_board* board);
 int dgnn_go_is_scorable(const dgnn_go_board* board);                             /* Score::is_scorable, utils/score.rs:105-117 */

@@ -3,6 +3,8 @@ tests: src/libdg_go/board.rs:280-411 (capture, capture_group, suicide_corner, su
 double_liberty_subtraction, black_starts, alternate_turns), src/libdg_go/board_fast.rs:547-562 (check_get_n_liberty_if),
 src/libdg_go/utils/ladder.rs:187-350 (all six).  The feature planes have no expected vectors in the reference; they are
 checked plane by plane against their definition (features.rs:99-251) on positions small enough to reason about."""
+import os
+
 import numpy as np
 
 B, W = 0, 1
@@ -529,3 +531,69 @@ def test_policy_play_and_expert_iteration(api):
     first = min(len(re.findall(r";[BW]\[", game.split("TV[")[0])) for game in ex_it["sgf"] if "TV[" in game)
     for a, b in zip(plain["record"], ex_it["record"]):
         assert np.array_equal(a[:max(first - 1, 0)], b[:max(first - 1, 0)])
+
+
+# ---- round 3: the bit-board forms the search calls (Benson, candidate moves) against the flood-fill forms they replaced
+
+def _simple_eye(board, color, x, y):
+    """is_eye, src/libdg_mcts/options.rs:192-213."""
+    own = lambda u, v: 0 <= u < 19 and 0 <= v < 19 and board.at(u, v) == color
+    cross = own(x + 1, y) + own(x - 1, y) + own(x, y + 1) + own(x, y - 1)
+    diagonal = own(x + 1, y + 1) + own(x + 1, y - 1) + own(x - 1, y + 1) + own(x - 1, y - 1)
+    edge_x, edge_y = x in (0, 18), y in (0, 18)
+    if edge_x and edge_y:
+        return cross >= 2 and diagonal >= 1
+    if edge_x or edge_y:
+        return cross >= 3 and diagonal >= 2
+    return cross >= 4 and diagonal >= 3
+
+
+def _check_fast_forms(api, board):
+    status = {}
+    for color in (0, 1):
+        status[color] = board.benson(color)
+        assert np.array_equal(status[color], board.benson_flood(color)), (board.count(), color)
+    for color in (0, 1):
+        standard, scoring = board.candidates(color), board.candidates(color, scoring=True)
+        assert standard[361] and not scoring[361]
+        for p in range(361):
+            x, y = p % 19, p // 19
+            valid = board.is_valid(color, x, y)
+            assert standard[p] == valid, (board.count(), color, x, y)
+            expect = valid and status[0][y, x] != 2 and status[1][y, x] != 2 and not _simple_eye(board, color, x, y)
+            assert scoring[p] == expect, (board.count(), color, x, y)
+    return int((status[0] == 1).any() or (status[1] == 1).any())
+
+
+def test_bitboard_benson_and_candidates_equal_the_flood_fill_forms(api):
+    """go.cpp: benson_sets / valid_moves / go_candidates_scoring (bit boards, what every rollout calls) against benson_flood (the
+    reference's steps, utils/benson.rs:62-190) and the per-point definitions (options.rs:44-214, board.rs:140-142): every 7th position
+    of the three reference games, and random games played to the end with the ScoringSearch rule (no own eyes filled), which leave
+    boards full of small eyes, unconditionally alive groups, captures and kos."""
+    import json as _json, re as _re
+    checked = alive = 0
+    for game in _json.load(open(os.path.join(os.path.dirname(__file__), "golden", "real_games.json")))["games"]:
+        board = api.Board(7.5)
+        for n, (color, vertex) in enumerate(_re.findall(r";([BW])\[([a-s]{2})\]", game["moves"])):
+            board.place(0 if color == "B" else 1, ord(vertex[0]) - 97, ord(vertex[1]) - 97)
+            if n % 7 == 0:
+                alive += _check_fast_forms(api, board)
+                checked += 1
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        board, color, passes = api.Board(0.5), 0, 0
+        while passes < 2 and board.count() < 500:
+            options = np.nonzero(board.candidates(color, scoring=True)[:361])[0]
+            if len(options) == 0:
+                passes += 1
+            else:
+                passes = 0
+                p = int(rng.choice(options))
+                board.place(color, p % 19, p // 19)
+                if board.count() % 9 == 0 or board.count() > 300:
+                    alive += _check_fast_forms(api, board)
+                    checked += 1
+            color ^= 1
+        assert board.check()
+    print(f"{checked} positions, {alive} with an unconditionally alive block")
+    assert checked > 150 and alive > 20
