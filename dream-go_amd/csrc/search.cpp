@@ -18,6 +18,9 @@
 // rule-free synthetic game with a synthetic self-play loop for throughput measurements of the host + device pipeline
 // without Go rules.  The synthetic game is NOT Go: every empty point is a legal move, nothing is ever captured, features
 // are pseudo-random bits of the position hash.  The real game is go.cpp.
+#include <immintrin.h>
+
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -46,34 +49,93 @@ void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, f
 {
     unsigned char candidate[DGNN_NUM_MOVES];
     ops->candidates(board, to_move, candidate);
-    for (int i = 0; i < 368; ++i) policy[i] = -std::numeric_limits<float>::infinity();
-    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (candidate[i]) policy[i] = 0.0f;
-    bool symmetric[8];
-    for (int t = 0; t < 8; ++t) symmetric[t] = t == 0 || (ops->is_symmetric && ops->is_symmetric(board, t));
-    indices[DGNN_NUM_POINTS] = DGNN_NUM_POINTS;
+    const float minus_inf = -std::numeric_limits<float>::infinity();
+    for (int i = 0; i < DGNN_NUM_MOVES; ++i) policy[i] = candidate[i] ? 0.0f : minus_inf;
+    for (int i = DGNN_NUM_MOVES; i < 368; ++i) policy[i] = minus_inf;
+    const uint16_t* maps[8];
+    int num_symmetric = 0;
+    for (int t = 1; t < 8; ++t) if (ops->is_symmetric && ops->is_symmetric(board, t)) maps[num_symmetric++] = symmetry_map(t);
+    for (int i = 0; i <= DGNN_NUM_POINTS; ++i) indices[i] = i;
+    if (num_symmetric == 0) return;                                           // almost every position after the first few stones
     for (int i = 0; i < DGNN_NUM_POINTS; ++i) {
         int target = i;
-        for (int t = 1; t < 8; ++t) if (symmetric[t]) target = std::min(target, dgnn_symmetry_apply(t, i));
+        for (int k = 0; k < num_symmetric; ++k) target = std::min(target, (int)maps[k][i]);
         indices[i] = target;
-        if (target != i) policy[i] = -std::numeric_limits<float>::infinity();
+        if (target != i) policy[i] = minus_inf;
     }
 }
+
+namespace {
+
+__attribute__((target("avx2,f16c")))
+void halfs_to_floats_f16c(const uint16_t* src, float* dst, int n)            // n a multiple of 8
+{
+    for (int i = 0; i < n; i += 8) _mm256_storeu_ps(dst + i, _mm256_cvtph_ps(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i))));
+}
+const bool kHaveF16c = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("f16c");
+
+// exact conversions either way: the hardware instruction and half_to_float give the same bits
+void halfs_to_floats(const uint16_t* src, float* dst, int n)
+{
+    const int vector = kHaveF16c ? n & ~7 : 0;
+    if (vector) halfs_to_floats_f16c(src, dst, vector);
+    for (int i = vector; i < n; ++i) dst[i] = half_to_float(src[i]);
+}
+
+// asm::sum_finite_f32 (src/libdg_mcts/asm/sum_finite.rs:23-58) in the order of its AVX2 form, which is the one an x86 host runs:
+// eight lanes, lane l sums the finite elements l, l + 8, ...; then ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)).  n a multiple of 8.
+float sum_finite_lanes_scalar(const float* v, int n)
+{
+    float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i += 8)
+        for (int l = 0; l < 8; ++l) lane[l] += std::isfinite(v[i + l]) ? v[i + l] : 0.0f;
+    return ((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
+}
+__attribute__((target("avx2")))
+float sum_finite_lanes_avx2(const float* v, int n)
+{
+    const __m256 sign = _mm256_set1_ps(-0.0f), inf = _mm256_set1_ps(std::numeric_limits<float>::infinity());
+    __m256 acc = _mm256_setzero_ps();
+    for (int i = 0; i < n; i += 8) {
+        const __m256 x = _mm256_loadu_ps(v + i);
+        const __m256 is_inf = _mm256_cmp_ps(_mm256_andnot_ps(sign, x), inf, _CMP_EQ_OQ);
+        const __m256 is_number = _mm256_cmp_ps(x, x, _CMP_EQ_OQ);
+        acc = _mm256_add_ps(acc, _mm256_andnot_ps(is_inf, _mm256_and_ps(is_number, x)));
+    }
+    float lane[8];
+    _mm256_storeu_ps(lane, acc);
+    return ((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
+}
+const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+
+}  // namespace
+
+float sum_finite(const float* v, int n) { return kHaveAvx2 ? sum_finite_lanes_avx2(v, n) : sum_finite_lanes_scalar(v, n); }
 
 // policy_helper.rs:87-103: de-transform the network's policy to the identity orientation and add it
 void add_valid_candidates(float* dst, const uint16_t* src_f16, const int* indices, int transform)
 {
-    const int inverse = dgnn_symmetry_inverse(transform);
-    dst[DGNN_NUM_POINTS] += half_to_float(src_f16[DGNN_NUM_POINTS]);
-    for (int i = 0; i < DGNN_NUM_POINTS; ++i) dst[indices[dgnn_symmetry_apply(inverse, i)]] += half_to_float(src_f16[i]);
+    float src[368];
+    halfs_to_floats(src_f16, src, DGNN_NUM_MOVES);
+    const uint16_t* inverse = symmetry_map(dgnn_symmetry_inverse(transform));
+    dst[DGNN_NUM_POINTS] += src[DGNN_NUM_POINTS];
+    for (int i = 0; i < DGNN_NUM_POINTS; ++i) dst[indices[inverse[i]]] += src[i];
 }
 
-void normalize_policy(float* policy, float sum_to)                            // policy_helper.rs:112-134
+// policy_helper.rs:112-134 over asm::sum_finite_f32 and asm::normalize_finite_f32 (asm/normalize_finite.rs:51-64): the sum in
+// the lane order of the reference's AVX2 form, the scaling as a multiplication by the reciprocal -- the EXACT reciprocal of its
+// portable path; its AVX2 path uses the 12-bit _mm_rcp_ps estimate, whose bits differ between CPU vendors.  policy holds 368 floats.
+void normalize_policy(float* policy, float sum_to)
 {
-    float sum = 0.0f;
-    int finite = 0;
-    for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(policy[i])) { sum += policy[i]; ++finite; }
-    if (sum < 1e-6f) { for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(policy[i])) policy[i] = sum_to / (float)finite; }
-    else { const float scale = sum / sum_to; for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(policy[i])) policy[i] /= scale; }
+    const float sum = sum_finite(policy, 368);
+    if (sum < 1e-6f) {
+        int finite = 0;
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) finite += std::isfinite(policy[i]);
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) if (std::isfinite(policy[i])) policy[i] = sum_to / (float)finite;
+    } else {
+        const float recip = 1.0f / (sum / sum_to);
+        for (int i = 0; i < 368; ++i) policy[i] *= recip;                     // -inf stays -inf
+    }
 }
 
 namespace {
