@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 
 #include "dgnn_internal.h"
@@ -40,6 +41,10 @@ struct Workspace {
 
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_done = nullptr;           // event behind the outputs' copies: what dgnn_forward_wait waits for
+    long long submit_ns = 0;                // when it was recorded
+    double wait_ns = 0.0;                   // how long submissions of `wait_boards` boards took lately (submit -> outputs on the host)
+    int wait_boards = 0;
     std::vector<hipEvent_t> tower_events;   // pairs, grown on demand by dgnn_forward_timed
 
     void* arena = nullptr;                  // one allocation, carved below
@@ -107,6 +112,7 @@ Workspace::~Workspace()
     for (hipEvent_t e : tower_events) (void)hipEventDestroy(e);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
+    if (ev_done) (void)hipEventDestroy(ev_done);
     if (arena) (void)hipFree(arena);
     if (d_tower_layers) (void)hipFree(d_tower_layers);
     if (pinned) (void)hipHostFree(pinned);
@@ -218,6 +224,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     DGNN_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));   // stream.rs:55
     DGNN_HIP(hipEventCreate(&ws->ev_begin));
     DGNN_HIP(hipEventCreate(&ws->ev_end));
+    DGNN_HIP(hipEventCreateWithFlags(&ws->ev_done, hipEventBlockingSync | hipEventDisableTiming));
 
     const size_t num_pos = (size_t)batch * DGNN_NUM_POINTS;
     const size_t sz_features = align_up(num_pos * DGNN_NUM_FEATURES * 2, 256);
@@ -474,6 +481,64 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     sv.value_out = ws->d_value;
     sv.batch = ws->active;
     DGNN_HIP(launch_softmax_value(sv, ws->stream));
+    return DGNN_OK;
+}
+
+// How a host thread waits for a submission.  hipStreamSynchronize SPINS on this runtime: one thread waiting for 3.3 ms passes
+// burns 1.8 cores, and so does hipEventSynchronize on an event created with hipEventBlockingSync (1.0 core; tools/wait_probe.sh) --
+// a leaf pool keeps two such waiters per device, more host CPU than the whole search.  So the waiter SLEEPS: for most of the time
+// the last submissions of this size took, then in 30 us naps between hipEventQuery calls (0.03 cores per waiter; the late wake-up
+// is hidden by the second batch in flight).  DGNN_WAIT=spin restores hipStreamSynchronize, DGNN_WAIT=event the blocking event.
+enum WaitMode { kWaitPoll = 0, kWaitSpin = 1, kWaitEvent = 2 };
+WaitMode wait_mode_from_env()
+{
+    const char* m = std::getenv("DGNN_WAIT");
+    if (m && std::strcmp(m, "spin") == 0) return kWaitSpin;
+    if (m && std::strcmp(m, "event") == 0) return kWaitEvent;
+    return kWaitPoll;
+}
+const WaitMode kWaitMode = wait_mode_from_env();
+
+long long now_ns()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+
+void nap_ns(long long ns)
+{
+    if (ns <= 0) return;
+    struct timespec ts = {(time_t)(ns / 1000000000ll), (long)(ns % 1000000000ll)};
+    nanosleep(&ts, nullptr);
+}
+
+int mark_submission(Workspace* ws)      // behind the last copy of a submission
+{
+    if (kWaitMode != kWaitSpin) DGNN_HIP(hipEventRecord(ws->ev_done, ws->stream));
+    ws->submit_ns = now_ns();
+    return DGNN_OK;
+}
+
+int wait_submission(Workspace* ws)
+{
+    if (kWaitMode == kWaitSpin) { DGNN_HIP(hipStreamSynchronize(ws->stream)); return DGNN_OK; }
+    if (kWaitMode == kWaitEvent) { DGNN_HIP(hipEventSynchronize(ws->ev_done)); return DGNN_OK; }
+    // the long sleep first: 85 % of what is left of the expected duration, scaled down for a smaller batch, at most 50 ms
+    if (ws->wait_boards > 0 && ws->wait_ns > 0.0) {
+        double expected = ws->wait_ns * (ws->active < ws->wait_boards ? (double)ws->active / ws->wait_boards : 1.0);
+        const long long left = (long long)(0.85 * expected) - (now_ns() - ws->submit_ns);
+        nap_ns(left < 50000000ll ? left : 50000000ll);
+    }
+    for (;;) {
+        const hipError_t q = hipEventQuery(ws->ev_done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { set_last_hip_error((int)q); return DGNN_HIP_ERROR; }
+        nap_ns(30000);
+    }
+    const double took = (double)(now_ns() - ws->submit_ns);
+    ws->wait_ns = (ws->wait_boards == ws->active && ws->wait_ns > 0.0) ? 0.75 * ws->wait_ns + 0.25 * took : took;
+    ws->wait_boards = ws->active;
     return DGNN_OK;
 }
 
@@ -817,6 +882,7 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
 
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
     ws->pending = true;
     return DGNN_OK;
 }
@@ -829,7 +895,7 @@ int dgnn_forward_wait(dgnn_workspace* handle, uint16_t* value_out, uint16_t* pol
 
     DGNN_HIP(hipSetDevice(ws->device));
     ws->pending = false;
-    DGNN_HIP(hipStreamSynchronize(ws->stream));   // graph.rs:155-156 (to_vec + synchronize)
+    { const int waited = wait_submission(ws); if (waited != DGNN_OK) return waited; }   // graph.rs:155-156 (to_vec + synchronize)
     const int split_status = resolve_split_failure(ws);
     if (split_status != DGNN_OK) { ws->active = ws->batch; return split_status; }
     if (value_out != ws->h_value) std::memcpy(value_out, ws->h_value, (size_t)ws->active * 2);
@@ -878,6 +944,7 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
 
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
     ws->pending = true;
     return DGNN_OK;
 }
@@ -911,6 +978,7 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
 
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
+    { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
     ws->pending = true;
     return DGNN_OK;
 }
