@@ -18,8 +18,11 @@
 // words, with the same observable counts; Fast::consistent() is the from-scratch flood fill they are tested against.
 // Zobrist numbers are this build's own (splitmix64 of a fixed seed): only equality of hashes is observable; the positions
 // of the reference's three real-game tests reproduce its expected hashes under its own table (tests/golden/).
+#include <immintrin.h>
+
 #include <algorithm>
 #include <atomic>
+#include <cstddef>
 #include <chrono>
 #include <cstring>
 #include <cmath>
@@ -767,20 +770,82 @@ inline BB flood(BB seed, const BB& within)                 // everything of `wit
         seed = next;
     }
 }
-struct StoneSets { BB stones[2], empty; };
+struct StoneSets { BB stones[2], empty, visited; };
+static_assert(offsetof(Fast, visited) == offsetof(Fast, stone) + kPoints && offsetof(Fast, head) >= offsetof(Fast, visited) + kPoints &&
+              offsetof(Fast, libs) == offsetof(Fast, head) + 2 * kPoints && offsetof(Fast, next) == offsetof(Fast, libs) + 2 * kPoints,
+              "the vector loads below read up to 31 bytes past an array's last point: they must stay inside the struct");
+void stone_sets_scalar(const Fast& b, StoneSets* s)
+{
+    for (int i = 0; i < 6; ++i) {
+        uint64_t black = 0, white = 0, visited = 0;
+        const int first = i * 64, last = std::min(first + 64, kPoints);
+        for (int p = first; p < last; ++p) {
+            black |= (uint64_t)(b.stone[p] == 1) << (p - first);
+            white |= (uint64_t)(b.stone[p] == 2) << (p - first);
+            visited |= (uint64_t)(b.visited[p] != 0) << (p - first);
+        }
+        s->stones[0].w[i] = black;
+        s->stones[1].w[i] = white;
+        s->visited.w[i] = visited;
+    }
+}
+__attribute__((target("avx2")))
+void stone_sets_avx2(const Fast& b, StoneSets* s)
+{
+    const __m256i one = _mm256_set1_epi8(1), two = _mm256_set1_epi8(2), zero = _mm256_setzero_si256();
+    uint32_t black[12], white[12], visited[12];
+    for (int k = 0; k < 12; ++k) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b.stone + 32 * k));
+        const __m256i u = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b.visited + 32 * k));
+        black[k] = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, one));
+        white[k] = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, two));
+        visited[k] = ~(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(u, zero));
+    }
+    for (int i = 0; i < 6; ++i) {
+        s->stones[0].w[i] = ((uint64_t)black[2 * i] | (uint64_t)black[2 * i + 1] << 32) & kMasks.board.w[i];
+        s->stones[1].w[i] = ((uint64_t)white[2 * i] | (uint64_t)white[2 * i + 1] << 32) & kMasks.board.w[i];
+        s->visited.w[i] = ((uint64_t)visited[2 * i] | (uint64_t)visited[2 * i + 1] << 32) & kMasks.board.w[i];
+    }
+}
+const bool kGoAvx2 = __builtin_cpu_supports("avx2");
 inline StoneSets stone_sets(const Fast& b)
 {
     StoneSets s;
-    for (int i = 0; i < 6; ++i) {
-        uint64_t black = 0, white = 0;
-        const int first = i * 64, last = std::min(first + 64, kPoints);
-        for (int p = first; p < last; ++p) { black |= (uint64_t)(b.stone[p] == 1) << (p - first); white |= (uint64_t)(b.stone[p] == 2) << (p - first); }
-        s.stones[0].w[i] = black;
-        s.stones[1].w[i] = white;
-    }
+    if (kGoAvx2) stone_sets_avx2(b, &s); else stone_sets_scalar(b, &s);
     s.empty = andnot(kMasks.board, s.stones[0] | s.stones[1]);
     return s;
 }
+// the heads of the blocks with fewer than two liberties, as a bit set (rarely any)
+BB weak_heads_scalar(const Fast& b)
+{
+    BB r;
+    std::memset(&r, 0, sizeof(r));
+    for (int p = 0; p < kPoints; ++p) if (b.stone[p] != kEmpty && b.head[p] == p && b.libs[p] < 2) r.set(p);
+    return r;
+}
+__attribute__((target("avx2")))
+BB weak_heads_avx2(const Fast& b)
+{
+    BB r;
+    std::memset(&r, 0, sizeof(r));
+    const __m256i step = _mm256_set1_epi16(16), two = _mm256_set1_epi16(2), zero = _mm256_setzero_si256();
+    __m256i index = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    for (int k = 0; k < 23; ++k, index = _mm256_add_epi16(index, step)) {
+        const __m256i head = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b.head + 16 * k));
+        const __m256i libs = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b.libs + 16 * k));
+        const __m256i stone = _mm256_cvtepu8_epi16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(b.stone + 16 * k)));
+        const __m256i hit = _mm256_andnot_si256(_mm256_cmpeq_epi16(stone, zero), _mm256_and_si256(_mm256_cmpeq_epi16(head, index), _mm256_cmpgt_epi16(two, libs)));
+        unsigned mask = (unsigned)_mm256_movemask_epi8(hit);
+        while (mask) {
+            const int p = 16 * k + (__builtin_ctz(mask) >> 1);
+            if (p < kPoints) r.set(p);
+            mask &= mask - 1;
+            mask &= mask - 1;      // two mask bits per 16-bit lane
+        }
+    }
+    return r;
+}
+inline BB weak_heads(const Fast& b) { return kGoAvx2 ? weak_heads_avx2(b) : weak_heads_scalar(b); }
 inline BB block_stones(const Fast& b, int q) { BB r; std::memset(&r, 0, sizeof(r)); int s = q; do { r.set(s); s = b.next[s]; } while (s != q); return r; }
 
 // Benson's unconditional life (utils/benson.rs:62-190), same result as benson_flood above, on bit boards.
@@ -974,14 +1039,17 @@ BB valid_moves(const GoBoard& g, const StoneSets& sets, int to_move)
     const Fast& f = g.inner;
     BB weak[2];                                                          // stones of blocks with fewer than two liberties
     std::memset(weak, 0, sizeof(weak));
-    for (int p = 0; p < kPoints; ++p)
-        if (f.stone[p] != kEmpty && f.head[p] == p && f.libs[p] < 2) weak[f.stone[p] - 1] = weak[f.stone[p] - 1] | block_stones(f, p);
+    for (BB heads = weak_heads(f); heads.any();) {
+        const int p = heads.lowest();
+        heads.w[p >> 6] &= ~(1ull << (p & 63));
+        weak[f.stone[p] - 1] = weak[f.stone[p] - 1] | block_stones(f, p);
+    }
     const BB support = sets.empty | andnot(sets.stones[to_move], weak[to_move]) | weak[1 - to_move];
     BB valid = sets.empty & neighbours_of(support);
-    for (int i = 0; i < 6; ++i) {                                        // super-ko: rare
-        const int first = i * 64, last = std::min(first + 64, kPoints);
-        for (int p = first; p < last; ++p)
-            if (f.visited[p] && valid.get(p) && g.is_ko(to_move, p)) valid.w[i] &= ~(1ull << (p - first));
+    for (BB ko = valid & sets.visited; ko.any();) {                      // super-ko: only on points that have held a stone
+        const int p = ko.lowest();
+        ko.w[p >> 6] &= ~(1ull << (p & 63));
+        if (g.is_ko(to_move, p)) valid.w[p >> 6] &= ~(1ull << (p & 63));
     }
     return valid;
 }
@@ -998,6 +1066,13 @@ void go_candidates(void* b, int to_move, unsigned char* out)                  //
     write_candidates(valid_moves(*g, stone_sets(g->inner), to_move), out);
     out[kPass] = 1;
 }
+void go_candidate_bits(void* b, int to_move, uint64_t* out)
+{
+    const GoBoard* g = static_cast<GoBoard*>(b);
+    const BB valid = valid_moves(*g, stone_sets(g->inner), to_move);
+    std::memcpy(out, valid.w, sizeof(valid.w));
+    out[kPass >> 6] |= 1ull << (kPass & 63);
+}
 int go_is_symmetric(void* b, int symmetry)                                    // symmetry.rs:136-144
 {
     const GoBoard* g = static_cast<GoBoard*>(b);
@@ -1007,9 +1082,8 @@ int go_is_symmetric(void* b, int symmetry)                                    //
 }
 uint64_t go_hash(void* b) { return static_cast<GoBoard*>(b)->hash; }      // BoardTuple, predictors/nn.rs:31-45
 void go_record(void* b, int to_move, int symmetry, uint8_t* out) { board_record(*static_cast<GoBoard*>(b), to_move, symmetry, reinterpret_cast<BoardRecord*>(out)); }
-void go_candidates_scoring(void* b, int to_move, unsigned char* out)          // ScoringPolicyChecker, options.rs:110-139
+BB scoring_set(const GoBoard* g, int to_move)                                // ScoringPolicyChecker, options.rs:110-139
 {
-    const GoBoard* g = static_cast<GoBoard*>(b);
     const StoneSets sets = stone_sets(g->inner);
     BB alive, eyes[2];
     benson_sets(g->inner, sets, 0, &alive, &eyes[0]);
@@ -1022,11 +1096,20 @@ void go_candidates_scoring(void* b, int to_move, unsigned char* out)          //
         closed.w[p >> 6] &= ~(1ull << (p & 63));
         if (is_simple_eye(g->inner, to_move, p)) candidates.w[p >> 6] &= ~(1ull << (p & 63));
     }
-    write_candidates(candidates, out);
+    return candidates;
+}
+void go_candidates_scoring(void* b, int to_move, unsigned char* out)
+{
+    write_candidates(scoring_set(static_cast<GoBoard*>(b), to_move), out);
     out[kPass] = 0;
 }
-const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric, go_hash, go_record};
-const dgnn_game_ops kGoScoringOps = {go_clone, go_destroy, go_place, go_features, go_candidates_scoring, go_is_symmetric, go_hash, go_record};
+void go_candidate_bits_scoring(void* b, int to_move, uint64_t* out)
+{
+    const BB set = scoring_set(static_cast<GoBoard*>(b), to_move);
+    std::memcpy(out, set.w, sizeof(set.w));
+}
+const dgnn_game_ops kGoOps = {go_clone, go_destroy, go_place, go_features, go_candidates, go_is_symmetric, go_hash, go_record, go_candidate_bits};
+const dgnn_game_ops kGoScoringOps = {go_clone, go_destroy, go_place, go_features, go_candidates_scoring, go_is_symmetric, go_hash, go_record, go_candidate_bits_scoring};
 
 struct Rng2 {
     uint64_t state;

@@ -43,15 +43,31 @@ struct Rng {      // splitmix64
 
 }  // namespace
 
+namespace {
+struct CandidateRows {          // eight candidate bits -> eight prior entries (0 for a candidate, -inf otherwise)
+    float row[256][8];
+    CandidateRows() { for (int b = 0; b < 256; ++b) for (int j = 0; j < 8; ++j) row[b][j] = (b >> j) & 1 ? 0.0f : -std::numeric_limits<float>::infinity(); }
+};
+const CandidateRows kCandidateRows;
+}  // namespace
+
 // pool/policy_helper.rs:28-76: legal candidates 0, everything else -inf; `indices` maps every point to the smallest index
 // among its images under the board's own symmetries (and the duplicates are set to -inf)
 void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, float* policy /*368*/, int* indices /*362*/)
 {
-    unsigned char candidate[DGNN_NUM_MOVES];
-    ops->candidates(board, to_move, candidate);
     const float minus_inf = -std::numeric_limits<float>::infinity();
-    for (int i = 0; i < DGNN_NUM_MOVES; ++i) policy[i] = candidate[i] ? 0.0f : minus_inf;
-    for (int i = DGNN_NUM_MOVES; i < 368; ++i) policy[i] = minus_inf;
+    if (ops->candidate_bits) {
+        uint64_t bits[6];
+        ops->candidate_bits(board, to_move, bits);
+        const uint8_t* bytes = reinterpret_cast<const uint8_t*>(bits);        // little endian: byte k holds moves 8 k .. 8 k + 7
+        for (int k = 0; k < 46; ++k) std::memcpy(policy + 8 * k, kCandidateRows.row[bytes[k]], 8 * sizeof(float));
+        for (int i = DGNN_NUM_MOVES; i < 368; ++i) policy[i] = minus_inf;
+    } else {
+        unsigned char candidate[DGNN_NUM_MOVES];
+        ops->candidates(board, to_move, candidate);
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) policy[i] = candidate[i] ? 0.0f : minus_inf;
+        for (int i = DGNN_NUM_MOVES; i < 368; ++i) policy[i] = minus_inf;
+    }
     const uint16_t* maps[8];
     int num_symmetric = 0;
     for (int t = 1; t < 8; ++t) if (ops->is_symmetric && ops->is_symmetric(board, t)) maps[num_symmetric++] = symmetry_map(t);

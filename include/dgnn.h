@@ -499,6 +499,7 @@ typedef struct dgnn_game_ops {
     int (*is_symmetric)(void* board, int symmetry);                                /* may be NULL: no elimination */
     uint64_t (*hash)(void* board);                                                 /* may be NULL: no transposition cache */
     void (*record)(void* board, int to_move, int symmetry, uint8_t* out /* DGNN_BOARD_RECORD_BYTES */);   /* may be NULL: only fp16 features */
+    void (*candidate_bits)(void* board, int to_move, uint64_t* out /* 6 words: bit i = move i may be searched */);   /* may be NULL: `candidates` is used */
 } dgnn_game_ops;
 
 /* One search on `root` from `board` (not modified): rollouts until root.total_count >= num_rollouts
