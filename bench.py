@@ -59,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-rollouts", type=int, default=800, help="--num-rollout of the self-play leg (BASELINE.json: 800)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
     ap.add_argument("--selfplay-batches", type=int, default=2, help="device batches the leaf pool keeps alive per GPU (nn.rs:64-67: 2 per device)")
+    ap.add_argument("--selfplay-host-threads", type=int, default=2,
+                    help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
                     help="where the 32 feature planes are built: on the device from 896-byte board records (default), or on the host like the reference")
     ap.add_argument("--force-dist", action="store_true",
@@ -229,15 +231,20 @@ def selfplay_leg(job, api, replicas, net, args):
     games = args.selfplay_games * job.world
     cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
     boards = args.selfplay_planes == "device"
-    if job.dry:
-        pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch, boards=boards)
+    if job.dry and boards:
+        # no GPU: the CPU stand-in behind a stand-in for the device (a batch of n boards takes 500 + 10.8 n us, one at a time: the
+        # 20x256 engine's 3.3 ms at 256 boards) -- what is measured is the HOST side alone, rollouts per second and core
+        pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=args.selfplay_batches,
+                                           workers_per_lane=args.selfplay_batches)
+    elif job.dry:
+        pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
     else:
         pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
                                         workers_per_device=args.selfplay_batches, boards=boards)
     cpu0, wall0 = time.process_time(), time.perf_counter()
     out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=args.selfplay_moves,
                                     num_rollouts=args.selfplay_rollouts, threads_per_search=1, seed=20260930, pool=pool, cache=cache,
-                                    device=job.tensor_device, leaves_per_thread=args.selfplay_leaves)
+                                    device=job.tensor_device, leaves_per_thread=args.selfplay_leaves, host_threads=args.selfplay_host_threads)
     cpu_seconds = time.process_time() - cpu0                                                  # this rank's threads, user + system
     cpu_cores_busy = cpu_seconds / max(time.perf_counter() - wall0, 1e-9)
     rank_rollouts = out["evals"] + out["cache_hits"]                                          # this rank's own games
@@ -250,7 +257,8 @@ def selfplay_leg(job, api, replicas, net, args):
     moves_per_sec = j["moves"] / sec
     leg = {
         "what": f"{args.selfplay_games} games in flight per GPU, first {args.selfplay_moves} stones of each, --num-rollout {args.selfplay_rollouts}, "
-                f"1 search thread x {args.selfplay_leaves} leaves per game, transposition cache 200001 x 8 shards, through the leaf pool "
+                f"1 search thread x {args.selfplay_leaves} leaves per game, games as " +
+                (f"fibers on {args.selfplay_host_threads} host threads" if args.selfplay_host_threads > 0 else "one OS thread each") + ", transposition cache 200001 x 8 shards, through the leaf pool "
                 "(PCIe-inclusive); random-init weights; feature planes built on the " +
                 ("DEVICE from 896-byte board records (dgnn_forward_boards)" if boards else "HOST (features::V1, 23 KB of fp16 per leaf)"),
         "seconds": sec, "games": j["games"], "moves": j["moves"],
@@ -276,6 +284,10 @@ def selfplay_leg(job, api, replicas, net, args):
     }
     # how many GPUs running THIS leg the box's CPU quota could feed: quota cores / cores one GPU's leg kept busy
     leg["gpus_feedable_at_quota"] = leg["host_cpus"] / max(cpu_cores_busy, 1e-9)
+    # the host's capacity: rollouts per second and busy core, this rank and every rank (8 pinned ranks on one box: --gpus 8 --dry)
+    leg["rollouts_per_sec_per_core"] = rank_rollouts / max(cpu_seconds, 1e-9)
+    leg["per_rank_rollouts_per_sec_per_core"] = job.gather_float(leg["rollouts_per_sec_per_core"])
+    leg["per_rank_host_cpus_busy"] = job.gather_float(cpu_cores_busy)
     return leg
 
 

@@ -224,6 +224,8 @@ SYMBOLS = [
     ("dgnn_batch_records", _u8p, [_vp]),
     ("dgnn_pool_create_devices_boards", ctypes.c_int, [_vp, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
     ("dgnn_pool_create_callbacks_boards", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_pool_create_board_callbacks", ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
+    ("dgnn_hash_boards_predictor", _vp, []),
     ("dgnn_pool_predict_boards", ctypes.c_int, [_vp, _u8p, ctypes.c_int, _u16p, _u16p]),
     ("dgnn_pool_takes_boards", ctypes.c_int, [_vp]),
     ("dgnn_pool_boards_predictor", _vp, []),
@@ -851,6 +853,17 @@ class LeafPool:
                "LeafPool.over_callbacks")
         return cls(None, _handle=out, _keep=(predict_fn, predict_ctx))
 
+    @classmethod
+    def over_dry_device(cls, base_us=0.0, per_board_us=0.0, max_batch_size=256, batches_per_lane=2, workers_per_lane=2):
+        """A pool of board records over the CPU stand-in (dgnn_hash_boards_predictor) behind a stand-in for the device: a batch of n
+        boards takes base_us + per_board_us * n of wall time, one batch at a time.  No GPU: the host side of self-play alone."""
+        out = ctypes.c_void_p()
+        device = DryDevice(float(base_us), float(per_board_us)) if (base_us or per_board_us) else None
+        _check(lib.dgnn_pool_create_board_callbacks(lib.dgnn_hash_boards_predictor(), ctypes.byref(device) if device is not None else None, 1,
+                                                    int(max_batch_size), int(batches_per_lane), int(workers_per_lane), ctypes.byref(out)),
+               "LeafPool.over_dry_device")
+        return cls(None, _handle=out, _keep=device)
+
     @property
     def takes_boards(self):
         return bool(lib.dgnn_pool_takes_boards(self._handle))
@@ -1112,11 +1125,15 @@ def undo(trace, undo_expanding):
 
 # ---- search driver (scope row f-2, second part): search.cpp ----
 
+class DryDevice(ctypes.Structure):
+    _fields_ = [("base_us", ctypes.c_double), ("per_board_us", ctypes.c_double)]
+
+
 class SelfplayParams(ctypes.Structure):
     _fields_ = [("num_games", ctypes.c_int), ("num_parallel", ctypes.c_int), ("first_game", ctypes.c_int), ("game_stride", ctypes.c_int),
                 ("max_moves", ctypes.c_int), ("num_rollouts", ctypes.c_int), ("num_ex_it_rollouts", ctypes.c_int),
                 ("threads_per_search", ctypes.c_int), ("leaves_per_thread", ctypes.c_int), ("cache_entries_per_game", ctypes.c_int),
-                ("seed", ctypes.c_uint64)]
+                ("seed", ctypes.c_uint64), ("host_threads", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 class SelfplayStats(ctypes.Structure):
@@ -1348,10 +1365,11 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
-                return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1, cache_per_game=0):
+                return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1, cache_per_game=0,
+                host_threads=0):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
     (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
-    num_parallel of them run at a time (0 = all)."""
+    num_parallel of them run at a time (0 = all); host_threads > 0 runs them as fibers on that many OS threads (csrc/fiber.h)."""
     fn, ctx = _predictor(pool)
     stats = SelfplayStats()
     if num_moves <= 0 or num_moves > 722:
@@ -1359,7 +1377,8 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
     params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
-                            int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed))
+                            int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed),
+                            int(host_threads), 0)
     play = lib.dgnn_selfplay_go_boards if _takes_boards(pool) else lib.dgnn_selfplay_go
     _check(play(fn, ctx, cache._handle if cache is not None else None, ctypes.byref(params), ctypes.byref(stats),
                 moves.ctypes.data_as(_ip) if moves is not None else None, sgf, len(sgf) if sgf is not None else 0), "selfplay_go")

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "dgnn_internal.h"
+#include "fiber.h"
 
 namespace dgnn {
 namespace {
@@ -161,6 +162,7 @@ struct LeafRequest {
     uint16_t* policy_out;
     int remaining;
     int status;
+    Fiber* fiber = nullptr;     // the caller is a fiber (fiber.h): made ready by whoever completes the request, instead of `done`
     std::mutex mutex;
     std::condition_variable done;
 };
@@ -173,6 +175,7 @@ struct LeafPool {
     // whichever device has a worker free) or, for tests and dry runs without a GPU, a predictor callback per lane.
     std::vector<int> devices;
     dgnn_predict_fn callback = nullptr;
+    dgnn_predict_boards_fn board_callback = nullptr;   // a callback that takes the records as they are
     void* callback_ctx = nullptr;
     int num_lanes = 1;
     std::unique_ptr<std::atomic<uint64_t>[]> lane_boards, lane_batches;
@@ -229,9 +232,13 @@ struct LeafPool {
                     std::memcpy(r->policy_out + (size_t)slot->index * DGNN_NUM_MOVES, policy.data() + (size_t)i * DGNN_NUM_MOVES,
                                 DGNN_NUM_MOVES * sizeof(uint16_t));
                 }
-                std::lock_guard<std::mutex> lock(r->mutex);
-                if (status != DGNN_OK) r->status = status;
-                if (--r->remaining == 0) r->done.notify_one();
+                Fiber* resume = nullptr;
+                {
+                    std::lock_guard<std::mutex> lock(r->mutex);
+                    if (status != DGNN_OK) r->status = status;
+                    if (--r->remaining == 0) { if (r->fiber) resume = r->fiber; else r->done.notify_one(); }
+                }
+                if (resume) fiber_make_ready(resume);      // (the request lives on the fiber's stack: not touched after this)
             }
         }
     }
@@ -518,7 +525,13 @@ void dgnn_batch_destroy(dgnn_batch* batch)
 int LeafPool::evaluate(int lane, dgnn_batch* batch, int n, uint16_t* value, uint16_t* policy)
 {
     int status;
-    if (callback) {
+    if (board_callback) {
+        status = board_callback(callback_ctx, dgnn_batch_records(batch), n, value, policy);
+        if (status == DGNN_OK) {
+            batcher->boards_evaluated.fetch_add((uint64_t)n, std::memory_order_relaxed);
+            batcher->batches_evaluated.fetch_add(1, std::memory_order_relaxed);
+        }
+    } else if (callback) {
         if (batcher->records) {
             // lanes that are predictor CALLBACKS (dry runs, the oracle as the predictor in the tests) take fp16 planes: the host
             // statement of the device kernel expands the records (go.cpp: record_to_packed).  A pool over devices never gets here.
@@ -637,6 +650,26 @@ int dgnn_pool_create_callbacks_boards(dgnn_predict_fn predict, void* predict_ctx
     return pool_create_callbacks(predict, predict_ctx, num_lanes, max_batch_size, batches_per_lane, workers_per_lane, true, out);
 }
 
+int dgnn_pool_create_board_callbacks(dgnn_predict_boards_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                                     int workers_per_lane, dgnn_pool** out)
+{
+    if (!predict || !out || num_lanes <= 0 || max_batch_size <= 0 || batches_per_lane <= 0 || workers_per_lane <= 0) return DGNN_BAD_ARGUMENT;
+    *out = nullptr;
+    dgnn_batcher* batcher = nullptr;
+    int status = batcher_create(nullptr, 0, max_batch_size, batches_per_lane * num_lanes, true, &batcher);
+    if (status != DGNN_OK) return status;
+    std::unique_ptr<LeafPool> pool(new (std::nothrow) LeafPool());
+    if (!pool) { dgnn_batcher_destroy(batcher); return DGNN_OUT_OF_MEMORY; }
+    pool->batcher = reinterpret_cast<Batcher*>(batcher);
+    pool->owns_batcher = true;
+    pool->board_callback = predict;
+    pool->callback_ctx = predict_ctx;
+    pool->num_lanes = num_lanes;
+    status = start_pool(pool, workers_per_lane, out);
+    if (status != DGNN_OK) dgnn_batcher_destroy(batcher);
+    return status;
+}
+
 static int pool_create_callbacks(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
                                  int workers_per_lane, bool records, dgnn_pool** out)
 {
@@ -712,6 +745,7 @@ int dgnn_pool_takes_boards(const dgnn_pool* handle) { return handle && reinterpr
 static int pool_predict(LeafPool* pool, const uint16_t* features, int batch_size, uint16_t* value_out, uint16_t* policy_out)
 {
     LeafRequest request;
+    request.fiber = fiber_current();
     request.value_out = value_out;
     request.policy_out = policy_out;
     request.remaining = batch_size;
@@ -731,6 +765,11 @@ static int pool_predict(LeafPool* pool, const uint16_t* features, int batch_size
     }
     pool->calls.fetch_add(1, std::memory_order_relaxed);
     pool->wake();
+    if (request.fiber) {
+        fiber_yield();                                     // resumed by the pool worker that completes the request
+        std::lock_guard<std::mutex> lock(request.mutex);   // (that worker may still be inside its critical section)
+        return request.status;
+    }
     std::unique_lock<std::mutex> lock(request.mutex);
     request.done.wait(lock, [&] { return request.remaining == 0; });
     return request.status;

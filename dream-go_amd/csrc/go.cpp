@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "dgnn_internal.h"
+#include "fiber.h"
 
 namespace dgnn {
 namespace {
@@ -1439,10 +1440,14 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
         records[(size_t)g] = header + sgf + territory_sgf(point_status) + ")";
     };
     std::atomic<int> next_game{0};
-    std::vector<std::thread> threads;
-    for (int t = 0; t < num_parallel; ++t)
-        threads.emplace_back([&] { for (int g; (g = next_game.fetch_add(1)) < num_games && status.load() == DGNN_OK;) game(g); });
-    for (std::thread& t : threads) t.join();
+    auto play = [&](int) { for (int g; (g = next_game.fetch_add(1)) < num_games && status.load() == DGNN_OK;) game(g); };
+    if (params->host_threads > 0 && fibers_available()) {
+        run_fibers(num_parallel, params->host_threads, play);             // num_parallel games in flight on host_threads OS threads
+    } else {
+        std::vector<std::thread> threads;
+        for (int t = 0; t < num_parallel; ++t) threads.emplace_back(play, t);
+        for (std::thread& t : threads) t.join();
+    }
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     stats->games = (uint64_t)num_games;
     stats->moves = moves.load();

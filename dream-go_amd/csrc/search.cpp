@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -337,12 +338,39 @@ int hash_predict(void*, const uint16_t* features, int n, uint16_t* value, uint16
     return DGNN_OK;
 }
 
+// The same stand-in on board records, with a stand-in for the DEVICE behind it: `ctx` (may be NULL) points to a dgnn_dry_device, and
+// a call then takes base_us + per_board_us * n of wall time, one call at a time -- like batches queueing on one GPU -- while the
+// calling thread sleeps.  `bench.py --dry` measures the host side of self-play against it (rollouts per second and core).
+int hash_predict_boards(void* ctx, const uint8_t* records, int n, uint16_t* value, uint16_t* policy)
+{
+    for (int b = 0; b < n; ++b) {
+        uint64_t h = 1469598103934665603ull, words[DGNN_BOARD_RECORD_BYTES / 8];
+        std::memcpy(words, records + (size_t)b * DGNN_BOARD_RECORD_BYTES, sizeof(words));
+        for (uint64_t w : words) { h ^= w; h *= 1099511628211ull; h ^= h >> 29; }
+        uint16_t* p = policy + (size_t)b * DGNN_NUM_MOVES;
+        for (int i = 0; i < DGNN_NUM_MOVES; ++i) {                           // fp16 in [2^-10, 2^-8): sums to about 1
+            h = h * 6364136223846793005ull + 1442695040888963407ull;
+            p[i] = (uint16_t)(0x1400u + ((h >> 40) & 0x7ffu));
+        }
+        value[b] = (uint16_t)(((h >> 20) & 0x8000u) | 0x2800u | ((h >> 8) & 0x3ffu));   // +-[0.03, 0.06)
+    }
+    if (ctx) {
+        dgnn_dry_device* device = static_cast<dgnn_dry_device*>(ctx);
+        static std::mutex one_at_a_time;
+        std::lock_guard<std::mutex> lock(one_at_a_time);
+        std::this_thread::sleep_for(std::chrono::nanoseconds((long long)(1000.0 * (device->base_us + device->per_board_us * n))));
+    }
+    return DGNN_OK;
+}
+
 }  // namespace
 }  // namespace dgnn
 
 using namespace dgnn;
 
 extern "C" {
+
+dgnn_predict_boards_fn dgnn_hash_boards_predictor(void) { return hash_predict_boards; }
 
 const dgnn_game_ops* dgnn_synthetic_game_ops(void) { return &kSyntheticOps; }
 

@@ -396,6 +396,9 @@ int dgnn_pool_create_devices_boards(dgnn_network* net, const int* devices, int n
                                     int workers_per_device, dgnn_pool** out);
 int dgnn_pool_create_callbacks_boards(dgnn_predict_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
                                       int workers_per_lane, dgnn_pool** out);
+/* ... and over copies of a predictor that takes the records themselves (no expansion on the host). */
+int dgnn_pool_create_board_callbacks(dgnn_predict_boards_fn predict, void* predict_ctx, int num_lanes, int max_batch_size, int batches_per_lane,
+                                     int workers_per_lane, dgnn_pool** out);
 int dgnn_pool_predict_boards(dgnn_pool* pool, const uint8_t* records, int batch_size, uint16_t* value_out, uint16_t* policy_out);
 int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool of board records */
 
@@ -487,6 +490,11 @@ int dgnn_choose_f64(const double* items, int n, double cutoff_percentile, double
 dgnn_predict_fn dgnn_pool_predictor(void);    /* ctx = a dgnn_pool*: the HIP engine behind the cross-caller batcher */
 dgnn_predict_fn dgnn_hash_predictor(void);    /* ctx unused: deterministic CPU stand-in (role of predictors/{random,fake}.rs) */
 dgnn_predict_boards_fn dgnn_pool_boards_predictor(void);   /* ctx = a dgnn_pool* of board records */
+/* The CPU stand-in on board records.  ctx NULL: returns at once; ctx = a dgnn_dry_device*: a call also takes
+ * base_us + per_board_us * n of wall time (the calling thread sleeps; calls are served one at a time, like batches on one GPU) --
+ * the host side of self-play measured without a GPU (bench.py --dry). */
+typedef struct dgnn_dry_device { double base_us, per_board_us; } dgnn_dry_device;
+dgnn_predict_boards_fn dgnn_hash_boards_predictor(void);
 
 /* The game behind the search: what libdg_go provides in the reference (Board::clone / place,
  * features::V1::get_features, the policy checker of pool/policy_helper.rs:36-48, symmetry::is_symmetric). */
@@ -628,6 +636,12 @@ typedef struct dgnn_selfplay_params {
     int cache_entries_per_game; /* > 0: every game gets a transposition table of its own with this many entries instead of the
                                    shared `cache` -- needed for reproducible games, see below */
     uint64_t seed;
+    int host_threads;         /* 0: one OS thread per game in flight (the reference's model, self_play.rs:478-495).  > 0: the games in flight
+                                 are FIBERS on this many host threads (csrc/fiber.h): a game that waits for the leaf pool switches, in
+                                 user space, to the next game of its thread instead of sleeping in the kernel -- hundreds of games per
+                                 core.  Same games, move for move (a game is a function of its seed and the network's outputs);
+                                 ignored (= 0) where fibers are not available. */
+    int reserved;
 } dgnn_selfplay_params;
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);

@@ -142,3 +142,37 @@ def test_pools_refuse_the_other_input_form(api):
     assert n == n2 == 8 and value == value2 and np.array_equal(prior, prior2)
     planes.close()
     records.close()
+
+
+def test_games_as_fibers_play_the_games_of_one_thread_per_game(api):
+    """csrc/fiber.h: with host_threads > 0 the games in flight are fibers on that many OS threads, switched in user space where a
+    game waits for the leaf pool.  A game is a function of its seed and the network's outputs, so the records are those of the
+    thread-per-game run -- with one, two and three scheduler threads, more games than fit in flight, and both pool forms."""
+    kw = dict(num_games=10, num_moves=10, num_rollouts=48, threads_per_search=1, leaves_per_thread=4, seed=91, cache_per_game=2048,
+              num_parallel=6, return_moves=True, return_sgf=True)
+    strip = lambda sgf: re.sub(r"DT\[[^\]]*\]", "", sgf)
+    reference = None
+    for boards in (True, False):
+        for host_threads in (0, 1, 2, 3):
+            pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=16, boards=boards)
+            out = api.selfplay_go(pool=pool, host_threads=host_threads, **kw)
+            pool.close()
+            games = [strip(g) for g in out["sgf"]]
+            if reference is None:
+                reference = (out["record"].copy(), games, out["evals"])
+            assert np.array_equal(out["record"], reference[0]) and games == reference[1] and out["evals"] == reference[2], (boards, host_threads)
+
+
+def test_fibers_over_the_dry_device_and_a_shared_table(api):
+    """256 games as fibers on two threads against the stand-in device (a batch takes base + per_board * n of wall time): the whole
+    host pipeline of the bench's self-play leg without a GPU.  With a table shared between games the trajectories depend on
+    timing; the totals must still add up."""
+    pool = api.LeafPool.over_dry_device(base_us=200.0, per_board_us=2.0, max_batch_size=256)
+    cache = api.LruCache(50_001, num_shards=4)
+    out = api.selfplay_go(num_games=256, num_moves=2, num_rollouts=64, threads_per_search=1, leaves_per_thread=8, seed=5, pool=pool, cache=cache,
+                          host_threads=2, return_moves=True)
+    stats = pool.stats()
+    pool.close()
+    assert out["moves"] == 512 and (out["record"][:, :2] >= 0).all()
+    assert stats["boards"] == out["evals"] and out["cache_hits"] > 0
+    print(f"256 fibers / 2 threads: {out['evals']} evals in {stats['batches']} batches (mean {stats['boards'] / stats['batches']:.0f}), {out['cache_hits']} table hits")
