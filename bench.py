@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-games", type=int, default=256, help="games in flight PER GPU in the measured self-play leg (0 = skip the leg)")
     ap.add_argument("--selfplay-moves", type=int, default=6, help="stones per game in the self-play leg (bounds its duration)")
     ap.add_argument("--selfplay-rollouts", type=int, default=800, help="--num-rollout of the self-play leg (BASELINE.json: 800)")
+    ap.add_argument("--selfplay-midgame", type=int, default=60,
+                    help="second self-play leg: the searched stones start after this many stones of policy play (0 = skip that leg)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
     ap.add_argument("--selfplay-batches", type=int, default=2, help="device batches the leaf pool keeps alive per GPU (nn.rs:64-67: 2 per device)")
     ap.add_argument("--selfplay-host-threads", type=int, default=2,
@@ -115,6 +117,20 @@ def cpu_baseline(text, features, batch, sample):
         "value": sample / dt, "unit": "evals/s", "cores": int(oracle.lib().dgo_num_threads()), "kind": "port",
         "sample": f"{sample} boards of the same batch, one dgo_forward call (oracle/dgnn_oracle.c, OpenMP), {dt:.1f} s",
     }, (value, policy)
+
+
+def real_game_positions(api):
+    """Every position of the three committed reference games (tests/golden/real_games.json; the SGF fixtures of
+    src/dg_tests/tests/real_games.rs) as (board, colour to move)."""
+    import re
+    out = []
+    for game in json.load(open(os.path.join(ROOT, "tests", "golden", "real_games.json")))["games"]:
+        board = api.Board(7.5)
+        for color, vertex in re.findall(r";([BW])\[([a-s]{2})\]", game["moves"]):
+            c = 0 if color == "B" else 1
+            board.place(c, ord(vertex[0]) - 97, ord(vertex[1]) - 97)
+            out.append((board.clone(), 1 - c))
+    return out
 
 
 class Job:
@@ -224,10 +240,12 @@ def broadcast_weights(job, api, net):
             "distinct_images_before": len(set(before)), "seconds_incl_comm_setup": seconds}
 
 
-def selfplay_leg(job, api, replicas, net, args):
-    """Whole pipeline, measured: Go boards -> feature planes -> search (1 thread x K leaves per game) -> transposition cache ->
-    leaf pool -> engine, `selfplay_games` games in flight per GPU for their first `selfplay_moves` stones
-    (self_play.rs:423-459; rollouts per move follow the win rate, :234-241).  Games are sharded `id mod world`."""
+def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
+    """Whole pipeline, measured: Go boards -> board records (planes on the device) -> search (1 thread x K leaves per game) ->
+    transposition cache -> leaf pool -> engine, `selfplay_games` games in flight per GPU for `selfplay_moves` searched stones each
+    (self_play.rs:423-459; rollouts per move follow the win rate, :234-241).  Games are sharded `id mod world`.
+    fast_forward > 0: every game is first played that many stones deep by policy play (--num-rollout 1, self_play.rs:369-405; not
+    timed) and the searched stones start from there: a MID-GAME leg (fewer table hits, narrower trees, more ladders and captures)."""
     games = args.selfplay_games * job.world
     cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
     boards = args.selfplay_planes == "device"
@@ -241,22 +259,34 @@ def selfplay_leg(job, api, replicas, net, args):
     else:
         pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
                                         workers_per_device=args.selfplay_batches, boards=boards)
+    opening = None
+    if fast_forward > 0:
+        ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=fast_forward, num_rollouts=1, threads_per_search=1,
+                                          seed=20260930, pool=pool, cache=api.LruCache(50_001, num_shards=8), device=job.tensor_device,
+                                          host_threads=args.selfplay_host_threads, return_moves=True)
+        opening = ahead["record"]
+        before = pool.stats()
+    else:
+        before = {"boards": 0, "batches": 0}
     cpu0, wall0 = time.process_time(), time.perf_counter()
-    out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=args.selfplay_moves,
+    out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=fast_forward + args.selfplay_moves,
                                     num_rollouts=args.selfplay_rollouts, threads_per_search=1, seed=20260930, pool=pool, cache=cache,
-                                    device=job.tensor_device, leaves_per_thread=args.selfplay_leaves, host_threads=args.selfplay_host_threads)
+                                    device=job.tensor_device, leaves_per_thread=args.selfplay_leaves, host_threads=args.selfplay_host_threads,
+                                    opening=opening)
     cpu_seconds = time.process_time() - cpu0                                                  # this rank's threads, user + system
     cpu_cores_busy = cpu_seconds / max(time.perf_counter() - wall0, 1e-9)
     rank_rollouts = out["evals"] + out["cache_hits"]                                          # this rank's own games
     st = pool.stats()
-    boards = sum(job.gather_int(st["boards"]))
-    batches = sum(job.gather_int(st["batches"]))
+    boards = sum(job.gather_int(st["boards"] - before["boards"]))
+    batches = sum(job.gather_int(st["batches"] - before["batches"]))
     pool.close()
     j = out["job"]
     sec = max(j["seconds"], 1e-9)
     moves_per_sec = j["moves"] / sec
     leg = {
-        "what": f"{args.selfplay_games} games in flight per GPU, first {args.selfplay_moves} stones of each, --num-rollout {args.selfplay_rollouts}, "
+        "what": f"{args.selfplay_games} games in flight per GPU, " +
+                (f"stones {fast_forward + 1}..{fast_forward + args.selfplay_moves} of each (the first {fast_forward} by policy play, not timed)" if fast_forward
+                 else f"first {args.selfplay_moves} stones of each") + f", --num-rollout {args.selfplay_rollouts}, "
                 f"1 search thread x {args.selfplay_leaves} leaves per game, games as " +
                 (f"fibers on {args.selfplay_host_threads} host threads" if args.selfplay_host_threads > 0 else "one OS thread each") + ", transposition cache 200001 x 8 shards, through the leaf pool "
                 "(PCIe-inclusive); random-init weights; feature planes built on the " +
@@ -272,8 +302,8 @@ def selfplay_leg(job, api, replicas, net, args):
         "assumed_stones_per_game": 250,
         "games_per_hour": moves_per_sec * 3600.0 / 250.0,
         "note": "games_per_hour = measured moves/s x 3600 / 250 stones (a trained net's game length; a random-init net plays to the "
-                "722-stone cap: whole games measured in profiles/, DESIGN.md section 8). Opening moves only: later moves see more cache hits "
-                "and narrower trees.",
+                "722-stone cap: whole games measured in profiles/, DESIGN.md section 8). " +
+                ("Mid-game stones." if fast_forward else "Opening moves only: games in flight share their first positions in the table."),
         "host_cpus": effective_cpus(),
         "host_cpu_affinity": f"{min(os.sched_getaffinity(0))}-{max(os.sched_getaffinity(0))} ({len(os.sched_getaffinity(0))} CPUs)",
         "host_cpus_busy": cpu_cores_busy,          # CPU time of rank 0's process over the leg / its wall time: cores kept busy
@@ -373,9 +403,11 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
 
-    selfplay = None
+    selfplay = selfplay_mid = None
     if args.selfplay_games > 0:
         selfplay = selfplay_leg(job, api, replicas, net, args)
+        if args.selfplay_midgame > 0:
+            selfplay_mid = selfplay_leg(job, api, replicas, net, args, fast_forward=args.selfplay_midgame)
 
     out = None
     if rank == 0:
@@ -404,6 +436,8 @@ def main():
                 "frac_of_mfma_peak": flops_eval * args.batch * args.steps / (total_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                 "gpu_ms_per_step": total_ms / args.steps, "flops_per_eval": flops_eval,
             }
+        if selfplay_mid is not None:
+            out["selfplay_midgame"] = selfplay_mid
         if selfplay is not None:
             out["selfplay"] = selfplay
             out["derived"] = {
@@ -411,27 +445,43 @@ def main():
                 "what": "engine evals/s (inputs resident) x 3600 / (250 stones x the MEASURED evals per move of the selfplay leg): what the "
                         "engine alone would allow; the pipeline figure is selfplay.games_per_hour",
             }
-        # the reference's own harness style (`dream_go --bench`, src/dg/bench/forward.rs:28-47): one thread, one workspace,
-        # synchronous forward() calls on host buffers -- PCIe-inclusive, reported beside `value`, never as `value`
+        # ---- PCIe-inclusive: host buffers in, host buffers out (the drop-in's own contract, graph.rs:130-131,155-156), never `value`
         if world == 1 and not job.dry:
-            reps = max(3, min(args.steps, 10))
-            api.forward(ws, features)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                api.forward(ws, features)
-            dt1 = time.perf_counter() - t1
-            out["reference_style"] = {
-                "boards_per_sec": args.batch * reps / dt1, "calls": reps, "batch": args.batch,
-                "what": "synchronous dgnn_forward on host buffers (H2D of 23 KB fp16 per board + pass + D2H per call), single thread",
-            }
+            positions = real_game_positions(api)
+            # (a) as a leaf pool drives the device: two workspaces, one submission always queued, the loop inside the library
+            ws2 = net.get_workspace(args.batch, device=device)
+            records = np.concatenate([positions[i % len(positions)][0].record(positions[i % len(positions)][1], i % 8) for i in range(args.batch)])
             packed = api.features_pack(features, args.batch)
-            api.forward_packed(ws, packed, args.batch)
+            reps = max(10, args.steps)
+            out["value_pcie_inclusive"] = {
+                "what": "evals/s with host buffers in and out, two workspaces in flight (dgnn_forward_submit_* / dgnn_forward_wait inside "
+                        "dgnn_forward_pipelined_timed: no interpreter in the loop), same network and batch as `value`",
+                "board_records": api.forward_pipelined_timed(ws, ws2, "records", records, args.batch, reps),     # 896 B per board, planes on the device
+                "packed_planes": api.forward_pipelined_timed(ws, ws2, "packed", packed, args.batch, reps),       # 1.5 KB per board
+                "fp16_planes": api.forward_pipelined_timed(ws, ws2, "planes", features, args.batch, reps),       # 23 KB per board: the reference's form
+                "steps": reps,
+            }
+            out["value_pcie_inclusive"]["records_vs_resident"] = out["value_pcie_inclusive"]["board_records"] / value
+            ws2.release()
+            # (b) the reference's own harness (`dream_go --bench`, src/dg/bench/forward.rs:37-47 under bench/benchmark.rs:37-53): every
+            # position of an SGF collection -- here the three committed games -- one at a time: planes on the host, repeated to the
+            # batch size, one synchronous forward(); positions per second over the whole walk, feature extraction included
             t1 = time.perf_counter()
-            for _ in range(reps):
-                api.forward_packed(ws, packed, args.batch)
+            for board, color in positions:
+                api.forward(ws, np.tile(board.get_features(color, 0).reshape(-1).view(np.uint16), args.batch))
+            dt1 = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            for board, color in positions:
+                api.forward_boards(ws, np.tile(board.record(color, 0), args.batch), args.batch)
             dt2 = time.perf_counter() - t1
-            out["reference_style"]["packed_boards_per_sec"] = args.batch * reps / dt2
-            out["reference_style"]["packed"] = "synchronous dgnn_forward_packed (1.5 KB of plane masks per board, expanded on the device)"
+            out["reference_style"] = {
+                "what": f"dream_go --bench style: {len(positions)} positions of the three committed games (tests/golden/real_games.json), each "
+                        f"repeated {args.batch} times and evaluated by one synchronous call from one thread (through the Python mirror)",
+                "boards_per_sec": args.batch * len(positions) / dt1, "boards_per_sec_records": args.batch * len(positions) / dt2,
+                "forms": "boards_per_sec: features::V1 on the host + dgnn_forward (the reference's flow); boards_per_sec_records: board record + "
+                         "dgnn_forward_boards (planes on the device)",
+                "positions": len(positions), "batch": args.batch,
+            }
         if bcast is not None:
             out["weight_broadcast"] = bcast
         if world == 1 and args.cpu_sample > 0 and not job.dry:

@@ -217,6 +217,7 @@ SYMBOLS = [
     ("dgnn_board_records_to_packed", ctypes.c_int, [_u8p, ctypes.c_int, _u32p]),
     ("dgnn_board_records_to_packed_device", ctypes.c_int, [ctypes.c_int, _u8p, ctypes.c_int, _u32p]),
     ("dgnn_go_board_record", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u8p]),
+    ("dgnn_forward_pipelined_timed", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     ("dgnn_go_benson_flood", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_go_candidates", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_batcher_create_boards", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
@@ -592,6 +593,17 @@ def board_records_to_packed(records, count, device=None):
         _check(lib.dgnn_board_records_to_packed_device(int(device), r.ctypes.data_as(_u8p), int(count), out.ctypes.data_as(_u32p)),
                "board_records_to_packed_device")
     return out
+
+
+def forward_pipelined_timed(ws_a, ws_b, form, data, count, steps):
+    """PCIe-inclusive evaluations per second with two workspaces in flight, the loop inside the library (include/dgnn.h).
+    form: "planes" (fp16 [count * 11552]), "packed" (uint32 [count * 368]) or "records" (uint8 [count * 896])."""
+    code = {"planes": 0, "packed": 1, "records": 2}[form]
+    a = np.ascontiguousarray(data)
+    seconds = ctypes.c_double()
+    _check(lib.dgnn_forward_pipelined_timed(ws_a.handle, ws_b.handle, code, a.ctypes.data_as(ctypes.c_void_p), int(count), int(steps),
+                                            ctypes.byref(seconds)), "forward_pipelined_timed")
+    return count * steps / seconds.value
 
 
 def layer_dense(x, batch, k_in, w_in_out, bias, n_out, alpha=1.0, relu=False, device=0):
@@ -1133,7 +1145,7 @@ class SelfplayParams(ctypes.Structure):
     _fields_ = [("num_games", ctypes.c_int), ("num_parallel", ctypes.c_int), ("first_game", ctypes.c_int), ("game_stride", ctypes.c_int),
                 ("max_moves", ctypes.c_int), ("num_rollouts", ctypes.c_int), ("num_ex_it_rollouts", ctypes.c_int),
                 ("threads_per_search", ctypes.c_int), ("leaves_per_thread", ctypes.c_int), ("cache_entries_per_game", ctypes.c_int),
-                ("seed", ctypes.c_uint64), ("host_threads", ctypes.c_int), ("reserved", ctypes.c_int)]
+                ("seed", ctypes.c_uint64), ("host_threads", ctypes.c_int), ("opening_len", ctypes.c_int), ("opening", ctypes.c_void_p)]
 
 
 class SelfplayStats(ctypes.Structure):
@@ -1366,7 +1378,7 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
                 return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1, cache_per_game=0,
-                host_threads=0):
+                host_threads=0, opening=None):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
     (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
     num_parallel of them run at a time (0 = all); host_threads > 0 runs them as fibers on that many OS threads (csrc/fiber.h)."""
@@ -1378,7 +1390,11 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
     params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
                             int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed),
-                            int(host_threads), 0)
+                            int(host_threads), 0, None)
+    if opening is not None:                                    # [num_games][opening_len] packed indices: every game starts from that position
+        opening = np.ascontiguousarray(opening, dtype=np.int32).reshape(num_games, -1)
+        params.opening_len = opening.shape[1]
+        params.opening = opening.ctypes.data_as(ctypes.c_void_p)
     play = lib.dgnn_selfplay_go_boards if _takes_boards(pool) else lib.dgnn_selfplay_go
     _check(play(fn, ctx, cache._handle if cache is not None else None, ctypes.byref(params), ctypes.byref(stats),
                 moves.ctypes.data_as(_ip) if moves is not None else None, sgf, len(sgf) if sgf is not None else 0), "selfplay_go")

@@ -1315,10 +1315,23 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
         int pass_count = 0;
         bool finished = false;
         if (moves_out) for (int m = 0; m < max_moves; ++m) moves_out[(size_t)g * max_moves + m] = -1;
+        int first_turn = 0;
+        if (params->opening && params->opening_len > 0) {                       // start from a given position (alternating colours, black first)
+            for (int m = 0; m < params->opening_len && m < max_moves; ++m) {
+                const int p = params->opening[(size_t)g * params->opening_len + m];
+                if (p < 0 || p >= kPoints || !board.is_valid(m & 1, p)) break;
+                if (moves_out) moves_out[(size_t)g * max_moves + board.count] = p;
+                char text[16];
+                dgnn_sgf_played(text, sizeof(text), m & 1, p, 0, nullptr, 0, 0.0f, -1, "");
+                sgf += text;
+                board.place(m & 1, p);
+                ++first_turn;
+            }
+        }
 
         // one turn per iteration, black first; the turn cap only guards against two players passing for ever on a board
         // that never becomes scorable (the reference would spin there)
-        for (int turn = 0; board.count < max_moves && turn < 4 * 722 && status.load() == DGNN_OK; ++turn) {
+        for (int turn = first_turn; board.count < max_moves && turn < 4 * 722 && status.load() == DGNN_OK; ++turn) {
             const int me = turn & 1;
             const bool allow_pass = is_scorable(board.inner);                  // self_play.rs:437
             const dgnn_game_ops* ops = allow_pass ? &kGoOps : &kGoScoringOps;   // predict_aux, self_play.rs:243-274

@@ -211,6 +211,12 @@ int dgnn_workspace_sync(dgnn_workspace* ws);
  * Any out pointer may be NULL. */
 int dgnn_forward_timed(dgnn_workspace* ws, int steps, float* total_ms, float* tower_ms, int* tower_launches);
 
+/* `steps` PCIe-inclusive evaluations of `count` boards from the same host buffer, alternating between two workspaces so that one
+ * submission is always queued behind the running one -- how a leaf pool drives a device (two batches alive, predictors/nn.rs:64-67).
+ * Host buffer in, host buffers out, no interpreter in the loop.  form: 0 = fp16 planes (dgnn_forward_submit_n), 1 = packed words
+ * (dgnn_forward_submit_packed), 2 = board records (dgnn_forward_submit_boards).  *seconds = wall time of the `steps` evaluations. */
+int dgnn_forward_pipelined_timed(dgnn_workspace* a, dgnn_workspace* b, int form, const void* input, int count, int steps, double* seconds);
+
 /* ---- layer-level entry point (parity tests) --------------------------------------------------- */
 
 /* One Conv2d::forward / forward_skip (src/libdg_nn/layers/conv2d.rs:171-220) on host buffers, for the
@@ -641,7 +647,9 @@ typedef struct dgnn_selfplay_params {
                                  user space, to the next game of its thread instead of sleeping in the kernel -- hundreds of games per
                                  core.  Same games, move for move (a game is a function of its seed and the network's outputs);
                                  ignored (= 0) where fibers are not available. */
-    int reserved;
+    int opening_len;          /* > 0: every game starts from a given position: the first opening_len entries of its row of `opening` are
+                                 placed, black first, before the first move is searched (a -1 ends a row early) */
+    const int* opening;       /* [num_games][opening_len] packed indices, e.g. the moves_out of an earlier call; NULL = empty boards */
 } dgnn_selfplay_params;
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
