@@ -218,6 +218,9 @@ def broadcast_weights(job, api, net):
     before = job.gather_int(net.weight_checksum())
     t0 = time.perf_counter()
     if job.dry:
+        from dream_go_amd import replicas
+        if not replicas.descriptors_agree(job.dist, job.torch, net.image_descriptor()):
+            raise RuntimeError("the ranks do not hold the same architecture / packing: refusing to broadcast")
         image = job.torch.from_numpy(net.weight_image_host())      # view of the library's host image
         job.dist.broadcast(image, src=0)
         after = job.gather_int(net.weight_checksum())

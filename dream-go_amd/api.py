@@ -36,6 +36,7 @@ HIP_ERROR = -3
 BAD_ARGUMENT = -4
 OUT_OF_MEMORY = -5
 UNSUPPORTED = -6
+BUSY = -7
 COMM_ERROR = -8
 
 NUM_FEATURES = 32
@@ -218,6 +219,11 @@ SYMBOLS = [
     ("dgnn_board_records_to_packed_device", ctypes.c_int, [ctypes.c_int, _u8p, ctypes.c_int, _u32p]),
     ("dgnn_go_board_record", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u8p]),
     ("dgnn_forward_pipelined_timed", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    ("dgnn_cache_clear", ctypes.c_int, [_vp]),
+    ("dgnn_pool_pause", ctypes.c_int, [_vp]),
+    ("dgnn_pool_resume", ctypes.c_int, [_vp]),
+    ("dgnn_network_weight_image_commit", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("dgnn_network_image_descriptor", ctypes.c_int, [_vp, _u64p]),
     ("dgnn_go_benson_flood", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_go_candidates", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_batcher_create_boards", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
@@ -475,6 +481,12 @@ class Network:
             arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
             _check(lib.dgnn_broadcast_weights_devices(self.handle, arr, len(devices)), "broadcast_weights_devices")
 
+    def image_descriptor(self):
+        """(image bytes, hash of architecture and packing): what the ranks of a broadcast must agree on before anything moves."""
+        d = (ctypes.c_uint64 * 2)()
+        _check(lib.dgnn_network_image_descriptor(self.handle, d), "image_descriptor")
+        return int(d[0]), int(d[1])
+
     def weight_checksum_device(self, device=0):
         c = ctypes.c_uint64()
         _check(lib.dgnn_network_weight_checksum_device(self.handle, device, ctypes.byref(c)), "weight_checksum_device")
@@ -727,6 +739,10 @@ class LruCache:
         _check(lib.dgnn_cache_insert(self._handle, int(board_hash), int(to_move), int(symmetry), int(bits),
                                      response._policy.view(np.uint16).ctypes.data_as(_u16p)), "LruCache.cache")
 
+    def clear(self):
+        """Drops every entry (weight refresh: the table holds the old network's outputs)."""
+        _check(lib.dgnn_cache_clear(self._handle), "LruCache.clear")
+
     def stats(self):
         e, h, m = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         _check(lib.dgnn_cache_stats(self._handle, ctypes.byref(e), ctypes.byref(h), ctypes.byref(m)), "LruCache.stats")
@@ -876,6 +892,13 @@ class LeafPool:
                "LeafPool.over_dry_device")
         return cls(None, _handle=out, _keep=device)
 
+    def pause(self):
+        """Returns when no worker holds a batch or a workspace (weights may be replaced); callers queue up until resume()."""
+        _check(lib.dgnn_pool_pause(self._handle), "LeafPool.pause")
+
+    def resume(self):
+        _check(lib.dgnn_pool_resume(self._handle), "LeafPool.resume")
+
     @property
     def takes_boards(self):
         return bool(lib.dgnn_pool_takes_boards(self._handle))
@@ -965,7 +988,7 @@ def sgf_played(color, packed_index, value=None, num_rollout=1, softmax=None, pri
 # ------------------------------------------------------------------------------------------------------------------
 
 BLACK, WHITE = 0, 1
-PROBE_FOUND, PROBE_NO_RESULT, PROBE_CONFLICT = 1, 0, -7
+PROBE_FOUND, PROBE_NO_RESULT, PROBE_CONFLICT = 1, 0, 2
 
 
 class config:

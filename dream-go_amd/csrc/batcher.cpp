@@ -184,6 +184,9 @@ struct LeafPool {
     std::mutex mutex;
     std::condition_variable work;
     bool stopping = false;
+    bool paused = false;            // dgnn_pool_pause: workers take no new batch (callers keep queueing and wait)
+    int evaluating = 0;             // workers between get_batch and the end of evaluate (under `mutex`)
+    std::condition_variable idle;   // signalled when `evaluating` drops to zero
     std::atomic<uint64_t> calls{0};
 
     bool ready() const
@@ -210,19 +213,26 @@ struct LeafPool {
                 // sleep until there is something queued AND a batch slot free (signalled by dgnn_pool_predict and by every
                 // batch that retires); the timeout only covers boards pushed into the batcher behind the pool's back
                 std::unique_lock<std::mutex> lock(mutex);
-                work.wait_for(lock, std::chrono::milliseconds(20), [&] { return stopping || ready(); });
+                work.wait_for(lock, std::chrono::milliseconds(20), [&] { return stopping || (!paused && ready()); });
                 if (stopping) return;
+                if (paused) continue;
+                ++evaluating;       // from here to done(): a pause waits for us
             }
+            auto done = [&] {
+                std::lock_guard<std::mutex> lock(mutex);
+                if (--evaluating == 0) idle.notify_all();
+            };
             dgnn_batch* batch = nullptr;
             // take whatever is queued as soon as a batch slot is free: with max_batches batches in flight the queue
             // fills up behind them, which is what makes the batches large under load and keeps latency low when idle
             (void)dgnn_batcher_get_batch(reinterpret_cast<dgnn_batcher*>(batcher), 1, &batch);
-            if (!batch) continue;
+            if (!batch) { done(); continue; }
             if (ready()) work.notify_one();         // more than one batch was queued: the next idle worker takes the rest
             const int n = dgnn_batch_size(batch);
             (void)dgnn_batch_tags(batch, tags.data());
             const int status = evaluate(lane, batch, n, value.data(), policy.data());
             dgnn_batch_destroy(batch);
+            done();
             wake();                                 // a batch slot is free again
             for (int i = 0; i < n; ++i) {
                 LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
@@ -322,6 +332,19 @@ int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int s
     if (s.index.size() > s.capacity) {                                          // lru_cache.rs:136-147: drop the tail
         s.index.erase(s.order.back().key);
         s.order.pop_back();
+    }
+    return DGNN_OK;
+}
+
+// Drops every entry (the counters stay): what a weight refresh needs -- the table holds the OLD network's outputs.
+int dgnn_cache_clear(dgnn_cache* cache)
+{
+    if (!cache) return DGNN_BAD_ARGUMENT;
+    Cache* c = reinterpret_cast<Cache*>(cache);
+    for (auto& s : c->shards) {
+        std::lock_guard<std::mutex> lock(s->mutex);
+        s->index.clear();
+        s->order.clear();
     }
     return DGNN_OK;
 }
@@ -704,6 +727,32 @@ void dgnn_pool_destroy(dgnn_pool* handle)
     if (pool->owns_batcher) b->release();      // the handle dgnn_batcher_create returned
     b->release();                              // the pool's own reference (start_pool)
     delete pool;
+}
+
+// Quiesce for a weight refresh: returns when no worker holds a batch (or a workspace) any more; predict calls made meanwhile
+// queue up and are served after dgnn_pool_resume -- by the new weights.  The sequence of a refresh inside a running job:
+//   dgnn_pool_pause -> dgnn_broadcast_weights / dgnn_network_set_weight_image -> dgnn_cache_clear -> dgnn_pool_resume
+// (the reference restarts the worker process instead, contrib/distr-env/run_worker.py:66-77).
+int dgnn_pool_pause(dgnn_pool* handle)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    std::unique_lock<std::mutex> lock(pool->mutex);
+    pool->paused = true;
+    pool->idle.wait(lock, [&] { return pool->evaluating == 0; });
+    return DGNN_OK;
+}
+
+int dgnn_pool_resume(dgnn_pool* handle)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    {
+        std::lock_guard<std::mutex> lock(pool->mutex);
+        pool->paused = false;
+    }
+    pool->work.notify_all();
+    return DGNN_OK;
 }
 
 int dgnn_pool_stats(dgnn_pool* handle, int* num_lanes, uint64_t* calls, uint64_t* boards, uint64_t* batches,

@@ -94,6 +94,7 @@ struct Network {
     Topology topo;
     std::vector<uint8_t> image;    // packed host weight image
     bool frozen = false;           // set once the first workspace exists
+    int checked_out = 0;           // workspaces handed out and not yet released (under `mutex`): weights are not replaced meanwhile
 
     std::mutex mutex;
     std::map<int, std::unique_ptr<DeviceState>> devices;

@@ -76,7 +76,11 @@ struct Workspace {
     bool up_in_tower = true;                // the up-layer is the first layer of the tower launch (DGNN_TOWER_UP=0: a launch of its own)
     int split_pref = 1;                     // DGNN_TOWER_SPLIT: 0 = never split a board inside the tower launch, 1 = where a workgroup
                                             // per board is not chosen, 2 = wherever a split is possible (A/B)
-    bool split_failed = false;              // a hand-off poll gave up once (not every workgroup was resident): per-layer launches from then on
+    bool split_failed = false;              // a hand-off poll gave up (not every workgroup was resident): per-layer launches for a while
+    int split_failures = 0;                 // how often that has happened: after kSplitMaxFailures the split stays off
+    int split_cooldown = 0;                 // passes still to run per layer before the split is tried again
+    bool inject_giveup = false;             // DGNN_SPLIT_INJECT_GIVEUP=1 when the workspace was built (fault injection for the tests)
+    bool injected = false;                  // ... and it has fired
     unsigned* d_split_sync = nullptr;       // [batch * 8] layers published per (board, channel block), then the give-up word
     unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
     unsigned* h_split_err = nullptr;        // pinned copy of that word, fetched with the outputs
@@ -94,11 +98,8 @@ struct DeviceState {
     int device = 0;
     int num_cus = 0;
     uint8_t* d_image = nullptr;
-    // tower_split_kernel needs all its workgroups resident at once: two such launches on different streams could each hold
-    // CUs the other is waiting for.  They are chained on the device instead (each waits for the event behind the previous one).
-    std::mutex split_mutex;
-    hipEvent_t split_done = nullptr;
-    bool split_recorded = false;
+    bool image_valid = false;               // d_image holds net->image (false between a reserve and the copy that fills it)
+    struct SplitChain* chain = nullptr;     // the device's chain of split-tower launches (process-global, see split_chain)
     std::map<int, std::vector<Workspace*>> idle;   // batch size -> pooled workspaces
     std::vector<Workspace*> all;                   // ownership
 
@@ -123,11 +124,33 @@ DeviceState::~DeviceState()
 {
     for (Workspace* ws : all) delete ws;
     (void)hipSetDevice(device);
-    if (split_done) (void)hipEventDestroy(split_done);
     if (d_image) (void)hipFree(d_image);
 }
 
 Network::~Network() { devices.clear(); }
+
+// tower_split_kernel needs all its workgroups resident at once: two such launches on different streams could each hold CUs the
+// other is waiting for, and both would spin until they give up.  They are chained on the device instead (each waits for the event
+// behind the previous one).  The chain belongs to the PHYSICAL device, not to a (network, device) pair: two networks on one GPU
+// -- a match between two nets -- chain through the same event.  (Another PROCESS on the same GPU is out of reach: that is what the
+// give-up word and the retry policy in resolve_split_failure are for.)
+struct SplitChain {
+    std::mutex mutex;
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+};
+SplitChain* split_chain(int device)
+{
+    static std::mutex table_mutex;
+    static std::map<int, SplitChain*> table;     // never freed: a few bytes per device for the life of the process
+    std::lock_guard<std::mutex> lock(table_mutex);
+    SplitChain*& chain = table[device];
+    if (!chain) {
+        chain = new SplitChain();
+        if (hipEventCreateWithFlags(&chain->done, hipEventDisableTiming) != hipSuccess) chain->done = nullptr;
+    }
+    return chain;
+}
 
 namespace {
 
@@ -137,7 +160,16 @@ size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
 int get_device_state(Network* net, int device, DeviceState** out, bool upload = true)
 {
     auto it = net->devices.find(device);
-    if (it != net->devices.end()) { *out = it->second.get(); return DGNN_OK; }
+    if (it != net->devices.end()) {
+        DeviceState* state = it->second.get();
+        if (upload && !state->image_valid) {          // reserved for a transfer that never filled it: never run on garbage
+            DGNN_HIP(hipSetDevice(device));
+            DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
+            state->image_valid = true;
+        }
+        *out = state;
+        return DGNN_OK;
+    }
 
     int count = 0;
     DGNN_HIP(hipGetDeviceCount(&count));
@@ -148,9 +180,13 @@ int get_device_state(Network* net, int device, DeviceState** out, bool upload = 
     if (!state) return DGNN_OUT_OF_MEMORY;
     state->device = device;
     DGNN_HIP(hipDeviceGetAttribute(&state->num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    DGNN_HIP(hipEventCreateWithFlags(&state->split_done, hipEventDisableTiming));
+    state->chain = split_chain(device);
+    if (!state->chain->done) return DGNN_HIP_ERROR;
     DGNN_HIP(hipMalloc((void**)&state->d_image, net->image.size()));
-    if (upload) DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
+    if (upload) {
+        DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
+        state->image_valid = true;
+    }
 
     *out = state.get();
     net->devices[device] = std::move(state);
@@ -210,6 +246,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         ws->up_in_tower = !(up && std::atoi(up) == 0);
         const char* split = std::getenv("DGNN_TOWER_SPLIT");
         if (split && *split) ws->split_pref = std::atoi(split);
+        const char* inject = std::getenv("DGNN_SPLIT_INJECT_GIVEUP");
+        ws->inject_giveup = inject && std::atoi(inject) == 1;
     }
 
     ws->board_env = read_board_switches();
@@ -407,13 +445,18 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
             const int mode = tower_mode(ws);
             if (mode > 0) {
                 const int groups = t.num_channels / 32 / mode;
-                std::lock_guard<std::mutex> chain(ws->dev->split_mutex);
-                if (ws->dev->split_recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, ws->dev->split_done, 0));
+                SplitChain* chain = ws->dev->chain;
+                std::lock_guard<std::mutex> chained(chain->mutex);
+                if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
                 (void)groups;
+                if (ws->inject_giveup && !ws->injected) {       // fault injection (tests): the launch finds the give-up word already set
+                    ws->injected = true;
+                    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * 8, 0xff, sizeof(unsigned), ws->stream));
+                }
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
                                             (size_t)ws->batch * 8, ws->d_split_sync + (size_t)ws->batch * 8, &ws->split_base, ws->stream));
-                DGNN_HIP(hipEventRecord(ws->dev->split_done, ws->stream));
-                ws->dev->split_recorded = true;
+                DGNN_HIP(hipEventRecord(chain->done, ws->stream));
+                chain->recorded = true;
             } else {
                 DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
             }
@@ -555,21 +598,60 @@ int enqueue_split_check(Workspace* ws, int input_form)
 }
 
 // After the stream has drained: a split tower whose workgroups were not all resident (the device is shared with another
-// process) gives up instead of hanging; its outputs are garbage.  Repeat the pass with one launch per layer and stay there.
-int resolve_split_failure(Workspace* ws)
+// process) gives up instead of hanging; its outputs are garbage.  The pass is repeated with one launch per layer, the next
+// kSplitCooldown passes of this workspace run per layer too, then the split is tried again (the other tenant may be gone); after
+// kSplitMaxFailures give-ups it stays off until dgnn_network_synchronize re-arms it.
+constexpr int kSplitCooldown = 64, kSplitMaxFailures = 3;
+
+int note_split_failure(Workspace* ws)
 {
-    if (!ws->split_pending) return DGNN_OK;
-    ws->split_pending = false;
-    if (*ws->h_split_err == 0) return DGNN_OK;
     *ws->h_split_err = 0;
     ws->split_failed = true;
-    std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer from now on\n", ws->device);
-    const int status = enqueue_forward(ws, -1, ws->pending_form);
+    ++ws->split_failures;
+    ws->split_cooldown = kSplitCooldown;
+    std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer %s\n", ws->device,
+                 ws->split_failures >= kSplitMaxFailures ? "from now on" : "for the next passes");
+    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * 8, 0, sizeof(unsigned), ws->stream));   // the word is sticky on the device
+    return DGNN_OK;
+}
+
+void rearm_split(Workspace* ws, bool forget)
+{
+    if (forget) ws->split_failures = 0;
+    if (ws->split_failures < kSplitMaxFailures) { ws->split_failed = false; ws->split_cooldown = 0; }
+}
+
+int resolve_split_failure(Workspace* ws)
+{
+    if (!ws->split_pending) {
+        if (ws->split_failed && ws->split_cooldown > 0 && --ws->split_cooldown == 0) rearm_split(ws, false);
+        return DGNN_OK;
+    }
+    ws->split_pending = false;
+    if (*ws->h_split_err == 0) return DGNN_OK;
+    int status = note_split_failure(ws);
+    if (status != DGNN_OK) return status;
+    status = enqueue_forward(ws, -1, ws->pending_form);
     if (status != DGNN_OK) return status;
     DGNN_HIP(hipMemcpyAsync(ws->h_value, ws->d_value, (size_t)ws->active * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipMemcpyAsync(ws->h_policy, ws->d_policy, (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipStreamSynchronize(ws->stream));
     return DGNN_OK;
+}
+
+// The resident / timed entry points (measurement harness) have no outputs to repeat: after their stream has drained they only
+// look at the give-up word, switch the workspace to per-layer launches and say so -- a timed run that computed garbage must not
+// be reported as a fast one.  Returns DGNN_OK, or DGNN_BUSY when the passes just timed gave up (run them again).
+int check_split_after_sync(Workspace* ws)
+{
+    if (tower_mode(ws) <= 0) return DGNN_OK;
+    unsigned err = 0;
+    DGNN_HIP(hipMemcpy(&err, ws->d_split_sync + (size_t)ws->batch * 8, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (err == 0) return DGNN_OK;
+    const int status = note_split_failure(ws);
+    if (status != DGNN_OK) return status;
+    DGNN_HIP(hipStreamSynchronize(ws->stream));
+    return DGNN_BUSY;
 }
 
 float env_softmax_temperature()
@@ -700,6 +782,7 @@ const char* dgnn_status_string(int status)
         case DGNN_OUT_OF_MEMORY: return "out of host memory";
         case DGNN_UNSUPPORTED: return "unsupported network architecture";
         case DGNN_COMM_ERROR: return "RCCL error";
+        case DGNN_BUSY: return "busy: workspaces are checked out, or a timed pass has to be repeated";
         default: return "unknown status";
     }
 }
@@ -802,6 +885,7 @@ int dgnn_network_get_workspace(dgnn_network* net, int device, int batch_size, dg
     if (!idle.empty()) {   // network.rs:137-140: candidates.try_pop()
         *out = reinterpret_cast<dgnn_workspace*>(idle.back());
         idle.pop_back();
+        ++n->checked_out;
         return DGNN_OK;
     }
 
@@ -809,6 +893,7 @@ int dgnn_network_get_workspace(dgnn_network* net, int device, int batch_size, dg
     status = create_workspace(n, dev, batch_size, &ws);
     if (status != DGNN_OK) { delete ws; return status; }
     dev->all.push_back(ws);
+    ++n->checked_out;
     *out = reinterpret_cast<dgnn_workspace*>(ws);
     return DGNN_OK;
 }
@@ -824,6 +909,7 @@ void dgnn_workspace_release(dgnn_workspace* handle)
     }
     std::lock_guard<std::mutex> lock(ws->net->mutex);
     ws->dev->idle[ws->batch].push_back(ws);
+    --ws->net->checked_out;
 }
 
 int dgnn_network_synchronize(dgnn_network* net)
@@ -838,6 +924,7 @@ int dgnn_network_synchronize(dgnn_network* net)
         if (hipSetDevice(dev->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
             status = DGNN_HIP_ERROR;   // "this should be allowed to fail", network.rs:150-153: keep going
 
+        for (Workspace* ws : dev->all) rearm_split(ws, /*forget=*/true);     // a tower that gave up may try its split again
         // self.workspaces.clear(): drop everything that is pooled; checked-out workspaces stay valid
         for (auto& bucket : dev->idle) {
             for (Workspace* ws : bucket.second) {
@@ -1154,7 +1241,7 @@ int dgnn_workspace_sync(dgnn_workspace* handle)
     Workspace* ws = W(handle);
     DGNN_HIP(hipSetDevice(ws->device));
     DGNN_HIP(hipStreamSynchronize(ws->stream));
-    return DGNN_OK;
+    return check_split_after_sync(ws);      // DGNN_BUSY: the passes since the last sync gave up on the split tower; run them again
 }
 
 int dgnn_forward_timed(dgnn_workspace* handle, int steps, float* total_ms, float* tower_ms, int* tower_launches)
@@ -1176,6 +1263,7 @@ int dgnn_forward_timed(dgnn_workspace* handle, int steps, float* total_ms, float
     }
     DGNN_HIP(hipEventRecord(ws->ev_end, ws->stream));
     DGNN_HIP(hipStreamSynchronize(ws->stream));
+    { const int gave_up = check_split_after_sync(ws); if (gave_up != DGNN_OK) return gave_up; }
 
     float ms = 0.0f;
     DGNN_HIP(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
@@ -1428,6 +1516,19 @@ int dgnn_network_weight_image_reserve(dgnn_network* net, int device, void** d_im
     return DGNN_OK;
 }
 
+// The range dgnn_network_weight_image_reserve handed out has been filled with this network's image by the caller (a transfer that
+// is known to have succeeded): from now on it is what the device's kernels read.
+int dgnn_network_weight_image_commit(dgnn_network* net, int device)
+{
+    if (!net) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+    auto it = n->devices.find(device);
+    if (it == n->devices.end()) return DGNN_BAD_ARGUMENT;
+    it->second->image_valid = true;
+    return DGNN_OK;
+}
+
 int dgnn_network_weight_checksum(const dgnn_network* net, uint64_t* checksum)
 {
     if (!net || !checksum) return DGNN_BAD_ARGUMENT;
@@ -1443,12 +1544,13 @@ int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src
     Network* n = N(net);
     std::lock_guard<std::mutex> lock(n->mutex);
     if (num_bytes != n->image.size()) return DGNN_BAD_ARGUMENT;
-    DeviceState* dev = nullptr;
-    int status = get_device_state(n, device, &dev);
-    if (status != DGNN_OK) return status;
+    // a forward that is in flight reads the image and the launch descriptors this call replaces: refuse while any workspace is
+    // checked out (a leaf pool holds one per batch it is evaluating: pause the pool first, dgnn_pool_pause)
+    if (n->checked_out > 0) return DGNN_BUSY;
 
-    // the new image on the host first: its header is checked against this network (same architecture, same packing)
-    // BEFORE anything is overwritten, and it carries the launch scalars (gates, temperature) the kernels are started with
+    // the new image on the host first: its header is checked against this network (same architecture, same packing) BEFORE
+    // anything is overwritten -- neither the host image nor any device copy -- and it carries the launch scalars (gates,
+    // temperature) the kernels are started with
     std::vector<uint8_t> incoming;
     const uint8_t* host = (const uint8_t*)src;
     if (src_on_device) {
@@ -1458,18 +1560,39 @@ int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src
         DGNN_HIP(hipMemcpy(incoming.data(), src, num_bytes, hipMemcpyDeviceToHost));
         host = incoming.data();
     }
-    status = adopt_image(*n, host, num_bytes);   // net->image, alpha per block, tau; refuses a foreign image
+    int status = adopt_image(*n, host, num_bytes);   // net->image, alpha per block, tau; refuses a foreign image, changing nothing
     if (status != DGNN_OK) return status;
 
-    // every device copy (devices first touched later upload net->image, which is now the new one)
-    for (auto& entry : n->devices) {
+    DeviceState* dev = nullptr;                      // the device the image sits on gets its copy from there
+    status = get_device_state(n, device, &dev, /*upload=*/false);
+    if (status != DGNN_OK) return status;
+    for (auto& entry : n->devices) {                 // every device copy (devices first touched later upload net->image, the new one)
         DeviceState* d = entry.second.get();
         DGNN_HIP(hipSetDevice(d->device));
-        DGNN_HIP(hipDeviceSynchronize());   // no forward may be reading the old image
-        if (!(d == dev && (const void*)d->d_image == src))
+        DGNN_HIP(hipDeviceSynchronize());            // (nothing is checked out, so nothing is in flight; belt and braces)
+        d->image_valid = false;
+        if (d == dev && src_on_device) {
+            if ((const void*)d->d_image != src) DGNN_HIP(hipMemcpy(d->d_image, src, num_bytes, hipMemcpyDeviceToDevice));
+        } else {
             DGNN_HIP(hipMemcpy(d->d_image, n->image.data(), num_bytes, hipMemcpyHostToDevice));
+        }
+        d->image_valid = true;
         for (Workspace* ws : d->all) ws->tower_layers_ready = false;   // the cached descriptors hold the old gates
     }
+    return DGNN_OK;
+}
+
+// What must agree between the ranks of a broadcast BEFORE a byte of the image moves: the image size and a hash of the
+// architecture and packing (blocks, channels, samples, filter layouts) -- not of the weights, gates or temperature, which are
+// what the broadcast is for.  descriptor[0] = bytes, descriptor[1] = the hash.
+int dgnn_network_image_descriptor(const dgnn_network* net, uint64_t* descriptor)
+{
+    if (!net || !descriptor) return DGNN_BAD_ARGUMENT;
+    const Topology& t = N(net)->topo;
+    descriptor[0] = (uint64_t)N(net)->image.size();
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t v : {(uint64_t)t.num_blocks, (uint64_t)t.num_channels, (uint64_t)t.num_samples, (uint64_t)t.layouts}) { h ^= v; h *= 1099511628211ull; }
+    descriptor[1] = h;
     return DGNN_OK;
 }
 

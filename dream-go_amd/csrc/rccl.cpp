@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -30,6 +31,7 @@ struct Rccl {
     decltype(&ncclCommCount) comm_count = nullptr;
     decltype(&ncclCommUserRank) comm_user_rank = nullptr;
     decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
@@ -42,6 +44,8 @@ const Rccl* rccl()
     static Rccl lib;
     static std::once_flag once;
     std::call_once(once, [] {
+        const char* off = std::getenv("DGNN_RCCL_DISABLE");                   // tests: behave as if librccl were not installed
+        if (off && std::atoi(off) == 1) return;
         // a copy that is already in the process first (same soname: PyTorch-ROCm ships one), then the ROCm installation
         const char* const names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         void* h = nullptr;
@@ -58,12 +62,13 @@ const Rccl* rccl()
         DGNN_SYM(comm_count, ncclCommCount);
         DGNN_SYM(comm_user_rank, ncclCommUserRank);
         DGNN_SYM(broadcast, ncclBroadcast);
+        DGNN_SYM(all_gather, ncclAllGather);
         DGNN_SYM(group_start, ncclGroupStart);
         DGNN_SYM(group_end, ncclGroupEnd);
         DGNN_SYM(error_string, ncclGetErrorString);
 #undef DGNN_SYM
         if (r.get_unique_id && r.comm_init_rank && r.comm_init_all && r.comm_destroy && r.comm_count && r.comm_user_rank &&
-            r.broadcast && r.group_start && r.group_end && r.error_string)
+            r.broadcast && r.all_gather && r.group_start && r.group_end && r.error_string)
             lib = r;
     });
     return lib.handle ? &lib : nullptr;
@@ -188,6 +193,13 @@ void dgnn_rccl_comm_destroy(dgnn_comm* comm)
     delete c;
 }
 
+// Collective.  Order of business, so that no failure leaves a rank computing on something it should not:
+//   1. every rank's (image bytes, architecture hash) is all-gathered and compared: ranks that do not hold the same architecture
+//      and packing would post broadcasts of different sizes -- a hang or a buffer overrun.  On a mismatch EVERY rank returns
+//      DGNN_BAD_ARGUMENT (each of them sees all descriptors) and nothing has been touched;
+//   2. receivers take the image into a STAGING buffer, not into the copy their kernels read;
+//   3. dgnn_network_set_weight_image checks the header of what arrived and only then replaces the host image, the device copy
+//      and the launch scalars (gates, temperature): a transfer that failed or delivered a foreign image changes nothing.
 int dgnn_broadcast_weights(dgnn_network* net, dgnn_comm* comm, int root)
 {
     if (!net || !comm) return DGNN_BAD_ARGUMENT;
@@ -196,23 +208,50 @@ int dgnn_broadcast_weights(dgnn_network* net, dgnn_comm* comm, int root)
     const Rccl* r = rccl();
     if (!r) return DGNN_COMM_ERROR;
 
-    void* d_image = nullptr;
-    size_t num_bytes = 0;
-    // the root sends its image (uploaded on first use); a receiver that has not touched the device yet only reserves the range
-    int status = c->rank == root ? dgnn_network_weight_image(net, c->device, &d_image, &num_bytes)
-                                 : dgnn_network_weight_image_reserve(net, c->device, &d_image, &num_bytes);
+    uint64_t mine[2];
+    int status = dgnn_network_image_descriptor(net, mine);
     if (status != DGNN_OK) return status;
+    const size_t num_bytes = (size_t)mine[0];
     DGNN_HIP_(hipSetDevice(c->device));
-    DGNN_HIP_(hipDeviceSynchronize());                   // no forward may be reading the image while it is replaced
     hipStream_t stream = nullptr;
     DGNN_HIP_(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    const ncclResult_t sent = r->broadcast(d_image, d_image, num_bytes, ncclUint8, root, c->comm, stream);
-    const hipError_t waited = hipStreamSynchronize(stream);
+
+    // 1. agree on what is about to move
+    std::vector<uint64_t> all((size_t)2 * c->num_ranks, 0);
+    uint64_t* d_desc = nullptr;
+    hipError_t hip = hipMalloc((void**)&d_desc, sizeof(uint64_t) * 2 * ((size_t)c->num_ranks + 1));
+    ncclResult_t nccl = ncclSuccess;
+    if (hip == hipSuccess) hip = hipMemcpyAsync(d_desc, mine, sizeof(mine), hipMemcpyHostToDevice, stream);
+    if (hip == hipSuccess) nccl = r->all_gather(d_desc, d_desc + 2, 2, ncclUint64, c->comm, stream);
+    if (hip == hipSuccess && nccl == ncclSuccess) hip = hipMemcpyAsync(all.data(), d_desc + 2, sizeof(uint64_t) * all.size(), hipMemcpyDeviceToHost, stream);
+    if (hip == hipSuccess && nccl == ncclSuccess) hip = hipStreamSynchronize(stream);
+    if (d_desc) (void)hipFree(d_desc);
+    if (nccl != ncclSuccess) { (void)hipStreamDestroy(stream); g_last_rccl_error = (int)nccl; return DGNN_COMM_ERROR; }
+    if (hip != hipSuccess) { (void)hipStreamDestroy(stream); set_last_hip_error((int)hip); return DGNN_HIP_ERROR; }
+    for (int k = 0; k < c->num_ranks; ++k)
+        if (all[2 * k] != all[2 * (size_t)root] || all[2 * k + 1] != all[2 * (size_t)root + 1]) { (void)hipStreamDestroy(stream); return DGNN_BAD_ARGUMENT; }
+
+    // 2. the transfer: the root sends the copy its kernels read (uploaded on first use), a receiver takes it into staging
+    void* buffer = nullptr;
+    bool staging = false;
+    if (c->rank == root) {
+        size_t n = 0;
+        status = dgnn_network_weight_image(net, c->device, &buffer, &n);
+        if (status != DGNN_OK) { (void)hipStreamDestroy(stream); return status; }
+    } else {
+        hip = hipMalloc(&buffer, num_bytes);
+        if (hip != hipSuccess) { (void)hipStreamDestroy(stream); set_last_hip_error((int)hip); return DGNN_HIP_ERROR; }
+        staging = true;
+    }
+    nccl = r->broadcast(buffer, buffer, num_bytes, ncclUint8, root, c->comm, stream);
+    hip = hipStreamSynchronize(stream);
     (void)hipStreamDestroy(stream);
-    if (sent != ncclSuccess) { g_last_rccl_error = (int)sent; return DGNN_COMM_ERROR; }
-    if (waited != hipSuccess) { set_last_hip_error((int)waited); return DGNN_HIP_ERROR; }
-    // receivers: the image in place, now also on the host, with ITS header's gates and temperature (a no-op copy on the root)
-    return dgnn_network_set_weight_image(net, c->device, d_image, num_bytes, 1);
+    if (nccl != ncclSuccess) { g_last_rccl_error = (int)nccl; status = DGNN_COMM_ERROR; }
+    else if (hip != hipSuccess) { set_last_hip_error((int)hip); status = DGNN_HIP_ERROR; }
+    // 3. receivers: header check, then the image and ITS gates and temperature become this network's (nothing to do on the root)
+    else if (staging) status = dgnn_network_set_weight_image(net, c->device, buffer, num_bytes, 1);
+    if (staging) (void)hipFree(buffer);
+    return status;
 }
 
 int dgnn_broadcast_weights_devices(dgnn_network* net, const int* devices, int num_devices)
@@ -224,23 +263,22 @@ int dgnn_broadcast_weights_devices(dgnn_network* net, const int* devices, int nu
     for (size_t i = 0; i < list.size(); ++i)
         for (size_t j = 0; j < i; ++j) if (list[i] == list[j]) return DGNN_BAD_ARGUMENT;   // one rank per device
 
-    // the first device gets the host image over PCIe (if it does not hold it yet), the others only reserve the range and
-    // receive it over xGMI -- with one device that is all there is to do
-    std::vector<void*> images(list.size());
+    // the first device gets the host image over PCIe (if it does not hold it yet); with one device that is all there is to do
+    std::vector<void*> images(list.size(), nullptr);
     size_t num_bytes = 0;
-    for (size_t i = 0; i < list.size(); ++i) {
-        const int status = i == 0 ? dgnn_network_weight_image(net, list[i], &images[i], &num_bytes)
-                                  : dgnn_network_weight_image_reserve(net, list[i], &images[i], &num_bytes);
-        if (status != DGNN_OK) return status;
-    }
-    if (list.size() == 1) return DGNN_OK;
+    int status = dgnn_network_weight_image(net, list[0], &images[0], &num_bytes);
+    if (status != DGNN_OK || list.size() == 1) return status;
 
+    // the library and the communicators BEFORE any receiver is touched: without them nothing has changed and the devices
+    // upload the host image themselves on first use (the reference's way, tensor.rs:123-141)
     const Rccl* r = rccl();
     if (!r) return DGNN_COMM_ERROR;
     std::vector<ncclComm_t> comms(list.size(), nullptr);
     DGNN_NCCL(r->comm_init_all(comms.data(), (int)list.size(), list.data()));
     std::vector<hipStream_t> streams(list.size(), nullptr);
-    int status = DGNN_OK;
+    // the others reserve their range and receive over xGMI; a reserved range counts as empty until the transfer is known to be
+    // good (engine.cpp: image_valid), so a failure below cannot leave a device computing on garbage
+    for (size_t i = 1; i < list.size() && status == DGNN_OK; ++i) status = dgnn_network_weight_image_reserve(net, list[i], &images[i], &num_bytes);
     for (size_t i = 0; i < list.size() && status == DGNN_OK; ++i) {
         if (hipSetDevice(list[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess)
@@ -264,12 +302,8 @@ int dgnn_broadcast_weights_devices(dgnn_network* net, const int* devices, int nu
         }
         if (comms[i]) (void)r->comm_destroy(comms[i]);
     }
-    if (status != DGNN_OK) {
-        // the receivers' ranges may hold anything now: fall back to the reference's way, a host upload per device
-        const void* host = nullptr;
-        size_t n = 0;
-        if (dgnn_network_weight_image_host(net, &host, &n) == DGNN_OK) (void)dgnn_network_set_weight_image(net, list[0], host, n, 0);
-    }
+    // good: the receivers' ranges are the image now.  Bad: they stay marked empty and are filled from the host on first use.
+    if (status == DGNN_OK) for (size_t i = 1; i < list.size(); ++i) (void)dgnn_network_weight_image_commit(net, list[i]);
     return status;
 }
 

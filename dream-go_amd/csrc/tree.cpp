@@ -284,7 +284,7 @@ int dgnn_tree_probe(dgnn_tree_node* root, const dgnn_board_ops* ops, void* board
         int next_child = 0;
         float next_value = 0.0f;
         const int r = select(current, !trace->entries.empty(), &next_child, &next_value);
-        if (r < 0) { undo(*trace, false); delete trace; return DGNN_PROBE_CONFLICT; }
+        if (r < 0) { undo(*trace, false); delete trace; return DGNN_PROBE_CONFLICT; }   // (select's own -1, not the ABI's value)
         if (r == 0) { delete trace; return DGNN_PROBE_NO_RESULT; }            // (the reference leaks the partial trace's virtual loss here too)
         trace->entries.push_back({current, current->to_move, next_child});
         if (next_child != kMoves - 1) {

@@ -40,6 +40,16 @@ def all_agree(dist, torch, value, device="cpu"):
     return len({int(g.item()) for g in gathered}) == 1
 
 
+def descriptors_agree(dist, torch, descriptor, device="cpu"):
+    """What dgnn_broadcast_weights does with RCCL before it moves the image, for a host-side broadcast (gloo, dry runs): every
+    rank's (image bytes, architecture hash) is all-gathered; True on EVERY rank only if all ranks hold the same architecture and
+    packing.  A rank with another network would otherwise post a broadcast of another size and hang the collective."""
+    mine = torch.tensor([int(v) & 0x7FFFFFFFFFFFFFFF for v in descriptor], dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, mine)
+    return all(bool((g == gathered[0]).all().item()) for g in gathered)
+
+
 def max_over_ranks(dist, torch, seconds, device="cpu"):
     """The job's wall time is the slowest rank's."""
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)

@@ -37,7 +37,8 @@ extern "C" {
 #define DGNN_BAD_ARGUMENT       -4  /* null pointer, batch <= 0, feature count != batch * 11552 (the debug_assert!s of graph.rs:124-125) */
 #define DGNN_OUT_OF_MEMORY      -5  /* host allocation failed */
 #define DGNN_UNSUPPORTED        -6  /* architecture outside what the kernels cover (num_channels not a multiple of 32, > 1024, ...) */
-#define DGNN_COMM_ERROR         -8  /* librccl missing or an RCCL call failed; see dgnn_last_rccl_error() (-7 is DGNN_PROBE_CONFLICT) */
+#define DGNN_BUSY               -7  /* the object is in use: weights cannot be replaced while workspaces are checked out; a timed pass gave up and must be repeated */
+#define DGNN_COMM_ERROR         -8  /* librccl missing or an RCCL call failed; see dgnn_last_rccl_error() */
 
 #define DGNN_NUM_FEATURES   32      /* features::V1::num_features(), src/libdg_go/utils/features.rs:88-90 */
 #define DGNN_NUM_POINTS     361     /* 19 x 19, src/libdg_nn/layers/conv2d.rs:50 */
@@ -257,6 +258,9 @@ int dgnn_network_weight_checksum(const dgnn_network* net, uint64_t* checksum);
 /* The same range without the upload when `device` is touched for the first time: what a RECEIVER of a broadcast needs
  * (contents undefined until the collective has landed and dgnn_network_set_weight_image adopted it). */
 int dgnn_network_weight_image_reserve(dgnn_network* net, int device, void** d_image, size_t* num_bytes);
+/* ... the caller has filled that range with this network's image (e.g. a broadcast that is known to have succeeded).  Until then the
+ * range counts as empty: the first workspace on the device uploads the host image instead of running on whatever the range holds. */
+int dgnn_network_weight_image_commit(dgnn_network* net, int device);
 
 /* Weight refresh.  `src` holds a whole image (`num_bytes` == the image size) produced by a network of the SAME architecture
  * and packing -- the image starts with a header (architecture, packing, residual gates `NN_residual/alpha:0`, soft-max
@@ -264,9 +268,13 @@ int dgnn_network_weight_image_reserve(dgnn_network* net, int device, void** d_im
  * changed.  `src` is a device pointer on `device` when src_on_device != 0 (e.g. the buffer an RCCL broadcast landed in; the
  * pointer dgnn_network_weight_image returned makes the device copy a no-op) or a host pointer otherwise.  Afterwards the
  * network launches with the SENDER's gates and temperature, its host image (dgnn_network_weight_image_host / _checksum), every
- * device copy and every cached launch descriptor are the new ones.  Waits for the devices to go idle first; no forward may be
- * in flight. */
+ * device copy and every cached launch descriptor are the new ones.  Returns DGNN_BUSY, changing nothing, while any workspace of
+ * the network is checked out (a forward may be in flight): release them -- pause a leaf pool with dgnn_pool_pause -- first. */
 int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src, size_t num_bytes, int src_on_device);
+
+/* What the ranks of a broadcast must agree on before a byte moves: descriptor[0] = image bytes, descriptor[1] = a hash of the
+ * architecture and packing (not of the weights, gates or temperature).  dgnn_broadcast_weights exchanges it itself. */
+int dgnn_network_image_descriptor(const dgnn_network* net, uint64_t* descriptor /* 2 */);
 
 /* FNV-1a checksum of the image as it currently sits in `device` memory (downloads it). */
 int dgnn_network_weight_checksum_device(dgnn_network* net, int device, uint64_t* checksum);
@@ -334,6 +342,7 @@ int dgnn_cache_fetch(dgnn_cache* cache, uint64_t board_hash, int to_move, int sy
 /* cache: stores the prediction remapped by symmetry.inverse(); a key that is already present is left untouched. */
 int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy);
 int dgnn_cache_stats(dgnn_cache* cache, uint64_t* entries, uint64_t* hits, uint64_t* misses);
+int dgnn_cache_clear(dgnn_cache* cache);     /* drops every entry: the table holds the outputs of the weights that are being replaced */
 
 /* Batcher / Batch (src/libdg_mcts/pool/batch.rs:24-123).  Leaf positions from any number of games and threads are
  * pushed with a caller-chosen 64-bit tag; get_batch hands out the NEWEST max_batch_size of them once at least
@@ -408,6 +417,13 @@ int dgnn_pool_create_board_callbacks(dgnn_predict_boards_fn predict, void* predi
 int dgnn_pool_predict_boards(dgnn_pool* pool, const uint8_t* records, int batch_size, uint16_t* value_out, uint16_t* policy_out);
 int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool of board records */
 
+/* Weight refresh inside a running job (f-4: "closes the RL loop"; the reference restarts the worker process,
+ * contrib/distr-env/run_worker.py:66-77):  dgnn_pool_pause -> dgnn_broadcast_weights or dgnn_network_set_weight_image ->
+ * dgnn_cache_clear -> dgnn_pool_resume.  pause returns when no worker holds a batch or a workspace any more (so the weights may be
+ * replaced: no DGNN_BUSY); predict calls made meanwhile queue up and are answered after resume -- by the new weights. */
+int dgnn_pool_pause(dgnn_pool* pool);
+int dgnn_pool_resume(dgnn_pool* pool);
+
 /* Counters: dgnn_pool_predict calls, boards / device batches evaluated, and the same per lane (device) for the first
  * lane_capacity lanes.  Any out pointer may be NULL. */
 int dgnn_pool_stats(dgnn_pool* pool, int* num_lanes, uint64_t* calls, uint64_t* boards, uint64_t* batches,
@@ -440,7 +456,7 @@ size_t dgnn_sgf_played(char* out, size_t capacity, int color, int packed_index, 
 #define DGNN_COLOR_WHITE 1
 #define DGNN_PROBE_FOUND      1     /* ProbeResult::Found    (tree.rs:996-1004) */
 #define DGNN_PROBE_NO_RESULT  0     /* ProbeResult::NoResult: no child with a finite value */
-#define DGNN_PROBE_CONFLICT  -7     /* ProbeResult::Conflict: the chosen child is being expanded by somebody else */
+#define DGNN_PROBE_CONFLICT   2     /* ProbeResult::Conflict: the chosen child is being expanded by somebody else (a result, not an error) */
 
 typedef struct dgnn_tree_node dgnn_tree_node;   /* Node, tree.rs:1027-1051 */
 typedef struct dgnn_trace dgnn_trace;           /* NodeTrace = Vec<(node, colour, child index)>, tree.rs:1387 */

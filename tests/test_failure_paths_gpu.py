@@ -1,0 +1,189 @@
+"""Failure paths under test on a real MI355X:
+  * the split tower's give-up (injected with DGNN_SPLIT_INJECT_GIVEUP=1): the pass is repeated per layer with the right outputs,
+    the workspace runs per layer for a while, tries the split again (cool-down), and dgnn_network_synchronize re-arms it;
+    the timed / resident entry points report the give-up (DGNN_BUSY) instead of timing garbage;
+  * weights cannot be replaced while a workspace is checked out (DGNN_BUSY); a refused image changes nothing;
+  * a weight refresh under leaf-pool traffic: pause -> set_weight_image -> cache clear -> resume;
+  * a broadcast without RCCL is refused up front and leaves the network as it was.
+"""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(outputs):
+    return outputs[0].view(np.uint16).copy(), outputs[1].view(np.uint16).copy()
+
+
+def test_split_tower_giveup_repeats_the_pass_per_layer_and_rearms(api, synth, monkeypatch, capfd):
+    blocks, channels, batch = 2, 256, 8
+    text = synth.to_json(synth.make_tensors(blocks, channels, seed=610))
+    features = synth.make_features(batch, seed=611)
+    monkeypatch.setenv("DGNN_TOWER", "0")
+    net = api.Network.from_json(text)
+    with net.get_workspace(batch) as ws:
+        assert ws.conv_kernel() == "conv3x3_board_kernel"
+        want = _bits(api.forward(ws, features).unwrap())
+    net.destroy()
+    monkeypatch.setenv("DGNN_TOWER", "1")
+    monkeypatch.setenv("DGNN_SPLIT_INJECT_GIVEUP", "1")
+    net = api.Network.from_json(text)
+    ws = net.get_workspace(batch)
+    assert ws.conv_kernel() == "tower_split_kernel"
+    got = _bits(api.forward(ws, features).unwrap())                 # the launch finds the give-up word set: repeated per layer
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert "gave up" in capfd.readouterr().err
+    assert ws.conv_kernel() == "conv3x3_board_kernel"               # per layer for the next passes ...
+    for _ in range(70):                                             # ... until the cool-down has run out (64 passes)
+        got = _bits(api.forward(ws, features).unwrap())
+        assert np.array_equal(got[1], want[1])
+    assert ws.conv_kernel() == "tower_split_kernel"                 # the split is tried again and works (the injection fires once)
+    got = _bits(api.forward(ws, features).unwrap())
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ws.release()
+    net.destroy()
+
+    net = api.Network.from_json(text)                               # the same with dgnn_network_synchronize as the re-arm
+    ws = net.get_workspace(batch)
+    api.forward(ws, features)
+    assert ws.conv_kernel() == "conv3x3_board_kernel"
+    net.synchronize()
+    assert ws.conv_kernel() == "tower_split_kernel"
+    got = _bits(api.forward(ws, features).unwrap())
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ws.release()
+    net.destroy()
+
+
+def test_timed_passes_report_a_giveup_instead_of_timing_garbage(api, synth, monkeypatch):
+    monkeypatch.setenv("DGNN_SPLIT_INJECT_GIVEUP", "1")
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 256, seed=620)))
+    with net.get_workspace(16) as ws:
+        ws.upload(synth.make_features(16, seed=621))
+        assert ws.conv_kernel() == "tower_split_kernel"
+        with pytest.raises(api.Error) as e:
+            ws.forward_timed(3)
+        assert e.value.status == api.BUSY
+        total_ms, tower_ms, launches = ws.forward_timed(3)          # per layer now: a valid measurement
+        assert launches == 3 * 4 and total_ms > 0
+    net.destroy()
+
+
+def test_weights_are_not_replaced_under_a_checked_out_workspace(api, synth):
+    batch = 4
+    features = synth.make_features(batch, seed=630)
+    net_a = api.Network.from_json(synth.to_json(synth.make_tensors(2, 64, seed=631)))
+    net_b = api.Network.from_json(synth.to_json(synth.make_tensors(2, 64, seed=632, alpha=0.25)))
+    image_b = net_b.weight_image_host().copy()
+    ws = net_a.get_workspace(batch)
+    before = _bits(api.forward(ws, features).unwrap())
+    with pytest.raises(api.Error) as e:
+        net_a.set_weight_image(0, image_b.ctypes.data, image_b.size, src_on_device=False)
+    assert e.value.status == api.BUSY
+    assert np.array_equal(_bits(api.forward(ws, features).unwrap())[1], before[1])      # nothing changed
+    ws.release()
+    net_a.set_weight_image(0, image_b.ctypes.data, image_b.size, src_on_device=False)
+    with net_a.get_workspace(batch) as ws, net_b.get_workspace(batch) as wb:
+        after, want = _bits(api.forward(ws, features).unwrap()), _bits(api.forward(wb, features).unwrap())
+    assert np.array_equal(after[0], want[0]) and np.array_equal(after[1], want[1]) and not np.array_equal(after[1], before[1])
+    # the device copy of a staged image: src_on_device with a buffer that is NOT the network's own range
+    d_image, num_bytes = net_b.weight_image(0)
+    net_c = api.Network.from_json(synth.to_json(synth.make_tensors(2, 64, seed=633)))
+    net_c.set_weight_image(0, d_image, num_bytes, src_on_device=True)
+    assert net_c.weight_checksum() == net_b.weight_checksum() == net_c.weight_checksum_device(0)
+    for n in (net_a, net_b, net_c):
+        n.destroy()
+
+
+def test_weight_refresh_under_pool_traffic(api, synth):
+    """quiesce -> replace -> flush -> resume (include/dgnn.h: dgnn_pool_pause) with eight threads calling the pool throughout:
+    every answer is exactly network A's or exactly network B's, A's only before the pause, B's only after the resume."""
+    text_a = synth.to_json(synth.make_sharp_tensors(2, 64, seed=640, policy_gain=8.0, value_gain=4.0))
+    text_b = synth.to_json(synth.make_sharp_tensors(2, 64, seed=641, policy_gain=8.0, value_gain=4.0))
+    net, net_b = api.Network.from_json(text_a), api.Network.from_json(text_b)
+    board = api.Board(7.5)
+    for i, (x, y) in enumerate([(3, 3), (15, 15), (3, 15), (15, 3), (9, 9)]):
+        board.place(i % 2, x, y)
+    record = board.record(1, 2)
+    with net.get_workspace(1) as ws:
+        out_a = _bits(api.forward_boards(ws, record, 1).unwrap())
+    with net_b.get_workspace(1) as ws:
+        out_b = _bits(api.forward_boards(ws, record, 1).unwrap())
+    assert not np.array_equal(out_a[1], out_b[1])
+    image_b = net_b.weight_image_host().copy()
+
+    pool = api.LeafPool.over_devices(net, [0], max_batch_size=32, batches_per_device=2, workers_per_device=2, boards=True)
+    cache = api.LruCache(1000, num_shards=2)
+    cache.cache(board.zobrist_hash(), 1, 0, pool.predict_boards(record, 1)[0])
+    stop, seen = threading.Event(), []
+
+    def caller():
+        while not stop.is_set():
+            t = time.perf_counter()
+            p = pool.predict_boards(record, 1)[0]
+            seen.append((t, p.policy().view(np.uint16).copy(), np.asarray(p.value()).view(np.uint16).copy()))
+
+    threads = [threading.Thread(target=caller) for _ in range(8)]
+    [t.start() for t in threads]
+    time.sleep(0.2)
+    with pytest.raises(api.Error) as e:                              # without the pause a worker holds a workspace sooner or later
+        for _ in range(200):
+            net.set_weight_image(0, image_b.ctypes.data, image_b.size, src_on_device=False)
+            net.set_weight_image(0, net.weight_image_host().copy().ctypes.data, image_b.size, src_on_device=False)
+    assert e.value.status == api.BUSY
+    # (the loop above may have swapped the image back and forth before it met a busy worker: both swaps are whole, start from A again)
+    pool.pause()
+    image_a = api.Network.from_json(text_a).weight_image_host().copy()
+    net.set_weight_image(0, image_a.ctypes.data, image_a.size, src_on_device=False)
+    pool.resume()
+    time.sleep(0.1)
+    t_pause = time.perf_counter()
+    pool.pause()
+    net.set_weight_image(0, image_b.ctypes.data, image_b.size, src_on_device=False)
+    cache.clear()
+    pool.resume()
+    t_resumed = time.perf_counter()
+    time.sleep(0.2)
+    stop.set()
+    [t.join() for t in threads]
+    pool.close()
+    assert len(cache) == 0 and cache.fetch(board.zobrist_hash(), 1, 0) is None
+    is_a = lambda s: np.array_equal(s[1], out_a[1][0:362]) and s[2] == out_a[0][0]
+    is_b = lambda s: np.array_equal(s[1], out_b[1][0:362]) and s[2] == out_b[0][0]
+    late = [s for s in seen if s[0] >= t_resumed]
+    settled = [s for s in seen if t_pause - 0.08 < s[0] < t_pause - 0.02]
+    assert all(is_a(s) or is_b(s) for s in seen[len(seen) // 2:])                 # never a mixture
+    assert late and all(is_b(s) for s in late)
+    assert settled and all(is_a(s) for s in settled)
+    print(f"{len(seen)} answers under traffic, {len(late)} after the refresh: all from the new weights")
+    net.destroy()
+    net_b.destroy()
+
+
+def test_broadcast_without_rccl_is_refused_up_front(api, synth, monkeypatch):
+    """with librccl missing, receivers used to be left holding a reserved, never-filled range.  Now the
+    library is checked before anything is reserved; the single-device form needs no RCCL at all."""
+    import subprocess, sys, os
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g; g.package()\n"
+        "from dream_go_amd import api, synth\n"
+        "import numpy as np\n"
+        "assert api.lib.dgnn_rccl_available() == 0\n"
+        "net = api.Network.from_json(synth.to_json(synth.make_tensors(1, 64, seed=650)))\n"
+        "f = synth.make_features(2, seed=651)\n"
+        "with net.get_workspace(2) as ws: a = api.forward(ws, f).unwrap()[1].view(np.uint16).copy()\n"
+        "net.broadcast_weights_devices([0])\n"                       # one device: nothing to send, no RCCL needed
+        "try:\n"
+        "    api.Comm.unique_id(); raise SystemExit('unique_id worked without RCCL')\n"
+        "except api.Error as e: assert e.status == api.COMM_ERROR\n"
+        "with net.get_workspace(2) as ws: b = api.forward(ws, f).unwrap()[1].view(np.uint16).copy()\n"
+        "assert np.array_equal(a, b)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, DGNN_RCCL_DISABLE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

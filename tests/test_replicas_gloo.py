@@ -140,3 +140,41 @@ def test_pin_to_compact_cpus_takes_a_slice_per_rank(monkeypatch):
     assert replicas.pin_to_compact_cpus(0, quota=16) == list(range(32, 48))
     monkeypatch.setenv("DGNN_PIN_CPUS", "0")
     assert replicas.pin_to_compact_cpus(0, quota=16) is None
+
+
+def _mismatch_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.package()
+    from dream_go_amd import api, replicas, synth
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        same = api.Network.from_json(synth.to_json(synth.make_tensors(1, 32, num_samples=2, seed=40 + rank)))
+        other = api.Network.from_json(synth.to_json(synth.make_tensors(1 + rank, 32, num_samples=2, seed=50)))   # rank 1: another depth
+        results[rank] = dict(same=replicas.descriptors_agree(dist, torch, same.image_descriptor()),
+                             other=replicas.descriptors_agree(dist, torch, other.image_descriptor()),
+                             bytes=(same.image_descriptor()[0], other.image_descriptor()[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_with_different_architectures_are_refused_before_anything_moves():
+    """dgnn_broadcast_weights trusted every rank to hold the same num_bytes; a rank with another
+    architecture hung the collective.  The library now all-gathers (image bytes, architecture hash) first and EVERY rank returns
+    DGNN_BAD_ARGUMENT on a mismatch (csrc/rccl.cpp); this is the same exchange over gloo (replicas.descriptors_agree, what
+    bench.py --dry runs): both ranks see the refusal, nobody posts a broadcast, nobody hangs."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as manager:
+        results = manager.dict()
+        procs = [ctx.Process(target=_mismatch_worker, args=(r, world, port, results)) for port in [_free_port()] for r in range(world)]
+        [p.start() for p in procs]
+        [p.join(180) for p in procs]
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        out = {r: dict(results[r]) for r in range(world)}
+    assert out[0]["same"] and out[1]["same"]                       # other weights, same architecture: fine
+    assert not out[0]["other"] and not out[1]["other"]             # refused on BOTH ranks
+    assert out[0]["bytes"][1] != out[1]["bytes"][1]
