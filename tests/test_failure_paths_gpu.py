@@ -125,7 +125,7 @@ def test_weight_refresh_under_pool_traffic(api, synth):
         while not stop.is_set():
             t = time.perf_counter()
             p = pool.predict_boards(record, 1)[0]
-            seen.append((t, p.policy().view(np.uint16).copy(), np.asarray(p.value()).view(np.uint16).copy()))
+            seen.append((t, p._policy.view(np.uint16).copy(), p._value.view(np.uint16)))
 
     threads = [threading.Thread(target=caller) for _ in range(8)]
     [t.start() for t in threads]
@@ -135,6 +135,7 @@ def test_weight_refresh_under_pool_traffic(api, synth):
             net.set_weight_image(0, image_b.ctypes.data, image_b.size, src_on_device=False)
             net.set_weight_image(0, net.weight_image_host().copy().ctypes.data, image_b.size, src_on_device=False)
     assert e.value.status == api.BUSY
+    t_loop_end = time.perf_counter()
     # (the loop above may have swapped the image back and forth before it met a busy worker: both swaps are whole, start from A again)
     pool.pause()
     image_a = api.Network.from_json(text_a).weight_image_host().copy()
@@ -156,6 +157,8 @@ def test_weight_refresh_under_pool_traffic(api, synth):
     is_b = lambda s: np.array_equal(s[1], out_b[1][0:362]) and s[2] == out_b[0][0]
     late = [s for s in seen if s[0] >= t_resumed]
     settled = [s for s in seen if t_pause - 0.08 < s[0] < t_pause - 0.02]
+    odd = [(round(s[0] - t_pause, 4), int((s[1] != out_a[1][0:362]).sum()), int((s[1] != out_b[1][0:362]).sum())) for s in seen if not (is_a(s) or is_b(s))]
+    print(f"{len(seen)} answers, {len(odd)} neither A nor B: {odd[:12]}; swap loop ended at {round(t_loop_end - t_pause, 4)}, resumed at {round(t_resumed - t_pause, 4)}")
     assert all(is_a(s) or is_b(s) for s in seen[len(seen) // 2:])                 # never a mixture
     assert late and all(is_b(s) for s in late)
     assert settled and all(is_a(s) for s in settled)
