@@ -26,8 +26,28 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+STAMP_PATH = os.path.join(LIB_DIR, "build.stamp")
+
+
+def _stamp():
+    """What an object file depends on besides its sources: the flags and the compiler.  Toggling DGNN_ABLATIONS=1 (or any flag)
+    must not link objects built for the other setting."""
+    try:
+        version = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout.strip().splitlines()[0]
+    except Exception:   # noqa: BLE001
+        version = "unknown hipcc"
+    return " ".join(FLAGS) + "\n" + version + "\n"
+
+
+def _stamp_matches():
+    try:
+        return open(STAMP_PATH).read() == _stamp()
+    except OSError:
+        return False
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not _stamp_matches():
         return True
     built = os.path.getmtime(LIB_PATH)
     for root in (CSRC, os.path.join(HERE, "..", "include")):
@@ -52,6 +72,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    if not _stamp_matches():
+        force = True                                       # other flags or another compiler: every object is stale
     objects, running = [], []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
@@ -69,6 +91,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(STAMP_PATH, "w") as f:
+        f.write(_stamp())
     return LIB_PATH
 
 

@@ -311,6 +311,10 @@ template <bool SPLIT>
 __device__ __forceinline__ uint4 load_row(const uint16_t* p)
 {
     const auto* const g = reinterpret_cast<const __attribute__((address_space(1))) u32x4*>((__UINTPTR_TYPE__)p);   // global, not flat (store_row)
+    // SPLIT (epilogue-skip variant only): the rows come from another workgroup of this launch, so the load must not be served by
+    // this CU's L1.  hipcc has no builtin for an sc1 load of 16 bytes; the non-temporal load it does have (`nt`) bypasses the L1
+    // as well (MI355X_MICROARCH.md, visibility table: "sc1 / sc0 sc1 / nt loads bypass L1 only") and is tracked by the compiler's
+    // own waitcnt insertion, which this code path relies on.  The K-loop form (load_row_asm) spells sc1.
     const u32x4 t = SPLIT ? __builtin_nontemporal_load(g) : *g;
     return make_uint4(t[0], t[1], t[2], t[3]);
 }
@@ -322,7 +326,7 @@ __device__ __forceinline__ uint4 load_row(const uint16_t* p)
 template <bool SPLIT>
 __device__ __forceinline__ void load_row_asm(u32x4& dst, const uint16_t* p)
 {
-    if constexpr (SPLIT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+    if constexpr (SPLIT) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");   // "sc1 both sides", like the DMA of the input chunks
     else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 template <int N>
