@@ -224,6 +224,7 @@ SYMBOLS = [
     ("dgnn_pool_resume", ctypes.c_int, [_vp]),
     ("dgnn_network_weight_image_commit", ctypes.c_int, [_vp, ctypes.c_int]),
     ("dgnn_network_image_descriptor", ctypes.c_int, [_vp, _u64p]),
+    ("dgnn_forward_pipelined_timed_n", ctypes.c_int, [_vpp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     ("dgnn_go_benson_flood", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_go_candidates", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte)]),
     ("dgnn_batcher_create_boards", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
@@ -615,6 +616,17 @@ def forward_pipelined_timed(ws_a, ws_b, form, data, count, steps):
     seconds = ctypes.c_double()
     _check(lib.dgnn_forward_pipelined_timed(ws_a.handle, ws_b.handle, code, a.ctypes.data_as(ctypes.c_void_p), int(count), int(steps),
                                             ctypes.byref(seconds)), "forward_pipelined_timed")
+    return count * steps / seconds.value
+
+
+def forward_pipelined_timed_n(workspaces, form, data, count, steps):
+    """forward_pipelined_timed with len(workspaces) submissions kept in flight."""
+    code = {"planes": 0, "packed": 1, "records": 2}[form]
+    a = np.ascontiguousarray(data)
+    handles = (ctypes.c_void_p * len(workspaces))(*[w.handle for w in workspaces])
+    seconds = ctypes.c_double()
+    _check(lib.dgnn_forward_pipelined_timed_n(handles, len(workspaces), code, a.ctypes.data_as(ctypes.c_void_p), int(count), int(steps),
+                                              ctypes.byref(seconds)), "forward_pipelined_timed_n")
     return count * steps / seconds.value
 
 

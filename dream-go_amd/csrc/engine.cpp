@@ -1283,31 +1283,37 @@ int dgnn_forward_timed(dgnn_workspace* handle, int steps, float* total_ms, float
 
 // PCIe-inclusive rate as a leaf pool drives a device: two workspaces, one submission always queued behind the running one
 // (two batches alive per device, predictors/nn.rs:64-67), host buffers in, host buffers out, no interpreter in the loop.
-int dgnn_forward_pipelined_timed(dgnn_workspace* wa, dgnn_workspace* wb, int form, const void* input, int count, int steps, double* seconds)
+int dgnn_forward_pipelined_timed_n(dgnn_workspace* const* ws, int in_flight, int form, const void* input, int count, int steps, double* seconds)
 {
-    if (!wa || !wb || wa == wb || !input || count <= 0 || steps <= 0 || !seconds || form < kInputFeatures || form > kInputRecords) return DGNN_BAD_ARGUMENT;
-    dgnn_workspace* ws[2] = {wa, wb};
-    if (count > W(wa)->batch || count > W(wb)->batch) return DGNN_BAD_ARGUMENT;
+    if (!ws || in_flight < 1 || in_flight > 8 || !input || count <= 0 || steps <= 0 || !seconds || form < kInputFeatures || form > kInputRecords) return DGNN_BAD_ARGUMENT;
+    for (int i = 0; i < in_flight; ++i) {
+        if (!ws[i] || count > W(ws[i])->batch) return DGNN_BAD_ARGUMENT;
+        for (int j = 0; j < i; ++j) if (ws[i] == ws[j]) return DGNN_BAD_ARGUMENT;
+    }
     std::vector<uint16_t> value((size_t)count), policy((size_t)count * DGNN_NUM_MOVES);
     auto submit = [&](dgnn_workspace* w) {
         return form == kInputFeatures ? dgnn_forward_submit_n(w, static_cast<const uint16_t*>(input), count)
              : form == kInputPacked   ? dgnn_forward_submit_packed(w, static_cast<const uint32_t*>(input), count)
                                       : dgnn_forward_submit_boards(w, static_cast<const uint8_t*>(input), count);
     };
-    int status = submit(ws[0]);                                  // warm: both workspaces have run once before the clock starts
-    if (status == DGNN_OK) status = submit(ws[1]);
-    if (status == DGNN_OK) status = dgnn_forward_wait(ws[0], value.data(), policy.data());
-    if (status == DGNN_OK) status = dgnn_forward_wait(ws[1], value.data(), policy.data());
+    int status = DGNN_OK;                                        // warm: every workspace has run once before the clock starts
+    for (int i = 0; i < in_flight && status == DGNN_OK; ++i) status = submit(ws[i]);
+    for (int i = 0; i < in_flight && status == DGNN_OK; ++i) status = dgnn_forward_wait(ws[i], value.data(), policy.data());
     if (status != DGNN_OK) return status;
     const long long t0 = now_ns();
-    status = submit(ws[0]);
-    for (int i = 1; i < steps && status == DGNN_OK; ++i) {
-        status = submit(ws[i & 1]);
-        if (status == DGNN_OK) status = dgnn_forward_wait(ws[(i - 1) & 1], value.data(), policy.data());
+    int submitted = 0, waited = 0;
+    while (waited < steps && status == DGNN_OK) {
+        while (submitted < steps && submitted - waited < in_flight && status == DGNN_OK) status = submit(ws[submitted++ % in_flight]);
+        if (status == DGNN_OK) status = dgnn_forward_wait(ws[waited++ % in_flight], value.data(), policy.data());
     }
-    if (status == DGNN_OK) status = dgnn_forward_wait(ws[(steps - 1) & 1], value.data(), policy.data());
     *seconds = (double)(now_ns() - t0) * 1e-9;
     return status;
+}
+
+int dgnn_forward_pipelined_timed(dgnn_workspace* wa, dgnn_workspace* wb, int form, const void* input, int count, int steps, double* seconds)
+{
+    dgnn_workspace* const both[2] = {wa, wb};
+    return dgnn_forward_pipelined_timed_n(both, 2, form, input, count, steps, seconds);
 }
 
 // ---------------------------------------------------------------------------------------------- layer level

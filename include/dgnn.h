@@ -217,6 +217,9 @@ int dgnn_forward_timed(dgnn_workspace* ws, int steps, float* total_ms, float* to
  * Host buffer in, host buffers out, no interpreter in the loop.  form: 0 = fp16 planes (dgnn_forward_submit_n), 1 = packed words
  * (dgnn_forward_submit_packed), 2 = board records (dgnn_forward_submit_boards).  *seconds = wall time of the `steps` evaluations. */
 int dgnn_forward_pipelined_timed(dgnn_workspace* a, dgnn_workspace* b, int form, const void* input, int count, int steps, double* seconds);
+/* The same with `in_flight` (1..8) distinct workspaces: as many submissions are kept queued on the device. */
+int dgnn_forward_pipelined_timed_n(dgnn_workspace* const* workspaces, int in_flight, int form, const void* input, int count, int steps,
+                                   double* seconds);
 
 /* ---- layer-level entry point (parity tests) --------------------------------------------------- */
 

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batches", type=str, default="1,2,4,8,16,32,64,128,256")
+    ap.add_argument("--in-flight", action="store_true",
+                    help="also: two and three submissions of that size in flight (what a leaf pool keeps on a device, predictors/nn.rs:64-67), "
+                         "PCIe-inclusive, the loop inside the library (dgnn_forward_pipelined_timed)")
     args = ap.parse_args()
     net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
     for batch in [int(b) for b in args.batches.split(",")]:
@@ -40,12 +43,18 @@ def main():
             for _ in range(5):
                 api.forward(ws, features)
             dt = time.perf_counter() - t0
-            print(json.dumps({
+            line = {
                 "net": f"{args.blocks}x{args.channels}", "batch": batch, "kernel": ws.conv_kernel(),
                 "evals_per_sec_resident": batch * args.steps / (total_ms * 1e-3), "ms_per_pass": total_ms / args.steps,
                 "residual_conv_us": tower_ms / max(launches, 1) * 1e3,
                 "evals_per_sec_host_buffers": batch * 5 / dt,
-            }), flush=True)
+            }
+            if args.in_flight:
+                packed = api.features_pack(features, batch)
+                with net.get_workspace(batch) as ws2, net.get_workspace(batch) as ws3:
+                    line["evals_per_sec_two_in_flight"] = api.forward_pipelined_timed_n([ws, ws2], "packed", packed, batch, 2 * args.steps)
+                    line["evals_per_sec_three_in_flight"] = api.forward_pipelined_timed_n([ws, ws2, ws3], "packed", packed, batch, 3 * args.steps)
+            print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
