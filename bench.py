@@ -67,8 +67,12 @@ def parse_args(argv=None):
                     help="where the 32 feature planes are built: on the device from 896-byte board records (default), or on the host like the reference")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
+    ap.add_argument("--lean", action="store_true", help="only the engine measurement (profiling passes): no PCIe-inclusive, reference-style or self-play legs")
     ap.add_argument("--dry", action="store_true", help="no GPU: gloo + the CPU hash predictor behind the leaf pool (CPU tests of the N > 1 path)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.lean:
+        args.selfplay_games, args.cpu_sample = 0, 0
+    return args
 
 
 def free_port():
@@ -449,7 +453,7 @@ def main():
                         "engine alone would allow; the pipeline figure is selfplay.games_per_hour",
             }
         # ---- PCIe-inclusive: host buffers in, host buffers out (the drop-in's own contract, graph.rs:130-131,155-156), never `value`
-        if world == 1 and not job.dry:
+        if world == 1 and not job.dry and not args.lean:
             positions = real_game_positions(api)
             # (a) as a leaf pool drives the device: two workspaces, one submission always queued, the loop inside the library
             ws2 = net.get_workspace(args.batch, device=device)

@@ -226,6 +226,12 @@ struct Split {
     static constexpr int CW = SL / CT;                 // waves along the channels
     static constexpr bool Chunked = NS <= 2;
     static constexpr bool AsmMfma = NS == 16;
+    // DirectA (round 3, the wide variant): the A (filter) fragments go from memory straight into the registers of the NEXT k-step
+    // (global_load_dwordx4, one k-step = 1536 MFMA-cycles ahead: more than a trip to HBM) instead of through a wave-private LDS
+    // ring.  With one wave per 64 channels no two waves ever want the same filter bytes, so the ring bought nothing but prefetch
+    // depth -- at the price of 16 KiB of LDS writes, four LDS-DMA instructions (the dearest instruction to issue beside MFMAs) and
+    // four ds_read_b128 per k-step and wave.
+    static constexpr bool DirectA = NS == 16;
     static constexpr int WAVES = NS == 1 ? 12 : NS == 16 ? 4 : 8;
     static constexpr int Threads = WAVES * 64;
     static constexpr int XP = (4 * kPieces + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
@@ -236,7 +242,7 @@ struct Split {
     static constexpr int RingBytes = kRing * SlabBytes;
     static constexpr int FChunkBytes = 9 * NS * 2048;  // Chunked: the workgroup's filter rows of one chunk, [tap][slice][k16][lane][8]
     static constexpr int BufStride = Chunked ? kXBufBytes + FChunkBytes : kXBufBytes;   // one of the two chunk buffers
-    static constexpr int LdsBytes = Chunked ? 2 * BufStride : kWBase + WAVES * RingBytes;
+    static constexpr int LdsBytes = Chunked ? 2 * BufStride : DirectA ? kWBase : kWBase + WAVES * RingBytes;
     static constexpr int Pieces = 4 * kPieces + 18 * NS;            // Chunked: DMA instructions per chunk, activations then filter
     static constexpr int PPW = (Pieces + WAVES - 1) / WAVES;        // ... per wave (4 at NS = 1, 8 at NS = 2; surplus ones repeat)
     // Chunked: piece j of a wave goes out behind the MFMA of pair piece_pair(j) of tap piece_tap(j) (early in the chunk: it
@@ -340,6 +346,17 @@ __device__ __forceinline__ void wait_z(u32x4& z0, u32x4& z1, u32x4& z2, u32x4& z
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3) : "n"(N) : "memory");
 }
 
+// DirectA: a filter fragment straight into registers, and the counted wait that hands four of them to the MFMAs behind it
+__device__ __forceinline__ void load_a_asm(half8& dst, const uint16_t* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_a(half8& a0, half8& a1, half8& a2, half8& a3)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N) : "memory");
+}
+
 // SKIP: 0 = no skip input, 1 = skip added in the epilogue (general), 2 = skip accumulated DURING the K loop (alpha1 != 0):
 // the row tiles of z are fetched one at a time while the memory system is otherwise idle and added to the fp32
 // accumulators as (alpha2 / alpha1) * z, so that the epilogue is store-only.  (With the skip read in the epilogue all
@@ -363,6 +380,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP, SL = S::SL;
     constexpr bool CHUNKED = S::Chunked;
     constexpr bool ASM = S::AsmMfma;                 // MFMAs from inline asm, accumulators of row tiles 0..7 in AGPRs (Split<16>)
+    constexpr bool DIRECT_A = S::DirectA;            // filter fragments by global loads into the next step's registers, no LDS ring
+    static_assert(!DIRECT_A || (ASM && CT == 2 && !CHUNKED && W == 4), "DirectA is written for the wide split");
     static_assert(!ASM || ABL == 0, "no ablations of the asm variant");
     constexpr int BUF = S::BufStride;
     static_assert(!CHUNKED || !(ABL & ~1), "the chunked kernels know ablation 1 (no MFMAs) only");
@@ -565,7 +584,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
 #pragma unroll
         for (int j = 0; j < XP; ++j) issue_x(0, buf0, j);
     }
-    if (!carry_in) {
+    if constexpr (DIRECT_A) {
+    } else if (!carry_in) {
         if constexpr (CHUNKED) {
             for (int q = wave; q < 18 * NS; q += S::WAVES) issue_f(0, buf0, q);
         } else {
@@ -573,6 +593,19 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             for (int s = 0; s < kRing; ++s) issue_w(s, s);
         }
     }
+    half8 af[2][CT][2];                               // [step parity][channel tile][k16]
+    // DirectA: fragment F = ct * 2 + k16 of k-step `st` of this wave's two filter tiles -> af[PAR]; steps past the last one read
+    // the next layer's filter (or the padding behind the last layer's): never used, they only keep every step alike
+    auto load_a = [&](auto par_c, int st) {
+        constexpr int PAR = decltype(par_c)::value;
+        const uint16_t* src = w_wave + (long)st * step_halfs;
+        asm volatile("" : "+v"(src));
+        static_for<W>([&](auto fc) {
+            constexpr int F = decltype(fc)::value;
+            load_a_asm(af[PAR][F / 2][F % 2], src + F * 512);
+        });
+    };
+    if constexpr (DIRECT_A) load_a(std::integral_constant<int, 0>(), 0);
     wait_vmcnt<0>();
     __syncthreads();
     const unsigned long long t_loop = tracing ? __builtin_amdgcn_s_memtime() : 0;
@@ -593,7 +626,6 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     // lds_younger() counts, for every MFMA, the LDS reads issued after the ones it needs (LDS returns in order).
     // Chunked kernels: the A fragments come out of the chunk buffer (tap-major), so tap 8 cannot request its successor's
     // (other buffer, published by the chunk barrier): tap 0 requests its own in front of its first B fragments.
-    half8 af[2][CT][2];                               // [step parity][channel tile][k16]
     half8 bf[BD];
     auto read_a = [&](auto par_c, auto off_c, unsigned addr) {       // the W fragments (tile, k16) of the slab at ring offset OFF
         constexpr int PAR = decltype(par_c)::value, OFF = decltype(off_c)::value;
@@ -608,7 +640,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         else wait_lgkm<Y>(b0, af[PAR][0][0], af[PAR][0][1], af[PAR][1][0], af[PAR][1][1]);
     };
     // step 0 of the layer (slab 0 landed: the prologue waited for everything)
-    if constexpr (PIPE && !CHUNKED) read_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), w_addr);
+    if constexpr (PIPE && !CHUNKED && !DIRECT_A) read_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), w_addr);
     auto run_chunk = [&](int chunk, auto zc_c) {
         constexpr int ZC = decltype(zc_c)::value;
         const int buf = (chunk + buf0) & 1;
@@ -660,8 +692,17 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 constexpr int I = decltype(ic)::value;
                 constexpr int K16 = I / RT, RTI = I % RT;
                 if constexpr (PIPE) {
-                    constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair(), CHUNKED, W>(I, FIRST, LAST);
-                    if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, P>(), bf[PH % BD]);
+                    constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair(), CHUNKED, (DIRECT_A ? 0 : W)>(I, FIRST, LAST);
+                    if constexpr (I == 0 && DIRECT_A) {
+                        // this step's A fragments were requested during the previous step (pairs w_pair(0..3)); younger than them are
+                        // that step's activation piece and the skip rows it asked for at its end
+                        constexpr int PT = (TAP + 8) % 9;                         // the previous tap
+                        constexpr bool Z_PREV = ZC >= 0 && TAP >= 1 && PT <= 5 && ZC * 6 + PT < 12;
+                        constexpr int N_A = FIRST ? 0 : (PT < XP ? 1 : 0) + (Z_PREV ? 2 * CT : 0);
+                        wait_a<N_A>(af[P][0][0], af[P][0][1], af[P][1][0], af[P][1][1]);
+                        wait_lgkm<YOUNGER>(bf[PH % BD]);
+                    }
+                    else if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, P>(), bf[PH % BD]);
                     else wait_lgkm<YOUNGER>(bf[(PH + I) % BD]);
                 } else {
                     constexpr bool MORE = I + BD - 1 < NP && !(ABL & 4);
@@ -686,7 +727,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 if constexpr (PIPE) {
                     if constexpr (I == S::a_pair() && CHUNKED) {
                         if constexpr (!LAST) read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr_c);
-                    } else if constexpr (I == S::a_pair()) {
+                    } else if constexpr (I == S::a_pair() && !DIRECT_A) {
                         if constexpr (!(ABL & 8)) wait_vmcnt<N_NEXT>();
                         read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr);
                     }
@@ -712,7 +753,15 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                         constexpr int J = decltype(jc)::value;
                         if constexpr (I == S::w_pair(J % W) + J / W) {
                             __builtin_amdgcn_sched_barrier(0);
-                            issue_w_piece(st0 + TAP + kRing, TAP % kRing, J % W);
+                            if constexpr (DIRECT_A) {
+                                // fragment J of the NEXT step into the other half of af: its last readers, the MFMAs of the
+                                // previous step, were issued a k-step ago
+                                const uint16_t* src = w_wave + (long)(st0 + TAP + 1) * step_halfs + J * 512;
+                                asm volatile("" : "+v"(src));
+                                load_a_asm(af[P ^ 1][J / 2][J % 2], src);
+                            } else {
+                                issue_w_piece(st0 + TAP + kRing, TAP % kRing, J % W);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     });
@@ -767,6 +816,15 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             wait_vmcnt<WI * (8 - (XP - 1))>();
         }
         if constexpr (CHUNKED) {
+        } else if constexpr (DIRECT_A) {
+            // tap 8 asked for the next step's A fragments into af[1]; tap 0 of the next chunk looks in af[0].  They were requested
+            // most of a k-step ago (and the barrier below waits for the slowest wave anyway)
+            wait_a<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                af[0][ct][0] = af[1][ct][0];
+                af[0][ct][1] = af[1][ct][1];
+            }
         } else if constexpr (PIPE) {
             // the only LDS reads still out are the A fragments of the next step (tap 8 requests no B read-ahead); tap 8
             // left them in af[1], tap 0 of the next chunk looks in af[0]
