@@ -341,17 +341,53 @@ def _conv3x3_numpy(x, w_krsc, bias, alpha1=1.0, alpha2=0.0, z=None, relu=True):
     return _r16(y).reshape(b, h, wd, cout)
 
 
-def forward_numpy(net, features, batch):
-    """Same dataflow as dgo_forward with numpy float32 GEMMs (different summation order)."""
+# Winograd F(2x2, 3x3) (Lavin & Gray 2015), emulated with the operand precisions a MI355X kernel would use: the transformed
+# filter U = G g G^T and the transformed input tile V = B^T d B are rounded to fp16 (MFMA operands), the 16 element-wise channel
+# contractions accumulate in fp32, the output transform A^T M A is fp32.  A NUMERICS study only: is the
+# 2.25x cheaper form inside the 1e-3 contract on this network?  tests/test_winograd_numerics.py, tools/winograd_numerics.py.
+_WG_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float32)
+_WG_G = np.array([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=np.float32)
+_WG_AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float32)
+
+
+def _conv3x3_winograd(x, w_krsc, bias, alpha1=1.0, alpha2=0.0, z=None, relu=True):
+    """Same contract as _conv3x3_numpy, through F(2x2, 3x3) with fp16 transformed operands and fp32 accumulation."""
+    b, h, wd, cin = x.shape
+    cout = w_krsc.shape[0]
+    th, tw = (h + 1) // 2, (wd + 1) // 2                               # 2x2 output tiles (10 x 10 on a 19 x 19 board)
+    xp = np.zeros((b, 2 * th + 2, 2 * tw + 2, cin), dtype=np.float32)
+    xp[:, 1:h + 1, 1:wd + 1, :] = x
+    # d[b, ty, tx, i, j, c] = xp[b, 2 ty + i, 2 tx + j, c]
+    d = np.stack([np.stack([xp[:, i:i + 2 * th:2, j:j + 2 * tw:2, :] for j in range(4)], axis=3) for i in range(4)], axis=3)
+    v = _r16(np.einsum("ik,btukld,jl->btuijd", _WG_BT, d, _WG_BT, optimize=True))        # B^T d B, rounded to fp16
+    u = _r16(np.einsum("ik,oklc,jl->ijoc", _WG_G, w_krsc, _WG_G, optimize=True))         # G g G^T, rounded to fp16
+    m = np.empty((b, th, tw, 4, 4, cout), dtype=np.float32)
+    for i in range(4):
+        for j in range(4):
+            m[:, :, :, i, j, :] = (v[:, :, :, i, j, :].reshape(-1, cin) @ u[i, j].T).reshape(b, th, tw, cout)   # fp32 accumulate
+    yt = np.einsum("ik,btuklo,jl->btuijo", _WG_AT, m, _WG_AT, optimize=True)              # A^T M A: [b, ty, tx, 2, 2, cout]
+    y = yt.transpose(0, 1, 3, 2, 4, 5).reshape(b, 2 * th, 2 * tw, cout)[:, :h, :wd, :].reshape(-1, cout)
+    y = np.float32(alpha1) * y + bias[None, :]
+    if alpha2 != 0.0:
+        y = y + np.float32(alpha2) * z.reshape(-1, cout)
+    if relu:
+        y = np.maximum(y, 0.0)
+    return _r16(y).reshape(b, h, wd, cout)
+
+
+def forward_numpy(net, features, batch, tower_conv=None):
+    """Same dataflow as dgo_forward with numpy float32 GEMMs (different summation order).  tower_conv: the convolution used for
+    the 2 * blocks residual layers (default the direct form; _conv3x3_winograd for the numerics study)."""
+    tower = tower_conv or _conv3x3_numpy
     c, s = net.num_channels, net.num_samples
     f = lambda a: a.view(np.float16).astype(np.float32)
     x = f(np.ascontiguousarray(features).view(np.uint16)).reshape(batch, 19, 19, NUM_FEATURES)
     t = _conv3x3_numpy(x, f(net.up_w).reshape(c, 3, 3, NUM_FEATURES), f(net.up_b))
     for r in net.res:
         a = np.float32(r["alpha"])
-        y = _conv3x3_numpy(t, f(r["w1"]).reshape(c, 3, 3, c), f(r["b1"]))
+        y = tower(t, f(r["w1"]).reshape(c, 3, 3, c), f(r["b1"]))
         b2 = _r16(a * f(r["b2"]))
-        t = _conv3x3_numpy(y, f(r["w2"]).reshape(c, 3, 3, c), b2, alpha1=a, alpha2=np.float32(1.0) - a, z=t)
+        t = tower(y, f(r["w2"]).reshape(c, 3, 3, c), b2, alpha1=a, alpha2=np.float32(1.0) - a, z=t)
     v1 = _conv3x3_numpy(t, f(net.value_conv_w).reshape(2, 3, 3, c), f(net.value_conv_b)).reshape(batch, 722)
     v2 = _r16(v1 @ f(net.value_linear_w)[:722].reshape(722, 1) + f(net.value_linear_b)[:1])
     value = _r16(np.tanh(v2)).reshape(batch)
