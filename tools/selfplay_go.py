@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
     ap.add_argument("--cache-per-game", type=int, default=0, help="> 0: a private table per game (reproducible games) instead of the shared one")
     ap.add_argument("--sgf", default=None)
+    ap.add_argument("--planes", choices=["device", "host"], default="device",
+                    help="where the feature planes are built: on the device from 896-byte board records (dgnn_forward_boards), or on the host")
+    ap.add_argument("--host-threads", type=int, default=2, help="the games in flight run as fibers on this many host threads (0 = one OS thread per game)")
     args = ap.parse_args()
 
     # one process per GPU (python -m torch.distributed.run --nproc-per-node N tools/selfplay_go.py ...): every rank owns an
@@ -60,15 +63,19 @@ def main():
         sys.path.insert(0, ROOT)
         import bench
         broadcast = bench.broadcast_weights(net, device, torch, dist, replicas)
-    batcher = api.Batcher(net, args.max_batch, args.max_batches, device=device)
-    pool = api.LeafPool(batcher, args.max_batches)
+    import time
+    pool = api.LeafPool.over_devices(net, [device], max_batch_size=args.max_batch, batches_per_device=args.max_batches,
+                                    workers_per_device=args.max_batches, boards=args.planes == "device")
     api.selfplay_go(2, 1, 16, 2, seed=1, pool=pool)          # warm: workspace, weight upload
     cache = api.LruCache(args.cache, 8) if args.cache > 0 else None
-    before = batcher.stats()
+    before = pool.stats()
+    cpu0, wall0 = time.process_time(), time.perf_counter()
     stats = replicas.selfplay_sharded(api, dist, torch, args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
                                       return_sgf=args.sgf is not None, device=f"cuda:{device}" if dist is not None else "cpu",
-                                      num_parallel=args.parallel, ex_it_rollouts=args.ex_it, leaves_per_thread=args.leaves, cache_per_game=args.cache_per_game)
-    after = batcher.stats()
+                                      num_parallel=args.parallel, ex_it_rollouts=args.ex_it, leaves_per_thread=args.leaves, cache_per_game=args.cache_per_game,
+                                      host_threads=args.host_threads)
+    host_cpus_busy = (time.process_time() - cpu0) / max(time.perf_counter() - wall0, 1e-9)
+    after = pool.stats()
     if args.sgf:
         with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
             f.write("\n".join(stats.get("sgf", [])) + "\n")
@@ -89,6 +96,7 @@ def main():
             "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1),
             "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
             "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
+            "feature_planes": args.planes, "host_threads": args.host_threads, "host_cpus_busy_rank0": host_cpus_busy,
             "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
             "sharding": "game_id mod world, one engine + batcher + pool + cache per rank, no data-path collective",
             "note": "real board / ladders / feature planes / Benson scoring (go.cpp), self_play_one game loop, PCIe-inclusive, random-init net",
