@@ -250,6 +250,19 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     assert run.returncode == 1 and "missing weights" in run.stderr
 
 
+def test_board_record_example_in_c(tmp_path):
+    """examples/forward_boards.c (strict C99): the record of a position, expanded by the host statement of the device kernel, equals
+    features::V1's planes; without a weights file the device half is skipped."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "forward_boards_example"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "forward_boards.c"), "-L" + os.path.join(root, "dream-go_amd", "lib"),
+                    "-ldgnn_hip", "-Wl,-rpath," + os.path.join(root, "dream-go_amd", "lib"), "-o", str(exe)], check=True)
+    run = subprocess.run([str(exe), str(tmp_path / "nothing.json")], capture_output=True, text=True)
+    assert run.returncode == 0 and "planes from the record equal the planes of features::V1" in run.stdout, run.stdout + run.stderr
+
+
 def test_selfplay_example_in_c(tmp_path):
     """examples/selfplay.c: the host rows (board, search, cache, game records) from strict C99 through the same header; without
     a weights file it plays on the CPU stand-in predictor, so it runs here."""

@@ -1,8 +1,11 @@
 // Driver for tools/sanitize_host.sh: whole self-play jobs on the CPU stand-in predictor (whole games with per-game tables and
 // batched leaves; expert iteration with four racing search threads and a shared table; games started as others end; the
 // synthetic game with eight threads per search), so that AddressSanitizer / UBSan / ThreadSanitizer see the host rows at work.
+#include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 #include "dgnn.h"
 int main() {
@@ -40,6 +43,52 @@ int main() {
                     (unsigned long long)boards, (unsigned long long)batches);
         dgnn_pool_destroy(pool);
         dgnn_batcher_destroy(batcher);
+        dgnn_cache_destroy(cache);
+    }
+    {   // round 3: board records through a records pool (the dry device), pause / cache clear / resume while games run
+        dgnn_pool* pool = nullptr;
+        dgnn_cache* cache = nullptr;
+        dgnn_dry_device device{100.0, 1.0};
+        dgnn_pool_create_board_callbacks(dgnn_hash_boards_predictor(), &device, 1, 32, 2, 2, &pool);
+        dgnn_cache_create(20000, 4, &cache);
+        dgnn_selfplay_params p{};
+        p.num_games = 16; p.num_parallel = 16; p.game_stride = 1; p.max_moves = 30; p.num_rollouts = 48; p.threads_per_search = 2;
+        p.leaves_per_thread = 4; p.seed = 78; p.host_threads = 0;
+        dgnn_selfplay_stats st;
+        std::thread refresher([&] {
+            for (int i = 0; i < 5; ++i) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(30));
+                dgnn_pool_pause(pool);
+                dgnn_cache_clear(cache);
+                dgnn_pool_resume(pool);
+            }
+        });
+        int rc = dgnn_selfplay_go_boards(dgnn_pool_boards_predictor(), pool, cache, &p, &st, nullptr, nullptr, 0);
+        refresher.join();
+        std::printf("records pool rc %d moves %llu evals %llu hits %llu\n", rc, (unsigned long long)st.moves, (unsigned long long)st.evals,
+                    (unsigned long long)st.cache_hits);
+        // ... and every record of a game against the host statement of the device kernel
+        dgnn_go_board* board = dgnn_go_board_new(6.5f);
+        std::vector<uint8_t> record(DGNN_BOARD_RECORD_BYTES);
+        std::vector<uint32_t> packed(DGNN_PACKED_WORDS), expect(DGNN_PACKED_WORDS);
+        std::vector<uint16_t> planes(DGNN_FEATURE_SIZE);
+        unsigned rng = 12345, mismatches = 0;
+        for (int m = 0, color = 0; m < 200; ++m) {
+            for (int tries = 0; tries < 50; ++tries) {
+                rng = rng * 1664525u + 1013904223u;
+                const int pnt = (int)((rng >> 8) % 361);
+                if (dgnn_go_is_valid(board, color, pnt % 19, pnt / 19)) { dgnn_go_place(board, color, pnt % 19, pnt / 19); break; }
+            }
+            color ^= 1;
+            dgnn_go_board_record(board, color, m % 8, record.data());
+            dgnn_board_records_to_packed(record.data(), 1, packed.data());
+            dgnn_go_features(board, color, m % 8, planes.data());
+            dgnn_features_pack(planes.data(), 1, expect.data());
+            mismatches += packed != expect;
+        }
+        std::printf("records vs planes: %u mismatches\n", mismatches);
+        dgnn_go_board_free(board);
+        dgnn_pool_destroy(pool);
         dgnn_cache_destroy(cache);
     }
     // synthetic self-play with many threads

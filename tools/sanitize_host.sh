@@ -21,14 +21,50 @@ int dgnn_forward_n(dgnn_workspace*, const uint16_t* features, int n, uint16_t* v
 {
     return dgnn_hash_predictor()(nullptr, features, n, value, policy);
 }
+int dgnn_forward_boards(dgnn_workspace*, const uint8_t* records, int n, uint16_t* value, uint16_t* policy)
+{
+    return dgnn_hash_boards_predictor()(nullptr, records, n, value, policy);
+}
+// engine.cpp's pack / unpack of the plane words (host code, restated for the stand-in)
+int dgnn_features_unpack(const uint32_t* packed, int count, uint16_t* f)
+{
+    for (int b = 0; b < count; ++b)
+        for (int pos = 0; pos < 361; ++pos)
+            for (int c = 0; c < 32; ++c) {
+                const uint32_t* in = packed + (size_t)b * DGNN_PACKED_WORDS;
+                f[(size_t)b * DGNN_FEATURE_SIZE + pos * 32 + c] = !((in[pos] >> c) & 1u) ? 0 : c == 0 ? (uint16_t)(in[361] & 0xffff) : c == 1 ? (uint16_t)(in[361] >> 16) : 0x3c00;
+            }
+    return DGNN_OK;
+}
+int dgnn_features_pack(const uint16_t* features, int count, uint32_t* packed)
+{
+    for (int b = 0; b < count; ++b) {
+        uint16_t v[2] = {0, 0};
+        uint32_t* out = packed + (size_t)b * DGNN_PACKED_WORDS;
+        for (int pos = 0; pos < 361; ++pos) {
+            uint32_t mask = 0;
+            for (int c = 0; c < 32; ++c) {
+                const uint16_t h = features[(size_t)b * DGNN_FEATURE_SIZE + pos * 32 + c];
+                if ((h & 0x7fff) == 0) continue;
+                if (c < 2) v[c] = h;
+                mask |= 1u << c;
+            }
+            out[pos] = mask;
+        }
+        out[361] = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+        for (int i = 362; i < DGNN_PACKED_WORDS; ++i) out[i] = 0;
+    }
+    return DGNN_OK;
+}
 void dgnn_workspace_release(dgnn_workspace*) {}
 int dgnn_device_count(int* count) { *count = 1; return DGNN_OK; }
 }
 STUBS
-FILES="$SRC/go.cpp $SRC/batcher.cpp $SRC/formats.cpp $SRC/tree.cpp $SRC/search.cpp $SRC/loader.cpp $TMP/stubs.cpp $ROOT/tools/sanitize_host.cpp"
-g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/asan" -lpthread
+FILES="$SRC/go.cpp $SRC/batcher.cpp $SRC/formats.cpp $SRC/tree.cpp $SRC/search.cpp $SRC/loader.cpp $SRC/fiber.cpp $TMP/stubs.cpp $ROOT/tools/sanitize_host.cpp"
+# (fibers switch stacks by hand: the sanitizer builds define DGNN_NO_FIBERS and run a thread per game, like host_threads = 0)
+g++ -O1 -g -std=c++17 -DDGNN_NO_FIBERS -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/asan" -lpthread
 echo "== AddressSanitizer + UBSan"; "$TMP/asan"
-g++ -O1 -g -std=c++17 -fsanitize=thread -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/tsan" -lpthread
+g++ -O1 -g -std=c++17 -DDGNN_NO_FIBERS -fsanitize=thread -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/tsan" -lpthread
 echo "== ThreadSanitizer"; TSAN_OPTIONS="halt_on_error=0" "$TMP/tsan" > "$TMP/tsan.out" 2>&1 || true
 grep -A6 "WARNING: ThreadSanitizer" "$TMP/tsan.out" | grep -E "#0" | sed 's/0x[0-9a-f]* //' | awk '{print $2, $3}' | sort | uniq -c | sort -rn
 tail -4 "$TMP/tsan.out"
