@@ -219,6 +219,7 @@ SYMBOLS = [
     ("dgnn_board_records_to_packed_device", ctypes.c_int, [ctypes.c_int, _u8p, ctypes.c_int, _u32p]),
     ("dgnn_go_board_record", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u8p]),
     ("dgnn_forward_pipelined_timed", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    ("dgnn_tree_node_to_pretty", ctypes.c_size_t, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     ("dgnn_cache_clear", ctypes.c_int, [_vp]),
     ("dgnn_pool_pause", ctypes.c_int, [_vp]),
     ("dgnn_pool_resume", ctypes.c_int, [_vp]),
@@ -1135,6 +1136,12 @@ class Node:
         _check(lib.dgnn_tree_node_softmax(self._handle, out.ctypes.data_as(_fp)), "Node.softmax")
         return out
 
+    def to_pretty(self):
+        """tree::to_pretty (tree.rs:1683-1731): the search summary stored with a move as C[]."""
+        buf = ctypes.create_string_buffer(4096)
+        lib.dgnn_tree_node_to_pretty(self._handle, buf, len(buf))
+        return buf.value.decode("ascii")
+
     def best(self, temperature, at=0.0):
         value, index = ctypes.c_float(), ctypes.c_int()
         _check(lib.dgnn_tree_node_best(self._handle, float(temperature), float(at), ctypes.byref(value), ctypes.byref(index)), "Node.best")
@@ -1422,7 +1429,7 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     if num_moves <= 0 or num_moves > 722:
         num_moves = 722
     moves = np.full(num_games * num_moves, -1, dtype=np.int32) if return_moves else None
-    sgf = ctypes.create_string_buffer(num_games * (num_moves * 1100 + 4 * 722 * 6 + 2048)) if return_sgf else None
+    sgf = ctypes.create_string_buffer(num_games * (num_moves * 2600 + 4 * 722 * 6 + 2048)) if return_sgf else None
     params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
                             int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed),
                             int(host_threads), 0, None)
@@ -1438,5 +1445,5 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     if return_moves:
         out["record"] = moves.reshape(num_games, num_moves)
     if return_sgf:
-        out["sgf"] = sgf.value.decode("ascii").splitlines()
+        out["sgf"] = [g for g in sgf.value.decode("ascii").split("\n") if g]     # (a record holds carriage returns: C[] text, self_play.rs:192)
     return out

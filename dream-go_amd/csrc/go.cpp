@@ -1365,8 +1365,8 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                 dgnn_tree_node_best(root, (!deterministic && board.count < 8) ? 0.8f : 0.0f, rng.uniform(), value_out, index_out);   // lib.rs:188-192
                 return root;
             };
-            // Played::from_mcts (self_play.rs:120-137): TR[] = the best move of the tree's prior, TV[] = the tree's size, P[] = its
-            // visit distribution.  (The reference also stores a pretty-printed principal variation as C[]; not reproduced.)
+            // Played::from_mcts (self_play.rs:120-137): C[] = tree::to_pretty, TR[] = the best move of the tree's prior, TV[] = the
+            // tree's size, P[] = its visit distribution.
             auto record_mcts = [&](char* out, size_t capacity, int point, float value, const dgnn_tree_node* tree) {
                 float softmax[DGNN_NUM_MOVES], tree_prior[DGNN_NUM_MOVES + 6];
                 dgnn_tree_node_softmax(tree, softmax);
@@ -1376,7 +1376,9 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                 if (prior_index < 0) prior_index = kPass;                      // Node::prior, tree.rs:1285-1289
                 int total = 0;
                 dgnn_tree_node_info(tree, nullptr, &total, nullptr, nullptr, nullptr);
-                dgnn_sgf_played(out, capacity, me, point, total, softmax, 1, value, prior_index, "");
+                char explain[2048];                                            // tree::to_pretty: eleven lines at most
+                if (dgnn_tree_node_to_pretty(tree, explain, sizeof(explain)) > sizeof(explain)) explain[0] = '\0';
+                dgnn_sgf_played(out, capacity, me, point, total, softmax, 1, value, prior_index, explain);
             };
             // Player::ex_it (self_play.rs:277-305) behind is_good_candidate (:315-319): one move in twenty gets a fresh, full-size
             // search whose visit distribution and value replace the record's; the move that was chosen stays
@@ -1393,7 +1395,7 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
             };
 
             int played = kPass;
-            char move[2048];
+            char move[4608];
             move[0] = '\0';
             if (limit > 1) {                                                   // Player::predict, self_play.rs:340-368
                 dgnn_tree_node* start = roots[me];

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "dgnn_internal.h"
@@ -500,6 +501,71 @@ int dgnn_choose(const int* items, int n, double cutoff_percentile, double temper
 int dgnn_choose_f64(const double* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out)
 {
     return choose_impl(items, n, cutoff_percentile, temperature, at, index_out, cum_out);
+}
+
+// tree::to_pretty (src/libdg_mcts/tree.rs:1620-1746, non-verbose): what Played::from_mcts stores as a move's explanation
+// (self_play.rs:136, written as C[...] with newlines as carriage returns, :191-193) --
+//   "Nodes: <visits>, Win: <visit-weighted value>%, PV: <greedy path>" and, for the ten best children in compare_children order,
+//   "<vertex> -> <child visits> (W: <value>% / <lower confidence bound>%) (N: <prior>%) PV: <vertex> <greedy path below it>".
+// Vertices are GTP style (no i column, row 1 at packed y = 0), "pass" for 361.
+namespace {
+std::string pretty_vertex(int i)                                             // PrettyVertex, tree.rs:1620-1640
+{
+    if (i == kMoves - 1) return "pass";
+    static const char letters[] = "abcdefghjklmnopqrst";
+    return std::string(1, letters[i % 19]) + std::to_string(i / 19 + 1);
+}
+int greedy_child(const TreeNode* node)                                       // GreedyPath::next, tree.rs:1659-1662
+{
+    int best = -1;
+    for (int i = 0; i < kMoves; ++i) {
+        if (node->count[i].load(std::memory_order_relaxed) == 0) continue;
+        if (best < 0 || compare_children(node, best, i) <= 0) best = i;      // max_by keeps the last maximum
+    }
+    return best < 0 ? kMoves - 1 : best;
+}
+std::string greedy_path(const TreeNode* node)                                // GreedyPath::new(node, 1) joined by blanks
+{
+    std::string out;
+    while (node) {
+        const int i = greedy_child(node);
+        if (node->count[i].load(std::memory_order_relaxed) < 1) break;
+        if (!out.empty()) out += ' ';
+        out += pretty_vertex(i);
+        node = node->ptr[i].load(std::memory_order_acquire);
+    }
+    return out;
+}
+}  // namespace
+
+size_t dgnn_tree_node_to_pretty(const dgnn_tree_node* handle, char* out, size_t capacity)
+{
+    if (!handle) return 0;
+    const TreeNode* root = reinterpret_cast<const TreeNode*>(handle);
+    std::vector<int> children;
+    for (int i = 0; i < kMoves; ++i) if (root->count[i].load(std::memory_order_relaxed) != 0) children.push_back(i);
+    std::stable_sort(children.begin(), children.end(), [&](int a, int b) { return compare_children(root, b, a) < 0; });   // best first
+    if (children.size() > 10) children.resize(10);
+    float total_value = 0.0f;
+    for (int i = 0; i < kMoves; ++i) {
+        const float v = (float)root->count[i].load(std::memory_order_relaxed) * root->value[i];
+        if (std::isfinite(v)) total_value += v;
+    }
+    const int total = root->total_count.load(std::memory_order_relaxed);
+    char line[256];
+    std::snprintf(line, sizeof(line), "Nodes: %d, Win: %.1f%%, PV: ", total, (double)(100.0f * (total_value / ((float)total + 1e-5f))));
+    std::string text = line + greedy_path(root) + "\n";
+    for (int i : children) {
+        const TreeNode* child = root->ptr[i].load(std::memory_order_acquire);
+        const std::string vertex = pretty_vertex(i);
+        std::snprintf(line, sizeof(line), "%5s -> %7d (W: %5.2f%% / %5.2f%%) (N: %5.2f%%) PV: %s ", vertex.c_str(),
+                      child ? child->total_count.load(std::memory_order_relaxed) : 0, (double)(100.0f * root->value[i]),
+                      (double)(100.0f * normal_lcb_m(root->value[i], value_std(root, i), root->count[i].load(std::memory_order_relaxed), total)),
+                      (double)(100.0f * root->prior[i]), vertex.c_str());
+        text += line + (child ? greedy_path(child) : std::string()) + "\n";
+    }
+    if (out && capacity > text.size()) std::memcpy(out, text.c_str(), text.size() + 1);
+    return text.size() + 1;
 }
 
 int dgnn_tree_node_best(const dgnn_tree_node* handle, float temperature, double at, float* value_out, int* index_out)

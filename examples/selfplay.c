@@ -7,6 +7,7 @@
  * Prints one GameResult::Ended record per game (src/libdg_mcts/game_result.rs:35-41), the format dream-go's trainer reads. */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "dgnn.h"
 
@@ -24,6 +25,7 @@ int main(int argc, char** argv)
     char* sgf;
     int status;
 
+    memset(&params, 0, sizeof params);          /* fields added later (host_threads, opening) default to "off" */
     params.num_games = argc > 2 ? atoi(argv[2]) : 2;
     params.num_parallel = 0;
     params.first_game = 0;
@@ -46,7 +48,7 @@ int main(int argc, char** argv)
         predict = dgnn_pool_predictor();
         predict_ctx = pool;
     }
-    capacity = (size_t)params.num_games * ((size_t)(params.max_moves ? params.max_moves : 722) * 1100 + 4 * 722 * 6 + 2048);
+    capacity = (size_t)params.num_games * ((size_t)(params.max_moves ? params.max_moves : 722) * 2600 + 4 * 722 * 6 + 2048);
     sgf = (char*)malloc(capacity);
     if (!sgf) return 1;
     status = dgnn_selfplay_go(predict, predict_ctx, NULL, &params, &stats, NULL, sgf, capacity);

@@ -504,6 +504,10 @@ int dgnn_tree_node_softmax(const dgnn_tree_node* node, float* out /* 362 */);   
 /* Node::best (tree.rs:1262-1283): greedy (LCB / visits / prior / value order) when temperature <= 0.09, else a visit-
  * proportional draw with `at` in [0, 1) standing in for thread_rng(). */
 int dgnn_tree_node_best(const dgnn_tree_node* node, float temperature, double at, float* value_out, int* index_out);
+/* tree::to_pretty (tree.rs:1620-1746, non-verbose): the human-readable summary of a search ("Nodes: .., Win: ..%, PV: .." and one
+ * line per child for the ten best) that Played::from_mcts stores with a move and Played::fmt writes as C[...] (self_play.rs:136,
+ * 191-193).  Returns the bytes needed including the NUL; writes when it fits. */
+size_t dgnn_tree_node_to_pretty(const dgnn_tree_node* node, char* out, size_t capacity);
 /* choose (src/libdg_mcts/choose.rs:54-88) on integer weights: 1 and *index_out / *cum_out when an item was chosen. */
 int dgnn_choose(const int* items, int n, double cutoff_percentile, double temperature, double at, int* index_out, double* cum_out);
 /* The same on real weights (a policy with -inf for illegal moves, as the policy play of self_play.rs:383-388 calls it). */
@@ -648,7 +652,7 @@ int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winn
  * (seed, game id, network outputs) for any leaves_per_thread: deterministic self-play with many leaves on the device --
  * provided the games do not share a transposition table (cache == NULL or cache_entries_per_game > 0): the table is keyed
  * like the reference's, by stones and colour only, while the feature planes also hold the last moves and the ko state. */
-typedef struct dgnn_selfplay_params {
+typedef struct dgnn_selfplay_params {     /* zero the whole struct first: fields are appended between versions and 0 means "off" */
     int num_games;            /* games this call plays */
     int num_parallel;         /* games in flight (--num-games of the reference); <= 0: all at once */
     int first_game;           /* global id of the first game, */

@@ -273,9 +273,13 @@ def test_selfplay_example_in_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
                     os.path.join(root, "examples", "selfplay.c"), "-L" + os.path.join(root, "dream-go_amd", "lib"),
                     "-ldgnn_hip", "-Wl,-rpath," + os.path.join(root, "dream-go_amd", "lib"), "-o", str(exe)], check=True)
-    first = subprocess.run([str(exe)], capture_output=True, text=True, check=True)
-    again = subprocess.run([str(exe)], capture_output=True, text=True, check=True)
-    games = first.stdout.strip().splitlines()
+    class Run:          # bytes, not text mode: a record holds carriage returns (the C[] text of every searched move, self_play.rs:192)
+        def __init__(self):
+            done = subprocess.run([str(exe)], capture_output=True, check=True)
+            self.stdout, self.stderr = done.stdout.decode("ascii"), done.stderr.decode("ascii")
+    first, again = Run(), Run()
+    games = [g for g in first.stdout.split("\n") if g]
+    assert all(g.count("C[Nodes: ") == 30 for g in games)
     assert len(games) == 2 and all(g.startswith("(;GM[1]FF[4]DT[") and g.endswith(")") for g in games)
     assert all(len(re.findall(r";[BW]\[[a-s]{2}\]", g)) == 30 for g in games)
     strip = lambda text: re.sub(r"DT\[[^\]]*\]", "", text)          # the date is the only thing that may differ between two runs

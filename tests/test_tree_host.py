@@ -7,6 +7,8 @@
 The reference's tests run on an empty board, where every point is a legal move: the prior carries no -inf and the board
 callback has nothing to do, so the tree can be exercised without any Go rules.
 """
+import re
+
 import numpy as np
 
 
@@ -319,3 +321,23 @@ def test_selfplay_with_batched_leaves_is_a_function_of_the_seed(api):
         for m, index in enumerate(record):
             assert replay.is_valid(m % 2, int(index % 19), int(index // 19))
             replay.place(m % 2, int(index % 19), int(index // 19))
+
+
+def test_to_pretty_summarises_a_search_like_the_reference(api):
+    """tree::to_pretty (src/libdg_mcts/tree.rs:1683-1731): "Nodes: N, Win: W%, PV: path" and a line per child, best first, with the
+    child's visits, value, lower confidence bound, prior and its own greedy path; vertices in GTP style (no i column)."""
+    prior = np.full(362, 1e-3, dtype=np.float32)
+    prior[3 * 19 + 3], prior[15 * 19 + 8], prior[361] = 0.5, 0.3, 0.01
+    root = api.Node(api.BLACK, 0.5, prior / prior.sum())
+    api.search_run(root, api.SyntheticBoard(7), num_rollouts=64, num_threads=1, seed=3)
+    text = root.to_pretty()
+    lines = text.strip("\n").split("\n")
+    counts = np.array([root.with_(i).count() for i in range(362)])
+    assert re.fullmatch(r"Nodes: %d, Win: \d+\.\d%%, PV: ([a-hj-t]\d+|pass)( ([a-hj-t]\d+|pass))*" % counts.sum(), lines[0]), lines[0]
+    assert len(lines) == 1 + min(10, int((counts > 0).sum()))
+    best_value, best = root.best(0.0)
+    first = re.fullmatch(r" *([a-hj-t]\d+|pass) -> +(\d+) \(W: +[\d.]+% / +-?[\d.]+%\) \(N: +[\d.]+%\) PV: ([a-hj-t]\d+|pass) ?(.*)", lines[1])
+    assert first, lines[1]
+    vertex = "pass" if best == 361 else "abcdefghjklmnopqrst"[best % 19] + str(best // 19 + 1)
+    assert first.group(1) == vertex == first.group(3) and lines[0].split("PV: ")[1].split(" ")[0] == vertex
+    assert "i" not in "".join(l.split("PV:")[1] for l in lines).replace("pass", "")

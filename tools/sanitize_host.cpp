@@ -18,7 +18,7 @@ int main() {
         if (mode != 0) dgnn_cache_create(20000, 4, &cache);
         dgnn_selfplay_stats st;
         std::vector<int> moves((size_t)6 * 722, -1);
-        std::vector<char> sgf((size_t)6 * (722 * 1100 + 40000));
+        std::vector<char> sgf((size_t)6 * (722 * 2600 + 40000));
         int rc = dgnn_selfplay_go(dgnn_hash_predictor(), nullptr, cache, &p, &st, moves.data(), sgf.data(), sgf.size());
         std::printf("mode %d rc %d games %llu moves %llu evals %llu hits %llu conflicts %llu ended %llu exit %llu\n", mode, rc,
                     (unsigned long long)st.games, (unsigned long long)st.moves, (unsigned long long)st.evals, (unsigned long long)st.cache_hits,
