@@ -43,14 +43,18 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRows = kBoardRows;                      // 400 padded rows per board
 constexpr int kHalo = 21;                              // rows above row 0 that a tap can reach (20 + 1)
 constexpr int kPieces = 7;                             // DMA instructions per k-slot (64 rows each, rows 400..447 unused)
-constexpr int kSlotRows = kHalo + kPieces * 64;        // 469
-constexpr int kSlotBytes = kSlotRows * 16;             // 7504
-constexpr int kXBufBytes = 4 * kSlotBytes;             // 30016: one 32-channel chunk
+constexpr int kSlotRows = 480;                         // 21 + 7 * 64 = 469 rows used; the k-slot stride is a multiple of 256 bytes:
+                                                       // a B fragment takes 16 rows from each of the chunk's four k-slots, and the
+                                                       // lane groups a ds_read_b128 is served in ({0-3, 12-15, 20-27}, ...) then
+                                                       // fall on 64 different banks
+static_assert(kSlotRows >= kHalo + kPieces * 64 && kSlotRows % 16 == 0, "k-slot stride");
+constexpr int kSlotBytes = kSlotRows * 16;             // 7680
+constexpr int kXBufBytes = 4 * kSlotBytes;             // 30720: one 32-channel chunk
 constexpr int kRing = 3;                               // filter slabs per wave in flight / in use
 constexpr int kWBase = 2 * kXBufBytes;
 constexpr int kThreads = 512;
@@ -177,18 +181,23 @@ constexpr int lds_younger_mfma_first(int I, bool first, bool last)
 // inline-asm section: operands come from LDS reads behind their own s_waitcnt; consecutive MFMAs on one accumulator are an
 // accumulate chain (no wait states); any OTHER reader or writer of an accumulator goes through mfma_fence() first.
 template <bool AGPR>
-__device__ __forceinline__ void mfma_asm(floatx16& c, const half8& a, const half8& b)
+__device__ __forceinline__ void mfma_asm(floatx4& c, const half8& a, const half8& b)
 {
-    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 // 8-pass MFMA result -> any reader but the next MFMA of the chain: 12 wait states; VALU write -> MFMA operand: 2.  One
 // statement in front of (BEFORE = true) or behind the VALU code that touches the tile, tied to it through the operand.
 template <bool AGPR, bool BEFORE>
-__device__ __forceinline__ void mfma_fence(floatx16& c)
+__device__ __forceinline__ void mfma_fence(floatx4& c0, floatx4& c1, floatx4& c2, floatx4& c3)
 {
-    if constexpr (AGPR) { if constexpr (BEFORE) asm volatile("s_nop 11" : "+a"(c)); else asm volatile("s_nop 1" : "+a"(c)); }
-    else { if constexpr (BEFORE) asm volatile("s_nop 11" : "+v"(c)); else asm volatile("s_nop 1" : "+v"(c)); }
+    if constexpr (AGPR) {
+        if constexpr (BEFORE) asm volatile("s_nop 11" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));
+        else asm volatile("s_nop 1" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));
+    } else {
+        if constexpr (BEFORE) asm volatile("s_nop 11" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        else asm volatile("s_nop 1" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+    }
 }
 
 // Work split of the 8 waves, template parameter NS = 32-channel slices per workgroup (a workgroup covers 32 * NS output
@@ -225,7 +234,12 @@ struct Split {
     static constexpr int CT = NS == 16 ? 2 : 1;        // 32-channel MFMA tiles per wave
     static constexpr int CW = SL / CT;                 // waves along the channels
     static constexpr bool Chunked = NS <= 2;
-    static constexpr bool AsmMfma = NS == 16;
+    // Every variant issues its MFMAs from inline asm with the accumulator tied to the destination ("+a" / "+v"): as a builtin the
+    // four-pass v_mfma_f32_16x16x32_f16 is untied to hipcc, whose register allocator then writes results into fresh registers
+    // and spills them (343 spilled registers in the K loop of the eight-wave skip variant).
+    static constexpr bool AsmMfma = true;
+    // the wide variant needs both register files: 32-row tiles 0..7 of both channel tiles in AGPRs (exactly 256), 8..11 in VGPRs
+    static constexpr bool acc_in_agpr(int rt32) { return NS == 16 && rt32 < 8; }
     // DirectA (round 3, the wide variant): the A (filter) fragments go from memory straight into the registers of the NEXT k-step
     // (global_load_dwordx4, one k-step = 1536 MFMA-cycles ahead: more than a trip to HBM) instead of through a wave-private LDS
     // ring.  With one wave per 64 channels no two waves ever want the same filter bytes, so the ring bought nothing but prefetch
@@ -250,18 +264,19 @@ struct Split {
     static constexpr int piece_tap(int j) { return NS == 1 ? j : j / 2; }
     static constexpr int piece_pair(int j) { return NS == 1 ? 1 : (j % 2 ? 4 : 1); }
     static constexpr int pieces_in_tap(int tap) { int n = 0; for (int j = 0; j < PPW; ++j) n += piece_tap(j) == tap ? 1 : 0; return n; }
-    static constexpr int NP = 2 * RT;                  // (k16, row tile) pairs per k-step, CT MFMAs each
-    static constexpr int BD = NS == 16 ? 3 : NS == 8 ? 5 : NS == 4 ? 4 : NS == 2 ? 5 : 2;   // B-fragment registers in rotation = pairs of read-ahead (<= NP)
-    // byte offset of the B fragment of pair i = k16 * RT + row tile relative to the lane's base row
-    static constexpr int b_offset(int i) { return (i / RT) * 2 * kSlotBytes + (i % RT) * 512; }
+    static constexpr int CT2 = 2 * CT;                 // 16-channel MFMA tiles per wave
+    static constexpr int RT2 = 2 * RT;                 // 16-row MFMA tiles per wave
+    static constexpr int NP = RT2;                     // "pairs" per k-step: one B fragment (16 rows x the chunk's 32 channels), CT2 MFMAs each
+    static constexpr int BD = NS == 16 ? 3 : NS == 8 ? 4 : NS == 4 ? 4 : NS == 2 ? 5 : 2;   // B-fragment registers in rotation = pairs of read-ahead (<= NP)
+    // byte offset of the B fragment of pair i = 16-row tile i relative to the lane's base row
+    static constexpr int b_offset(int i) { return i * 256; }
     // pair index behind which the j-th filter piece / the activation piece of the step is issued
     static constexpr int w_pair(int j) { return NS == 16 ? 2 + 4 * j : NS == 8 ? 3 + 7 * j : NS == 4 ? 1 + 3 * j : j; }
     static constexpr int x_pair() { return NS == 16 ? 17 : NS == 8 ? 14 : NS == 4 ? 6 : 2; }
     // pair at which the NEXT step's A fragments are requested (behind this step's DMA instructions)
     static constexpr int a_pair() { return NS == 16 ? 19 : NS == 8 ? 17 : NS == 4 ? 8 : NS == 2 ? 3 : 0; }
 };
-static_assert(Split<8>::LdsBytes <= 160 * 1024 && Split<4>::LdsBytes <= 160 * 1024 && Split<2>::LdsBytes <= 160 * 1024 &&
-              Split<16>::LdsBytes <= 160 * 1024, "LDS budget");
+static_assert(Split<4>::LdsBytes <= 160 * 1024 && Split<2>::LdsBytes <= 160 * 1024 && Split<16>::LdsBytes <= 160 * 1024, "LDS budget");
 static_assert(Split<1>::BD <= Split<1>::NP && Split<2>::BD <= Split<2>::NP, "the B rotation reaches one step ahead at most");
 
 // A board split over G = C_out / (32 * NS) workgroups INSIDE one launch (tower_split_kernel): what a workgroup needs to
@@ -377,12 +392,11 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                                                const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, 0, nullptr}, const int carry = 0)
 {
     using S = Split<NS>;
-    constexpr int CT = S::CT, RT = S::RT, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP, SL = S::SL;
+    constexpr int CT = S::CT, RT = S::RT, CT2 = S::CT2, RT2 = S::RT2, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP, SL = S::SL;
     constexpr bool CHUNKED = S::Chunked;
-    constexpr bool ASM = S::AsmMfma;                 // MFMAs from inline asm, accumulators of row tiles 0..7 in AGPRs (Split<16>)
+    constexpr bool ASM = S::AsmMfma;                 // MFMAs from inline asm (Split<16>: accumulators of row tiles 0..7 in AGPRs)
     constexpr bool DIRECT_A = S::DirectA;            // filter fragments by global loads into the next step's registers, no LDS ring
     static_assert(!DIRECT_A || (ASM && CT == 2 && !CHUNKED && W == 4), "DirectA is written for the wide split");
-    static_assert(!ASM || ABL == 0, "no ablations of the asm variant");
     constexpr int BUF = S::BufStride;
     static_assert(!CHUNKED || !(ABL & ~1), "the chunked kernels know ablation 1 (no MFMAs) only");
     const bool x0_in_flight = (carry & kX0InFlight) != 0;
@@ -489,72 +503,81 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     };
 
     // ---- fragment read addresses ----
-    // B (rows): lane l reads row tile * 32 + (l & 31), k-slot k16 * 2 + (l >> 5); tap shift is an immediate.
-    const int x_lane = (lane >> 5) * kSlotBytes + (g * (RT * 32) + (lane & 31)) * 16;
-    // A (filter): fragment ct * 2 + k16, lane-linear.
-    // A (filter): fragment k16, lane-linear: in the wave's ring, or (Chunked) in the chunk buffer behind the activations
+    // B (rows): lane l reads row tile * 16 + (l & 15), k-slot l >> 4 (the 32 channels of the chunk); tap shift is an immediate.
+    const int x_lane = (lane >> 4) * kSlotBytes + (g * (RT * 32) + (lane & 15)) * 16;
+    // A (filter): fragment = 16-channel tile, lane-linear: in the wave's ring, or (Chunked) in the chunk buffer behind the activations
     const int w_lane = CHUNKED ? kXBufBytes + wn * 2048 + lane * 16 : kWBase + wave * S::RingBytes + lane * 16;
     const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)lds;
     const unsigned w_addr = lds_base + w_lane;
 
-    floatx16 acc[CT][RT];
+    floatx4 acc[CT2][RT2];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < CT2; ++ct)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT2; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][rt][r] = 0.0f;
+            for (int r = 0; r < 4; ++r) acc[ct][rt][r] = 0.0f;
+    // the four 16 x 16 accumulator tiles of 32-row tile R x 32-channel tile C, as one fence statement (asm variant)
+    auto fence_block = [&](auto before_c, auto r_c, auto c_c) {
+        constexpr bool BEFORE = decltype(before_c)::value;
+        constexpr int R = decltype(r_c)::value, C = decltype(c_c)::value;
+        mfma_fence<S::acc_in_agpr(R), BEFORE>(acc[2 * C][2 * R], acc[2 * C + 1][2 * R], acc[2 * C][2 * R + 1], acc[2 * C + 1][2 * R + 1]);
+    };
     if constexpr (ASM) {
         // hipcc materialises these zeros lazily -- a v_accvgpr_mov / v_mov of the tuple straight in front of the tile's first
         // MFMA, which as an asm statement gets no hazard padding (VALU write -> MFMA operand: two wait states; found by
         // tools/asm_lint.py as one stale accumulator register).  A statement per tile pins the zeros in their registers here.
         static_for<RT>([&](auto rc) {
-            constexpr int R = decltype(rc)::value;
-            mfma_fence<(R < 8), false>(acc[0][R]);
-            if constexpr (CT == 2) mfma_fence<(R < 8), false>(acc[CT - 1][R]);
+            fence_block(std::false_type(), rc, std::integral_constant<int, 0>());
+            if constexpr (CT == 2) fence_block(std::false_type(), rc, std::integral_constant<int, CT - 1>());
         });
     }
 
-    // ---- skip input, 16-byte accesses: lanes 0..31 read the whole 16-byte row of k-slot k, lanes 32..63 that of
-    // k-slot k + 1; one v_permlane32_swap per dword then gives every lane its 4 channels of both k-slots ----
-    const int hi = lane >> 5;
+    // ---- 16-byte accesses to rows of y / z.  The accumulator tile of 16 channels x 16 rows gives lane group h = lane >> 4 the four
+    // channels 4 h .. 4 h + 3 of row lane & 15: half h & 1 of the 16-byte row of k-slot h >> 1.  For the two tiles (X, Y) of a
+    // 32-channel tile one v_permlane16_swap per dword (odd lane groups of X <-> even lane groups of Y) turns "8 bytes of two
+    // k-slots" into "the whole 16-byte row of ONE k-slot": lane group h then owns k-slot sigma(h) = 0, 2, 1, 3 of the tile's four.
+    // The swap is its own inverse, so a 16-byte load of the same rows followed by it delivers the skip input in accumulator order.
+    const int h4 = lane >> 4;
+    const int slot_of_lane = ((h4 & 1) << 1) | (h4 >> 1);
     const int co_base = (nb * SL + wn * CT) * 32;
-    // element offset of (this wave's k-slot 0 (+1 for the upper half-wave), row 0); k-slot stride = 400 rows * 8
-    const long ep_base = (((long)b * (cout / 8) + co_base / 8 + hi) * kRows) * 8;
-    auto row_of = [&](int rt) { return g * (RT * 32) + rt * 32 + (lane & 31); };
-    u32x4 zl[CT][2];                                  // one row tile of z in flight: per channel tile two k-slot pairs
+    // element offset of (this lane's k-slot of the wave's first 32-channel tile, row 0); k-slot stride = 400 rows * 8
+    const long ep_base = (((long)b * (cout / 8) + co_base / 8 + slot_of_lane) * kRows) * 8;
+    auto row_of = [&](int rt16) { return g * (RT * 32) + rt16 * 16 + (lane & 15); };
+    u32x4 zl[CT][2];                                  // one 32-row tile of z in flight: per 32-channel tile its two 16-row halves
     const uint16_t* const z_lane = a.z + ep_base + row_of(0) * 8;
-    // Row tile `rt` of this wave -- or, for a wave that does not own board row tile T (`mine` false), ZEROS: the same k-slots'
-    // pad rows 384..399, which no kernel ever writes.  A load either way, never a branch: at the join of a branch hipcc copies
-    // the destination registers -- of an asm load, before the data is there (tools/asm_lint.py).
+    // Row tile `rt` (32 rows) of this wave -- or, for a wave that does not own board row tile T (`mine` false), ZEROS: the same
+    // k-slots' pad rows 384..399, which no kernel ever writes.  A load either way, never a branch: at the join of a branch hipcc
+    // copies the destination registers -- of an asm load, before the data is there (tools/asm_lint.py).
     const long z_pad_rows = (long)(384 + (lane & 15) - row_of(0)) * 8;          // from z_lane's row to a pad row of the k-slot
     auto load_z_unit = [&](int rt, bool mine) {
         const uint16_t* p = z_lane + (mine ? (long)rt * 32 * 8 : z_pad_rows);
+        const int half_stride = mine ? 16 * 8 : 0;
         asm volatile("" : "+v"(p));                   // opaque per use: keeps the 24 addresses from being hoisted out of
                                                       // the K loop (they would be spilled), one 64-bit add per load instead
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int pair = 0; pair < 2; ++pair)      // k-slot ct * 4 + pair * 2 (+ hi)
-                load_row_asm<SPLIT>(zl[ct][pair], p + ((ct * 4 + pair * 2) * kRows) * 8);
+            for (int half = 0; half < 2; ++half)      // rows rt * 32 + half * 16 .., k-slot ct * 4 + sigma(h)
+                load_row_asm<SPLIT>(zl[ct][half], p + (long)(ct * 4 * kRows) * 8 + half * half_stride);
     };
     const float zscale = SKIP == 2 ? a.alpha2 / a.alpha1 : 0.0f;
     auto add_z_tile = [&](auto rt_c, auto ct_c) {
         constexpr int RTI = decltype(rt_c)::value, CTI = decltype(ct_c)::value;
-        if constexpr (ASM) mfma_fence<(RTI < 8), true>(acc[CTI][RTI]);      // the tile's last MFMA may be the step's last
+        if constexpr (ASM) fence_block(std::true_type(), rt_c, ct_c);      // a tile's last MFMA may be the step's last
 #pragma unroll
-        for (int pair = 0; pair < 2; ++pair) {
-            const auto sx = __builtin_amdgcn_permlane32_swap(zl[CTI][pair][0], zl[CTI][pair][2], false, false);
-            const auto sy = __builtin_amdgcn_permlane32_swap(zl[CTI][pair][1], zl[CTI][pair][3], false, false);
-            const half4 z0 = __builtin_bit_cast(half4, make_uint2(sx[0], sy[0]));   // k-slot pair * 2
-            const half4 z1 = __builtin_bit_cast(half4, make_uint2(sx[1], sy[1]));   // k-slot pair * 2 + 1
+        for (int half = 0; half < 2; ++half) {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(zl[CTI][half][0], zl[CTI][half][2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(zl[CTI][half][1], zl[CTI][half][3], false, false);
+            const half4 zx = __builtin_bit_cast(half4, make_uint2(s0[0], s1[0]));   // channel tile 2 * CTI
+            const half4 zy = __builtin_bit_cast(half4, make_uint2(s0[1], s1[1]));   // channel tile 2 * CTI + 1
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                acc[CTI][RTI][pair * 8 + jj] = __builtin_fmaf(zscale, (float)z0[jj], acc[CTI][RTI][pair * 8 + jj]);
-                acc[CTI][RTI][pair * 8 + 4 + jj] = __builtin_fmaf(zscale, (float)z1[jj], acc[CTI][RTI][pair * 8 + 4 + jj]);
+                acc[2 * CTI][2 * RTI + half][jj] = __builtin_fmaf(zscale, (float)zx[jj], acc[2 * CTI][2 * RTI + half][jj]);
+                acc[2 * CTI + 1][2 * RTI + half][jj] = __builtin_fmaf(zscale, (float)zy[jj], acc[2 * CTI + 1][2 * RTI + half][jj]);
             }
         }
-        if constexpr (ASM) mfma_fence<(RTI < 8), false>(acc[CTI][RTI]);
+        if constexpr (ASM) fence_block(std::false_type(), rt_c, ct_c);
     };
     auto add_z_unit = [&](auto rt_c) {
         add_z_tile(rt_c, std::integral_constant<int, 0>());
@@ -593,8 +616,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             for (int s = 0; s < kRing; ++s) issue_w(s, s);
         }
     }
-    half8 af[2][CT][2];                               // [step parity][channel tile][k16]
-    // DirectA: fragment F = ct * 2 + k16 of k-step `st` of this wave's two filter tiles -> af[PAR]; steps past the last one read
+    half8 af[2][CT][2];                               // [step parity][32-channel tile][16-channel half]: fragment F of a slab is af[.][F / 2][F % 2]
+    // DirectA: fragment F (16 channels x the chunk's 32 input channels) of k-step `st` of this wave's two filter tiles -> af[PAR]; steps past the last one read
     // the next layer's filter (or the padding behind the last layer's): never used, they only keep every step alike
     auto load_a = [&](auto par_c, int st) {
         constexpr int PAR = decltype(par_c)::value;
@@ -690,7 +713,6 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             }
             static_for<NP>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
-                constexpr int K16 = I / RT, RTI = I % RT;
                 if constexpr (PIPE) {
                     constexpr int YOUNGER = lds_younger_mfma_first<NP, BD, S::a_pair(), CHUNKED, (DIRECT_A ? 0 : W)>(I, FIRST, LAST);
                     if constexpr (I == 0 && DIRECT_A) {
@@ -711,18 +733,14 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                     if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, 0>(), bf[0]);
                     else wait_lgkm<YOUNGER>(bf[I % BD]);
                 }
+                // pair I = 16-row tile I: its B fragment (16 rows x 32 channels) meets the wave's CT2 filter fragments (16 channels x 32)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
+                for (int c2 = 0; c2 < S::CT2; ++c2) {
                     if constexpr (ABL & 1) {
-                        asm volatile("" ::"v"(af[P][ct][K16]), "v"(bf[(PH + I) % BD]));
-                    } else if constexpr (ASM) {
-                        mfma_asm<(RTI < 8)>(acc[ct][RTI], af[P][ct][K16], bf[(PH + I) % BD]);     // volatile asm: stays in program order
+                        asm volatile("" ::"v"(af[P][c2 / 2][c2 % 2]), "v"(bf[(PH + I) % BD]));
                     } else {
-                        acc[ct][RTI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][ct][K16], bf[(PH + I) % BD], acc[ct][RTI], 0, 0, 0);
+                        mfma_asm<S::acc_in_agpr(I / 2)>(acc[c2][I], af[P][c2 / 2][c2 % 2], bf[(PH + I) % BD]);     // volatile asm: stays in program order
                     }
-                    // keep the MFMA above the reads below: its result feeds an empty asm that the (volatile, ordered) reads follow
-                    // (not with four waves: their accumulators live in AGPRs and a "v" constraint would copy them back and forth)
-                    if constexpr (PIPE && S::WAVES == 8) asm volatile("" : "+v"(acc[ct][RTI]));
                 }
                 if constexpr (PIPE) {
                     if constexpr (I == S::a_pair() && CHUNKED) {
@@ -881,69 +899,61 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     }
 
     // ---- epilogue ----
-    // D[i][j]: j = lane & 31 = row within the tile, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = channel within the
-    // 32-channel tile.  For k = r >> 2 the lane owns 4 consecutive channels 8k + 4 * (lane >> 5) .. + 3 of k-slot k:
-    // one 8-byte access; the two half-waves together cover 32 rows x 16 bytes = 512 contiguous bytes.
-    float bias[CT][4][4];
+    // D[i][j] of a 16 x 16 tile: j = lane & 15 = row within the tile, i = 4 * (lane >> 4) + r = channel within the tile: the lane owns
+    // 4 consecutive channels = 8 bytes of a k-slot row; v_permlane16_swap over the two tiles of a 32-channel tile makes that the
+    // whole 16-byte row of k-slot sigma(lane >> 4) (see the skip input above; T21 of the CDNA guide): each store covers four
+    // contiguous 256-byte runs.
+    float bias[S::CT2][4];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int c2 = 0; c2 < S::CT2; ++c2) {
+        const half4 b4 = *reinterpret_cast<const __attribute__((address_space(1))) half4*>((__UINTPTR_TYPE__)(a.bias + co_base + c2 * 16 + h4 * 4));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const half4 b4 = *reinterpret_cast<const __attribute__((address_space(1))) half4*>((__UINTPTR_TYPE__)(a.bias + co_base + ct * 32 + k * 8 + hi * 4));
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) bias[ct][k][jj] = (float)b4[jj];
-        }
+        for (int jj = 0; jj < 4; ++jj) bias[c2][jj] = (float)b4[jj];
+    }
 
-    // 16-byte accesses (T21 of the CDNA guide): the two half-waves hold the low / high 8 bytes of the same 16-byte
-    // row of a k-slot.  For a pair of k-slots (k, k + 1) one v_permlane32_swap per dword turns that into
-    // "lanes 0..31 own the whole row of k-slot k, lanes 32..63 the whole row of k-slot k + 1": half as many memory
-    // instructions, each covering two contiguous 512-byte runs.
     const uint16_t* const zb = a.z + ep_base;
     uint16_t* const yb = a.y + ep_base;
 
-    uint4 zq[2][CT * 2];                              // skip rows of two tiles in flight: [tile parity][ct * 2 + pair]
-    auto load_z = [&](int rt) {
+    uint4 zq[2][CT];                                  // skip rows of two 16-row tiles in flight: [tile parity][32-channel tile]
+    auto load_z = [&](int rt16) {
         if constexpr (SKIP == 1) {
 #pragma unroll
-            for (int q = 0; q < CT * 2; ++q)          // q = ct * 2 + pair -> k-slot ct * 4 + pair * 2 (+ hi)
-                zq[rt & 1][q] = load_row<SPLIT>(zb + (((q >> 1) * 4 + (q & 1) * 2) * kRows + row_of(rt)) * 8);
+            for (int ct = 0; ct < CT; ++ct) zq[rt16 & 1][ct] = load_row<SPLIT>(zb + ((long)(ct * 4) * kRows + row_of(rt16)) * 8);
         }
     };
     load_z(0);
     load_z(1);
     if constexpr (ASM) {
-        // the K loop's last MFMAs are a few instructions back: one fence per accumulator tile before anything reads it
+        // the K loop's last MFMAs are a few instructions back: a fence per block of accumulator tiles before anything reads it
         static_for<RT>([&](auto rc) {
-            constexpr int R = decltype(rc)::value;
-            mfma_fence<(R < 8), true>(acc[0][R]);
-            if constexpr (CT == 2) mfma_fence<(R < 8), true>(acc[CT - 1][R]);
+            fence_block(std::true_type(), rc, std::integral_constant<int, 0>());
+            if constexpr (CT == 2) fence_block(std::true_type(), rc, std::integral_constant<int, CT - 1>());
         });
     }
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    for (int rt = 0; rt < S::RT2; ++rt) {
         const int row = row_of(rt);
         const unsigned live = ((row % 20 != 19) && row < 380) ? 0xffffffffu : 0u;   // pad column / pad row -> zero
 #pragma unroll
-        for (int q = 0; q < CT * 2; ++q) {
-            const int ct = q >> 1, k0 = (q & 1) * 2;
-            // skip values for k-slots k0 (za) and k0 + 1 (zb2), 4 channels each, after the half exchange
-            uint2 za = make_uint2(0, 0), zb2 = make_uint2(0, 0);
+        for (int ct = 0; ct < CT; ++ct) {
+            // skip values of the two channel tiles (4 channels each) after the exchange
+            uint2 zx = make_uint2(0, 0), zy = make_uint2(0, 0);
             if constexpr (SKIP == 1) {
-                const uint4 v = zq[rt & 1][q];
-                const auto sx = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
-                za = make_uint2(sx[0], sy[0]);
-                zb2 = make_uint2(sx[1], sy[1]);
+                const uint4 v = zq[rt & 1][ct];
+                const auto s0 = __builtin_amdgcn_permlane16_swap(v.x, v.z, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(v.y, v.w, false, false);
+                zx = make_uint2(s0[0], s1[0]);
+                zy = make_uint2(s0[1], s1[1]);
             }
             uint2 out[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const int k = k0 + kk;
-                const half4 z4 = __builtin_bit_cast(half4, kk == 0 ? za : zb2);
+                const int c2 = 2 * ct + kk;
+                const half4 z4 = __builtin_bit_cast(half4, kk == 0 ? zx : zy);
                 float t[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    t[jj] = __builtin_fmaf(a.alpha1, acc[ct][rt][k * 4 + jj], bias[ct][k][jj]);
+                    t[jj] = __builtin_fmaf(a.alpha1, acc[c2][rt][jj], bias[c2][jj]);
                     if constexpr (SKIP == 1) t[jj] = __builtin_fmaf(a.alpha2, (float)z4[jj], t[jj]);
                 }
                 // relu behind the conversion: the same bits as max(t, 0) in fp32 first (rounding is monotone, 0 is exact, a NaN gives 0 either way)
@@ -951,17 +961,17 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 if constexpr (RELU) { y01 = pk_relu_f16(y01); y23 = pk_relu_f16(y23); }
                 out[kk] = make_uint2(y01 & live, y23 & live);
             }
-            const auto sx = __builtin_amdgcn_permlane32_swap(out[0].x, out[1].x, false, false);
-            const auto sy = __builtin_amdgcn_permlane32_swap(out[0].y, out[1].y, false, false);
-            const uint4 unit = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-            store_row<SPLIT>(yb + ((ct * 4 + k0) * kRows + row) * 8, unit);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(out[0].x, out[1].x, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(out[0].y, out[1].y, false, false);
+            const uint4 unit = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            store_row<SPLIT>(yb + ((long)(ct * 4) * kRows + row) * 8, unit);
             // hand-over: channels 0..31 are the next layer's first input chunk; its place is activation buffer 0, which
             // nobody reads any more (the last chunk sits in buffer 1, and the barrier that ended it came after every
             // wave's last DMA into buffer 0 had landed)
             if (ct == 0 && wn == 0 && nb == 0 && hand_over)
-                *reinterpret_cast<uint4*>(lds + buf_next * BUF + (k0 + hi) * kSlotBytes + (kHalo + row) * 16) = unit;
+                *reinterpret_cast<uint4*>(lds + buf_next * BUF + slot_of_lane * kSlotBytes + (kHalo + row) * 16) = unit;
         }
-        if (rt + 2 < RT) load_z(rt + 2);
+        if (rt + 2 < S::RT2) load_z(rt + 2);
     }
     if (a.timing) {
         wait_vmcnt<0>();
@@ -1146,7 +1156,7 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
             return;
         }
     }
-    if constexpr (NS == 8 || NS == 4) {
+    if constexpr (NS == 4) {
         // measurement only (tools/ablate.sh), residual shapes: 1 = no MFMAs, 2 = no in-loop DMA, 3 = both, 32 = the K loop
         // without the software pipeline across steps
         if (ablate != 0 && relu && skip != 1) {
@@ -1184,8 +1194,11 @@ int conv_board_pick_ns(int batch, int cout, int forced_ns)
     int best = slices % 8 == 0 ? 8 : slices % 4 == 0 ? 4 : 2;
     while (best > 1 && (long)batch * (slices / best) < 192) best /= 2;
     if ((forced_ns == 1 || forced_ns == 2 || forced_ns == 4 || forced_ns == 8) && slices % forced_ns == 0) best = forced_ns;
-    if (forced_ns == 16 && slices % 8 == 0) best = 16;          // the wide variant of NS = 8 (Split<16>)
-    return best;
+    if (forced_ns == 16 && slices % 8 == 0) best = 8;
+    // eight slices per workgroup are always the wide split (Split<16>: four waves x two 32-channel tiles).  The eight-wave form of
+    // rounds 1-2 (Split<8>) is gone: with v_mfma_f32_16x16x32_f16 its skip-folding variants no longer fit 256 registers, and an
+    // accumulator the compiler spills behind an asm MFMA is read before the matrix pipe has written it.
+    return best == 8 ? 16 : best;
 }
 
 BoardSwitches read_board_switches()
@@ -1219,15 +1232,9 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
     if (batch <= 0 || count <= 0) return hipSuccess;
     if (!tower_board_supported(batch, channels)) return hipErrorInvalidValue;
     const dim3 grid(batch, 1);
-    // A 256-channel tower walks with the wide work split (Split<16>: four waves, two channel tiles each; bit-identical to
-    // Split<8>, half its LDS reads, +2.7 % at batch 256).  DGNN_TOWER_WIDE=0: the eight-wave split (A/B, tests).
-    static const int wide = [] { const char* e = std::getenv("DGNN_TOWER_WIDE"); return e ? std::atoi(e) : 1; }();
-    if (channels == 256 && wide == 1) {
-        hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count);
-        return hipGetLastError();
-    }
+    // A 256-channel tower walks with the wide work split (Split<16>: four waves, two 32-channel tiles each)
     switch (channels / 32) {
-        case 8: hipLaunchKernelGGL((tower_board_kernel<8>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+        case 8: hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count); break;
         case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
         default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count); break;
     }
@@ -1304,7 +1311,6 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches
     const int ablate = env.ablate;
     switch (conv_board_pick_ns(args.batch, args.cout, env.ns)) {
         case 16: launch_board_variant<16>(args, skip, relu, 0, stream); break;
-        case 8: launch_board_variant<8>(args, skip, relu, ablate, stream); break;
         case 4: launch_board_variant<4>(args, skip, relu, ablate, stream); break;
         case 2: launch_board_variant<2>(args, skip, relu, 0, stream); break;
         default: launch_board_variant<1>(args, skip, relu, ablate, stream); break;

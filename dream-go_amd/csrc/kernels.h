@@ -55,7 +55,7 @@ constexpr int kBoardRows = 400;   // padded slot-major layout: 20 rows x 20 colu
 
 struct ConvBoardLaunch {
     const uint16_t* x;     // input  [batch][cin / 8][400][8] fp16 (padded slot-major, pads zero)
-    const uint16_t* w;     // filter [9 * cin / 32 k-steps][cout / 32 slices][2 k16][64 lanes][8] fp16 (pack_filter_board)
+    const uint16_t* w;     // filter [9 * cin / 32 k-steps][cout / 16 tiles][64 lanes][8] fp16 (pack_filter_board)
                            //        + 3 k-steps of readable padding behind the last one
     const uint16_t* bias;  // [cout] fp16
     const uint16_t* z;     // skip, same layout as y, read only when alpha2 != 0

@@ -120,11 +120,11 @@ void pack_filter_board(const uint16_t* krsc, int cout, int cin, uint16_t* dst)
     for (int chunk = 0; chunk < cin / 32; ++chunk)
         for (int tap = 0; tap < 9; ++tap)
             for (int slice = 0; slice < slices; ++slice)
-                for (int k16 = 0; k16 < 2; ++k16)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int co = slice * 32 + (lane & 31);
-                        const int ci = chunk * 32 + k16 * 16 + (lane >> 5) * 8;
-                        uint16_t* out = dst + (((((size_t)chunk * 9 + tap) * slices + slice) * 2 + k16) * 64 + lane) * 8;
+                for (int half = 0; half < 2; ++half)          // the A fragment of v_mfma_f32_16x16x32_f16: 16 channels x 32 input channels,
+                    for (int lane = 0; lane < 64; ++lane) {   // lane l = row l & 15, k = 8 * (l >> 4) .. + 7
+                        const int co = slice * 32 + half * 16 + (lane & 15);
+                        const int ci = chunk * 32 + (lane >> 4) * 8;
+                        uint16_t* out = dst + (((((size_t)chunk * 9 + tap) * slices + slice) * 2 + half) * 64 + lane) * 8;
                         const uint16_t* src = krsc + ((size_t)co * 9 + tap) * cin + ci;
                         for (int e = 0; e < 8; ++e) out[e] = src[e];
                     }

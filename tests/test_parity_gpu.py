@@ -178,7 +178,7 @@ def test_board_kernel_asymmetric_taps(api, oracle, monkeypatch):
     (2, 64, 64, 0.5, False),
 ])
 @pytest.mark.parametrize("skip_mode", ["0", "1"])     # skip folded into the K loop (default) / added in the epilogue
-@pytest.mark.parametrize("ns", ["8", "4", "2", "1"])  # 32-channel slices per workgroup (ignored when it does not divide C_out / 32); 1 = four waves
+@pytest.mark.parametrize("ns", ["16", "4", "2", "1"])  # 32-channel slices per workgroup (ignored when it does not divide C_out / 32); 16 = eight on four waves, 1 = twelve waves
 def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode, ns):
     monkeypatch.setenv("DGNN_BOARD_SKIP", skip_mode)
     monkeypatch.setenv("DGNN_BOARD_NS", ns)
@@ -197,7 +197,7 @@ def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout,
     assert mismatched <= 0.02 * got.size
 
 
-@pytest.mark.parametrize("ns", ["8", "4", "2", "1"])
+@pytest.mark.parametrize("ns", ["16", "4", "2", "1"])
 def test_board_kernel_exact_under_full_load(api, monkeypatch, ns):
     """configs[2] layer shape at full size (256 boards = 256 workgroups, every CU busy): integer-valued data make the
     generic kernel a bit-exact reference; three runs must be identical (a DMA / ring race shows up as run-to-run

@@ -321,20 +321,3 @@ def test_pool_over_device_lanes(api, synth):
     with pytest.raises(api.Error) as e:
         api.LeafPool.over_devices(net, [0, 97])
     assert e.value.status == api.BAD_ARGUMENT
-
-
-# --------------------------------------------------------------------------------------------- the two work splits of the tower
-
-def test_wide_and_eight_wave_tower_give_the_same_bits():
-    """The 256-channel tower runs four waves x two channel tiles per workgroup (MFMAs from inline asm, accumulators placed in AGPRs /
-    VGPRs by hand); DGNN_TOWER_WIDE=0 selects the eight-wave split.  The summation order per output is the same by construction:
-    the two must agree bit for bit (tools/wide_check.py runs each in its own process -- the switch is read once -- over 20 and 3
-    blocks, batch 256 / 200 / 131, three inputs each).  Also one layer with and without a skip input, wide against eight waves
-    (tools/layer_cmp_wide.py)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "wide_check.py")], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "bit for bit" in out.stdout, out.stdout + out.stderr
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "layer_cmp_wide.py")], capture_output=True, text=True, timeout=600)
-    assert "noskip differing elements: 0 " in out.stdout and "skip differing elements: 0 " in out.stdout, out.stdout + out.stderr
