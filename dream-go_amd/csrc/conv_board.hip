@@ -44,6 +44,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 constexpr int kRows = kBoardRows;                      // 400 padded rows per board
 constexpr int kHalo = 21;                              // rows above row 0 that a tap can reach (20 + 1)
@@ -91,32 +92,30 @@ __device__ __forceinline__ half8 lds_read(unsigned addr)
     return v;
 }
 
-// s_waitcnt lgkmcnt(N); the fragments named here are "produced" by the wait as far as the compiler is concerned, so
-// no consumer can be scheduled above it (an MFMA is register-only: a "memory" clobber alone would not hold it).
-template <int N>
-__device__ __forceinline__ void wait_lgkm(half8& f0)
+// s_waitcnt lgkmcnt(N).  The readers of the fragments it releases are asm volatile statements too (the MFMAs), and volatile asm
+// statements keep their program order, so the wait names no operands: a wait that "produces" a fragment ("+v") makes hipcc put
+// an s_nop between it and the MFMA behind it (its hazard rule for a register an asm statement defines) -- 24 of them per k-step.
+template <int N, class... Frag>
+__device__ __forceinline__ void wait_lgkm(Frag&...)
 {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f0) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
+// The same waits where COMPILER code reads the fragments next (the copies at a chunk boundary): there the wait must "produce" them,
+// or hipcc is free to move its v_mov above the wait.
 template <int N>
-__device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1)
+__device__ __forceinline__ void wait_lgkm_for(half8& f0, half8& f1)
 {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2)
-{
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f0), "+v"(f1), "+v"(f2) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2, half8& f3)
+__device__ __forceinline__ void wait_lgkm_for(half8& f0, half8& f1, half8& f2, half8& f3)
 {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N));
 }
 template <int N>
-__device__ __forceinline__ void wait_lgkm(half8& f0, half8& f1, half8& f2, half8& f3, half8& f4)
+__device__ __forceinline__ void wait_vm_for(half8& a0, half8& a1, half8& a2, half8& a3)
 {
-    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4) : "n"(N));
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N) : "memory");
 }
 
 template <class F, int... I>
@@ -185,6 +184,14 @@ __device__ __forceinline__ void mfma_asm(floatx4& c, const half8& a, const half8
 {
     if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// The first MFMA of a layer on an accumulator takes the inline constant 0 as its C operand: no zero-initialisation of 384 registers
+// per layer (320 VALU instructions of a tower layer's prologue).  Early clobber: a destination in VGPRs must not land on A or B.
+template <bool AGPR>
+__device__ __forceinline__ void mfma_asm_init(floatx4& c, const half8& a, const half8& b)
+{
+    if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
 // 8-pass MFMA result -> any reader but the next MFMA of the chain: 12 wait states; VALU write -> MFMA operand: 2.  One
 // statement in front of (BEFORE = true) or behind the VALU code that touches the tile, tied to it through the operand.
@@ -362,14 +369,18 @@ __device__ __forceinline__ void wait_z(u32x4& z0, u32x4& z1, u32x4& z2, u32x4& z
 }
 
 // DirectA: a filter fragment straight into registers, and the counted wait that hands four of them to the MFMAs behind it
-__device__ __forceinline__ void load_a_asm(half8& dst, const uint16_t* p)
+// (scalar base + the lane's byte offset + an immediate: the k-step's base is one scalar add, no VALU address arithmetic and no
+// register an asm statement "defines" in front of the load -- hipcc pads that with an s_nop)
+template <int OFF>
+__device__ __forceinline__ void load_a_asm(half8& dst, const uint16_t* sbase, unsigned lane_bytes)
 {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+    static_assert(OFF >= 0 && OFF < 4096, "global_load immediate offset");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_bytes), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void wait_a(half8& a0, half8& a1, half8& a2, half8& a3)
+__device__ __forceinline__ void wait_a(half8&, half8&, half8&, half8&)
 {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");      // no "+v" operands: see wait_lgkm
 }
 
 // SKIP: 0 = no skip input, 1 = skip added in the epilogue (general), 2 = skip accumulated DURING the K loop (alpha1 != 0):
@@ -389,6 +400,7 @@ __device__ __forceinline__ void wait_a(half8& a0, half8& a1, half8& a2, half8& a
 constexpr int kHandedOver = 2, kX0InFlight = 1, kChained = 4, kStartBuffer = 8;
 template <int NS, int SKIP, bool RELU, int ABL, bool SPLIT = false>
 __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb,
+                                               half8 (&af)[2][Split<NS>::CT][2],
                                                const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, 0, nullptr}, const int carry = 0)
 {
     using S = Split<NS>;
@@ -510,29 +522,21 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)lds;
     const unsigned w_addr = lds_base + w_lane;
 
-    floatx4 acc[CT2][RT2];
+    floatx4 acc[CT2][RT2];                            // defined by the layer's first k-step (mfma_asm_init)
+    if constexpr (ABL & 1) {
 #pragma unroll
-    for (int ct = 0; ct < CT2; ++ct)
+        for (int ct = 0; ct < CT2; ++ct)
 #pragma unroll
-        for (int rt = 0; rt < RT2; ++rt)
+            for (int rt = 0; rt < RT2; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ct][rt][r] = 0.0f;
+                for (int r = 0; r < 4; ++r) acc[ct][rt][r] = 0.0f;
+    }
     // the four 16 x 16 accumulator tiles of 32-row tile R x 32-channel tile C, as one fence statement (asm variant)
     auto fence_block = [&](auto before_c, auto r_c, auto c_c) {
         constexpr bool BEFORE = decltype(before_c)::value;
         constexpr int R = decltype(r_c)::value, C = decltype(c_c)::value;
         mfma_fence<S::acc_in_agpr(R), BEFORE>(acc[2 * C][2 * R], acc[2 * C + 1][2 * R], acc[2 * C][2 * R + 1], acc[2 * C + 1][2 * R + 1]);
     };
-    if constexpr (ASM) {
-        // hipcc materialises these zeros lazily -- a v_accvgpr_mov / v_mov of the tuple straight in front of the tile's first
-        // MFMA, which as an asm statement gets no hazard padding (VALU write -> MFMA operand: two wait states; found by
-        // tools/asm_lint.py as one stale accumulator register).  A statement per tile pins the zeros in their registers here.
-        static_for<RT>([&](auto rc) {
-            fence_block(std::false_type(), rc, std::integral_constant<int, 0>());
-            if constexpr (CT == 2) fence_block(std::false_type(), rc, std::integral_constant<int, CT - 1>());
-        });
-    }
-
     // ---- 16-byte accesses to rows of y / z.  The accumulator tile of 16 channels x 16 rows gives lane group h = lane >> 4 the four
     // channels 4 h .. 4 h + 3 of row lane & 15: half h & 1 of the 16-byte row of k-slot h >> 1.  For the two tiles (X, Y) of a
     // 32-channel tile one v_permlane16_swap per dword (odd lane groups of X <-> even lane groups of Y) turns "8 bytes of two
@@ -616,19 +620,25 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             for (int s = 0; s < kRing; ++s) issue_w(s, s);
         }
     }
-    half8 af[2][CT][2];                               // [step parity][32-channel tile][16-channel half]: fragment F of a slab is af[.][F / 2][F % 2]
+    // af[step parity][32-channel tile][16-channel half]: fragment F of a slab is af[.][F / 2][F % 2].  The caller's: DirectA hands the
+    // next layer's step-0 fragments over in af[0] (the last k-step of a layer fetches them instead of the padding behind its filter).
     // DirectA: fragment F (16 channels x the chunk's 32 input channels) of k-step `st` of this wave's two filter tiles -> af[PAR]; steps past the last one read
     // the next layer's filter (or the padding behind the last layer's): never used, they only keep every step alike
+    const uint16_t* const w_wave_s = a.w + (long)(nb * SL + wn * CT) * 1024;      // uniform: the wave's first fragment of k-step 0
+    // the step behind the last one: the next layer's step 0 when there is a layer to hand over to, else the padding behind the filter
+    const uint16_t* const w_past_s = a.w_next ? a.w_next + (long)(nb * SL + wn * CT) * 1024 - (long)nsteps_total * step_halfs : w_wave_s;
+    const unsigned lane_bytes = lane * 16;
     auto load_a = [&](auto par_c, int st) {
         constexpr int PAR = decltype(par_c)::value;
-        const uint16_t* src = w_wave + (long)st * step_halfs;
-        asm volatile("" : "+v"(src));
+        const uint16_t* const src = w_wave_s + (long)st * step_halfs;
         static_for<W>([&](auto fc) {
             constexpr int F = decltype(fc)::value;
-            load_a_asm(af[PAR][F / 2][F % 2], src + F * 512);
+            load_a_asm<F * 1024>(af[PAR][F / 2][F % 2], src, lane_bytes);
         });
     };
-    if constexpr (DIRECT_A) load_a(std::integral_constant<int, 0>(), 0);
+    if constexpr (DIRECT_A) {
+        if (!carry_in) load_a(std::integral_constant<int, 0>(), 0);
+    }
     wait_vmcnt<0>();
     __syncthreads();
     const unsigned long long t_loop = tracing ? __builtin_amdgcn_s_memtime() : 0;
@@ -664,8 +674,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     };
     // step 0 of the layer (slab 0 landed: the prologue waited for everything)
     if constexpr (PIPE && !CHUNKED && !DIRECT_A) read_a(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), w_addr);
-    auto run_chunk = [&](int chunk, auto zc_c) {
+    auto run_chunk = [&](int chunk, auto zc_c, auto first_c) {
         constexpr int ZC = decltype(zc_c)::value;
+        constexpr bool FIRST_CHUNK = decltype(first_c)::value;      // chunk 0 of the layer: its tap 0 defines the accumulators
         const int buf = (chunk + buf0) & 1;
         const int next_chunk = chunk + 1 < nchunks ? chunk + 1 : 0;    // the last chunk re-fetches chunk 0 (unused):
                                                                        // keeps the DMA count per step constant
@@ -733,26 +744,22 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                     if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, 0>(), bf[0]);
                     else wait_lgkm<YOUNGER>(bf[I % BD]);
                 }
-                // pair I = 16-row tile I: its B fragment (16 rows x 32 channels) meets the wave's CT2 filter fragments (16 channels x 32)
-#pragma unroll
-                for (int c2 = 0; c2 < S::CT2; ++c2) {
-                    if constexpr (ABL & 1) {
-                        asm volatile("" ::"v"(af[P][c2 / 2][c2 % 2]), "v"(bf[(PH + I) % BD]));
-                    } else {
-                        mfma_asm<S::acc_in_agpr(I / 2)>(acc[c2][I], af[P][c2 / 2][c2 % 2], bf[(PH + I) % BD]);     // volatile asm: stays in program order
-                    }
-                }
-                if constexpr (PIPE) {
-                    if constexpr (I == S::a_pair() && CHUNKED) {
-                        if constexpr (!LAST) read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr_c);
-                    } else if constexpr (I == S::a_pair() && !DIRECT_A) {
-                        if constexpr (!(ABL & 8)) wait_vmcnt<N_NEXT>();
-                        read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr);
-                    }
-                    constexpr int T = I + BD;
-                    if constexpr (T < NP) bf[(PH + T) % BD] = lds_read<XOFF + S::b_offset(T)>(x_addr);
-                    else if constexpr (!LAST) bf[(PH + T) % BD] = lds_read<XOFF_NEXT + S::b_offset(T - NP)>(x_addr);
-                }
+                // pair I = 16-row tile I: its B fragment (16 rows x 32 channels) meets the wave's CT2 filter fragments (16 channels x 32).
+                // A four-pass MFMA leaves two or three issue slots in its shadow: the pair's memory instructions go out between
+                // its two halves, the LDS read that refills the B register behind its last MFMA.
+                auto mfmas = [&](auto from_c, auto to_c) {
+                    static_for<decltype(to_c)::value - decltype(from_c)::value>([&](auto cc) {
+                        constexpr int C2 = decltype(from_c)::value + decltype(cc)::value;
+                        if constexpr (ABL & 1) {
+                            asm volatile("" ::"v"(af[P][C2 / 2][C2 % 2]), "v"(bf[(PH + I) % BD]));
+                        } else if constexpr (FIRST_CHUNK && TAP == 0) {
+                            mfma_asm_init<S::acc_in_agpr(I / 2)>(acc[C2][I], af[P][C2 / 2][C2 % 2], bf[(PH + I) % BD]);
+                        } else {
+                            mfma_asm<S::acc_in_agpr(I / 2)>(acc[C2][I], af[P][C2 / 2][C2 % 2], bf[(PH + I) % BD]);     // volatile asm: stays in program order
+                        }
+                    });
+                };
+                mfmas(std::integral_constant<int, 0>(), std::integral_constant<int, CT2 / 2>());
                 if constexpr (CHUNKED) {
                     // this wave's share of the NEXT chunk's activations and filter rows -> the other buffer
                     static_for<S::PPW>([&](auto jc) {
@@ -774,9 +781,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                             if constexpr (DIRECT_A) {
                                 // fragment J of the NEXT step into the other half of af: its last readers, the MFMAs of the
                                 // previous step, were issued a k-step ago
-                                const uint16_t* src = w_wave + (long)(st0 + TAP + 1) * step_halfs + J * 512;
-                                asm volatile("" : "+v"(src));
-                                load_a_asm(af[P ^ 1][J / 2][J % 2], src);
+                                const uint16_t* const base = (TAP == 8 && st0 + 9 >= nsteps_total) ? w_past_s : w_wave_s;
+                                load_a_asm<J * 1024>(af[P ^ 1][J / 2][J % 2], base + (long)(st0 + TAP + 1) * step_halfs, lane_bytes);
                             } else {
                                 issue_w_piece(st0 + TAP + kRing, TAP % kRing, J % W);
                             }
@@ -788,6 +794,18 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                         issue_x(next_chunk, buf ^ 1, TAP);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                }
+                mfmas(std::integral_constant<int, CT2 / 2>(), std::integral_constant<int, CT2>());
+                if constexpr (PIPE) {
+                    if constexpr (I == S::a_pair() && CHUNKED) {
+                        if constexpr (!LAST) read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr_c);
+                    } else if constexpr (I == S::a_pair() && !DIRECT_A) {
+                        if constexpr (!(ABL & 8)) wait_vmcnt<N_NEXT>();
+                        read_a(std::integral_constant<int, P ^ 1>(), std::integral_constant<int, WOFF_NEXT>(), w_addr);
+                    }
+                    constexpr int T = I + BD;
+                    if constexpr (T < NP) bf[(PH + T) % BD] = lds_read<XOFF + S::b_offset(T)>(x_addr);
+                    else if constexpr (!LAST) bf[(PH + T) % BD] = lds_read<XOFF_NEXT + S::b_offset(T - NP)>(x_addr);
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -837,7 +855,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         } else if constexpr (DIRECT_A) {
             // tap 8 asked for the next step's A fragments into af[1]; tap 0 of the next chunk looks in af[0].  They were requested
             // most of a k-step ago (and the barrier below waits for the slowest wave anyway)
-            wait_a<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
+            wait_vm_for<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 af[0][ct][0] = af[1][ct][0];
@@ -846,8 +864,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         } else if constexpr (PIPE) {
             // the only LDS reads still out are the A fragments of the next step (tap 8 requests no B read-ahead); tap 8
             // left them in af[1], tap 0 of the next chunk looks in af[0]
-            if constexpr (CT == 1) wait_lgkm<0>(af[1][0][0], af[1][0][1]);
-            else wait_lgkm<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
+            if constexpr (CT == 1) wait_lgkm_for<0>(af[1][0][0], af[1][0][1]);
+            else wait_lgkm_for<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 af[0][ct][0] = af[1][ct][0];
@@ -862,13 +880,15 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    int first_loop_chunk = 0;
+    int first_loop_chunk = 1;
     if constexpr (SKIP == 2) {          // the launcher guarantees nchunks >= 2
-        run_chunk(0, std::integral_constant<int, 0>());
-        run_chunk(1, std::integral_constant<int, 1>());
+        run_chunk(0, std::integral_constant<int, 0>(), std::true_type());
+        run_chunk(1, std::integral_constant<int, 1>(), std::false_type());
         first_loop_chunk = 2;
+    } else {
+        run_chunk(0, std::integral_constant<int, -1>(), std::true_type());
     }
-    for (int chunk = first_loop_chunk; chunk < nchunks; ++chunk) run_chunk(chunk, std::integral_constant<int, -1>());
+    for (int chunk = first_loop_chunk; chunk < nchunks; ++chunk) run_chunk(chunk, std::integral_constant<int, -1>(), std::false_type());
 
     const unsigned long long t_epilogue = tracing ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -952,9 +972,16 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 const half4 z4 = __builtin_bit_cast(half4, kk == 0 ? zx : zy);
                 float t[4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    t[jj] = __builtin_fmaf(a.alpha1, acc[c2][rt][jj], bias[c2][jj]);
-                    if constexpr (SKIP == 1) t[jj] = __builtin_fmaf(a.alpha2, (float)z4[jj], t[jj]);
+                for (int jj = 0; jj < 4; jj += 2) {
+                    // two fp32 fmas per instruction (v_pk_fma_f32: same rounding per element; no MFMA is running beside it here)
+                    const floatx2 av = {acc[c2][rt][jj], acc[c2][rt][jj + 1]}, bv = {bias[c2][jj], bias[c2][jj + 1]}, sv = {a.alpha1, a.alpha1};
+                    const floatx2 tv = __builtin_elementwise_fma(sv, av, bv);
+                    t[jj] = tv[0];
+                    t[jj + 1] = tv[1];
+                }
+                if constexpr (SKIP == 1) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) t[jj] = __builtin_fmaf(a.alpha2, (float)z4[jj], t[jj]);
                 }
                 // relu behind the conversion: the same bits as max(t, 0) in fp32 first (rounding is monotone, 0 is exact, a NaN gives 0 either way)
                 unsigned y01 = cvt_pk_f16(t[0], t[1]), y23 = cvt_pk_f16(t[2], t[3]);
@@ -1005,7 +1032,8 @@ __global__ __launch_bounds__(Split<NS>::Threads)
 void conv3x3_board_kernel(ConvBoardLaunch a)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
-    conv_board_body<NS, SKIP, RELU, ABL>(a, lds, blockIdx.x, blockIdx.y);
+    half8 af[2][Split<NS>::CT][2];
+    conv_board_body<NS, SKIP, RELU, ABL>(a, lds, blockIdx.x, blockIdx.y, af);
 }
 
 // The whole residual tower of one board in one workgroup.  A board's convolutions depend on that board only, and with
@@ -1021,14 +1049,15 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
     int carry = 0;
+    half8 af[2][Split<NS>::CT][2];                    // the filter fragments in registers, handed from layer to layer (DirectA)
     for (int i = 0; i < count; ++i) {
         // the descriptors carry the hand-over fields (w_next, carry_in); a layer ends with its own loads and stores waited
         // for, and the next one starts with a barrier behind workgroup-scope fences (__syncthreads): this board's y is
         // visible to this workgroup's loads
         const ConvBoardLaunch a = layers[i];
         const SplitSync none{nullptr, nullptr, 0, 1, 0, nullptr};
-        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0, none, carry);
-        else carry = conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0, none, carry);
+        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0, af, none, carry);
+        else carry = conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0, af, none, carry);
         carry |= kChained;
     }
 }
@@ -1050,11 +1079,12 @@ void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, i
     const int b = (q / groups) * 8 + xcd;
     if (b >= batch) return;
     int carry = 0;
+    half8 af[2][Split<NS>::CT][2];
     for (int i = 0; i < count; ++i) {
         const ConvBoardLaunch a = layers[i];
         const SplitSync sync{done, err, i, groups, base, trace};
-        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, sync, carry);
-        else carry = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, sync, carry);
+        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, af, sync, carry);
+        else carry = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, af, sync, carry);
         carry |= kChained;
     }
 }
@@ -1307,7 +1337,7 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches
     if (!conv_board_supported(args.cin, args.cout)) return hipErrorInvalidValue;
     const bool relu = args.relu != 0;
     // skip folded into the K loop needs two chunks to spread its row tiles over and a usable alpha2 / alpha1
-    const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && args.alpha1 != 0.0f && !env.epilogue_skip) ? 2 : 1;
+    const int skip = args.alpha2 == 0.0f ? 0 : (args.cin >= 64 && skip_scale_foldable(args.alpha1, args.alpha2) && !env.epilogue_skip) ? 2 : 1;
     const int ablate = env.ablate;
     switch (conv_board_pick_ns(args.batch, args.cout, env.ns)) {
         case 16: launch_board_variant<16>(args, skip, relu, 0, stream); break;

@@ -72,7 +72,7 @@ struct Topology {
     int num_channels = 0;
     int num_samples = 0;
     float softmax_temperature = 0.709888f;
-    bool gates_nonzero = true;   // no residual gate is 0 (alpha1 of every conv_2 != 0): what the one-launch tower needs
+    bool gates_nonzero = true;   // every residual gate can be folded in during the K loop (skip_scale_foldable): what the one-launch tower needs
 
     ConvParams up;
     std::vector<ConvParams> res1, res2;

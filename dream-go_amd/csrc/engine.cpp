@@ -72,6 +72,8 @@ struct Workspace {
     bool use_board = false;                 // padded slot-major layout + one-board-per-workgroup kernel (conv_board.hip)
     bool use_tower = false;                 // the residual tower as ONE launch where a workgroup owns a whole board (DGNN_TOWER)
     ConvBoardLaunch* d_tower_layers = nullptr;   // 2 * blocks descriptors for tower_board_kernel, filled on first use
+    unsigned long long* d_tower_timing = nullptr;   // measurement only (DGNN_TOWER_TIMING): per-layer s_memtime stamps of a whole-board tower
+    int tower_timing_layers = 0;
     bool tower_layers_ready = false;
     bool up_in_tower = true;                // the up-layer is the first layer of the tower launch (DGNN_TOWER_UP=0: a launch of its own)
     int split_pref = 1;                     // DGNN_TOWER_SPLIT: 0 = never split a board inside the tower launch, 1 = where a workgroup
@@ -116,6 +118,7 @@ Workspace::~Workspace()
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (arena) (void)hipFree(arena);
     if (d_tower_layers) (void)hipFree(d_tower_layers);
+    if (d_tower_timing) (void)hipFree(d_tower_timing);
     if (pinned) (void)hipHostFree(pinned);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -434,6 +437,16 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     describe(t.res2[i], ws->d_act[tmp], ws->d_act[c], ws->d_act[next]);
                     c = next;
                 }
+                // measurement only (tools/tower_trace.py): DGNN_TOWER_TIMING=<file> gives every layer of a whole-board tower its own
+                // block of s_memtime stamps [workgroup][wave][start, K loop, epilogue, end]; dumped after every launch
+                static const char* const timing_path = std::getenv("DGNN_TOWER_TIMING");
+                if (timing_path && *timing_path && tower_mode(ws) < 0) {
+                    const size_t words = (size_t)layers.size() * ws->batch * 8 * 4;
+                    if (!ws->d_tower_timing) DGNN_HIP(hipMalloc((void**)&ws->d_tower_timing, words * 8));
+                    DGNN_HIP(hipMemset(ws->d_tower_timing, 0, words * 8));
+                    for (size_t l = 0; l < layers.size(); ++l) layers[l].timing = ws->d_tower_timing + l * ws->batch * 8 * 4;
+                    ws->tower_timing_layers = (int)layers.size();
+                }
                 const char* carry = std::getenv("DGNN_TOWER_CARRY");          // =0: no hand-over between the layers (A/B)
                 if (!(carry && std::atoi(carry) == 0))
                     for (size_t l = 0; l + 1 < layers.size(); ++l) { layers[l].w_next = layers[l + 1].w; layers[l + 1].carry_in = 1; }
@@ -459,6 +472,18 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 chain->recorded = true;
             } else {
                 DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
+                if (ws->d_tower_timing) {
+                    DGNN_HIP(hipStreamSynchronize(ws->stream));
+                    const size_t words = (size_t)ws->tower_timing_layers * ws->batch * 8 * 4;
+                    std::vector<unsigned long long> h(words);
+                    DGNN_HIP(hipMemcpy(h.data(), ws->d_tower_timing, words * 8, hipMemcpyDeviceToHost));
+                    if (FILE* f = std::fopen(std::getenv("DGNN_TOWER_TIMING"), "wb")) {
+                        const int header[4] = {ws->tower_timing_layers, ws->batch, 8, 4};
+                        std::fwrite(header, sizeof(int), 4, f);
+                        std::fwrite(h.data(), 8, words, f);
+                        std::fclose(f);
+                    }
+                }
             }
             for (int i = 0; i < t.num_blocks; ++i) cur = (cur + 2) % 3;
         } else {

@@ -75,6 +75,15 @@ struct ConvBoardLaunch {
     int relu;
 };
 
+// The board kernels fold the skip input into the accumulators DURING the K loop as (alpha2 / alpha1) * z: alpha1 must not be 0 and
+// the ratio must be a finite number (a gate of 0 takes the epilogue form, which only the per-layer launcher has).
+inline bool skip_scale_foldable(float alpha1, float alpha2)
+{
+    if (alpha1 == 0.0f) return false;
+    const float r = alpha2 / alpha1;
+    return r == r && r <= 3.0e38f && r >= -3.0e38f;
+}
+
 // A/B switches of the board kernel, read from the environment ONCE per workspace (read_board_switches), never per launch:
 // DGNN_BOARD_NS=1|2|4|8 (slices per workgroup), DGNN_BOARD_SKIP=1 (skip added in the epilogue), DGNN_CONV_ABLATE (tools/ablate.sh).
 struct BoardSwitches {

@@ -8,6 +8,7 @@
 //   policy_head.rs:87-89      b_l <- fp16(tau * b_l)      (cudnnScaleTensor)
 //   dense.rs:182-189          dense filter transpose      (not needed: the head kernel consumes [in][out])
 #include "dgnn_internal.h"
+#include "kernels.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -194,7 +195,7 @@ int adopt_image(Network& net, const uint8_t* image, size_t num_bytes)
     }
     topo.softmax_temperature = h.softmax_temperature;
     topo.gates_nonzero = true;
-    for (const ConvParams& p : topo.res2) topo.gates_nonzero = topo.gates_nonzero && p.alpha1 != 0.0f;
+    for (const ConvParams& p : topo.res2) topo.gates_nonzero = topo.gates_nonzero && skip_scale_foldable(p.alpha1, p.alpha2);
     if (image != net.image.data()) std::memcpy(net.image.data(), image, num_bytes);
     return DGNN_OK;
 }
@@ -257,7 +258,7 @@ int build_network(Network& net)
     }
     topo.num_blocks = (int)topo.res1.size();
     topo.gates_nonzero = true;
-    for (const ConvParams& p : topo.res2) topo.gates_nonzero = topo.gates_nonzero && p.alpha1 != 0.0f;
+    for (const ConvParams& p : topo.res2) topo.gates_nonzero = topo.gates_nonzero && skip_scale_foldable(p.alpha1, p.alpha2);
 
     const int head = 2 + topo.num_blocks;   // graph.rs:54-55
     const std::string policy = scope(head, "p_policy");

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Same-box A/B of two builds of libdgnn_hip.so:  tools/ab_lib.sh <other.so> <batches> [blocks channels]
-# alternates the two libraries (B A B A) so that clock drift shows up as spread, not as a difference.
-other=$1; batches=$2; blocks=${3:-20}; channels=${4:-256}
+# Same-box A/B of builds of libdgnn_hip.so:  tools/ab_lib.sh <other.so>[,<other2.so>...] <batches> [blocks channels]
+# alternates the libraries (B A B A) so that clock drift shows up as spread, not as a difference.
+others=$1; batches=$2; blocks=${3:-20}; channels=${4:-256}
 for rep in 1 2; do
-  for lib in "$other" ""; do
+  for lib in ${others//,/ } ""; do
     DGNN_LIBRARY=$lib python tools/sweep.py --blocks $blocks --channels $channels --batches $batches --steps 30 2>/dev/null | \
       python -c "import sys,json
 for l in sys.stdin:
