@@ -23,3 +23,10 @@ done
 cd $root
 sh tools/mfma_peak.sh 4 > $out/mfma_peak.txt 2>&1
 ls $out
+# round 3: three submissions in flight (the leaf pool's regime), the per-layer stamps of the whole-board tower, the energy probes
+python tools/sweep.py --blocks 20 --channels 256 --in-flight --batches 96,112,128,129,136,144,152,160,176,192,224,256 > $out/batch_sweep_in_flight_20x256.jsonl 2>/dev/null
+python tools/tower_trace.py 256 > $out/tower_trace_256.txt 2>&1
+python tools/tower_trace.py 192 > $out/tower_trace_192.txt 2>&1
+sh tools/mfma_energy.sh 4 mfma_energy > $out/mfma_energy.txt 2>&1
+sh tools/mfma_energy.sh 4 mfma_energy2 > $out/mfma_energy2.txt 2>&1
+ls $out
