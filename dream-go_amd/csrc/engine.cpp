@@ -814,7 +814,14 @@ const char* dgnn_status_string(int status)
 
 int dgnn_last_hip_error(void) { return g_last_hip_error; }
 
-const char* dgnn_version(void) { return "dgnn-hip 0.2 (gfx950; board kernel mfma_f32_32x32x16_f16)"; }
+const char* dgnn_version(void)
+{
+#ifdef DGNN_ABLATIONS
+    return "dgnn-hip 0.3 (gfx950; board kernel mfma_f32_16x16x32_f16; +ablations: tile kernels, ablated board kernels)";
+#else
+    return "dgnn-hip 0.3 (gfx950; board kernel mfma_f32_16x16x32_f16)";
+#endif
+}
 
 int dgnn_device_count(int* count)
 {

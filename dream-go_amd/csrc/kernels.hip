@@ -335,4 +335,13 @@ hipError_t launch_heads(const HeadsLaunch& args, hipStream_t stream)
     return hipGetLastError();
 }
 
+#ifndef DGNN_ABLATIONS
+// The NHWC tile kernels of round 1 (conv_tile.hip: 40 % of the MFMA roof against the board kernel's 58 %) are A/B baselines, not
+// product: they are compiled only into a library built with DGNN_ABLATIONS=1.  Without them the selector never offers them and
+// DGNN_CONV=tile1|tile2|tile3 falls through to the generic kernel.
+bool conv_tile_supported(int, int) { return false; }
+int conv_tile_pick_fm(int, int) { return 8; }
+hipError_t launch_conv3x3_tile(const ConvTileLaunch&, int, int, hipStream_t) { return hipErrorNotSupported; }
+#endif
+
 }  // namespace dgnn
