@@ -237,10 +237,15 @@ __device__ __forceinline__ void mfma_fence(floatx4& c0, floatx4& c1, floatx4& c2
 //            its MFMAs from inline asm with the accumulator's register file spelled out: row tiles 0..7 in AGPRs, 8..11 in VGPRs.
 template <int NS>
 struct Split {
-    static constexpr int SL = NS == 16 ? 8 : NS;       // 32-channel slices per workgroup
+    // NS = 32 ("row split", round 3): the ONE slice of NS = 1 on half a board -- (board, channel block, row half) workgroups of six
+    // waves x one 32-row tile.  The smallest-batch split is bound by the LDS (twelve waves read the same two filter fragments and
+    // their own two activation fragments per k-step: 48 KB against 128 B per clock); taking the parallelism from the rows instead
+    // of more waves halves that per CU and fills 256 CUs with 16 boards of 256 channels or 32 boards of 128.
+    static constexpr int RS = NS == 32 ? 2 : 1;        // row halves a board is split into (workgroups per channel block)
+    static constexpr int SL = NS == 16 ? 8 : NS == 32 ? 1 : NS;       // 32-channel slices per workgroup
     static constexpr int CT = NS == 16 ? 2 : 1;        // 32-channel MFMA tiles per wave
     static constexpr int CW = SL / CT;                 // waves along the channels
-    static constexpr bool Chunked = NS <= 2;
+    static constexpr bool Chunked = NS <= 2 || NS == 32;
     // Every variant issues its MFMAs from inline asm with the accumulator tied to the destination ("+a" / "+v"): as a builtin the
     // four-pass v_mfma_f32_16x16x32_f16 is untied to hipcc, whose register allocator then writes results into fresh registers
     // and spills them (343 spilled registers in the K loop of the eight-wave skip variant).
@@ -253,23 +258,27 @@ struct Split {
     // depth -- at the price of 16 KiB of LDS writes, four LDS-DMA instructions (the dearest instruction to issue beside MFMAs) and
     // four ds_read_b128 per k-step and wave.
     static constexpr bool DirectA = NS == 16;
-    static constexpr int WAVES = NS == 1 ? 12 : NS == 16 ? 4 : 8;
+    static constexpr int WAVES = NS == 1 ? 12 : NS == 16 ? 4 : NS == 32 ? 6 : 8;
     static constexpr int Threads = WAVES * 64;
-    static constexpr int XP = (4 * kPieces + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
-    static constexpr int RG = WAVES / CW;              // row groups
-    static constexpr int RT = 12 / RG;                 // 32-row MFMA tiles per wave
+    static constexpr int XP = (4 * (NS == 32 ? 5 : kPieces) + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
+    static constexpr int RG = WAVES / CW;              // row groups of the workgroup
+    static constexpr int RT = 12 / RS / RG;            // 32-row MFMA tiles per wave
+    // activation pieces (64 rows) per k-slot the workgroup fetches: all seven, or -- a row half needs its 192 rows and 21 above /
+    // below -- pieces 0..4 (upper half) / 2..6 (lower half)
+    static constexpr int XPS = RS == 2 ? 5 : kPieces;
+    static constexpr int first_piece(int rh) { return RS == 2 && rh ? 2 : 0; }
     static constexpr int W = 2 * CT;                   // DMA instructions (1 KiB fragments) per filter slab: (tile, k16)
     static constexpr int SlabBytes = W * 1024;
     static constexpr int RingBytes = kRing * SlabBytes;
-    static constexpr int FChunkBytes = 9 * NS * 2048;  // Chunked: the workgroup's filter rows of one chunk, [tap][slice][k16][lane][8]
+    static constexpr int FChunkBytes = 9 * SL * 2048;  // Chunked: the workgroup's filter rows of one chunk, [tap][slice][k16][lane][8]
     static constexpr int BufStride = Chunked ? kXBufBytes + FChunkBytes : kXBufBytes;   // one of the two chunk buffers
     static constexpr int LdsBytes = Chunked ? 2 * BufStride : DirectA ? kWBase : kWBase + WAVES * RingBytes;
-    static constexpr int Pieces = 4 * kPieces + 18 * NS;            // Chunked: DMA instructions per chunk, activations then filter
+    static constexpr int Pieces = 4 * XPS + 18 * SL;                // Chunked: DMA instructions per chunk, activations then filter
     static constexpr int PPW = (Pieces + WAVES - 1) / WAVES;        // ... per wave (4 at NS = 1, 8 at NS = 2; surplus ones repeat)
     // Chunked: piece j of a wave goes out behind the MFMA of pair piece_pair(j) of tap piece_tap(j) (early in the chunk: it
     // has to land before the chunk barrier)
-    static constexpr int piece_tap(int j) { return NS == 1 ? j : j / 2; }
-    static constexpr int piece_pair(int j) { return NS == 1 ? 1 : (j % 2 ? 4 : 1); }
+    static constexpr int piece_tap(int j) { return SL == 1 ? j : j / 2; }
+    static constexpr int piece_pair(int j) { return SL == 1 ? 1 : (j % 2 ? 4 : 1); }
     static constexpr int pieces_in_tap(int tap) { int n = 0; for (int j = 0; j < PPW; ++j) n += piece_tap(j) == tap ? 1 : 0; return n; }
     static constexpr int CT2 = 2 * CT;                 // 16-channel MFMA tiles per wave
     static constexpr int RT2 = 2 * RT;                 // 16-row MFMA tiles per wave
@@ -284,7 +293,8 @@ struct Split {
     static constexpr int a_pair() { return NS == 16 ? 19 : NS == 8 ? 17 : NS == 4 ? 8 : NS == 2 ? 3 : 0; }
 };
 static_assert(Split<4>::LdsBytes <= 160 * 1024 && Split<2>::LdsBytes <= 160 * 1024 && Split<16>::LdsBytes <= 160 * 1024, "LDS budget");
-static_assert(Split<1>::BD <= Split<1>::NP && Split<2>::BD <= Split<2>::NP, "the B rotation reaches one step ahead at most");
+static_assert(Split<1>::BD <= Split<1>::NP && Split<2>::BD <= Split<2>::NP && Split<32>::BD <= Split<32>::NP, "the B rotation reaches one step ahead at most");
+static_assert(Split<32>::PPW <= 9 && Split<32>::RT == 1 && Split<32>::NP == 2, "row split: a piece per tap");
 
 // A board split over G = C_out / (32 * NS) workgroups INSIDE one launch (tower_split_kernel): what a workgroup needs to
 // know about the others.  Every workgroup publishes "layer i of my channel block is in memory" by storing i + 1 into
@@ -401,9 +411,12 @@ constexpr int kHandedOver = 2, kX0InFlight = 1, kChained = 4, kStartBuffer = 8;
 template <int NS, int SKIP, bool RELU, int ABL, bool SPLIT = false>
 __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* const lds, const int b, const int nb,
                                                half8 (&af)[2][Split<NS>::CT][2],
-                                               const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, 0, nullptr}, const int carry = 0)
+                                               const SplitSync sync = SplitSync{nullptr, nullptr, 0, 1, 0, nullptr}, const int carry = 0,
+                                               const int rh = 0)
 {
     using S = Split<NS>;
+    constexpr int RS = S::RS;                        // row halves per channel block (2: `rh` says which one this workgroup is)
+    static_assert(RS == 1 || (SPLIT && S::Chunked), "the row split exists inside the split tower only");
     constexpr int CT = S::CT, RT = S::RT, CT2 = S::CT2, RT2 = S::RT2, W = S::W, NP = S::NP, BD = S::BD, XP = S::XP, SL = S::SL;
     constexpr bool CHUNKED = S::Chunked;
     constexpr bool ASM = S::AsmMfma;                 // MFMAs from inline asm (Split<16>: accumulators of row tiles 0..7 in AGPRs)
@@ -420,7 +433,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % S::CW;                     // channel position: slices wn * CT .. wn * CT + CT - 1 of the workgroup's SL
-    const int g = wave / S::CW;                      // row group
+    const int g = wave / S::CW + rh * S::RG;         // row group OF THE BOARD: 32-row tiles g * RT .. g * RT + RT - 1
     const int cin = a.cin;
     const int cout = a.cout;
     const int nchunks = cin / 32;
@@ -466,9 +479,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     // number of DMA instructions and the vmcnt bookkeeping below is one set of constants.
     auto issue_x_from = [&](const uint16_t* board, int chunk, int buf, int j) {
         int p = wave + S::WAVES * j;
-        if (p >= 4 * kPieces) p -= S::WAVES;
-        const int s = p / kPieces;
-        const int i = p - s * kPieces;
+        if (p >= 4 * S::XPS) p -= S::WAVES;
+        const int s = p / S::XPS;
+        const int i = p - s * S::XPS + S::first_piece(rh);
         const uint16_t* src = board + ((long)(chunk * 4 + s) * kRows + i * 64) * 8;
         char* const dst = lds + buf * BUF + s * kSlotBytes + (kHalo + i * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -477,10 +490,10 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     auto issue_x = [&](int chunk, int buf, int j) { issue_x_from(x_board, chunk, buf, j); };
     // Chunked: piece q (0 .. 18 * NS - 1 = [tap][slice][k16]) of the workgroup's filter rows of `chunk` -> buffer `buf`.  Chunks
     // past the last one belong to the next layer when there is one to hand over to.
-    const uint16_t* const w_group = a.w + (long)(nb * NS) * 1024 + lane * 8;
-    const uint16_t* const w_next_group = a.w_next ? a.w_next + (long)(nb * NS) * 1024 + lane * 8 - (long)nsteps_total * step_halfs : w_group;
+    const uint16_t* const w_group = a.w + (long)(nb * SL) * 1024 + lane * 8;
+    const uint16_t* const w_next_group = a.w_next ? a.w_next + (long)(nb * SL) * 1024 + lane * 8 - (long)nsteps_total * step_halfs : w_group;
     auto issue_f = [&](int chunk, int buf, int q) {
-        const int tap = q / (2 * NS), rest = q - tap * (2 * NS);
+        const int tap = q / (2 * SL), rest = q - tap * (2 * SL);
         const int st = chunk * 9 + tap;
         const uint16_t* src = (st >= nsteps_total ? w_next_group : w_group) + (long)st * step_halfs + rest * 512;
         char* const dst = lds + buf * BUF + kXBufBytes + q * 1024;
@@ -491,27 +504,42 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     auto issue_piece = [&](int x_chunk, int f_chunk, int buf, int j) {
         int p = wave + S::WAVES * j;
         if (p >= S::Pieces) p -= S::WAVES;            // a surplus instruction repeats the wave's previous piece
-        if (p < 4 * kPieces) {
-            const int sl = p / kPieces;
-            const int i = p - sl * kPieces;
+        if (p < 4 * S::XPS) {
+            const int sl = p / S::XPS;
+            const int i = p - sl * S::XPS + S::first_piece(rh);        // a row half fetches five of the seven 64-row pieces
             const uint16_t* src = x_board + ((long)(x_chunk * 4 + sl) * kRows + i * 64) * 8;
             char* const dst = lds + buf * BUF + sl * kSlotBytes + (kHalo + i * 64) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, SPLIT ? 16 : 0);
         } else {
-            issue_f(f_chunk, buf, p - 4 * kPieces);
+            issue_f(f_chunk, buf, p - 4 * S::XPS);
         }
     };
-    // SPLIT: the flag of the workgroup that produces input chunk c (its channel block is c / NS)
+    // SPLIT: the flag of the workgroup that produces input chunk c (its channel block is c / SL).  Row split: a channel block has
+    // two producers, flags [block][row half]; a consumer needs its own half of the rows and 21 of the other one, so BOTH -- its own
+    // channel block included, whose other half a sibling workgroup writes.
     unsigned* const done_board = SPLIT ? sync.done + (long)b * sync.groups : nullptr;
     auto await_chunk = [&](int c) {       // lane 0 of wave 0 only; the caller's next barrier tells everybody
-        if (c / SL != nb) wait_published(done_board + c / SL, sync.base + (unsigned)sync.epoch, sync.err);
+        const unsigned want = sync.base + (unsigned)sync.epoch;
+        if constexpr (RS == 2) {
+            wait_published(done_board + (c / SL) * 2 + (rh ^ 1), want, sync.err);
+            if (c / SL != nb) wait_published(done_board + (c / SL) * 2 + rh, want, sync.err);
+        } else {
+            if (c / SL != nb) wait_published(done_board + c / SL, want, sync.err);
+        }
     };
     // A look at a producer's flag costs a round trip to the L2 (some 600 cycles): it is requested EARLY -- a plain load that
     // completes while the waves compute -- and only a flag that was not up yet is polled where the data is needed.
-    auto peek_chunk = [&](int c) -> unsigned {          // wave 0: the flag of chunk c's producer now (own chunks: "published")
-        if (c / SL == nb) return ~0u;
-        return __hip_atomic_load(done_board + c / SL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto peek_chunk = [&](int c) -> unsigned {          // wave 0: the flag of chunk c's producer(s) now (own chunks: "published")
+        if constexpr (RS == 2) {
+            const unsigned other = __hip_atomic_load(done_board + (c / SL) * 2 + (rh ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c / SL == nb) return other;
+            const unsigned same = __hip_atomic_load(done_board + (c / SL) * 2 + rh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return other < same ? other : same;
+        } else {
+            if (c / SL == nb) return ~0u;
+            return __hip_atomic_load(done_board + c / SL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
 
     // ---- fragment read addresses ----
@@ -592,7 +620,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     if constexpr (SPLIT) {
         // chunk 0 (and chunk 1, whose pieces go out during chunk 0) must have been published by their producers; the
         // workgroup that produced chunk 0 itself found it in LDS (carry_in) and, unless NS == 1, owns chunk 1 too
-        const bool must_wait = sync.epoch > 0 && ((nb != 0 && !x0_in_flight) || (SL == 1 && nchunks > 1));
+        const bool must_wait = sync.epoch > 0 && (((RS == 2 || nb != 0) && !x0_in_flight) || (SL == 1 && nchunks > 1));
         // (channel block 0 without a hand-over reads back its own output: no flag to wait for)
         if (must_wait) {
             if (tid == 0) {
@@ -607,14 +635,14 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     // a chained layer without a hand-over fetches chunk 0 -- rows that OTHER waves of this workgroup stored a moment ago (each
     // wave has waited for its own stores only): meet them first
     if ((carry & kChained) != 0 && !carry_in) __syncthreads();
-    if (!carry_in || (SPLIT && nb != 0 && !x0_in_flight)) {
+    if (!carry_in || (SPLIT && (RS == 2 || nb != 0) && !x0_in_flight)) {     // (row split: nobody finds chunk 0 in LDS, it lacks the sibling's rows)
 #pragma unroll
         for (int j = 0; j < XP; ++j) issue_x(0, buf0, j);
     }
     if constexpr (DIRECT_A) {
     } else if (!carry_in) {
         if constexpr (CHUNKED) {
-            for (int q = wave; q < 18 * NS; q += S::WAVES) issue_f(0, buf0, q);
+            for (int q = wave; q < 18 * SL; q += S::WAVES) issue_f(0, buf0, q);
         } else {
 #pragma unroll
             for (int s = 0; s < kRing; ++s) issue_w(s, s);
@@ -703,8 +731,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             constexpr int N = 2 * WI + ((TAP + 6) % 9 < XP) + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP);
             // ... after slab st + 1, seen from pair AP of step st (all of this step's DMA instructions come before AP)
             constexpr int N_NEXT = 2 * WI + ((TAP + 7) % 9 < XP) + ((TAP + 8) % 9 < XP) + (TAP < XP);
-            constexpr int WOFF = CHUNKED ? TAP * NS * 2048 : (TAP % kRing) * S::SlabBytes;
-            constexpr int WOFF_NEXT = CHUNKED ? (TAP + 1) % 9 * NS * 2048 : ((TAP + 1) % kRing) * S::SlabBytes;
+            constexpr int WOFF = CHUNKED ? TAP * SL * 2048 : (TAP % kRing) * S::SlabBytes;
+            constexpr int WOFF_NEXT = CHUNKED ? (TAP + 1) % 9 * SL * 2048 : ((TAP + 1) % kRing) * S::SlabBytes;
             constexpr int XOFF = (kHalo + SHIFT) * 16;
             constexpr int XOFF_NEXT = (kHalo + SHIFT_NEXT) * 16;
             constexpr bool FIRST = TAP == 0, LAST = TAP == 8;
@@ -912,7 +940,13 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         }
     };
     if constexpr (SPLIT) {
-        if (may_prefetch_x0 && wave == 0) flag_x0 = __hip_atomic_load(done_board, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (may_prefetch_x0 && wave == 0) {
+            flag_x0 = __hip_atomic_load(done_board, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (RS == 2) {          // both row halves of channel block 0
+                const unsigned other = __hip_atomic_load(done_board + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flag_x0 = other < flag_x0 ? other : flag_x0;
+            }
+        }
         if constexpr (!CHUNKED) {             // NS = 4: look and request now, in front of the epilogue (the longer epilogue covers it)
             if (may_prefetch_x0) prefetch_x0();
         }
@@ -995,7 +1029,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             // hand-over: channels 0..31 are the next layer's first input chunk; its place is activation buffer 0, which
             // nobody reads any more (the last chunk sits in buffer 1, and the barrier that ended it came after every
             // wave's last DMA into buffer 0 had landed)
-            if (ct == 0 && wn == 0 && nb == 0 && hand_over)
+            if (RS == 1 && ct == 0 && wn == 0 && nb == 0 && hand_over)
                 *reinterpret_cast<uint4*>(lds + buf_next * BUF + slot_of_lane * kSlotBytes + (kHalo + row) * 16) = unit;
         }
         if (rt + 2 < S::RT2) load_z(rt + 2);
@@ -1018,9 +1052,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     if constexpr (SPLIT) {
         // every wave's write-through stores have left (vmcnt counts stores): one lane says so to the rest of the board
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(done_board + nb, sync.base + (unsigned)sync.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(done_board + nb * RS + rh, sync.base + (unsigned)sync.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sync.trace != nullptr && tid == 0) {
-            unsigned long long* out = sync.trace + (((long)sync.epoch * a.batch + b) * sync.groups + nb) * 4;
+            unsigned long long* out = sync.trace + (((long)sync.epoch * a.batch + b) * sync.groups + nb * RS + rh) * 4;
             out[0] = t_start; out[1] = t_loop; out[2] = t_epilogue | (x0_next ? 1ull << 63 : 0ull); out[3] = __builtin_amdgcn_s_memtime();
         }
     }
@@ -1075,7 +1109,9 @@ void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, i
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes + 16];    // + one word of workgroup-wide agreement
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int nb = q % groups;
+    constexpr int RS = Split<NS>::RS;                 // `groups` = workgroups per board = channel blocks x row halves
+    const int nb = (q % groups) / RS;
+    const int rh = (q % groups) % RS;
     const int b = (q / groups) * 8 + xcd;
     if (b >= batch) return;
     int carry = 0;
@@ -1083,8 +1119,8 @@ void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, i
     for (int i = 0; i < count; ++i) {
         const ConvBoardLaunch a = layers[i];
         const SplitSync sync{done, err, i, groups, base, trace};
-        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, af, sync, carry);
-        else carry = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, af, sync, carry);
+        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, af, sync, carry, rh);
+        else carry = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, af, sync, carry, rh);
         carry |= kChained;
     }
 }
@@ -1280,6 +1316,9 @@ int tower_split_ns(int batch, int channels, int num_cus)
     if (slices != 2 && slices != 4 && slices != 8) return 0;
     int ns = slices;
     while (ns > 1 && (long)batch * (slices / ns) < 192 && (long)batch * (slices / ns) * 2 <= num_cus) ns /= 2;
+    // one slice per workgroup and still room for twice the workgroups: split the rows too (Split<32>; DGNN_TOWER_ROWSPLIT=0: never)
+    static const int rowsplit = [] { const char* e = std::getenv("DGNN_TOWER_ROWSPLIT"); return e ? std::atoi(e) : 1; }();
+    if (ns == 1 && slices >= 4 && rowsplit != 0 && (long)batch * slices * 2 <= num_cus) return 32;
     return ns == slices ? 0 : ns;
 }
 
@@ -1288,8 +1327,8 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     const int slices = channels / 32;
-    if (ns < 1 || ns >= slices || slices % ns != 0) return hipErrorInvalidValue;
-    const int groups = slices / ns;
+    if (ns != 32 && (ns < 1 || ns >= slices || slices % ns != 0)) return hipErrorInvalidValue;
+    const int groups = ns == 32 ? slices * 2 : slices / ns;          // workgroups per board (row split: channel blocks x 2 row halves)
     if ((size_t)batch * groups > done_words) return hipErrorInvalidValue;
     // The flags are never reset between launches: a launch publishes *base + 1 .. *base + count, the next one counts from
     // above that (whatever batch size or split it uses: every stale word is below its base).  Only a counter about to wrap
@@ -1311,6 +1350,7 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
         (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
     }
     switch (ns) {
+        case 32: hipLaunchKernelGGL((tower_split_kernel<32>), grid, dim3(Split<32>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
         case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
         case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
         default: hipLaunchKernelGGL((tower_split_kernel<1>), grid, dim3(Split<1>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;

@@ -33,6 +33,8 @@ void set_last_hip_error(int code) { g_last_hip_error = code; }
         }                                                   \
     } while (0)
 
+constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 8 channel blocks x 2 row halves (kernels.h: launch_tower_split)
+
 struct Workspace {
     Network* net = nullptr;
     DeviceState* dev = nullptr;
@@ -83,7 +85,7 @@ struct Workspace {
     int split_cooldown = 0;                 // passes still to run per layer before the split is tried again
     bool inject_giveup = false;             // DGNN_SPLIT_INJECT_GIVEUP=1 when the workspace was built (fault injection for the tests)
     bool injected = false;                  // ... and it has fired
-    unsigned* d_split_sync = nullptr;       // [batch * 8] layers published per (board, channel block), then the give-up word
+    unsigned* d_split_sync = nullptr;       // [batch * kSplitWordsPerBoard] layers published per (board, channel block, row half), then the give-up word
     unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
     unsigned* h_split_err = nullptr;        // pinned copy of that word, fetched with the outputs
     bool split_pending = false;             // the submission in flight used tower_split_kernel
@@ -281,7 +283,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
     const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
     const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
-    const size_t sz_split = align_up(((size_t)batch * 8 + 1) * sizeof(unsigned), 256);
+    const size_t sz_split = align_up(((size_t)batch * kSplitWordsPerBoard + 1) * sizeof(unsigned), 256);
     const size_t sz_records = align_up((size_t)batch * DGNN_BOARD_RECORD_BYTES, 256);
     const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split + sz_records;
 
@@ -457,17 +459,17 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
             const int layer_count = 2 * t.num_blocks + (up_in_tower ? 1 : 0);
             const int mode = tower_mode(ws);
             if (mode > 0) {
-                const int groups = t.num_channels / 32 / mode;
+                const int groups = mode == 32 ? t.num_channels / 32 * 2 : t.num_channels / 32 / mode;
                 SplitChain* chain = ws->dev->chain;
                 std::lock_guard<std::mutex> chained(chain->mutex);
                 if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
                 (void)groups;
                 if (ws->inject_giveup && !ws->injected) {       // fault injection (tests): the launch finds the give-up word already set
                     ws->injected = true;
-                    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * 8, 0xff, sizeof(unsigned), ws->stream));
+                    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, 0xff, sizeof(unsigned), ws->stream));
                 }
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
-                                            (size_t)ws->batch * 8, ws->d_split_sync + (size_t)ws->batch * 8, &ws->split_base, ws->stream));
+                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, &ws->split_base, ws->stream));
                 DGNN_HIP(hipEventRecord(chain->done, ws->stream));
                 chain->recorded = true;
             } else {
@@ -617,7 +619,7 @@ int enqueue_split_check(Workspace* ws, int input_form)
     ws->split_pending = mode > 0;
     ws->pending_form = input_form;
     if (mode > 0) {
-        DGNN_HIP(hipMemcpyAsync(ws->h_split_err, ws->d_split_sync + (size_t)ws->batch * 8, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream));
+        DGNN_HIP(hipMemcpyAsync(ws->h_split_err, ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream));
     }
     return DGNN_OK;
 }
@@ -636,7 +638,7 @@ int note_split_failure(Workspace* ws)
     ws->split_cooldown = kSplitCooldown;
     std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer %s\n", ws->device,
                  ws->split_failures >= kSplitMaxFailures ? "from now on" : "for the next passes");
-    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * 8, 0, sizeof(unsigned), ws->stream));   // the word is sticky on the device
+    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, 0, sizeof(unsigned), ws->stream));   // the word is sticky on the device
     return DGNN_OK;
 }
 
@@ -671,7 +673,7 @@ int check_split_after_sync(Workspace* ws)
 {
     if (tower_mode(ws) <= 0) return DGNN_OK;
     unsigned err = 0;
-    DGNN_HIP(hipMemcpy(&err, ws->d_split_sync + (size_t)ws->batch * 8, sizeof(unsigned), hipMemcpyDeviceToHost));
+    DGNN_HIP(hipMemcpy(&err, ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (err == 0) return DGNN_OK;
     const int status = note_split_failure(ws);
     if (status != DGNN_OK) return status;
