@@ -113,6 +113,11 @@ __device__ __forceinline__ void wait_lgkm_for(half8& f0, half8& f1, half8& f2, h
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N));
 }
 template <int N>
+__device__ __forceinline__ void wait_vm_for(half8& a0, half8& a1)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a0), "+v"(a1) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void wait_vm_for(half8& a0, half8& a1, half8& a2, half8& a3)
 {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "n"(N) : "memory");
@@ -257,7 +262,7 @@ struct Split {
     // ring.  With one wave per 64 channels no two waves ever want the same filter bytes, so the ring bought nothing but prefetch
     // depth -- at the price of 16 KiB of LDS writes, four LDS-DMA instructions (the dearest instruction to issue beside MFMAs) and
     // four ds_read_b128 per k-step and wave.
-    static constexpr bool DirectA = NS == 16;
+    static constexpr bool DirectA = NS == 16 || NS == 4;
     static constexpr int WAVES = NS == 1 ? 12 : NS == 16 ? 4 : NS == 32 ? 6 : 8;
     static constexpr int Threads = WAVES * 64;
     static constexpr int XP = (4 * (NS == 32 ? 5 : kPieces) + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
@@ -388,7 +393,7 @@ __device__ __forceinline__ void load_a_asm(half8& dst, const uint16_t* sbase, un
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_bytes), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void wait_a(half8&, half8&, half8&, half8&)
+__device__ __forceinline__ void wait_a()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");      // no "+v" operands: see wait_lgkm
 }
@@ -421,7 +426,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     constexpr bool CHUNKED = S::Chunked;
     constexpr bool ASM = S::AsmMfma;                 // MFMAs from inline asm (Split<16>: accumulators of row tiles 0..7 in AGPRs)
     constexpr bool DIRECT_A = S::DirectA;            // filter fragments by global loads into the next step's registers, no LDS ring
-    static_assert(!DIRECT_A || (ASM && CT == 2 && !CHUNKED && W == 4), "DirectA is written for the wide split");
+    static_assert(!DIRECT_A || (ASM && !CHUNKED), "DirectA: asm MFMAs, filter not in the chunk buffer");
     constexpr int BUF = S::BufStride;
     static_assert(!CHUNKED || !(ABL & ~1), "the chunked kernels know ablation 1 (no MFMAs) only");
     const bool x0_in_flight = (carry & kX0InFlight) != 0;
@@ -760,7 +765,7 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                         constexpr int PT = (TAP + 8) % 9;                         // the previous tap
                         constexpr bool Z_PREV = ZC >= 0 && TAP >= 1 && PT <= 5 && ZC * 6 + PT < 12;
                         constexpr int N_A = FIRST ? 0 : (PT < XP ? 1 : 0) + (Z_PREV ? 2 * CT : 0);
-                        wait_a<N_A>(af[P][0][0], af[P][0][1], af[P][1][0], af[P][1][1]);
+                        wait_a<N_A>();
                         wait_lgkm<YOUNGER>(bf[PH % BD]);
                     }
                     else if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, P>(), bf[PH % BD]);
@@ -883,7 +888,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         } else if constexpr (DIRECT_A) {
             // tap 8 asked for the next step's A fragments into af[1]; tap 0 of the next chunk looks in af[0].  They were requested
             // most of a k-step ago (and the barrier below waits for the slowest wave anyway)
-            wait_vm_for<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
+            if constexpr (CT == 1) wait_vm_for<0>(af[1][0][0], af[1][0][1]);
+            else wait_vm_for<0>(af[1][0][0], af[1][0][1], af[1][1][0], af[1][1][1]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 af[0][ct][0] = af[1][ct][0];
