@@ -670,12 +670,16 @@ def test_small_batches_split_a_board_inside_the_tower_launch(api, synth, monkeyp
 
 @pytest.mark.parametrize("blocks,channels,batch,split", [
     (3, 256, 128, "1"), (3, 256, 100, "1"), (2, 256, 64, "1"), (2, 256, 37, "1"), (3, 256, 20, "1"), (2, 256, 1, "1"),
-    (4, 128, 128, "1"), (4, 128, 70, "1"), (3, 128, 40, "1"), (3, 128, 3, "1"), (3, 64, 50, "2"), (2, 64, 128, "2")])
+    (4, 128, 128, "1"), (4, 128, 70, "1"), (3, 128, 40, "1"), (3, 128, 3, "1"), (3, 64, 50, "2"), (2, 64, 128, "2"),
+    # the row split (a channel block's rows over two workgroups: batch * C / 32 * 2 <= 256 CUs) at and around its limits
+    (3, 256, 16, "1"), (2, 256, 9, "1"), (3, 256, 17, "1"), (3, 128, 32, "1"), (4, 128, 17, "1"), (3, 128, 33, "1")])
 def test_split_tower_equals_one_launch_per_layer(api, synth, blocks, channels, batch, split, monkeypatch):
     """tower_split_kernel: the workgroups of a board hand their channel blocks to each other inside one launch (per-board
     flags, write-through stores, L1-bypassing loads).  Same per-layer code, same contraction order as conv3x3_board_kernel:
     the outputs must be bit-identical to one launch per layer, pass after pass (a hand-off that let a workgroup read a
-    channel block too early would show up as a mismatch on some pass)."""
+    channel block too early would show up as a mismatch on some pass).  Round 3: where one 32-channel slice per workgroup still
+    leaves half the CUs idle the rows are split too (tower_split_kernel<32>: flags per (board, block, row half), a consumer waits for
+    its sibling's 21 halo rows as well)."""
     text = synth.to_json(synth.make_tensors(blocks, channels, seed=191))
     monkeypatch.setenv("DGNN_TOWER", "0")
     net = api.Network.from_json(text)
