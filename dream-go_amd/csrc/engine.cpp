@@ -595,20 +595,31 @@ int wait_submission(Workspace* ws)
     if (kWaitMode == kWaitSpin) { DGNN_HIP(hipStreamSynchronize(ws->stream)); return DGNN_OK; }
     if (kWaitMode == kWaitEvent) { DGNN_HIP(hipEventSynchronize(ws->ev_done)); return DGNN_OK; }
     // the long sleep first: 85 % of what is left of the expected duration, scaled down for a smaller batch, at most 50 ms
+    bool napped = false;
     if (ws->wait_boards > 0 && ws->wait_ns > 0.0) {
         double expected = ws->wait_ns * (ws->active < ws->wait_boards ? (double)ws->active / ws->wait_boards : 1.0);
         const long long left = (long long)(0.85 * expected) - (now_ns() - ws->submit_ns);
-        nap_ns(left < 50000000ll ? left : 50000000ll);
+        if (left > 0) { nap_ns(left < 50000000ll ? left : 50000000ll); napped = true; }
     }
+    int polls = 0;
     for (;;) {
         const hipError_t q = hipEventQuery(ws->ev_done);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) { set_last_hip_error((int)q); return DGNN_HIP_ERROR; }
         nap_ns(30000);
+        ++polls;
     }
     const double took = (double)(now_ns() - ws->submit_ns);
-    ws->wait_ns = (ws->wait_boards == ws->active && ws->wait_ns > 0.0) ? 0.75 * ws->wait_ns + 0.25 * took : took;
-    ws->wait_boards = ws->active;
+    if (napped && polls == 0) {
+        // done before the long sleep ended: `took` is the sleep, not the pass.  Averaging it in would keep an over-estimate alive
+        // for dozens of passes (a pass can never look shorter than 85 % of the estimate): one slow pass -- the first one, with its
+        // lazy initialisation; a hiccup -- and a synchronous caller sleeps 85 % of THAT from then on (seen as 14 ms per 3.4 ms pass in
+        // a batch sweep).  Halve the estimate until a poll is needed again.
+        ws->wait_ns *= 0.5;
+    } else {
+        ws->wait_ns = (ws->wait_boards == ws->active && ws->wait_ns > 0.0) ? 0.75 * ws->wait_ns + 0.25 * took : took;
+        ws->wait_boards = ws->active;
+    }
     return DGNN_OK;
 }
 
