@@ -1,5 +1,5 @@
 // conv3x3_board_kernel -- residual-tower convolution on the PADDED SLOT-MAJOR activation layout, one 19x19 board
-// per 512-thread workgroup (C_out a multiple of 256, C_in a multiple of 32).  Same contract as conv3x3_kernel
+// per workgroup (C_out a multiple of 64, C_in a multiple of 32).  Same contract as conv3x3_kernel
 // (kernels.hip):  y = act(alpha1 * conv3x3(x, w) + alpha2 * z + bias)   [conv2d.rs:171-220 of the reference].
 //
 // Activation layout (x, z, y):  [board][C / 8][400 rows][8 channels] fp16.  A board is 20 rows x 20 columns, row =
@@ -11,22 +11,20 @@
 //     perfectly coalesced, and 16 or 32 consecutive rows of one k-slot are contiguous in LDS: conflict-free
 //     ds_read_b128 fragment reads without a swizzle.
 //
-// Work split: 8 waves = 4 along the output channels (64 each) x 2 along the rows (192 each = 6 MFMA row tiles;
-// rows 384..399 are pad row 19 and are never computed).  v_mfma_f32_32x32x16_f16, A = filter rows (channels),
-// B = board rows: 2 x 6 accumulator tiles per wave (192 registers).
+// Arithmetic: v_mfma_f32_16x16x32_f16 from inline asm, A = a 16-channel x 32-k filter fragment, B = 16 board rows x the chunk's 32
+// input channels (the lane's 16-byte row of k-slot lane >> 4): a 16 x 16 accumulator tile per MFMA, one 32-deep dot product per
+// (chunk, tap).  The part charges 14 % less for this shape than for 32x32x16 at its power cap (tools/mfma_energy.hip).
+// Work splits (struct Split below): the shipped one at 256 channels is four waves x (64 channels x all 384 rows) = 96 accumulator
+// tiles = 384 registers per wave, one wave per SIMD; smaller splits share a board between 2 .. 16 workgroups.
 //
 // K loop: chunk-major (32 input channels), tap-minor.
 //   activations  one chunk = 4 k-slots x 400 rows is DMA'd into LDS ONCE and serves all 9 taps (the tap is an
 //                immediate offset of the fragment read).  Double buffered; the next chunk's 28 DMA pieces are spread
-//                over the first 4 taps of the current chunk; ONE workgroup barrier per chunk (8 per launch at
-//                C_in = 256) -- within a chunk the waves run free, so the two waves of a SIMD interleave naturally.
-//   filter       every wave streams ONLY the rows of its own 64 output channels, pre-packed by the host in MFMA
-//                fragment order, through a WAVE-PRIVATE 3-slab LDS ring (4 KiB per k-step): no cross-wave
-//                synchronisation at all, ordering is the issuing wave's own counted s_waitcnt vmcnt.  A slab is
-//                re-filled right after the MFMAs that consumed it were issued (in-order issue => their operand
-//                reads have retired), i.e. 2 full k-steps before it is needed again.
-// LDS-DMA traffic per board and layer: 205 KiB activations + 2 x 1.18 MiB filter (waves w and w + 4 each hold a
-// copy) for 36.9k MFMA-cycles per SIMD, one third of what the NHWC tile kernel (conv_tile.hip) moves per FLOP.
+//                over the first taps of the current chunk; ONE workgroup barrier per chunk (8 per layer at C_in = 256).
+//   filter       pre-packed by the host in MFMA fragment order.  Wide and four-slice splits: straight from memory into the
+//                registers of the NEXT k-step (DirectA); one- and two-slice splits: the workgroup's rows of a chunk beside the
+//                chunk's activations in the same double buffer (Chunked).  Every wave's ordering is its own counted s_waitcnt.
+// rows 384..399 are pad row 19 and are never computed.
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -212,34 +210,27 @@ __device__ __forceinline__ void mfma_fence(floatx4& c0, floatx4& c1, floatx4& c2
     }
 }
 
-// Work split of the 8 waves, template parameter NS = 32-channel slices per workgroup (a workgroup covers 32 * NS output
-// channels of one board; grid.y = C_out / (32 * NS)):
-//   NS = 8   8 slices x 1 row group of 384 rows (12 row tiles per wave)      C_out % 256 == 0, one workgroup per board
-//   NS = 4   4 slices x 2 row groups of 192 rows (6 row tiles per wave)      C_out % 128 == 0
-//   NS = 2   2 slices x 4 row groups of 96 rows  (3 row tiles per wave)      C_out % 64 == 0
-// A wave owns ONE 32-channel MFMA tile column, so every filter byte is fetched by 8 / NS waves (once at NS = 8).  Smaller NS
-// = more, smaller workgroups per board: used for narrow networks and to fill the chip at small batch sizes.
-// History: a layout with two channel tiles per wave and two waves per 64-channel slice fetched every
-// filter slab twice and was 2 % slower; one with the k-step's whole slab in a ring shared by all waves (barrier every
-// third k-step) was 1 % slower still.  tools/clock_probe.sh shows why such differences are small: the kernel runs at the
-// POWER-LIMITED shader clock (1.62 GHz with the MFMA pipe busy 76 % of the cycles; 1.94 GHz with the DMA ablated, 1.92 GHz
-// with the B-fragment reads ablated) -- saved cycles come back as a lower clock unless bytes moved per MFMA go down too.
-// Filter packing (host, pack_filter_board): [k-step][C_out / 32 slices][k16][64 lanes][8 halfs], k-step = chunk * 9 + tap,
-// lane l holds w[co = slice * 32 + (l & 31)][tap][ci = chunk * 32 + k16 * 16 + (l >> 5) * 8 .. + 8].
+// Work splits, template parameter NS (a workgroup covers 32 * SL output channels of one board; grid.y = C_out / (32 * SL)):
+//   NS = 16  ("wide", the shipped split at 256 channels: a workgroup per board) 8 slices on FOUR waves x two 32-channel tiles x
+//            all 384 rows: a B fragment feeds four 16-channel MFMA tiles, every filter byte is fetched once.  384 accumulator
+//            registers per wave (one wave per SIMD, 512 registers): 32-row tiles 0..7 in AGPRs, 8..11 in VGPRs, spelled out in
+//            the asm constraints.  (NS = 8, the eight-wave split of rounds 1-2 -- one 32-channel tile per wave, twice the LDS
+//            reads -- is gone: DGNN_BOARD_NS=8 means 16.)
+//   NS = 4   4 slices x 2 row groups of 192 rows, eight waves (6 row tiles per wave)      C_out % 128 == 0
+//   NS = 2   2 slices x 4 row groups of 96 rows, eight waves (3 row tiles per wave)       C_out % 64 == 0
 //   NS = 1   1 slice x 12 row groups of 32 rows (one row tile per wave), TWELVE waves, three per SIMD: the latency variant for
-//            the smallest batches (twice the workgroups per board).  [Round 1 / early round 2: four waves x 3 row tiles, one
-//            per SIMD -- a lone wave issues its 6 MFMAs, 8 LDS reads and 3 DMA instructions of a k-step one after the
-//            other: 400..460 cycles per k-step for 192 cycles of MFMA.]
-// NS <= 2 are CHUNKED: the waves of such a workgroup share few slices, so a wave-private filter ring fetches every byte 4
-// (NS = 2) or 12 times.  Instead the workgroup's filter rows of one 32-channel chunk (9 taps x NS slices x 2 KiB) sit next to
-// the chunk's activations in the SAME double buffer, fetched once by all waves together and published by the chunk barrier
-// that is there anyway: no counted vmcnt per k-step, 4 (NS = 1) or 8 (NS = 2) DMA instructions per wave and chunk instead of
-// 25 / 22.
-//   NS = 16  ("wide") the 8 slices of NS = 8 on FOUR waves x TWO channel tiles x 12 row tiles: a B fragment feeds two MFMAs, so the
-//            workgroup reads half the activation bytes from LDS per FLOP and still fetches every filter byte once.  384
-//            accumulator registers per wave (one wave per SIMD, 512 registers): hipcc cannot place them by itself (it puts every
-//            MFMA accumulator of a function in AGPRs, 256 at most, and spills the rest by the thousand), so this variant issues
-//            its MFMAs from inline asm with the accumulator's register file spelled out: row tiles 0..7 in AGPRs, 8..11 in VGPRs.
+//            small batches (twice the workgroups per board).  [Four waves x 3 row tiles, one per SIMD, is slower: round 1 and
+//            again round 3 -- 0.25 against 0.224 ms per pass at 9x128.]
+//   NS = 32  the one slice of NS = 1 on HALF a board: six waves x one row tile, two workgroups per channel block (row split)
+// Smaller splits = more, smaller workgroups per board: narrow networks, and filling the chip at small batch sizes.
+// Filter packing (host, pack_filter_board): [k-step][C_out / 16 tiles][64 lanes][8 halfs], k-step = chunk * 9 + tap,
+// lane l holds w[co = tile * 16 + (l & 15)][tap][ci = chunk * 32 + (l >> 4) * 8 .. + 8].
+// NS = 1, 2, 32 are CHUNKED: the waves of such a workgroup share few slices, so wave-private fetches would bring every filter byte
+// 4 .. 12 times.  Instead the workgroup's filter rows of one 32-channel chunk (9 taps x SL slices x 2 KiB) sit next to the chunk's
+// activations in the SAME double buffer, fetched once by all waves together and published by the chunk barrier that is there
+// anyway.  (Per-wave global loads of the fragments -- DirectA for these splits -- were measured in round 3: 0.6 -> 1.1 ms per pass.)
+// The kernel runs at the POWER-LIMITED shader clock: saved cycles partly come back as a lower clock unless the joules per MFMA go
+// down too.
 template <int NS>
 struct Split {
     // NS = 32 ("row split", round 3): the ONE slice of NS = 1 on half a board -- (board, channel block, row half) workgroups of six
