@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdgnn_hip.so")
 
-SOURCES = ["loader.cpp", "network.cpp", "engine.cpp", "rccl.cpp", "batcher.cpp", "formats.cpp", "tree.cpp", "search.cpp", "go.cpp", "fiber.cpp", "kernels.hip", "conv_board.hip", "heads.hip", "features.hip"]
+SOURCES = ["loader.cpp", "network.cpp", "engine.cpp", "rccl.cpp", "batcher.cpp", "formats.cpp", "tree.cpp", "search.cpp", "go.cpp", "fiber.cpp", "kernels.hip", "conv_board.hip", "conv_board_tower.hip", "heads.hip", "features.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 if os.environ.get("DGNN_ABLATIONS", "0") == "1":        # the timing-only ablated kernels of tools/ablate*.sh and the NHWC tile kernels of
     FLAGS.append("-DDGNN_ABLATIONS")                    # round 1 (conv_tile.hip): A/B baselines, not part of the shipped library

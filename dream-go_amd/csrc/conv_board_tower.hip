@@ -1,0 +1,154 @@
+// The residual tower as ONE launch: tower_board_kernel (a workgroup per board walks all layers) and tower_split_kernel (a board
+// split over several workgroups that hand channel blocks -- and, row split, row halves -- to each other).  Body: conv_board_body.h.
+#include "conv_board_body.h"
+
+namespace dgnn {
+namespace {
+
+template <int NS>
+__global__ __launch_bounds__(Split<NS>::Threads)
+void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
+{
+    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
+    int carry = 0;
+    half8 af[2][Split<NS>::CT][2];                    // the filter fragments in registers, handed from layer to layer (DirectA)
+    for (int i = 0; i < count; ++i) {
+        // the descriptors carry the hand-over fields (w_next, carry_in); a layer ends with its own loads and stores waited
+        // for, and the next one starts with a barrier behind workgroup-scope fences (__syncthreads): this board's y is
+        // visible to this workgroup's loads
+        const ConvBoardLaunch a = layers[i];
+        const SplitSync none{nullptr, nullptr, 0, 1, 0, nullptr};
+        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0, af, none, carry);
+        else carry = conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0, af, none, carry);
+        carry |= kChained;
+    }
+}
+
+// The same walk with a board SPLIT over G = C / (32 * NS) workgroups (NS < C / 32): the batch is too small for a workgroup
+// per board to fill the chip.  Between two layers a workgroup needs the other channel blocks of its own board and nothing
+// else: per-board hand-offs (SplitSync) instead of 2 * blocks kernel boundaries, with the next layer's filter slabs already
+// in flight while the workgroup waits.  Placement: linear block id L runs on XCD L % 8 (observed, used for speed only --
+// the hand-off is agent-scope and does not depend on it), so the G workgroups of a board take ids that are congruent
+// mod 8 and share an L2.  All batch * G workgroups must be resident at once (the launcher keeps that <= the CU count).
+template <int NS>
+__global__ __launch_bounds__(Split<NS>::Threads)
+void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, int batch, int groups, unsigned base, unsigned* done,
+                        unsigned* err, unsigned long long* trace)
+{
+    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes + 16];    // + one word of workgroup-wide agreement
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    constexpr int RS = Split<NS>::RS;                 // `groups` = workgroups per board = channel blocks x row halves
+    const int nb = (q % groups) / RS;
+    const int rh = (q % groups) % RS;
+    const int b = (q / groups) * 8 + xcd;
+    if (b >= batch) return;
+    int carry = 0;
+    half8 af[2][Split<NS>::CT][2];
+    for (int i = 0; i < count; ++i) {
+        const ConvBoardLaunch a = layers[i];
+        const SplitSync sync{done, err, i, groups, base, trace};
+        if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0, true>(a, lds, b, nb, af, sync, carry, rh);
+        else carry = conv_board_body<NS, 0, true, 0, true>(a, lds, b, nb, af, sync, carry, rh);
+        carry |= kChained;
+    }
+}
+
+// [B][361][C] NHWC -> [B][C / 8][400][8]; pad rows / columns are written as zero.
+}  // namespace
+
+// smallest batch for which a workgroup per board is preferred at 128 / 256 channels (DGNN_TOWER_MIN_BATCH, read once)
+static int tower_min_batch()
+{
+    static const int v = [] { const char* e = std::getenv("DGNN_TOWER_MIN_BATCH"); return e && std::atoi(e) > 0 ? std::atoi(e) : 129; }();
+    return v;
+}
+
+bool tower_board_supported(int batch, int channels)
+{
+    const int slices = channels / 32;
+    // a workgroup per board: at 64 channels always (the layers are short, launches would dominate), at 128 / 256 channels
+    // from 129 boards on: a board split over two workgroups would need more workgroups than there are CUs (two rounds per
+    // layer), and a chip that is only half full clocks higher (power cap) -- measured 20x256, batch 144 / 160 / 176: 56.4 k /
+    // 60.2 k / 63.6 k evals/s against 43.5 k / 47.5 k / 50.9 k with one launch per layer (profiles/r02/sweep_*.jsonl)
+    return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || ((slices == 4 || slices == 8) && batch >= tower_min_batch()));
+}
+
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream)
+{
+    if (batch <= 0 || count <= 0) return hipSuccess;
+    if (!tower_board_supported(batch, channels)) return hipErrorInvalidValue;
+    const dim3 grid(batch, 1);
+    // A 256-channel tower walks with the wide work split (Split<16>: four waves, two 32-channel tiles each)
+    switch (channels / 32) {
+        case 8: hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count); break;
+        case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count); break;
+    }
+    return hipGetLastError();
+}
+
+// Slices per workgroup of the split tower, 0 = not applicable.  The rule of conv_board_pick_ns (fewest workgroups per board
+// that still put a workgroup on most CUs) under one more condition: every workgroup of the launch is resident at once.
+int tower_split_ns(int batch, int channels, int num_cus)
+{
+    if (!conv_board_supported(channels, channels) || batch <= 0) return 0;
+    const int slices = channels / 32;
+    if (slices != 2 && slices != 4 && slices != 8) return 0;
+    int ns = slices;
+    while (ns > 1 && (long)batch * (slices / ns) < 192 && (long)batch * (slices / ns) * 2 <= num_cus) ns /= 2;
+    // one slice per workgroup and still room for twice the workgroups: split the rows too (Split<32>; DGNN_TOWER_ROWSPLIT=0: never)
+    static const int rowsplit = [] { const char* e = std::getenv("DGNN_TOWER_ROWSPLIT"); return e ? std::atoi(e) : 1; }();
+    if (ns == 1 && slices >= 4 && rowsplit != 0 && (long)batch * slices * 2 <= num_cus) return 32;
+    return ns == slices ? 0 : ns;
+}
+
+hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
+                              size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream)
+{
+    if (batch <= 0 || count <= 0) return hipSuccess;
+    const int slices = channels / 32;
+    if (ns != 32 && (ns < 1 || ns >= slices || slices % ns != 0)) return hipErrorInvalidValue;
+    const int groups = ns == 32 ? slices * 2 : slices / ns;          // workgroups per board (row split: channel blocks x 2 row halves)
+    if ((size_t)batch * groups > done_words) return hipErrorInvalidValue;
+    // The flags are never reset between launches: a launch publishes *base + 1 .. *base + count, the next one counts from
+    // above that (whatever batch size or split it uses: every stale word is below its base).  Only a counter about to wrap
+    // costs a fill.
+    if (*base > 0xf0000000u) {
+        const hipError_t st = hipMemsetAsync(d_done, 0, done_words * sizeof(unsigned), stream);
+        if (st != hipSuccess) return st;
+        *base = 0;
+    }
+    const unsigned launch_base = *base;
+    *base += (unsigned)count + 1u;
+    const dim3 grid((batch + 7) / 8 * 8 * groups);
+    // measurement only: DGNN_SPLIT_TRACE=<file> dumps wave 0's stamps of every (layer, board, channel block) of each launch
+    static const char* const trace_path = std::getenv("DGNN_SPLIT_TRACE");
+    unsigned long long* d_trace = nullptr;
+    const size_t trace_words = (size_t)count * batch * groups * 4;
+    if (trace_path && *trace_path) {
+        if (hipMalloc((void**)&d_trace, trace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
+    }
+    switch (ns) {
+        case 32: hipLaunchKernelGGL((tower_split_kernel<32>), grid, dim3(Split<32>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
+        case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
+        case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
+        default: hipLaunchKernelGGL((tower_split_kernel<1>), grid, dim3(Split<1>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
+    }
+    const hipError_t launched = hipGetLastError();
+    if (d_trace) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(trace_words);
+        (void)hipMemcpy(h.data(), d_trace, trace_words * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_trace);
+        if (FILE* f = std::fopen(trace_path, "wb")) {
+            const int header[4] = {count, batch, groups, ns};
+            std::fwrite(header, sizeof(int), 4, f);
+            std::fwrite(h.data(), 8, trace_words, f);
+            std::fclose(f);
+        }
+    }
+    return launched;
+}
+
+}  // namespace dgnn
