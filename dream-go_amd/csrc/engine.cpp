@@ -46,6 +46,7 @@ struct Workspace {
     hipEvent_t ev_done = nullptr;           // event behind the outputs' copies: what dgnn_forward_wait waits for
     long long submit_ns = 0;                // when it was recorded
     double wait_ns = 0.0;                   // how long submissions of `wait_boards` boards took lately (submit -> outputs on the host)
+    double wait_last = 0.0;                 // ... the most recent one (wait_submission)
     int wait_boards = 0;
     std::vector<hipEvent_t> tower_events;   // pairs, grown on demand by dgnn_forward_timed
 
@@ -610,15 +611,28 @@ int wait_submission(Workspace* ws)
         ++polls;
     }
     const double took = (double)(now_ns() - ws->submit_ns);
+    const double scaled = ws->wait_ns * (ws->wait_boards > 0 && ws->active < ws->wait_boards ? (double)ws->active / ws->wait_boards : 1.0);
     if (napped && polls == 0) {
-        // done before the long sleep ended: `took` is the sleep, not the pass.  Averaging it in would keep an over-estimate alive
-        // for dozens of passes (a pass can never look shorter than 85 % of the estimate): one slow pass -- the first one, with its
-        // lazy initialisation; a hiccup -- and a synchronous caller sleeps 85 % of THAT from then on (seen as 14 ms per 3.4 ms pass in
-        // a batch sweep).  Halve the estimate until a poll is needed again.
-        ws->wait_ns *= 0.5;
+        // done before the long sleep ended: `took` is the sleep, not the pass.  Averaging it in would keep an over-estimate alive for
+        // dozens of passes (a pass can never look shorter than 85 % of the estimate): forget it, the next passes are polled from
+        // their start and measure themselves.
+        ws->wait_ns = 0.0;
+        ws->wait_last = 0.0;
+    } else if (ws->wait_ns <= 0.0 || took > 2.0 * scaled) {
+        // no estimate yet, or a pass more than twice as long as expected: ONE such sample sends nobody to sleep -- the first pass of
+        // a workspace carries kernel loads and the first touch of its staging buffers (60 ms seen), and a synchronous caller then
+        // slept 85 % of that (a batch sweep showed 14 ms per 3.4 ms pass).  Two in a row are believed, at the shorter of the two.
+        if (ws->wait_last > 0.0) {
+            ws->wait_ns = took < ws->wait_last ? took : ws->wait_last;
+            ws->wait_boards = ws->active;
+            ws->wait_last = 0.0;
+        } else {
+            ws->wait_last = took;
+        }
     } else {
-        ws->wait_ns = (ws->wait_boards == ws->active && ws->wait_ns > 0.0) ? 0.75 * ws->wait_ns + 0.25 * took : took;
+        ws->wait_ns = ws->wait_boards == ws->active ? 0.75 * ws->wait_ns + 0.25 * took : took;
         ws->wait_boards = ws->active;
+        ws->wait_last = 0.0;
     }
     return DGNN_OK;
 }
