@@ -119,19 +119,14 @@ static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool rel
         }
     }
     if constexpr (NS == 4) {
-        // measurement only (tools/ablate.sh), residual shapes: 1 = no MFMAs, 2 = no in-loop DMA, 3 = both, 32 = the K loop
-        // without the software pipeline across steps
-        if (ablate != 0 && relu && skip != 1) {
+        // measurement only (tools/ablate.sh, tools/ablate2.sh; garbage results), residual shapes of the four-slice split:
+        // 1 = no MFMAs, 3 = neither MFMAs nor in-loop memory instructions (filter loads, activation pieces), 16 = no barrier at the
+        // chunk boundaries.  (Round 2's 2 / 8 / 24 / 32 / 64 priced the wave-private filter ring, which this split no longer has.)
+        if ((ablate == 1 || ablate == 3 || ablate == 16) && relu && skip != 1) {
             if (skip == 2) {
-                switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 2: DGNN_BOARD(2, true, 2); break;
-                                  case 3: DGNN_BOARD(2, true, 3); break; case 64: DGNN_BOARD(2, true, 64); break;
-                                  case 8: DGNN_BOARD(2, true, 8); break; case 16: DGNN_BOARD(2, true, 16); break; case 24: DGNN_BOARD(2, true, 24); break;
-                                  default: DGNN_BOARD(2, true, 32); break; }
+                switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 3: DGNN_BOARD(2, true, 3); break; default: DGNN_BOARD(2, true, 16); break; }
             } else {
-                switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 2: DGNN_BOARD(0, true, 2); break;
-                                  case 3: DGNN_BOARD(0, true, 3); break; case 64: DGNN_BOARD(0, true, 64); break;
-                                  case 8: DGNN_BOARD(0, true, 8); break; case 16: DGNN_BOARD(0, true, 16); break; case 24: DGNN_BOARD(0, true, 24); break;
-                                  default: DGNN_BOARD(0, true, 32); break; }
+                switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 3: DGNN_BOARD(0, true, 3); break; default: DGNN_BOARD(0, true, 16); break; }
             }
             return;
         }

@@ -778,7 +778,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                     static_for<decltype(to_c)::value - decltype(from_c)::value>([&](auto cc) {
                         constexpr int C2 = decltype(from_c)::value + decltype(cc)::value;
                         if constexpr (ABL & 1) {
-                            asm volatile("" ::"v"(af[P][C2 / 2][C2 % 2]), "v"(bf[(PH + I) % BD]));
+                            const half8& fa = af[P][C2 / 2][C2 % 2];     // (named first: an asm operand alone does not make a generic
+                            const half8& fb = bf[(PH + I) % BD];         // lambda capture the array)
+                            asm volatile("" ::"v"(fa), "v"(fb));
                         } else if constexpr (FIRST_CHUNK && TAP == 0) {
                             mfma_asm_init<S::acc_in_agpr(I / 2)>(acc[C2][I], af[P][C2 / 2][C2 % 2], bf[(PH + I) % BD]);
                         } else {

@@ -1,13 +1,14 @@
 #!/bin/bash
 # needs a library built with the ablated kernels:  DGNN_ABLATIONS=1 python dream-go_amd/build.py --force
 # Component pricing of the residual convolution (results of ablated runs are garbage; only the timing matters).
-#   1 = no MFMA, 2 = no in-loop DMA, 4 = no in-loop B-fragment reads, 3 = neither MFMA nor DMA, 8 = DMA issued but never waited for,
+#   1 = no MFMA, 3 = neither MFMA nor in-loop memory instructions,
 #   16 = no barrier at the chunk boundaries (what a barrier-free K loop could gain at most)
+# Round 3: the ablated variants exist for the four-slice split only (the wide split has none): DGNN_BOARD_NS=4 selects it.
 out=${1:-gpurun_out/ablate.jsonl}
 : > "$out"
-for ab in 0 1 2 4 3 8 16; do
+for ab in 0 1 3 16; do
   echo "# ablate=$ab" >> "$out"
-  DGNN_TOWER=0 DGNN_CONV=${VARIANT:-board} DGNN_CONV_ABLATE=$ab python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | tail -1 >> "$out"
+  DGNN_TOWER=0 DGNN_BOARD_NS=${NS:-4} DGNN_CONV=${VARIANT:-board} DGNN_CONV_ABLATE=$ab python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | tail -1 >> "$out"
 done
 python - "$out" <<'PY'
 import json, sys
