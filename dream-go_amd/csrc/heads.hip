@@ -19,6 +19,7 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPoints = 361;
 constexpr int kMoves = 362;
@@ -28,11 +29,9 @@ constexpr int kMovesPad = 384;                         // 12 MFMA tiles of 32
 constexpr int kRows = kBoardRows;
 constexpr int kHalo = 21;
 constexpr int kPieces = 7;
-constexpr int kSlotRows = kHalo + kPieces * 64;        // 469
-constexpr int kSlotBytes = kSlotRows * 16;             // 7504
-constexpr int kXBufBytes = 4 * kSlotBytes;             // 30016: one 32-channel chunk of activations
-constexpr int kWBufBytes = 9 * 2 * 1024;               // 18432: one 32-channel chunk of the 32-row filter, all taps
-constexpr int kBufBytes = kXBufBytes + kWBufBytes;
+constexpr int kSlotRows = 480;                         // 21 + 7 * 64 = 469 used; the k-slot stride is a multiple of 256 bytes (the B
+constexpr int kSlotBytes = kSlotRows * 16;             // fragment of v_mfma_f32_16x16x32_f16 takes 16 rows from each of four k-slots)
+constexpr int kXBufBytes = 4 * kSlotBytes;             // 30720: one 32-channel chunk of activations
 constexpr int kHeadThreads = 256;
 
 __device__ __forceinline__ _Float16 round_to_half(float t)
@@ -44,19 +43,32 @@ __device__ __forceinline__ _Float16 round_to_half(float t)
 __device__ __forceinline__ float half_bits_to_float(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ uint16_t float_to_half_bits(float f) { return __builtin_bit_cast(uint16_t, round_to_half(f)); }
 
-// 4 waves; wave w owns row tiles 3w .. 3w + 2 (rows 96w .. 96w + 95) of the board and all 32 (padded) output channels.
-// Per 32-channel chunk the activations (28 DMA pieces) and the chunk's filter rows for all 9 taps (18 pieces) are
-// brought into one of two LDS buffers; one barrier per chunk.
+// Round 3: v_mfma_f32_16x16x32_f16 on NT tiles of 16 output channels (S + 2 = 10 of them at the reference's 8 samples: ONE tile
+// instead of a 32-row tile that was two thirds padding), and -- small batches, where a workgroup per board leaves most CUs idle
+// and the kernel is a latency chain over the chunks -- a board's rows over THREE workgroups (grid.y = 3: rows 128 q .. 128 q + 127,
+// four of the seven activation pieces per k-slot).  4 waves; wave w owns TPW 16-row tiles: rows 96 w .. (a workgroup per board) or
+// 128 q + 32 w .. (row split).  Per 32-channel chunk the activations and the chunk's filter rows for all 9 taps (9 * NT pieces)
+// are brought into one of two LDS buffers; one barrier per chunk.  The arithmetic per output does not depend on the split.
+template <int NT, int TPW>
 __global__ __launch_bounds__(kHeadThreads)
 void head_conv_board_kernel(HeadConvLaunch a)
 {
+    constexpr int kWBufBytes = 9 * NT * 1024;          // one 32-channel chunk of the filter, all taps
+    constexpr int kBufBytes = kXBufBytes + kWBufBytes;
+    constexpr bool SPLIT = TPW == 2;
     __shared__ __attribute__((aligned(16))) char lds[2 * kBufBytes];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
+    const int q = SPLIT ? blockIdx.y : 0;
     const int nchunks = a.cin / 32;
+    const int row0 = SPLIT ? 128 * q + 32 * wave : 96 * wave;       // first board row of this wave
+    // 64-row activation pieces this workgroup needs per k-slot: all seven, or those covering rows 128 q - 21 .. 128 q + 148
+    const int piece0 = SPLIT ? (q == 0 ? 0 : q == 1 ? 1 : 3) : 0;
+    constexpr int NPIECE = SPLIT ? 4 : kPieces;
+    constexpr int TOTAL = 4 * NPIECE + 9 * NT;
 
     if (tid < 2 * 4 * kHalo) {           // halo rows of both activation buffers
         const int buf = tid / (4 * kHalo);
@@ -71,18 +83,18 @@ void head_conv_board_kernel(HeadConvLaunch a)
 
     auto issue = [&](int chunk, int buf) {
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const int p = wave + 4 * j;          // 0..45: 28 activation pieces, then 18 filter pieces
-            if (p < 4 * kPieces) {
-                const int s = p / kPieces;
-                const int i = p - s * kPieces;
+        for (int j = 0; j < (TOTAL + 3) / 4; ++j) {
+            const int p = wave + 4 * j;          // activation pieces, then 9 * NT filter pieces
+            if (p < 4 * NPIECE) {
+                const int s = p / NPIECE;
+                const int i = p - s * NPIECE + piece0;
                 const uint16_t* src = x_board + ((long)(chunk * 4 + s) * kRows + i * 64) * 8;
                 char* const dst = lds + buf * kBufBytes + s * kSlotBytes + (kHalo + i * 64) * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            } else if (p < 4 * kPieces + 18) {
-                const int f = p - 4 * kPieces;   // tap * 2 + k16
-                const uint16_t* src = w_lane + ((long)chunk * 18 + f) * 512;
+            } else if (p < TOTAL) {
+                const int f = p - 4 * NPIECE;    // tap * NT + tile
+                const uint16_t* src = w_lane + ((long)chunk * 9 * NT + f) * 512;
                 char* const dst = lds + buf * kBufBytes + kXBufBytes + f * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -90,17 +102,20 @@ void head_conv_board_kernel(HeadConvLaunch a)
         }
     };
 
-    floatx16 acc[3];
+    floatx4 acc[NT][TPW];
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][t][r] = 0.0f;
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int x_lane = (lane >> 5) * kSlotBytes + (wave * 96 + (lane & 31)) * 16;
+    // B fragment: lane l reads row (l & 15) of its 16-row tile from k-slot l >> 4; A fragment: lane-linear
+    const int x_lane = (lane >> 4) * kSlotBytes + (row0 + (lane & 15)) * 16;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         if (chunk + 1 < nchunks) issue(chunk + 1, buf ^ 1);
@@ -109,14 +124,14 @@ void head_conv_board_kernel(HeadConvLaunch a)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int shift = (tap / 3 - 1) * 20 + (tap % 3 - 1);
+            half8 af[NT];
 #pragma unroll
-            for (int k16 = 0; k16 < 2; ++k16) {
-                const half8 af = *reinterpret_cast<const half8*>(wb + (tap * 2 + k16) * 1024);
+            for (int nt = 0; nt < NT; ++nt) af[nt] = *reinterpret_cast<const half8*>(wb + (tap * NT + nt) * 1024);
 #pragma unroll
-                for (int rt = 0; rt < 3; ++rt) {
-                    const half8 bf = *reinterpret_cast<const half8*>(xb + k16 * 2 * kSlotBytes + rt * 512 + (kHalo + shift) * 16);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[rt], 0, 0, 0);
-                }
+            for (int t = 0; t < TPW; ++t) {
+                const half8 bf = *reinterpret_cast<const half8*>(xb + t * 256 + (kHalo + shift) * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt], bf, acc[nt][t], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next chunk landed; this chunk's reads retired
@@ -124,26 +139,28 @@ void head_conv_board_kernel(HeadConvLaunch a)
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // D[i][j]: j = lane & 31 = row within the tile, i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output channel.
+    // D[i][j] of a 16 x 16 tile: j = lane & 15 = row within the tile, i = 4 * (lane >> 4) + r = output channel within the tile.
     // Channels 0 .. S-1 are the policy planes, S and S + 1 the value planes; both outputs are compact NHWC.
     const int samples = a.samples;
-    const int hi = lane >> 5;
+    const int h4 = lane >> 4;
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) {
-        const int row = wave * 96 + rt * 32 + (lane & 31);
+    for (int t = 0; t < TPW; ++t) {
+        const int row = row0 + t * 16 + (lane & 15);
         const int y = row / 20, x = row - y * 20;
         if (x == 19 || y >= 19) continue;
         const long pos = (long)b * kPoints + y * 19 + x;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (c >= samples + 2) continue;
-            float t = acc[rt][r] + half_bits_to_float(a.bias[c]);
-            t = __builtin_fmaxf(t, 0.0f);                             // conv2d.rs:119-125: ReLU on both head convolutions
-            const uint16_t bits = float_to_half_bits(t);
-            if (c < samples) a.policy_features[pos * samples + c] = bits;
-            else a.value_features[pos * 2 + (c - samples)] = bits;
-        }
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = nt * 16 + 4 * h4 + r;
+                if (c >= samples + 2) continue;
+                float tv = acc[nt][t][r] + half_bits_to_float(a.bias[c]);
+                tv = __builtin_fmaxf(tv, 0.0f);                        // conv2d.rs:119-125: ReLU on both head convolutions
+                const uint16_t bits = float_to_half_bits(tv);
+                if (c < samples) a.policy_features[pos * samples + c] = bits;
+                else a.value_features[pos * 2 + (c - samples)] = bits;
+            }
     }
 }
 
@@ -349,7 +366,14 @@ void softmax_value_kernel(SoftmaxValueLaunch a)
 hipError_t launch_head_conv_board(const HeadConvLaunch& args, hipStream_t stream)
 {
     if (args.batch <= 0) return hipSuccess;
-    hipLaunchKernelGGL(head_conv_board_kernel, dim3(args.batch), dim3(kHeadThreads), 0, stream, args);
+    // a board's rows over three workgroups where a workgroup per board would leave two thirds of the CUs idle
+    const bool split = args.batch * 3 <= 256;
+    const bool one_tile = args.samples + 2 <= 16;
+    const dim3 grid(args.batch, split ? 3 : 1);
+    if (one_tile && split) hipLaunchKernelGGL((head_conv_board_kernel<1, 2>), grid, dim3(kHeadThreads), 0, stream, args);
+    else if (one_tile) hipLaunchKernelGGL((head_conv_board_kernel<1, 6>), grid, dim3(kHeadThreads), 0, stream, args);
+    else if (split) hipLaunchKernelGGL((head_conv_board_kernel<2, 2>), grid, dim3(kHeadThreads), 0, stream, args);
+    else hipLaunchKernelGGL((head_conv_board_kernel<2, 6>), grid, dim3(kHeadThreads), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -120,7 +120,7 @@ hipError_t launch_board_records(const uint8_t* records, uint32_t* packed, uint16
 
 struct HeadConvLaunch {
     const uint16_t* x;          // tower output [batch][cin / 8][400][8] fp16 (padded slot-major)
-    const uint16_t* w;          // [cin / 32][9 taps][2 k16][64 lanes][8] fp16: rows 0..S-1 policy conv, S..S+1 value conv, rest 0
+    const uint16_t* w;          // [cin / 32][9 taps][NT tiles of 16 rows][64 lanes][8] fp16 (NT = 1 for S + 2 <= 16, else 2): rows 0..S-1 policy conv, S..S+1 value conv, rest 0
     const uint16_t* bias;       // [32] fp16, same row order
     uint16_t* policy_features;  // [batch][361][S] fp16
     uint16_t* value_features;   // [batch][361][2] fp16

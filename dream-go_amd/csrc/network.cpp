@@ -298,8 +298,8 @@ int build_network(Network& net)
     pack_dense_transposed(reinterpret_cast<const uint16_t*>(pw->bytes.data()), (int)policy_in, DGNN_NUM_MOVES, topo.policy_k_pad,
                           reinterpret_cast<uint16_t*>(image.data() + topo.policy_wt_offset));
 
-    // both head convolutions as one filter with 32 (zero padded) output rows, in the fragment order of
-    // head_conv_board_kernel: [chunk][tap][k16][lane][8], lane l = row (l & 31), channels chunk*32 + k16*16 + (l>>5)*8 ..
+    // both head convolutions as one filter of NT tiles of 16 (zero padded) output rows, in the fragment order of
+    // head_conv_board_kernel: [chunk][tap][tile][lane][8], lane l = row tile * 16 + (l & 15), channels chunk * 32 + (l >> 4) * 8 ..
     topo.head_w_board_offset = 0;
     if ((layouts & kPackBoard) && c % 32 == 0 && s + 2 <= 32) {
         const HostTensor* pcw = find_half(t, policy + "/conv_1:0", (size_t)s * 9 * c);
@@ -307,17 +307,18 @@ int build_network(Network& net)
         const HostTensor* vcw = find_half(t, value + "/conv_1:0", (size_t)2 * 9 * c);
         const HostTensor* vcb = find_half(t, value + "/conv_1/offset:0", 2);
         if (!pcw || !pcb || !vcw || !vcb) return DGNN_MALFORMED_WEIGHTS;
-        topo.head_w_board_offset = reserve(image, (size_t)(c / 32) * 18 * 512 * sizeof(uint16_t));
+        const int tiles = s + 2 <= 16 ? 1 : 2;
+        topo.head_w_board_offset = reserve(image, (size_t)(c / 32) * 9 * tiles * 512 * sizeof(uint16_t));
         uint16_t* dst = reinterpret_cast<uint16_t*>(image.data() + topo.head_w_board_offset);
         const uint16_t* pwsrc = reinterpret_cast<const uint16_t*>(pcw->bytes.data());
         const uint16_t* vwsrc = reinterpret_cast<const uint16_t*>(vcw->bytes.data());
         for (int chunk = 0; chunk < c / 32; ++chunk)
             for (int tap = 0; tap < 9; ++tap)
-                for (int k16 = 0; k16 < 2; ++k16)
+                for (int tile = 0; tile < tiles; ++tile)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const int row = lane & 31;
-                        const int ci = chunk * 32 + k16 * 16 + (lane >> 5) * 8;
-                        uint16_t* out = dst + ((((size_t)chunk * 9 + tap) * 2 + k16) * 64 + lane) * 8;
+                        const int row = tile * 16 + (lane & 15);
+                        const int ci = chunk * 32 + (lane >> 4) * 8;
+                        uint16_t* out = dst + ((((size_t)chunk * 9 + tap) * tiles + tile) * 64 + lane) * 8;
                         const uint16_t* src = nullptr;
                         if (row < s) src = pwsrc + ((size_t)row * 9 + tap) * c + ci;
                         else if (row < s + 2) src = vwsrc + ((size_t)(row - s) * 9 + tap) * c + ci;
