@@ -88,7 +88,8 @@ struct Workspace {
     bool injected = false;                  // ... and it has fired
     unsigned* d_split_sync = nullptr;       // [batch * kSplitWordsPerBoard] layers published per (board, channel block, row half), then the give-up word
     unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
-    unsigned* h_split_err = nullptr;        // pinned copy of that word, fetched with the outputs
+    unsigned* d_split_err = nullptr;        // the give-up word: the last four bytes of the value block
+    unsigned* h_split_err = nullptr;        // pinned copy of that word: it arrives with the outputs (one copy for value, word and policy)
     bool split_pending = false;             // the submission in flight used tower_split_kernel
     int pending_form = 0;                   // ... and took this input form (what to repeat if it gave up)
     bool use_tile = true;                   // tuned tile kernel where the layer shape allows (DGNN_CONV=v1 disables)
@@ -280,11 +281,12 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_nhwc = ws->use_board ? align_up(num_pos * t.num_channels * 2, 256) : 0;
     const size_t sz_pf = align_up(num_pos * t.num_samples * 2, 256);
     const size_t sz_vf = align_up(num_pos * 2 * 2, 256);
-    const size_t sz_value = align_up((size_t)batch * 2, 256);
+    const size_t sz_value = align_up((size_t)batch * 2 + sizeof(unsigned), 256);   // + the split tower's give-up word in its last four bytes:
+                                                                                   // it travels with the outputs (enqueue_outputs)
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
     const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
     const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
-    const size_t sz_split = align_up(((size_t)batch * kSplitWordsPerBoard + 1) * sizeof(unsigned), 256);
+    const size_t sz_split = align_up((size_t)batch * kSplitWordsPerBoard * sizeof(unsigned), 256);
     const size_t sz_records = align_up((size_t)batch * DGNN_BOARD_RECORD_BYTES, 256);
     const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split + sz_records;
 
@@ -297,6 +299,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_policy_features = (uint16_t*)p; p += sz_pf;
     ws->d_value_features = (uint16_t*)p; p += sz_vf;
     ws->d_value = (uint16_t*)p; p += sz_value;
+    ws->d_split_err = (unsigned*)(p - sizeof(unsigned));
     ws->d_policy = (uint16_t*)p; p += sz_policy;
     ws->d_logits = (uint16_t*)p; p += sz_logits;
     ws->d_packed = (uint32_t*)p; p += sz_packed;
@@ -313,8 +316,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->h_packed = (uint32_t*)h; h += sz_packed;
     ws->h_records = h; h += sz_records;
     ws->h_value = (uint16_t*)h; h += sz_value;
+    ws->h_split_err = (unsigned*)(h - sizeof(unsigned));
     ws->h_policy = (uint16_t*)h; h += sz_policy;
-    ws->h_split_err = (unsigned*)h;
     *ws->h_split_err = 0;
 
     *out = ws.release();
@@ -467,10 +470,10 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 (void)groups;
                 if (ws->inject_giveup && !ws->injected) {       // fault injection (tests): the launch finds the give-up word already set
                     ws->injected = true;
-                    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, 0xff, sizeof(unsigned), ws->stream));
+                    DGNN_HIP(hipMemsetAsync(ws->d_split_err, 0xff, sizeof(unsigned), ws->stream));
                 }
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
-                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, &ws->split_base, ws->stream));
+                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->stream));
                 DGNN_HIP(hipEventRecord(chain->done, ws->stream));
                 chain->recorded = true;
             } else {
@@ -653,10 +656,7 @@ int enqueue_split_check(Workspace* ws, int input_form)
     const int mode = tower_mode(ws);
     ws->split_pending = mode > 0;
     ws->pending_form = input_form;
-    if (mode > 0) {
-        DGNN_HIP(hipMemcpyAsync(ws->h_split_err, ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream));
-    }
-    return DGNN_OK;
+    return DGNN_OK;                         // (the word itself arrives with the outputs: enqueue_outputs)
 }
 
 // After the stream has drained: a split tower whose workgroups were not all resident (the device is shared with another
@@ -673,7 +673,7 @@ int note_split_failure(Workspace* ws)
     ws->split_cooldown = kSplitCooldown;
     std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer %s\n", ws->device,
                  ws->split_failures >= kSplitMaxFailures ? "from now on" : "for the next passes");
-    DGNN_HIP(hipMemsetAsync(ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, 0, sizeof(unsigned), ws->stream));   // the word is sticky on the device
+    DGNN_HIP(hipMemsetAsync(ws->d_split_err, 0, sizeof(unsigned), ws->stream));   // the word is sticky on the device
     return DGNN_OK;
 }
 
@@ -707,7 +707,7 @@ int check_split_after_sync(Workspace* ws)
 {
     if (tower_mode(ws) <= 0) return DGNN_OK;
     unsigned err = 0;
-    DGNN_HIP(hipMemcpy(&err, ws->d_split_sync + (size_t)ws->batch * kSplitWordsPerBoard, sizeof(unsigned), hipMemcpyDeviceToHost));
+    DGNN_HIP(hipMemcpy(&err, ws->d_split_err, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (err == 0) return DGNN_OK;
     const int status = note_split_failure(ws);
     if (status != DGNN_OK) return status;
