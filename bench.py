@@ -60,7 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-midgame", type=int, default=60,
                     help="second self-play leg: the searched stones start after this many stones of policy play (0 = skip that leg)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
-    ap.add_argument("--selfplay-batches", type=int, default=2, help="device batches the leaf pool keeps alive per GPU (nn.rs:64-67: 2 per device)")
+    ap.add_argument("--selfplay-batches", type=int, default=3,
+                    help="device batches the leaf pool keeps alive per GPU (the reference keeps 2, nn.rs:64-67; a third keeps the CUs supplied "
+                         "while the batches are partial: DESIGN.md 11.7 -- opening leg 74.0 -> 77.4 k evals/s, mid-game unchanged)")
     ap.add_argument("--selfplay-host-threads", type=int, default=2,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
@@ -296,7 +298,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
                  else f"first {args.selfplay_moves} stones of each") + f", --num-rollout {args.selfplay_rollouts}, "
                 f"1 search thread x {args.selfplay_leaves} leaves per game, games as " +
                 (f"fibers on {args.selfplay_host_threads} host threads" if args.selfplay_host_threads > 0 else "one OS thread each") + ", transposition cache 200001 x 8 shards, through the leaf pool "
-                "(PCIe-inclusive); random-init weights; feature planes built on the " +
+                f"({args.selfplay_batches} device batches alive, PCIe-inclusive); random-init weights; feature planes built on the " +
                 ("DEVICE from 896-byte board records (dgnn_forward_boards)" if boards else "HOST (features::V1, 23 KB of fp16 per leaf)"),
         "seconds": sec, "games": j["games"], "moves": j["moves"],
         "evals_per_sec": j["evals"] / sec,                          # predictor evaluations (cache misses) per second, whole job
