@@ -60,9 +60,10 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-midgame", type=int, default=60,
                     help="second self-play leg: the searched stones start after this many stones of policy play (0 = skip that leg)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
-    ap.add_argument("--selfplay-batches", type=int, default=3,
-                    help="device batches the leaf pool keeps alive per GPU (the reference keeps 2, nn.rs:64-67; a third keeps the CUs supplied "
-                         "while the batches are partial: DESIGN.md 11.7 -- opening leg 74.0 -> 77.4 k evals/s, mid-game unchanged)")
+    ap.add_argument("--selfplay-batches", type=int, default=2,
+                    help="device batches the leaf pool keeps alive per GPU (the reference keeps 2, nn.rs:64-67).  A third raises the engine's "
+                         "rate on partial batches (opening leg 75.7 -> 77.1 k evals/s) and LOWERS the moves per second (239 -> 206): more "
+                         "leaves in flight are more duplicate evaluations past the transposition table (hit ratio 0.60 -> 0.53)")
     ap.add_argument("--selfplay-host-threads", type=int, default=2,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",

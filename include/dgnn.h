@@ -393,8 +393,9 @@ typedef int (*dgnn_predict_boards_fn)(void* ctx, const uint8_t* records, int n, 
 /* NnPredictor over SEVERAL devices in one process (src/libdg_mcts/predictors/nn.rs:46-108: one queue, `2 x devices` batches
  * alive, every batch sent to the next device of Device::all()).  One queue shared by all devices; `workers_per_device`
  * threads are bound to each device and a batch goes to whichever device has a worker free (the reference's round robin
- * without its head-of-line blocking); `batches_per_device` x devices batches alive (the reference: 2; 3 keep an MI355X supplied
- * while the batches are partial -- 129 .. 200 boards of 256: 76-81 k instead of 57-75 k evals/s).  devices == NULL: every
+ * without its head-of-line blocking); `batches_per_device` x devices batches alive (the reference: 2.  A third keeps an MI355X
+ * supplied while the batches are partial -- 76-81 k instead of 57-75 k evals/s at 129 .. 200 boards of 256 -- but a search behind a
+ * shared transposition table then evaluates more positions twice: measure moves per second, not evals: DESIGN.md 11.7).  devices == NULL: every
  * visible device.  The pool owns its batcher.  dgnn_pool_predict / dgnn_pool_predictor() work on it unchanged, so one host
  * process (dgnn_selfplay_go, a GTP engine) drives all GPUs of a node. */
 int dgnn_pool_create_devices(dgnn_network* net, const int* devices, int num_devices, int max_batch_size, int batches_per_device,

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
     ap.add_argument("--leaves", type=int, default=1, help="leaves a search thread keeps in flight per predictor call (1 = the reference's worker)")
     ap.add_argument("--max-batch", type=int, default=256)
-    ap.add_argument("--max-batches", type=int, default=3)
+    ap.add_argument("--max-batches", type=int, default=2, help="device batches the pool keeps alive (a third costs moves: more duplicate evaluations past the table, DESIGN.md 11.7)")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
