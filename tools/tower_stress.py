@@ -26,7 +26,7 @@ def main():
     shapes = ((20, 256, 256), (9, 128, 256), (6, 64, 77), (20, 256, 200))
     expect = "tower_board_kernel"
     if args.split:
-        shapes = ((20, 256, 128), (20, 256, 64), (20, 256, 32), (20, 256, 90), (9, 128, 128), (9, 128, 32), (20, 256, 7))
+        shapes = ((20, 256, 128), (20, 256, 64), (20, 256, 32), (20, 256, 90), (9, 128, 128), (9, 128, 32), (20, 256, 7), (20, 256, 16), (9, 128, 17), (20, 256, 1))
         expect = "tower_split_kernel"
     for blocks, channels, batch in shapes:
         text = synth.to_json(synth.make_tensors(blocks, channels, seed=7))
