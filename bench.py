@@ -35,6 +35,7 @@ import socket
 import subprocess
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -331,6 +332,141 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     return leg
 
 
+class DryWorkspace:
+    """`--dry`: what the legs below use of api.WorkspaceGuard, over the CPU stand-in (dgnn_hash_predictor).  Like the engine's
+    workspace it EVALUATES WHAT IS RESIDENT: upload() and every synchronous forward overwrite the resident batch (engine.cpp: the
+    planes of a dgnn_forward land in ws->d_features), forward_resident() evaluates whatever was left there.  A leg that forgets to
+    upload its own inputs therefore fails here exactly as it does on the device (tests/test_bench_dry.py)."""
+
+    def __init__(self, api, batch_size):
+        self.api, self.batch_size, self.resident, self.out = api, batch_size, None, None
+        self._predict = api.PREDICT_FN(api.lib.dgnn_hash_predictor())
+
+    def _evaluate(self, features):
+        n = self.batch_size
+        f = np.ascontiguousarray(features, dtype=np.uint16).reshape(-1)
+        assert f.size == n * 11552
+        value, policy = np.empty(n, dtype=np.uint16), np.empty(n * 362, dtype=np.uint16)
+        u16p = self.api._u16p
+        status = self._predict(None, f.ctypes.data_as(u16p), n, value.ctypes.data_as(u16p), policy.ctypes.data_as(u16p))
+        assert status == 0
+        return self.api.OutputMap(value.view(np.float16), policy.view(np.float16))
+
+    def upload(self, features):
+        self.resident = np.array(np.asarray(features).view(np.uint16).reshape(-1), copy=True)
+
+    def forward_resident(self):
+        self.out = self._evaluate(self.resident)
+
+    def sync(self):
+        pass
+
+    def download(self):
+        return self.out
+
+    def release(self):
+        pass
+
+
+class DryForward:
+    """`--dry`: api.forward / api.forward_boards over DryWorkspace (same residency rule)."""
+
+    def __init__(self, api):
+        self.api = api
+
+    def forward(self, ws, features):
+        ws.upload(features)
+        ws.forward_resident()
+        return ws.download()
+
+    def forward_boards(self, ws, records, count):
+        planes = self.api.features_unpack(self.api.board_records_to_packed(records, count), count)     # host statement (go.cpp)
+        return self.forward(ws, planes)
+
+
+def reference_style_leg(fw, api, ws, positions, batch):
+    """The reference's own harness (`dream_go --bench`, src/dg/bench/forward.rs:37-47 under bench/benchmark.rs:37-53): every
+    position of an SGF collection -- here the three committed games -- one at a time: planes on the host, repeated to the batch
+    size, one synchronous forward(); positions per second over the whole walk, feature extraction included.  NOTE: every call
+    overwrites the workspace's resident inputs (the last game position x batch stays behind)."""
+    t1 = time.perf_counter()
+    for board, color in positions:
+        fw.forward(ws, np.tile(board.get_features(color, 0).reshape(-1).view(np.uint16), batch))
+    dt1 = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    for board, color in positions:
+        fw.forward_boards(ws, np.tile(board.record(color, 0), batch), batch)
+    dt2 = time.perf_counter() - t1
+    return {
+        "what": f"dream_go --bench style: {len(positions)} positions of the three committed games (tests/golden/real_games.json), each "
+                f"repeated {batch} times and evaluated by one synchronous call from one thread (through the Python mirror)",
+        "boards_per_sec": batch * len(positions) / dt1, "boards_per_sec_records": batch * len(positions) / dt2,
+        "forms": "boards_per_sec: features::V1 on the host + dgnn_forward (the reference's flow); boards_per_sec_records: board record + "
+                 "dgnn_forward_boards (planes on the device)",
+        "positions": len(positions), "batch": batch,
+    }
+
+
+def parity_entry(ws, features, n, ref_value, ref_policy, what):
+    """The resident-input path (upload -> dgnn_forward_resident -> download: what `value` times) on `features`, against the checker's
+    outputs for THE SAME features.  The upload is part of the leg: whatever an earlier leg left in the workspace is gone (VERDICT r03
+    weak #1: since d4c9b12 the sample was taken on the last game position the reference-style walk had left there)."""
+    f = np.ascontiguousarray(np.asarray(features).view(np.uint16).reshape(-1))
+    ws.upload(f)
+    ws.forward_resident()
+    ws.sync()
+    got = ws.download()
+    gv = got.value.astype(np.float32)[:n]
+    gp = got.policy.astype(np.float32)[:n * 362].reshape(n, 362)
+    rv = np.asarray(ref_value).view(np.float16).astype(np.float32)[:n]
+    rp = np.asarray(ref_policy).view(np.float16).astype(np.float32)[:n * 362].reshape(n, 362)
+    entry = {"what": what, "boards": n, "inputs_crc32": zlib.crc32(f[:n * 11552].tobytes()),
+             "max_abs_value_diff": float(np.abs(gv - rv).max()), "max_abs_policy_diff": float(np.abs(gp - rp).max()), "tolerance": 1e-3}
+    # board identity: board i's output is nearer to the checker's output of board i than to that of any other board
+    hip = np.concatenate([gp, gv[:, None]], axis=1).astype(np.float64)
+    ref = np.concatenate([rp, rv[:, None]], axis=1).astype(np.float64)
+    distance = np.abs(hip[:, None, :] - ref[None, :, :]).max(axis=2)
+    own = np.diag(distance).copy()
+    np.fill_diagonal(distance, np.inf)
+    other = distance.min(axis=1) if n > 1 else np.full(n, np.inf)
+    entry["own_distance_max"] = float(own.max())
+    entry["nearest_other_board_min"] = float(other.min()) if n > 1 else None
+    entry["boards_nearest_to_their_own"] = int(np.sum(own < other))
+    entry["policy_max_range"] = [float(rp.max(axis=1).min()), float(rp.max(axis=1).max())]
+    entry["distinct_argmax"] = int(len(set(rp.argmax(axis=1).tolist())))
+    entry["value_range"] = [float(rv.min()), float(rv.max())]
+    return entry
+
+
+def real_game_features(positions, batch, first=3):
+    """`batch` DISTINCT feature tensors: positions spread over the three committed games, symmetry = index mod 8 (the workload of
+    tests/test_round3_gpu.py)."""
+    picks = np.linspace(first, len(positions) - 1, batch).astype(int)
+    planes = [positions[i][0].get_features(positions[i][1], symmetry=k % 8).reshape(-1) for k, i in enumerate(picks)]
+    return np.concatenate(planes).view(np.uint16)
+
+
+def sharpened_parity(api, synth, args, device, positions, n):
+    """A parity number that a mixed-up batch cannot pass: the He-init network of `value` forgets its input
+    (ANY board is within 1e-3 of ANY other), so this entry runs a SHARPENED network of the same architecture
+    (synth.make_sharp_tensors, dense gains 6 / 4: north_star's 1e-3 applies, tests/test_round3_gpu.py) on `n` distinct positions of
+    the committed games and reports the error next to the distance to the nearest OTHER board."""
+    from oracle import oracle
+    text = synth.to_json(synth.make_sharp_tensors(args.blocks, args.channels, seed=2020, policy_gain=6.0, value_gain=4.0))
+    features = real_game_features(positions, args.batch)
+    tensors, _ = oracle.load_weights(text)
+    ref_value, ref_policy = oracle.OracleNetwork(tensors).forward(np.ascontiguousarray(features[:n * 11552]), n)
+    net = api.Network.from_json(text)
+    ws = net.get_workspace(args.batch, device=device)
+    try:
+        return parity_entry(ws, features, n, ref_value, ref_policy,
+                            f"sharpened {args.blocks}x{args.channels} net (residual gate 0.1, dense gains 6 / 4), {n} distinct positions of the three "
+                            "committed games x 8 symmetries; HIP resident path vs oracle/dgnn_oracle.c")
+    finally:
+        ws.release()
+        net.destroy()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -456,60 +592,56 @@ def main():
                         "engine alone would allow; the pipeline figure is selfplay.games_per_hour",
             }
         # ---- PCIe-inclusive: host buffers in, host buffers out (the drop-in's own contract, graph.rs:130-131,155-156), never `value`
-        if world == 1 and not job.dry and not args.lean:
+        fw = DryForward(api) if job.dry else api
+        leg_ws = DryWorkspace(api, args.batch) if job.dry else ws
+        positions = None
+        if world == 1 and not args.lean:
             positions = real_game_positions(api)
-            # (a) as a leaf pool drives the device: two workspaces, one submission always queued, the loop inside the library
-            ws2 = net.get_workspace(args.batch, device=device)
-            records = np.concatenate([positions[i % len(positions)][0].record(positions[i % len(positions)][1], i % 8) for i in range(args.batch)])
-            packed = api.features_pack(features, args.batch)
-            reps = max(10, args.steps)
-            out["value_pcie_inclusive"] = {
-                "what": "evals/s with host buffers in and out, two workspaces in flight (dgnn_forward_submit_* / dgnn_forward_wait inside "
-                        "dgnn_forward_pipelined_timed: no interpreter in the loop), same network and batch as `value`",
-                "board_records": api.forward_pipelined_timed(ws, ws2, "records", records, args.batch, reps),     # 896 B per board, planes on the device
-                "packed_planes": api.forward_pipelined_timed(ws, ws2, "packed", packed, args.batch, reps),       # 1.5 KB per board
-                "fp16_planes": api.forward_pipelined_timed(ws, ws2, "planes", features, args.batch, reps),       # 23 KB per board: the reference's form
-                "steps": reps,
-            }
-            out["value_pcie_inclusive"]["records_vs_resident"] = out["value_pcie_inclusive"]["board_records"] / value
-            ws2.release()
-            # (b) the reference's own harness (`dream_go --bench`, src/dg/bench/forward.rs:37-47 under bench/benchmark.rs:37-53): every
-            # position of an SGF collection -- here the three committed games -- one at a time: planes on the host, repeated to the
-            # batch size, one synchronous forward(); positions per second over the whole walk, feature extraction included
-            t1 = time.perf_counter()
-            for board, color in positions:
-                api.forward(ws, np.tile(board.get_features(color, 0).reshape(-1).view(np.uint16), args.batch))
-            dt1 = time.perf_counter() - t1
-            t1 = time.perf_counter()
-            for board, color in positions:
-                api.forward_boards(ws, np.tile(board.record(color, 0), args.batch), args.batch)
-            dt2 = time.perf_counter() - t1
-            out["reference_style"] = {
-                "what": f"dream_go --bench style: {len(positions)} positions of the three committed games (tests/golden/real_games.json), each "
-                        f"repeated {args.batch} times and evaluated by one synchronous call from one thread (through the Python mirror)",
-                "boards_per_sec": args.batch * len(positions) / dt1, "boards_per_sec_records": args.batch * len(positions) / dt2,
-                "forms": "boards_per_sec: features::V1 on the host + dgnn_forward (the reference's flow); boards_per_sec_records: board record + "
-                         "dgnn_forward_boards (planes on the device)",
-                "positions": len(positions), "batch": args.batch,
-            }
+            if not job.dry:
+                # (a) as a leaf pool drives the device: two workspaces, one submission always queued, the loop inside the library
+                ws2 = net.get_workspace(args.batch, device=device)
+                records = np.concatenate([positions[i % len(positions)][0].record(positions[i % len(positions)][1], i % 8) for i in range(args.batch)])
+                packed = api.features_pack(features, args.batch)
+                reps = max(10, args.steps)
+                out["value_pcie_inclusive"] = {
+                    "what": "evals/s with host buffers in and out, two workspaces in flight (dgnn_forward_submit_* / dgnn_forward_wait inside "
+                            "dgnn_forward_pipelined_timed: no interpreter in the loop), same network and batch as `value`",
+                    "board_records": api.forward_pipelined_timed(ws, ws2, "records", records, args.batch, reps),     # 896 B per board, planes on the device
+                    "packed_planes": api.forward_pipelined_timed(ws, ws2, "packed", packed, args.batch, reps),       # 1.5 KB per board
+                    "fp16_planes": api.forward_pipelined_timed(ws, ws2, "planes", features, args.batch, reps),       # 23 KB per board: the reference's form
+                    "steps": reps,
+                }
+                out["value_pcie_inclusive"]["records_vs_resident"] = out["value_pcie_inclusive"]["board_records"] / value
+                ws2.release()
+            # (b) the reference's own harness; a dry run walks every 16th position (the order of the legs is what it is for)
+            out["reference_style"] = reference_style_leg(fw, api, leg_ws, positions[::16] if job.dry else positions, args.batch)
         if bcast is not None:
             out["weight_broadcast"] = bcast
-        if world == 1 and args.cpu_sample > 0 and not job.dry:
-            # the CPU baseline runs as an unpinned process would (its OpenMP team is created here and inherits this mask): the
-            # pinning is the GPU pipeline's business, and neighbours on the box may sit on the same low-numbered cores
-            if pinned is not None:
-                os.sched_setaffinity(0, unpinned)
-            baseline, (ref_value, ref_policy) = cpu_baseline(text, features, args.batch, args.cpu_sample)
-            if pinned is not None:
-                os.sched_setaffinity(0, pinned)
-            out["cpu_baseline"] = baseline
-            ws.forward_resident()
-            ws.sync()
-            got = ws.download()
+        if world == 1 and args.cpu_sample > 0:
             n = min(args.cpu_sample, args.batch)
-            dv = float(np.abs(got.value.astype(np.float32)[:n] - ref_value.view(np.float16).astype(np.float32)).max())
-            dp = float(np.abs(got.policy.astype(np.float32)[:n * 362] - ref_policy.view(np.float16).astype(np.float32)).max())
-            out["parity_vs_oracle"] = {"boards": n, "max_abs_value_diff": dv, "max_abs_policy_diff": dp, "tolerance": 1e-3}
+            if job.dry:
+                # the checker of a dry run is the stand-in itself, called directly on the batch
+                ref = DryWorkspace(api, args.batch)._evaluate(features)
+                ref_value, ref_policy = ref.value, ref.policy
+                flat_what = "DRY RUN: CPU hash predictor vs itself (the leg order is what is under test)"
+            else:
+                # the CPU baseline runs as an unpinned process would (its OpenMP team is created here and inherits this mask): the
+                # pinning is the GPU pipeline's business, and neighbours on the box may sit on the same low-numbered cores
+                if pinned is not None:
+                    os.sched_setaffinity(0, unpinned)
+                baseline, (ref_value, ref_policy) = cpu_baseline(text, features, args.batch, args.cpu_sample)
+                if pinned is not None:
+                    os.sched_setaffinity(0, pinned)
+                out["cpu_baseline"] = baseline
+                flat_what = "the network and batch of `value` (He-init, Bernoulli(0.2) planes): HIP resident path vs oracle/dgnn_oracle.c"
+            parity = {"flat": parity_entry(leg_ws, features, n, ref_value, ref_policy, flat_what)}
+            if not job.dry and not args.lean and positions is not None:
+                if pinned is not None:
+                    os.sched_setaffinity(0, unpinned)
+                parity["sharpened"] = sharpened_parity(api, synth, args, device, positions, min(n, len(positions) - 3))
+                if pinned is not None:
+                    os.sched_setaffinity(0, pinned)
+            out["parity_vs_oracle"] = parity
         line = json.dumps(out)
     else:
         line = None

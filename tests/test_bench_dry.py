@@ -51,3 +51,46 @@ def test_single_rank_dry_run_needs_no_process_group():
     assert run.returncode == 0, run.stderr[-2000:]
     line = json.loads(run.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and "weight_broadcast" not in line and line["selfplay"]["games"] == 2
+
+
+def test_single_rank_dry_run_parity_sample_sees_the_inputs_it_is_compared_on():
+    """since d4c9b12 the line's parity sample evaluated what the reference-style walk had LEFT in the workspace
+    (the last game position) and compared it with the oracle's outputs on the Bernoulli batch.  The dry run executes the same leg
+    order against a stand-in with the same residency rule; its checker is the stand-in called directly: any difference is a leg
+    that did not upload its own inputs."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry", *SMALL],
+                         capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["reference_style"]["positions"] > 0                   # the leg that disturbs the workspace DID run before the sample
+    flat = line["parity_vs_oracle"]["flat"]
+    assert flat["boards"] == 8 and flat["max_abs_value_diff"] == 0.0 and flat["max_abs_policy_diff"] == 0.0
+    assert flat["boards_nearest_to_their_own"] == 8 and flat["nearest_other_board_min"] > 0
+
+
+def test_the_parity_leg_can_fail_when_a_leg_leaves_other_inputs_behind():
+    """The same legs, driven by hand: after the reference-style walk a forward_resident() WITHOUT an upload evaluates the last game
+    position (what bench.py did in round 3) -- different from the batch's outputs; parity_entry uploads and agrees bit for bit."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    import __graft_entry__ as graft
+    graft.package()
+    from dream_go_amd import api, synth
+    batch = 4
+    features = synth.make_features(batch, seed=7)
+    ws, fw = bench.DryWorkspace(api, batch), bench.DryForward(api)
+    ref = bench.DryWorkspace(api, batch)._evaluate(features)
+    ws.upload(features)
+    positions = bench.real_game_positions(api)[:40:8]
+    bench.reference_style_leg(fw, api, ws, positions, batch)
+    ws.forward_resident()                                              # round 3's bug: no upload in front of it
+    stale = ws.download()
+    assert np.abs(stale.policy.astype(np.float32) - ref.policy.astype(np.float32)).max() > 0
+    assert not np.array_equal(ws.resident, features)
+    entry = bench.parity_entry(ws, features, batch, ref.value, ref.policy, "test")
+    assert entry["max_abs_value_diff"] == 0.0 and entry["max_abs_policy_diff"] == 0.0 and entry["boards_nearest_to_their_own"] == batch
+    assert np.array_equal(ws.resident, features)
+    # and a batch whose boards were rotated by one is caught by the identity count even when every diff is "small"
+    rolled = bench.parity_entry(ws, np.roll(features.reshape(batch, -1), 1, axis=0).reshape(-1), batch, ref.value, ref.policy, "rolled")
+    assert rolled["boards_nearest_to_their_own"] == 0
