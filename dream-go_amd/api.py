@@ -221,6 +221,9 @@ SYMBOLS = [
     ("dgnn_forward_pipelined_timed", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     ("dgnn_tree_node_to_pretty", ctypes.c_size_t, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     ("dgnn_cache_clear", ctypes.c_int, [_vp]),
+    ("dgnn_cache_generation", ctypes.c_uint64, [_vp]),
+    ("dgnn_cache_insert_at", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint16, _u16p]),
+    ("dgnn_pool_generation", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_pause", ctypes.c_int, [_vp]),
     ("dgnn_pool_resume", ctypes.c_int, [_vp]),
     ("dgnn_network_weight_image_commit", ctypes.c_int, [_vp, ctypes.c_int]),
@@ -753,8 +756,17 @@ class LruCache:
                                      response._policy.view(np.uint16).ctypes.data_as(_u16p)), "LruCache.cache")
 
     def clear(self):
-        """Drops every entry (weight refresh: the table holds the old network's outputs)."""
+        """Drops every entry (weight refresh: the table holds the old network's outputs) and starts a new generation."""
         _check(lib.dgnn_cache_clear(self._handle), "LruCache.clear")
+
+    def generation(self):
+        return int(lib.dgnn_cache_generation(self._handle))
+
+    def cache_at(self, generation, board_hash, to_move, symmetry, response):
+        """cache() of an answer whose miss was seen at `generation`: dropped when the table has been cleared since."""
+        bits = np.asarray(response._value).view(np.uint16)
+        _check(lib.dgnn_cache_insert_at(self._handle, int(generation), int(board_hash), int(to_move), int(symmetry), int(bits),
+                                        response._policy.view(np.uint16).ctypes.data_as(_u16p)), "LruCache.cache_at")
 
     def stats(self):
         e, h, m = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
@@ -911,6 +923,10 @@ class LeafPool:
 
     def resume(self):
         _check(lib.dgnn_pool_resume(self._handle), "LeafPool.resume")
+
+    def generation(self):
+        """Completed pauses (weight refreshes) so far."""
+        return int(lib.dgnn_pool_generation(self._handle))
 
     @property
     def takes_boards(self):

@@ -109,6 +109,9 @@ struct CacheShard {
 struct Cache {
     std::vector<std::unique_ptr<CacheShard>> shards;
     std::atomic<uint64_t> hits{0}, misses{0};
+    // bumped by dgnn_cache_clear BEFORE the shards are emptied: an answer that was requested under an older generation (a miss seen
+    // before a weight refresh) is not stored afterwards (dgnn_cache_insert_at)
+    std::atomic<uint64_t> generation{0};
 
     CacheShard& shard(const CacheKey& k) { return *shards[CacheKeyHash()(k) % shards.size()]; }
 };
@@ -187,6 +190,7 @@ struct LeafPool {
     bool paused = false;            // dgnn_pool_pause: workers take no new batch (callers keep queueing and wait)
     int evaluating = 0;             // workers between get_batch and the end of evaluate (under `mutex`)
     std::condition_variable idle;   // signalled when `evaluating` drops to zero
+    std::atomic<uint64_t> generation{0};   // completed pauses: what a game compares per move to drop its PRIVATE table after a refresh
     std::atomic<uint64_t> calls{0};
 
     bool ready() const
@@ -232,7 +236,6 @@ struct LeafPool {
             (void)dgnn_batch_tags(batch, tags.data());
             const int status = evaluate(lane, batch, n, value.data(), policy.data());
             dgnn_batch_destroy(batch);
-            done();
             wake();                                 // a batch slot is free again
             for (int i = 0; i < n; ++i) {
                 LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
@@ -250,6 +253,7 @@ struct LeafPool {
                 }
                 if (resume) fiber_make_ready(resume);      // (the request lives on the fiber's stack: not touched after this)
             }
+            done();     // after the answers are with their requests: a pause returns with no old-weights answer still on its way
         }
     }
 };
@@ -315,13 +319,15 @@ int dgnn_cache_fetch(dgnn_cache* cache, uint64_t board_hash, int to_move, int sy
     return 1;
 }
 
-int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy)
+static int cache_insert(Cache* c, bool checked, uint64_t generation, uint64_t board_hash, int to_move, int symmetry, uint16_t value,
+                        const uint16_t* policy)
 {
-    if (!cache || !policy || symmetry < 0 || symmetry >= 8) return DGNN_BAD_ARGUMENT;
-    Cache* c = reinterpret_cast<Cache*>(cache);
     const CacheKey key{board_hash, to_move};
     CacheShard& s = c->shard(key);
     std::lock_guard<std::mutex> lock(s.mutex);
+    // under the shard's lock: a clear that bumped the generation before this load drops the answer here; one that bumps it later
+    // takes this lock after us and drops the entry with the rest of the shard
+    if (checked && c->generation.load(std::memory_order_seq_cst) != generation) return DGNN_OK;
     if (s.index.find(key) != s.index.end()) return DGNN_OK;                    // lru_cache.rs:121: present keys are left alone
     s.order.emplace_front();
     CacheEntry& e = s.order.front();
@@ -336,11 +342,33 @@ int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int s
     return DGNN_OK;
 }
 
+int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy)
+{
+    if (!cache || !policy || symmetry < 0 || symmetry >= 8) return DGNN_BAD_ARGUMENT;
+    return cache_insert(reinterpret_cast<Cache*>(cache), false, 0, board_hash, to_move, symmetry, value, policy);
+}
+
+uint64_t dgnn_cache_generation(const dgnn_cache* cache)
+{
+    return cache ? reinterpret_cast<const Cache*>(cache)->generation.load(std::memory_order_seq_cst) : 0;
+}
+
+// The insert of an answer whose MISS was seen at `generation` (dgnn_cache_generation read before the fetch): dropped when the table
+// has been cleared since -- the answer may come from the weights the clear was for (a request in flight across
+// pause -> set weights -> clear -> resume used to put the old network's output back into the emptied table).
+int dgnn_cache_insert_at(dgnn_cache* cache, uint64_t generation, uint64_t board_hash, int to_move, int symmetry, uint16_t value,
+                         const uint16_t* policy)
+{
+    if (!cache || !policy || symmetry < 0 || symmetry >= 8) return DGNN_BAD_ARGUMENT;
+    return cache_insert(reinterpret_cast<Cache*>(cache), true, generation, board_hash, to_move, symmetry, value, policy);
+}
+
 // Drops every entry (the counters stay): what a weight refresh needs -- the table holds the OLD network's outputs.
 int dgnn_cache_clear(dgnn_cache* cache)
 {
     if (!cache) return DGNN_BAD_ARGUMENT;
     Cache* c = reinterpret_cast<Cache*>(cache);
+    c->generation.fetch_add(1, std::memory_order_seq_cst);          // first: answers requested before this point are no longer stored
     for (auto& s : c->shards) {
         std::lock_guard<std::mutex> lock(s->mutex);
         s->index.clear();
@@ -740,7 +768,13 @@ int dgnn_pool_pause(dgnn_pool* handle)
     std::unique_lock<std::mutex> lock(pool->mutex);
     pool->paused = true;
     pool->idle.wait(lock, [&] { return pool->evaluating == 0; });
+    pool->generation.fetch_add(1, std::memory_order_seq_cst);
     return DGNN_OK;
+}
+
+uint64_t dgnn_pool_generation(const dgnn_pool* handle)
+{
+    return handle ? reinterpret_cast<const LeafPool*>(handle)->generation.load(std::memory_order_seq_cst) : 0;
 }
 
 int dgnn_pool_resume(dgnn_pool* handle)

@@ -103,7 +103,7 @@ int tower_split_ns(int batch, int channels, int num_cus)
 }
 
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
-                              size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream)
+                              size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream, bool inject_missing)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     const int slices = channels / 32;
@@ -120,7 +120,9 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
     }
     const unsigned launch_base = *base;
     *base += (unsigned)count + 1u;
-    const dim3 grid((batch + 7) / 8 * 8 * groups);
+    // inject_missing (fault injection, tests): the last eight workgroups of the launch never start -- what a launch that is not fully
+    // resident looks like to the others: their consumers poll a flag nobody publishes and give up after kGiveUpTicks
+    const dim3 grid((batch + 7) / 8 * 8 * groups - (inject_missing ? 8 : 0));
     // measurement only: DGNN_SPLIT_TRACE=<file> dumps wave 0's stamps of every (layer, board, channel block) of each launch
     static const char* const trace_path = std::getenv("DGNN_SPLIT_TRACE");
     unsigned long long* d_trace = nullptr;

@@ -151,6 +151,8 @@ struct Predictor {
     {
         return takes_records() ? boards(ctx, buffer, n, value, policy) : features(ctx, reinterpret_cast<const uint16_t*>(buffer), n, value, policy);
     }
+    // completed weight refreshes of the pool behind this predictor (dgnn_pool_generation); 0 for any other predictor (search.cpp)
+    uint64_t generation() const;
     bool usable_with(const dgnn_game_ops* ops) const { return takes_records() ? ops->record != nullptr : (features != nullptr && ops->features != nullptr); }
 };
 

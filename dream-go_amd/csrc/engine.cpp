@@ -84,7 +84,9 @@ struct Workspace {
     bool split_failed = false;              // a hand-off poll gave up (not every workgroup was resident): per-layer launches for a while
     int split_failures = 0;                 // how often that has happened: after kSplitMaxFailures the split stays off
     int split_cooldown = 0;                 // passes still to run per layer before the split is tried again
-    bool inject_giveup = false;             // DGNN_SPLIT_INJECT_GIVEUP=1 when the workspace was built (fault injection for the tests)
+    int inject_giveup = 0;                  // DGNN_SPLIT_INJECT_GIVEUP when the workspace was built (fault injection for the tests): 1 = the
+                                            // launch finds the give-up word set; 2 = eight workgroups of the launch never start (the others
+                                            // really wait, and really time out)
     bool injected = false;                  // ... and it has fired
     unsigned* d_split_sync = nullptr;       // [batch * kSplitWordsPerBoard] layers published per (board, channel block, row half), then the give-up word
     unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
@@ -254,7 +256,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         const char* split = std::getenv("DGNN_TOWER_SPLIT");
         if (split && *split) ws->split_pref = std::atoi(split);
         const char* inject = std::getenv("DGNN_SPLIT_INJECT_GIVEUP");
-        ws->inject_giveup = inject && std::atoi(inject) == 1;
+        ws->inject_giveup = inject ? std::atoi(inject) : 0;
     }
 
     ws->board_env = read_board_switches();
@@ -468,12 +470,14 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 std::lock_guard<std::mutex> chained(chain->mutex);
                 if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
                 (void)groups;
-                if (ws->inject_giveup && !ws->injected) {       // fault injection (tests): the launch finds the give-up word already set
+                bool missing = false;
+                if (ws->inject_giveup != 0 && !ws->injected) {  // fault injection (tests)
                     ws->injected = true;
-                    DGNN_HIP(hipMemsetAsync(ws->d_split_err, 0xff, sizeof(unsigned), ws->stream));
+                    if (ws->inject_giveup == 1) DGNN_HIP(hipMemsetAsync(ws->d_split_err, 0xff, sizeof(unsigned), ws->stream));
+                    else missing = true;
                 }
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
-                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->stream));
+                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->stream, missing));
                 DGNN_HIP(hipEventRecord(chain->done, ws->stream));
                 chain->recorded = true;
             } else {

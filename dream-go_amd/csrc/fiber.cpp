@@ -11,10 +11,26 @@
 #include <thread>
 #include <vector>
 
-#if defined(__x86_64__) && !defined(DGNN_NO_FIBERS) && !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
+#if defined(__x86_64__) && !defined(DGNN_NO_FIBERS)
 #define DGNN_FIBERS 1
 #else
 #define DGNN_FIBERS 0
+#endif
+
+// The sanitizers follow a hand-written stack switch when they are told about it (round 4: what ships is what is sanitized):
+// ASan needs the bounds of the stack that is switched TO and a slot for the fake stack of the one that is left
+// (__sanitizer_start/finish_switch_fiber), TSan a context per fiber (__tsan_create_fiber / __tsan_switch_to_fiber).
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define DGNN_ASAN_FIBERS 1
+#else
+#define DGNN_ASAN_FIBERS 0
+#endif
+#if defined(__SANITIZE_THREAD__)
+#include <sanitizer/tsan_interface.h>
+#define DGNN_TSAN_FIBERS 1
+#else
+#define DGNN_TSAN_FIBERS 0
 #endif
 
 #if DGNN_FIBERS && !defined(__HIP_DEVICE_COMPILE__)
@@ -60,6 +76,8 @@ struct Fiber {
     const std::function<void(int)>* body = nullptr;
     int index = 0;
     bool finished = false;
+    void* asan_fake_stack = nullptr;           // sanitizer builds only: ASan's fake stack while switched out, TSan's fiber context
+    void* tsan_fiber = nullptr;
 };
 
 namespace {
@@ -72,18 +90,56 @@ struct Scheduler {
     void* sp = nullptr;                        // the scheduler thread's own context while a fiber runs
     Fiber* current = nullptr;
     int live = 0;
+    void* asan_fake_stack = nullptr;           // sanitizer builds only: the scheduler thread's own contexts
+    const void* asan_stack_bottom = nullptr;
+    size_t asan_stack_size = 0;
+    void* tsan_fiber = nullptr;
 };
 
 thread_local Scheduler* tls_scheduler = nullptr;
 
 #if DGNN_FIBERS
+// fiber -> its scheduler
+void switch_to_scheduler(Scheduler* s, Fiber* f, bool for_good)
+{
+#if DGNN_ASAN_FIBERS
+    __sanitizer_start_switch_fiber(for_good ? nullptr : &f->asan_fake_stack, s->asan_stack_bottom, s->asan_stack_size);
+#endif
+#if DGNN_TSAN_FIBERS
+    __tsan_switch_to_fiber(s->tsan_fiber, 0);
+#endif
+    (void)for_good;
+    dgnn_fiber_switch(&f->sp, s->sp);
+#if DGNN_ASAN_FIBERS
+    __sanitizer_finish_switch_fiber(f->asan_fake_stack, &s->asan_stack_bottom, &s->asan_stack_size);     // resumed by the scheduler
+#endif
+}
+
+// scheduler -> fiber
+void switch_to_fiber(Scheduler* s, Fiber* f)
+{
+#if DGNN_ASAN_FIBERS
+    __sanitizer_start_switch_fiber(&s->asan_fake_stack, static_cast<char*>(f->stack) + kGuardBytes, kStackBytes);
+#endif
+#if DGNN_TSAN_FIBERS
+    __tsan_switch_to_fiber(f->tsan_fiber, 0);
+#endif
+    dgnn_fiber_switch(&s->sp, f->sp);
+#if DGNN_ASAN_FIBERS
+    __sanitizer_finish_switch_fiber(s->asan_fake_stack, nullptr, nullptr);
+#endif
+}
+
 void fiber_entry()
 {
     Scheduler* s = tls_scheduler;
     Fiber* f = s->current;
+#if DGNN_ASAN_FIBERS
+    __sanitizer_finish_switch_fiber(nullptr, &s->asan_stack_bottom, &s->asan_stack_size);     // first time on this stack: learn the scheduler's
+#endif
     (*f->body)(f->index);
     f->finished = true;
-    dgnn_fiber_switch(&f->sp, s->sp);          // never resumed
+    switch_to_scheduler(s, f, true);           // never resumed
     std::abort();
 }
 
@@ -101,12 +157,18 @@ bool prepare(Fiber* f)
     *--slot = reinterpret_cast<uint64_t>(&fiber_entry);
     for (int i = 0; i < 6; ++i) *--slot = 0;
     f->sp = slot;
+#if DGNN_TSAN_FIBERS
+    f->tsan_fiber = __tsan_create_fiber(0);
+#endif
     return true;
 }
 
 void scheduler_loop(Scheduler* s)
 {
     tls_scheduler = s;
+#if DGNN_TSAN_FIBERS
+    s->tsan_fiber = __tsan_get_current_fiber();
+#endif
     std::vector<Fiber*> batch;
     while (s->live > 0) {
         {
@@ -117,9 +179,16 @@ void scheduler_loop(Scheduler* s)
         }
         for (Fiber* f : batch) {
             s->current = f;
-            dgnn_fiber_switch(&s->sp, f->sp);
+            switch_to_fiber(s, f);
             s->current = nullptr;
-            if (f->finished) { munmap(f->stack, kStackBytes + kGuardBytes); f->stack = nullptr; --s->live; }
+            if (f->finished) {
+#if DGNN_TSAN_FIBERS
+                __tsan_destroy_fiber(f->tsan_fiber);
+#endif
+                munmap(f->stack, kStackBytes + kGuardBytes);
+                f->stack = nullptr;
+                --s->live;
+            }
         }
         batch.clear();
     }
@@ -135,14 +204,13 @@ Fiber* fiber_current() { return tls_scheduler ? tls_scheduler->current : nullptr
 
 void fiber_make_ready(Fiber* f)
 {
+    // The notify happens UNDER the mutex: the Scheduler lives on run_fibers' stack, and once the lock is released the scheduler
+    // thread may run the last fibers to completion (woken by another waker or spuriously) and destroy it -- a notify after the
+    // unlock could then signal a dead condition variable.
     Scheduler* s = f->scheduler;
-    bool wake;
-    {
-        std::lock_guard<std::mutex> lock(s->mutex);
-        s->ready.push_back(f);
-        wake = s->sleeping;
-    }
-    if (wake) s->cv.notify_one();
+    std::lock_guard<std::mutex> lock(s->mutex);
+    s->ready.push_back(f);
+    if (s->sleeping) s->cv.notify_one();
 }
 
 void fiber_yield()
@@ -150,7 +218,7 @@ void fiber_yield()
 #if DGNN_FIBERS
     Scheduler* s = tls_scheduler;
     Fiber* f = s->current;
-    dgnn_fiber_switch(&f->sp, s->sp);
+    switch_to_scheduler(s, f, false);
 #endif
 }
 

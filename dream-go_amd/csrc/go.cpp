@@ -1331,8 +1331,15 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
 
         // one turn per iteration, black first; the turn cap only guards against two players passing for ever on a board
         // that never becomes scorable (the reference would spin there)
+        uint64_t weights_seen = predictor.generation();
         for (int turn = first_turn; board.count < max_moves && turn < 4 * 722 && status.load() == DGNN_OK; ++turn) {
             const int me = turn & 1;
+            // a weight refresh of the pool (dgnn_pool_pause ... resume) cannot reach a table that is the game's own: the game
+            // drops it itself, before the first search that could be served the replaced network's outputs
+            if (private_cache > 0) {
+                const uint64_t now = predictor.generation();
+                if (now != weights_seen) { dgnn_cache_clear(cache); weights_seen = now; }
+            }
             const bool allow_pass = is_scorable(board.inner);                  // self_play.rs:437
             const dgnn_game_ops* ops = allow_pass ? &kGoOps : &kGoScoringOps;   // predict_aux, self_play.rs:243-274
             const bool deterministic = !allow_pass;                            // ScoringSearch::deterministic, options.rs:160-162

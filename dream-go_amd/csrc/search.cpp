@@ -184,7 +184,7 @@ struct SearchShared {
 // with one thread deterministic while K leaves are on the device.
 void search_worker(SearchShared* s, uint64_t seed)
 {
-    struct Leaf { void* board; dgnn_trace* trace; int to_move; int transform; uint64_t key; };
+    struct Leaf { void* board; dgnn_trace* trace; int to_move; int transform; uint64_t key; uint64_t generation; };
     const int capacity = std::max(1, s->leaves_per_thread);
     Rng rng{seed};
     std::vector<uint16_t> policy((size_t)capacity * DGNN_NUM_MOVES), value((size_t)capacity);
@@ -224,12 +224,13 @@ void search_worker(SearchShared* s, uint64_t seed)
                 else over = true;                                             // NoResult: the search is over (:164-166)
                 break;
             }
-            Leaf leaf{board, trace, 0, 0, 0};
+            Leaf leaf{board, trace, 0, 0, 0, 0};
             int last_color = 0;
             dgnn_trace_get(trace, dgnn_trace_len(trace) - 1, nullptr, &last_color, nullptr);
             leaf.to_move = 1 - last_color;                                    // event.rs:48-49
             leaf.transform = (int)(rng.next() % 8);                           // event.rs:47
             leaf.key = cached ? s->ops->hash(board) : 0;
+            leaf.generation = cached ? dgnn_cache_generation(s->cache) : 0;   // before the fetch: the answer to this miss belongs to it
             uint16_t v = 0;
             if (cached && dgnn_cache_fetch(s->cache, leaf.key, leaf.to_move, leaf.transform, &v, policy.data()) == 1) {   // event.rs:50-51
                 s->cache_hits.fetch_add(1, std::memory_order_relaxed);
@@ -265,7 +266,7 @@ void search_worker(SearchShared* s, uint64_t seed)
         s->evals.fetch_add((uint64_t)n, std::memory_order_relaxed);
         for (int i = 0; i < n; ++i) {
             const uint16_t* p = policy.data() + (size_t)i * DGNN_NUM_MOVES;
-            if (cached) dgnn_cache_insert(s->cache, leaves[i].key, leaves[i].to_move, leaves[i].transform, value[i], p);    // worker_thread.rs:111
+            if (cached) dgnn_cache_insert_at(s->cache, leaves[i].generation, leaves[i].key, leaves[i].to_move, leaves[i].transform, value[i], p);    // worker_thread.rs:111
             finish(leaves[i], value[i], p);
         }
     }
@@ -388,6 +389,13 @@ void dgnn_synthetic_board_free(void* board) { syn_destroy(board); }
 
 dgnn_predict_fn dgnn_hash_predictor(void) { return hash_predict; }
 dgnn_predict_fn dgnn_pool_predictor(void) { return pool_predict; }
+
+uint64_t dgnn::Predictor::generation() const
+{
+    const bool pool = takes_records() ? boards == pool_predict_boards : features == pool_predict;
+    return pool ? dgnn_pool_generation(static_cast<const dgnn_pool*>(ctx)) : 0;
+}
+
 dgnn_predict_boards_fn dgnn_pool_boards_predictor(void) { return pool_predict_boards; }
 
 int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,
@@ -443,6 +451,7 @@ int dgnn::full_forward(const dgnn_game_ops* ops, void* board, int to_move, const
         value += (0.5f * half_to_float(v) + 0.5f) * 0.125f;
         for (int i = 0; i < DGNN_NUM_MOVES; ++i) policy_out[i] += one[i];
     };
+    const uint64_t generation = cached ? dgnn_cache_generation(cache) : 0;
     for (int t = 0; t < 8; ++t) {
         uint16_t v = 0, p[DGNN_NUM_MOVES];
         if (cached && dgnn_cache_fetch(cache, key, to_move, t, &v, p) == 1) { accumulate(t, v, p); continue; }
@@ -455,7 +464,7 @@ int dgnn::full_forward(const dgnn_game_ops* ops, void* board, int to_move, const
         if (status != DGNN_OK) return status;
         for (int k = 0; k < num_missing; ++k) {
             accumulate(missing[k], values[k], policies.data() + (size_t)k * DGNN_NUM_MOVES);
-            if (cached) dgnn_cache_insert(cache, key, to_move, missing[k], values[k], policies.data() + (size_t)k * DGNN_NUM_MOVES);
+            if (cached) dgnn_cache_insert_at(cache, generation, key, to_move, missing[k], values[k], policies.data() + (size_t)k * DGNN_NUM_MOVES);
         }
     }
     *value_out = value;

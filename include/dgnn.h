@@ -346,6 +346,12 @@ int dgnn_cache_fetch(dgnn_cache* cache, uint64_t board_hash, int to_move, int sy
 int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy);
 int dgnn_cache_stats(dgnn_cache* cache, uint64_t* entries, uint64_t* hits, uint64_t* misses);
 int dgnn_cache_clear(dgnn_cache* cache);     /* drops every entry: the table holds the outputs of the weights that are being replaced */
+/* A clear also starts a new GENERATION of the table.  A caller that evaluates its misses asynchronously reads the generation before
+ * the fetch and stores the answer with dgnn_cache_insert_at: an answer whose miss predates a clear is dropped instead of putting
+ * the replaced network's output back into the emptied table (the search driver and dgnn_full_forward do this). */
+uint64_t dgnn_cache_generation(const dgnn_cache* cache);
+int dgnn_cache_insert_at(dgnn_cache* cache, uint64_t generation, uint64_t board_hash, int to_move, int symmetry, uint16_t value,
+                         const uint16_t* policy);
 
 /* Batcher / Batch (src/libdg_mcts/pool/batch.rs:24-123).  Leaf positions from any number of games and threads are
  * pushed with a caller-chosen 64-bit tag; get_batch hands out the NEWEST max_batch_size of them once at least
@@ -428,6 +434,9 @@ int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool
  * replaced: no DGNN_BUSY); predict calls made meanwhile queue up and are answered after resume -- by the new weights. */
 int dgnn_pool_pause(dgnn_pool* pool);
 int dgnn_pool_resume(dgnn_pool* pool);
+/* Completed pauses so far.  Games with a transposition table of their own (dgnn_selfplay_params.cache_entries_per_game > 0), which
+ * dgnn_cache_clear cannot reach, compare it before every move and empty their table when it has changed. */
+uint64_t dgnn_pool_generation(const dgnn_pool* pool);
 
 /* Counters: dgnn_pool_predict calls, boards / device batches evaluated, and the same per lane (device) for the first
  * lane_capacity lanes.  Any out pointer may be NULL. */

@@ -190,3 +190,38 @@ def test_broadcast_without_rccl_is_refused_up_front(api, synth, monkeypatch):
     env = dict(os.environ, DGNN_RCCL_DISABLE="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_a_launch_that_is_not_fully_resident_gives_up_within_milliseconds(api, synth, monkeypatch, capfd):
+    """DGNN_SPLIT_INJECT_GIVEUP=2 launches the split tower WITHOUT its last eight workgroups -- what a launch whose
+    workgroups are not co-resident looks like to the others.  Their consumers really poll, really time out (kGiveUpTicks = 50 ms of the
+    100 MHz clock; round 3: 2^31 ticks = 21 s), the pass is repeated per layer: bit-equal to the per-layer path and < 0.2 s end to end."""
+    blocks, channels, batch = 2, 256, 16
+    text = synth.to_json(synth.make_tensors(blocks, channels, seed=650))
+    features = synth.make_features(batch, seed=651)
+    monkeypatch.setenv("DGNN_TOWER", "0")
+    net = api.Network.from_json(text)
+    with net.get_workspace(batch) as ws:
+        want = _bits(api.forward(ws, features).unwrap())
+    net.destroy()
+    monkeypatch.setenv("DGNN_TOWER", "1")
+    monkeypatch.setenv("DGNN_SPLIT_INJECT_GIVEUP", "2")
+    net = api.Network.from_json(text)
+    ws = net.get_workspace(batch)
+    assert ws.conv_kernel() == "tower_split_kernel"
+    t0 = time.perf_counter()
+    got = _bits(api.forward(ws, features).unwrap())
+    seconds = time.perf_counter() - t0
+    print(f"pass with eight workgroups missing: {seconds * 1e3:.1f} ms end to end")
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert "gave up" in capfd.readouterr().err
+    assert 0.02 < seconds < 0.2                                     # it DID wait (not the pre-set word of mode 1), and not for long
+    assert ws.conv_kernel() == "conv3x3_board_kernel"
+    net.synchronize()                                               # re-arm: the next split launch is whole again
+    assert ws.conv_kernel() == "tower_split_kernel"
+    t0 = time.perf_counter()
+    got = _bits(api.forward(ws, features).unwrap())
+    assert time.perf_counter() - t0 < 0.02
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ws.release()
+    net.destroy()

@@ -91,6 +91,38 @@ int main() {
         dgnn_pool_destroy(pool);
         dgnn_cache_destroy(cache);
     }
+    {   // round 4: what SHIPS -- 256 games as fibers on two host threads (csrc/fiber.cpp: a hand-written stack switch, announced to
+        // ASan with __sanitizer_start/finish_switch_fiber and to TSan with __tsan_create_fiber / __tsan_switch_to_fiber), board records
+        // through a records pool whose workers make the fibers ready again, a refresh (pause / clear / resume) while they run
+        dgnn_pool* pool = nullptr;
+        dgnn_cache* cache = nullptr;
+        dgnn_dry_device device{200.0, 2.0};
+        dgnn_pool_create_board_callbacks(dgnn_hash_boards_predictor(), &device, 1, 256, 2, 2, &pool);
+        dgnn_cache_create(200001, 8, &cache);
+        dgnn_selfplay_params p{};
+        p.num_games = 256; p.num_parallel = 256; p.game_stride = 1; p.max_moves = 4; p.num_rollouts = 64; p.threads_per_search = 1;
+        p.leaves_per_thread = 8; p.seed = 79; p.host_threads = 2;
+        dgnn_selfplay_stats st;
+        std::thread refresher([&] {
+            for (int i = 0; i < 3; ++i) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(200));
+                dgnn_pool_pause(pool);
+                dgnn_cache_clear(cache);
+                dgnn_pool_resume(pool);
+            }
+        });
+        int rc = dgnn_selfplay_go_boards(dgnn_pool_boards_predictor(), pool, cache, &p, &st, nullptr, nullptr, 0);
+        refresher.join();
+        std::printf("fibers: 256 games on 2 host threads rc %d moves %llu evals %llu hits %llu\n", rc, (unsigned long long)st.moves,
+                    (unsigned long long)st.evals, (unsigned long long)st.cache_hits);
+        // the same with a table per game (the reproducible mode) and games started as others end
+        p.num_games = 48; p.num_parallel = 32; p.max_moves = 12; p.cache_entries_per_game = 2000; p.seed = 80; p.host_threads = 3;
+        rc = dgnn_selfplay_go_boards(dgnn_pool_boards_predictor(), pool, nullptr, &p, &st, nullptr, nullptr, 0);
+        std::printf("fibers: 48 games (32 in flight) on 3 host threads, private tables rc %d moves %llu evals %llu\n", rc,
+                    (unsigned long long)st.moves, (unsigned long long)st.evals);
+        dgnn_pool_destroy(pool);
+        dgnn_cache_destroy(cache);
+    }
     // synthetic self-play with many threads
     dgnn_selfplay_stats st;
     int rc = dgnn_selfplay_synthetic(dgnn_hash_predictor(), nullptr, 4, 4, 60, 8, 3, &st);

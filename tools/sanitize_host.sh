@@ -61,10 +61,10 @@ int dgnn_device_count(int* count) { *count = 1; return DGNN_OK; }
 }
 STUBS
 FILES="$SRC/go.cpp $SRC/batcher.cpp $SRC/formats.cpp $SRC/tree.cpp $SRC/search.cpp $SRC/loader.cpp $SRC/fiber.cpp $TMP/stubs.cpp $ROOT/tools/sanitize_host.cpp"
-# (fibers switch stacks by hand: the sanitizer builds define DGNN_NO_FIBERS and run a thread per game, like host_threads = 0)
-g++ -O1 -g -std=c++17 -DDGNN_NO_FIBERS -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/asan" -lpthread
-echo "== AddressSanitizer + UBSan"; "$TMP/asan"
-g++ -O1 -g -std=c++17 -DDGNN_NO_FIBERS -fsanitize=thread -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/tsan" -lpthread
+# Fibers are ON (round 4): fiber.cpp announces its stack switch to the sanitizers; the driver runs 256 games on two host threads
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/asan" -lpthread
+echo "== AddressSanitizer + UBSan"; ASAN_OPTIONS="detect_stack_use_after_return=1" "$TMP/asan"
+g++ -O1 -g -std=c++17 -fsanitize=thread -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/tsan" -lpthread
 echo "== ThreadSanitizer"; TSAN_OPTIONS="halt_on_error=0" "$TMP/tsan" > "$TMP/tsan.out" 2>&1 || true
 grep -A6 "WARNING: ThreadSanitizer" "$TMP/tsan.out" | grep -E "#0" | sed 's/0x[0-9a-f]* //' | awk '{print $2, $3}' | sort | uniq -c | sort -rn
 tail -4 "$TMP/tsan.out"
