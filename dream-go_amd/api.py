@@ -80,6 +80,7 @@ SYMBOLS = [
     ("dgnn_workspace_conv_kernel", ctypes.c_char_p, [_vp]),
     ("dgnn_workspace_upload", ctypes.c_int, [_vp, _u16p, ctypes.c_size_t]),
     ("dgnn_workspace_download", ctypes.c_int, [_vp, _u16p, _u16p]),
+    ("dgnn_workspace_download_pre", ctypes.c_int, [_vp, _u16p, _u16p]),
     ("dgnn_forward_resident", ctypes.c_int, [_vp]),
     ("dgnn_workspace_sync", ctypes.c_int, [_vp]),
     ("dgnn_forward_timed", ctypes.c_int, [_vp, ctypes.c_int, _fp, _fp, _ip]),
@@ -373,6 +374,13 @@ class WorkspaceGuard:
         policy = np.empty(self.batch_size * NUM_MOVES, dtype=np.uint16)
         _check(lib.dgnn_workspace_download(self.handle, value.ctypes.data_as(_u16p), policy.ctypes.data_as(_u16p)), "download")
         return OutputMap(value.view(np.float16), policy.view(np.float16))
+
+    def download_pre(self):
+        """(logits fp16 [batch, 362], pre-tanh value fp16 [batch]) of the last forward on this workspace (test-only entry)."""
+        logits = np.empty(self.batch_size * NUM_MOVES, dtype=np.uint16)
+        value = np.empty(self.batch_size, dtype=np.uint16)
+        _check(lib.dgnn_workspace_download_pre(self.handle, logits.ctypes.data_as(_u16p), value.ctypes.data_as(_u16p)), "download_pre")
+        return logits.view(np.float16).reshape(self.batch_size, NUM_MOVES), value.view(np.float16)
 
     def forward_resident(self):
         _check(lib.dgnn_forward_resident(self.handle), "forward_resident")

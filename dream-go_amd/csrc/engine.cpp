@@ -61,6 +61,7 @@ struct Workspace {
     uint16_t* d_value_features = nullptr;   // [batch][361][2]
     uint16_t* d_logits = nullptr;           // [batch][384] fp16 policy logits
     uint16_t* d_value = nullptr;            // [batch]
+    uint16_t* d_value_pre = nullptr;        // [batch] the value head's dense output before tanh (parity tests: dgnn_workspace_download_pre)
     uint16_t* d_policy = nullptr;           // [batch][362]
 
     void* pinned = nullptr;                 // host staging, one allocation
@@ -290,7 +291,8 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
     const size_t sz_split = align_up((size_t)batch * kSplitWordsPerBoard * sizeof(unsigned), 256);
     const size_t sz_records = align_up((size_t)batch * DGNN_BOARD_RECORD_BYTES, 256);
-    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split + sz_records;
+    const size_t sz_vpre = align_up((size_t)batch * 2, 256);
+    const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split + sz_records + sz_vpre;
 
     DGNN_HIP(hipMalloc(&ws->arena, total));
     // board path: pad rows 384..399 of every k-slot are never written by the kernels and must read as zero
@@ -307,6 +309,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_packed = (uint32_t*)p; p += sz_packed;
     ws->d_split_sync = (unsigned*)p; p += sz_split;
     ws->d_records = p; p += sz_records;
+    ws->d_value_pre = (uint16_t*)p; p += sz_vpre;
     if (ws->use_board) {
         ws->d_features_board = (uint16_t*)p; p += sz_fboard;
         ws->d_tower_nhwc = (uint16_t*)p;
@@ -557,6 +560,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     sv.value_b = (const uint16_t*)(image + t.value_b_offset);
     sv.policy_out = ws->d_policy;
     sv.value_out = ws->d_value;
+    sv.value_pre_out = ws->d_value_pre;
     sv.batch = ws->active;
     DGNN_HIP(launch_softmax_value(sv, ws->stream));
     return DGNN_OK;
@@ -1296,6 +1300,19 @@ int dgnn_workspace_download(dgnn_workspace* handle, uint16_t* value_out, uint16_
     return DGNN_OK;
 }
 
+// Test-only (include/dgnn.h): the two fp16 tensors in front of the output activations, as the LAST pass on this workspace left them.
+int dgnn_workspace_download_pre(dgnn_workspace* handle, uint16_t* logits_out, uint16_t* value_pre_out)
+{
+    if (!handle || !logits_out || !value_pre_out) return DGNN_BAD_ARGUMENT;
+    Workspace* ws = W(handle);
+    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(hipMemcpy2DAsync(logits_out, DGNN_NUM_MOVES * 2, ws->d_logits, 384 * 2, DGNN_NUM_MOVES * 2, (size_t)ws->batch, hipMemcpyDeviceToHost,
+                              ws->stream));
+    DGNN_HIP(hipMemcpyAsync(value_pre_out, ws->d_value_pre, (size_t)ws->batch * 2, hipMemcpyDeviceToHost, ws->stream));
+    DGNN_HIP(hipStreamSynchronize(ws->stream));
+    return DGNN_OK;
+}
+
 int dgnn_forward_resident(dgnn_workspace* handle)
 {
     if (!handle) return DGNN_BAD_ARGUMENT;
@@ -1552,6 +1569,7 @@ int dgnn_layer_heads(int device, const uint16_t* logits, const uint16_t* value_f
         sv.value_b = (const uint16_t*)(d + sz_l + sz_vf + sz_w);
         sv.policy_out = (uint16_t*)(d + sz_l + sz_vf + sz_w + sz_b);
         sv.value_out = (uint16_t*)(d + sz_l + sz_vf + sz_w + sz_b + sz_p);
+        sv.value_pre_out = nullptr;
         sv.batch = batch;
         err = launch_softmax_value(sv, nullptr);
     }

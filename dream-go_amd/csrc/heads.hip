@@ -356,8 +356,9 @@ void softmax_value_kernel(SoftmaxValueLaunch a)
         part = __builtin_fmaf(half_bits_to_float(vf[k]), half_bits_to_float(a.value_w[k]), part);
     part = wave_sum(part);
     if (lane == 0) {
-        const float v = (float)round_to_half(part + half_bits_to_float(a.value_b[0]));
-        a.value_out[b] = float_to_half_bits(tanhf(v));
+        const _Float16 pre = round_to_half(part + half_bits_to_float(a.value_b[0]));
+        if (a.value_pre_out) a.value_pre_out[b] = __builtin_bit_cast(uint16_t, pre);
+        a.value_out[b] = float_to_half_bits(tanhf((float)pre));
     }
 }
 

@@ -153,6 +153,8 @@ struct SoftmaxValueLaunch {
     const uint16_t* value_b;        // [1] fp16
     uint16_t* policy_out;           // [batch][362] fp16
     uint16_t* value_out;            // [batch] fp16
+    uint16_t* value_pre_out;        // [batch] fp16 or nullptr: the value head's dense output BEFORE tanh (the fp16 tensor value_head.rs:80
+                                    // materialises; read back by the parity tests, dgnn_workspace_download_pre)
     int batch;
 };
 hipError_t launch_softmax_value(const SoftmaxValueLaunch& args, hipStream_t stream);

@@ -103,6 +103,29 @@ def make_sharp_tensors(num_blocks, num_channels, num_samples=8, seed=1, alpha=0.
     return out
 
 
+def make_centered_tensors(num_blocks, num_channels, num_samples=8, seed=1, alpha=0.5, conv_gain=1.5, policy_gain=6.0, value_gain=4.0):
+    """A discriminating random-init network AT THE REFERENCE'S DEFAULT GATE (alpha = 0.5, residual_block.rs:50):
+    make_sharp_tensors keeps the input alive by making nine tenths of every block the skip path -- which also attenuates the
+    convolution errors a parity test is after by ten per block.  What makes the He-init tower forget its input is the COMMON MODE:
+    activations behind a ReLU are all positive, a random filter answers their mean with a large input-independent offset, and
+    twenty blocks later that offset is all there is.  Here every residual filter is made zero-mean over its 9 * Cin inputs (the
+    common mode is not amplified) and scaled by conv_gain (about 1.5 keeps the variance of the differential part stationary through
+    `relu(0.5 conv + 0.5 t)`; measured with the oracle on the committed games: 20x256 with 1.5 / gains 6, 4: policy maxima
+    0.06 ... 0.55, values -0.84 ... 0.88; with 1.55: maxima up to 0.99, values at both ends of tanh; 9x128 with 1.6 / gains 8, 1.5:
+    0.10 ... 0.81, -0.99 ... 0.75).  Half of every block is convolution: its errors reach the outputs undamped."""
+    out = make_tensors(num_blocks, num_channels, num_samples, seed, alpha)
+    for name in list(out):
+        if "_residual/conv_" in name and name.endswith(":0") and "offset" not in name:
+            array, tag = out[name]
+            w = array.reshape(num_channels, -1)
+            out[name] = (((w - w.mean(axis=1, keepdims=True)) * conv_gain).reshape(-1), tag)
+    head = 2 + num_blocks
+    for name, gain in ((f"{head:02d}p_policy/linear_1:0", policy_gain), (f"{head:02d}v_value/linear_2:0", value_gain)):
+        array, tag = out[name]
+        out[name] = (array * gain, tag)
+    return out
+
+
 def to_json(tensors, model_name="synthetic"):
     doc = {name: _entry(array, tag) for name, (array, tag) in tensors.items()}
     doc["model_name:0"] = model_name     # string-valued entry, ignored by the loader (loader.rs:47)

@@ -248,6 +248,12 @@ int dgnn_layer_dense(int device, const uint16_t* x, int batch, int k_in, const u
 int dgnn_layer_heads(int device, const uint16_t* logits, const uint16_t* value_features, int batch, const uint16_t* value_w,
                      const uint16_t* value_b, uint16_t* policy_out, uint16_t* value_out);
 
+/* Test-only: the two fp16 tensors the reference materialises IN FRONT of the output activations, as the last forward on `ws` left
+ * them -- the temperature-scaled policy logits, input of cudnnSoftmaxForward (policy_head.rs:95-100; [batch][362]) and the value
+ * head's dense output, input of tanh (value_head.rs:80-81; [batch]).  The parity tests bound the error there, in fp16 ulps: a
+ * probability moves by p (1 - p) dlogit, so a tolerance in probability space says little about a peaked soft-max. */
+int dgnn_workspace_download_pre(dgnn_workspace* ws, uint16_t* logits_out, uint16_t* value_pre_out);
+
 /* ---- multi-GPU: weight image for an RCCL broadcast ------------------------------------------ */
 
 /* The packed, kernel-native weight image of `net` on `device` (uploaded on first use) and its size.

@@ -130,6 +130,20 @@ void dgo_f32_to_f16_array(const float* src, uint16_t* dst, size_t n)
     for (size_t i = 0; i < n; ++i) dst[i] = dgo_f32_to_f16(src[i]);
 }
 
+/* The fp16 value nearest to a DOUBLE (ties to even), returned as a float that converts exactly: the "exact arithmetic, same
+ * rounding points" variant of the network (dgo_forward_ex, accumulate_f64) rounds every materialised tensor ONCE -- going through
+ * float first would round twice. */
+static float dgo_round_f64_to_f16_value(double x)
+{
+    if (!(x == x) || x == 0.0 || isinf(x)) return (float)x;
+    int e;
+    (void)frexp(fabs(x), &e);                    /* |x| = m * 2^e, m in [0.5, 1): floor(log2 |x|) = e - 1 */
+    int exponent = e - 1;
+    if (exponent < -14) exponent = -14;          /* subnormal range: fixed spacing 2^-24 */
+    const double ulp = ldexp(1.0, exponent - 10);
+    return (float)(nearbyint(x / ulp) * ulp);    /* power-of-two scaling is exact; nearbyint rounds ties to even */
+}
+
 /* ---------------------------------------------------------------------------
  * cudnnScaleTensor on an fp16 tensor: b <- fp16(alpha * b).
  * src/libdg_cuda/cudnn/scale_tensor.rs:43-60; used by residual_block.rs:72-74
@@ -164,6 +178,82 @@ void dgo_transpose_in_out(const uint16_t* w_in_out, uint16_t* w_out_in, int num_
  * relu != 0 -> ReLU, else identity.
  * ------------------------------------------------------------------------- */
 #define DGO_CO_BLOCK 64
+
+/* The same layer with EXACT products and sums (double: a product of two fp16 values is exact, a sum of a few thousand of them
+ * loses nothing that matters) and the same single rounding to fp16 per output: what both fp32 implementations -- this file's and
+ * the HIP kernels' -- approximate.  Used only as the yardstick of tests/test_round4_gpu.py ("is the HIP path as near to the exact
+ * result as the fp32 oracle is?"). */
+static int dgo_conv3x3_f64(const uint16_t* x, int batch, int size, int cin,
+                           const uint16_t* w, const uint16_t* bias, int cout,
+                           float alpha1, float alpha2, const uint16_t* z, int relu,
+                           uint16_t* y)
+{
+    const size_t num_pos = (size_t)batch * size * size;
+    const int cout_pad = (cout + DGO_CO_BLOCK - 1) / DGO_CO_BLOCK * DGO_CO_BLOCK;
+    float* xf = (float*)malloc(sizeof(float) * (num_pos * cin + 1));
+    float* wf = (float*)calloc((size_t)9 * cin * cout_pad, sizeof(float));
+    if (!xf || !wf) { free(xf); free(wf); return DGO_OUT_OF_MEMORY; }
+    dgo_f16_to_f32_array(x, xf, num_pos * cin);
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < cout; ++co)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < cin; ++ci)
+                wf[((size_t)tap * cin + ci) * cout_pad + co] = dgo_f16_to_f32(w[((size_t)co * 9 + tap) * cin + ci]);
+    const long num_blocks = (cout + DGO_CO_BLOCK - 1) / DGO_CO_BLOCK;
+    const long num_units = (long)batch * num_blocks;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long unit = 0; unit < num_units; ++unit) {
+        const int b = (int)(unit / num_blocks);
+        const int co0 = (int)(unit % num_blocks) * DGO_CO_BLOCK;
+        const int co_end = (co0 + DGO_CO_BLOCK < cout) ? DGO_CO_BLOCK : cout - co0;
+        for (int yy = 0; yy < size; ++yy) {
+            for (int xx = 0; xx < size; ++xx) {
+                const size_t out_pos = ((size_t)b * size + yy) * size + xx;
+                double acc[DGO_CO_BLOCK];
+                for (int j = 0; j < DGO_CO_BLOCK; ++j) acc[j] = 0.0;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int sy = yy + tap / 3 - 1;
+                    const int sx = xx + tap % 3 - 1;
+                    if (sy < 0 || sy >= size || sx < 0 || sx >= size) continue;
+                    const float* xin = xf + (((size_t)b * size + sy) * size + sx) * cin;
+                    const float* wt = wf + (size_t)tap * cin * cout_pad + co0;
+                    for (int ci = 0; ci < cin; ++ci) {
+                        const double v = (double)xin[ci];
+                        const float* wr = wt + (size_t)ci * cout_pad;
+                        for (int j = 0; j < DGO_CO_BLOCK; ++j) acc[j] += v * (double)wr[j];
+                    }
+                }
+                for (int j = 0; j < co_end; ++j) {
+                    const int co = co0 + j;
+                    double t = (double)alpha1 * acc[j] + (double)dgo_f16_to_f32(bias[co]);
+                    if (alpha2 != 0.0f) t += (double)alpha2 * (double)dgo_f16_to_f32(z[out_pos * cout + co]);
+                    if (relu && !(t > 0.0)) t = 0.0;
+                    y[out_pos * cout + co] = dgo_f32_to_f16(dgo_round_f64_to_f16_value(t));
+                }
+            }
+        }
+    }
+    free(xf); free(wf);
+    return DGO_OK;
+}
+
+static int dgo_dense_f64(const uint16_t* x, int batch, int num_in, const uint16_t* w_out_in, const uint16_t* bias, int num_out,
+                         float alpha1, int relu, uint16_t* y)
+{
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < batch; ++b) {
+        const uint16_t* xb = x + (size_t)b * num_in;
+        for (int o = 0; o < num_out; ++o) {
+            const uint16_t* wr = w_out_in + (size_t)o * num_in;
+            double acc = 0.0;
+            for (int i = 0; i < num_in; ++i) acc += (double)dgo_f16_to_f32(xb[i]) * (double)dgo_f16_to_f32(wr[i]);
+            double t = (double)alpha1 * acc + (double)dgo_f16_to_f32(bias[o]);
+            if (relu && !(t > 0.0)) t = 0.0;
+            y[(size_t)b * num_out + o] = dgo_f32_to_f16(dgo_round_f64_to_f16_value(t));
+        }
+    }
+    return DGO_OK;
+}
 
 int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
                 const uint16_t* w, const uint16_t* bias, int cout,
@@ -336,10 +426,31 @@ typedef struct {
 
 /* graph.rs:123-158.  features: [batch][361][32] fp16 (HWC, features.rs:52-60);
  * value_out: [batch] fp16; policy_out: [batch][362] fp16. */
+/* dgo_forward_ex: the same pass, optionally handing out the two fp16 tensors in FRONT of the output activations -- the
+ * temperature-scaled logits (input of the soft-max, policy_head.rs:95-100; [batch][362]) and the value head's dense output (input of
+ * tanh, value_head.rs:80-81; [batch]) -- and optionally with exact (double) products and sums inside every layer, same fp16
+ * rounding points (accumulate_f64 != 0: the yardstick both fp32 implementations are measured against). */
+int dgo_forward_ex(const dgo_network* net, const uint16_t* features, int batch,
+                   uint16_t* value_out, uint16_t* policy_out, uint16_t* logits_out, uint16_t* value_pre_out, int accumulate_f64);
+
 int dgo_forward(const dgo_network* net, const uint16_t* features, int batch,
                 uint16_t* value_out, uint16_t* policy_out)
 {
+    return dgo_forward_ex(net, features, batch, value_out, policy_out, NULL, NULL, 0);
+}
+
+static int conv_any(int f64, const uint16_t* x, int batch, int size, int cin, const uint16_t* w, const uint16_t* bias, int cout,
+                    float alpha1, float alpha2, const uint16_t* z, int relu, uint16_t* y)
+{
+    return f64 ? dgo_conv3x3_f64(x, batch, size, cin, w, bias, cout, alpha1, alpha2, z, relu, y)
+               : dgo_conv3x3(x, batch, size, cin, w, bias, cout, alpha1, alpha2, z, relu, y);
+}
+
+int dgo_forward_ex(const dgo_network* net, const uint16_t* features, int batch,
+                   uint16_t* value_out, uint16_t* policy_out, uint16_t* logits_out, uint16_t* value_pre_out, int accumulate_f64)
+{
     if (!net || !features || !value_out || !policy_out || batch <= 0) return DGO_BAD_ARGUMENT;
+    const int f64 = accumulate_f64 != 0;
 
     const int size = net->board_size;
     const int num_pos = size * size;
@@ -363,7 +474,7 @@ int dgo_forward(const dgo_network* net, const uint16_t* features, int batch,
     }
 
     /* up_block.rs:56: relu(conv(features, W_up) + b_up) */
-    status = dgo_conv3x3(features, batch, size, net->num_features, net->up_w, net->up_b, c,
+    status = conv_any(f64, features, batch, size, net->num_features, net->up_w, net->up_b, c,
                          1.0f, 0.0f, NULL, 1, t0);
     if (status) goto done;
 
@@ -371,14 +482,14 @@ int dgo_forward(const dgo_network* net, const uint16_t* features, int batch,
     for (int i = 0; i < net->num_blocks; ++i) {
         const float alpha = net->res_alpha[i];
 
-        status = dgo_conv3x3(t0, batch, size, c, net->res_w1[i], net->res_b1[i], c,
+        status = conv_any(f64, t0, batch, size, c, net->res_w1[i], net->res_b1[i], c,
                              1.0f, 0.0f, NULL, 1, t1);
         if (status) goto done;
 
         memcpy(bias_tmp, net->res_b2[i], sizeof(uint16_t) * (size_t)c);
         dgo_scale(bias_tmp, (size_t)c, alpha); /* residual_block.rs:72-74 */
 
-        status = dgo_conv3x3(t1, batch, size, c, net->res_w2[i], bias_tmp, c,
+        status = conv_any(f64, t1, batch, size, c, net->res_w2[i], bias_tmp, c,
                              alpha, 1.0f - alpha, t0, 1, t2);
         if (status) goto done;
 
@@ -386,21 +497,23 @@ int dgo_forward(const dgo_network* net, const uint16_t* features, int batch,
     }
 
     /* value_head.rs:66-84 */
-    status = dgo_conv3x3(t0, batch, size, c, net->value_conv_w, net->value_conv_b, 2,
+    status = conv_any(f64, t0, batch, size, c, net->value_conv_w, net->value_conv_b, 2,
                          1.0f, 0.0f, NULL, 1, value_1);
     if (status) goto done;
     /* [722][1] -> [1][722] is the identity permutation */
-    status = dgo_dense(value_1, batch, num_pos * 2, net->value_linear_w, net->value_linear_b, 1,
-                       1.0f, 0, value_out);
+    status = f64 ? dgo_dense_f64(value_1, batch, num_pos * 2, net->value_linear_w, net->value_linear_b, 1, 1.0f, 0, value_out)
+                 : dgo_dense(value_1, batch, num_pos * 2, net->value_linear_w, net->value_linear_b, 1, 1.0f, 0, value_out);
     if (status) goto done;
-    dgo_tanh(value_out, (size_t)batch);
+    if (value_pre_out) memcpy(value_pre_out, value_out, sizeof(uint16_t) * (size_t)batch);
+    if (f64) { for (int b = 0; b < batch; ++b) value_out[b] = dgo_f32_to_f16(dgo_round_f64_to_f16_value(tanh((double)dgo_f16_to_f32(value_out[b])))); }
+    else dgo_tanh(value_out, (size_t)batch);
 
     /* policy_head.rs:78-103 */
     {
         const float tau = 1.0f / net->softmax_temperature; /* policy_head.rs:46 */
         const int num_out = num_pos + 1;
 
-        status = dgo_conv3x3(t0, batch, size, c, net->policy_conv_w, net->policy_conv_b, s,
+        status = conv_any(f64, t0, batch, size, c, net->policy_conv_w, net->policy_conv_b, s,
                              1.0f, 0.0f, NULL, 1, policy_1);
         if (status) goto done;
 
@@ -408,9 +521,22 @@ int dgo_forward(const dgo_network* net, const uint16_t* features, int batch,
         memcpy(bias_tmp, net->policy_linear_b, sizeof(uint16_t) * (size_t)num_out);
         dgo_scale(bias_tmp, (size_t)num_out, tau); /* policy_head.rs:87-89 */
 
-        status = dgo_dense(policy_1, batch, num_pos * s, policy_wt, bias_tmp, num_out, tau, 0, policy_2);
+        status = f64 ? dgo_dense_f64(policy_1, batch, num_pos * s, policy_wt, bias_tmp, num_out, tau, 0, policy_2)
+                     : dgo_dense(policy_1, batch, num_pos * s, policy_wt, bias_tmp, num_out, tau, 0, policy_2);
         if (status) goto done;
-        dgo_softmax(policy_2, batch, num_out, policy_out);
+        if (logits_out) memcpy(logits_out, policy_2, sizeof(uint16_t) * (size_t)batch * num_out);
+        if (f64) {
+            for (int b = 0; b < batch; ++b) {
+                const uint16_t* xb = policy_2 + (size_t)b * num_out;
+                double max_value = -INFINITY, sum = 0.0;
+                for (int i = 0; i < num_out; ++i) { const double v = (double)dgo_f16_to_f32(xb[i]); if (v > max_value) max_value = v; }
+                for (int i = 0; i < num_out; ++i) sum += exp((double)dgo_f16_to_f32(xb[i]) - max_value);
+                for (int i = 0; i < num_out; ++i)
+                    policy_out[(size_t)b * num_out + i] = dgo_f32_to_f16(dgo_round_f64_to_f16_value(exp((double)dgo_f16_to_f32(xb[i]) - max_value) / sum));
+            }
+        } else {
+            dgo_softmax(policy_2, batch, num_out, policy_out);
+        }
     }
 
 done:

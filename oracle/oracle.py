@@ -196,6 +196,8 @@ def lib():
         L.dgo_transpose_in_out.restype = None
         L.dgo_forward.argtypes = [ctypes.POINTER(_CNetwork), u16p, ctypes.c_int, u16p, u16p]
         L.dgo_forward.restype = ctypes.c_int
+        L.dgo_forward_ex.argtypes = [ctypes.POINTER(_CNetwork), u16p, ctypes.c_int, u16p, u16p, u16p, u16p, ctypes.c_int]
+        L.dgo_forward_ex.restype = ctypes.c_int
         L.dgo_f32_to_f16.argtypes = [ctypes.c_float]
         L.dgo_f32_to_f16.restype = ctypes.c_uint16
         L.dgo_f16_to_f32.argtypes = [ctypes.c_uint16]
@@ -317,6 +319,21 @@ class OracleNetwork:
         status = lib().dgo_forward(ctypes.byref(c), fp, batch, value.ctypes.data_as(u16p), policy.ctypes.data_as(u16p))
         assert status == 0, status
         return value, policy
+
+    def forward_ex(self, features, batch, accumulate_f64=False):
+        """-> (value[batch], policy[batch*362], logits[batch*362], value_pre[batch]) fp16 bits: the outputs plus the two fp16 tensors
+        in front of the soft-max / tanh (policy_head.rs:95-100, value_head.rs:80-81).  accumulate_f64: exact products and sums inside
+        every layer, same fp16 rounding points -- the yardstick, not the oracle."""
+        feats, fp = _u16(features)
+        assert feats.size == batch * NUM_POINTS * NUM_FEATURES
+        value, value_pre = np.empty(batch, dtype=np.uint16), np.empty(batch, dtype=np.uint16)
+        policy, logits = np.empty(batch * NUM_MOVES, dtype=np.uint16), np.empty(batch * NUM_MOVES, dtype=np.uint16)
+        c = self._c_struct()
+        u16p = ctypes.POINTER(ctypes.c_uint16)
+        status = lib().dgo_forward_ex(ctypes.byref(c), fp, batch, value.ctypes.data_as(u16p), policy.ctypes.data_as(u16p),
+                                      logits.ctypes.data_as(u16p), value_pre.ctypes.data_as(u16p), 1 if accumulate_f64 else 0)
+        assert status == 0, status
+        return value, policy, logits, value_pre
 
 
 # ------------------------------------------------------------------ independent numpy statement (cross-check only)

@@ -195,7 +195,7 @@ def test_broadcast_without_rccl_is_refused_up_front(api, synth, monkeypatch):
 def test_a_launch_that_is_not_fully_resident_gives_up_within_milliseconds(api, synth, monkeypatch, capfd):
     """DGNN_SPLIT_INJECT_GIVEUP=2 launches the split tower WITHOUT its last eight workgroups -- what a launch whose
     workgroups are not co-resident looks like to the others.  Their consumers really poll, really time out (kGiveUpTicks = 50 ms of the
-    100 MHz clock; round 3: 2^31 ticks = 21 s), the pass is repeated per layer: bit-equal to the per-layer path and < 0.2 s end to end."""
+    100 MHz s_memrealtime clock; round 3: 2^31 shader cycles, about a second), the pass is repeated per layer: bit-equal to the per-layer path and < 0.2 s end to end."""
     blocks, channels, batch = 2, 256, 16
     text = synth.to_json(synth.make_tensors(blocks, channels, seed=650))
     features = synth.make_features(batch, seed=651)
