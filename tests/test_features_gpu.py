@@ -49,3 +49,36 @@ def test_forward_boards_gives_the_bits_of_forward_on_the_same_planes(api, synth,
     assert np.array_equal(a[0].view(np.uint16), b[0].view(np.uint16)) and np.array_equal(a[1].view(np.uint16), b[1].view(np.uint16))
     assert np.array_equal(a[0].view(np.uint16)[:half], c[0].view(np.uint16))
     assert np.array_equal(a[1].view(np.uint16)[: half * 362], c[1].view(np.uint16))
+
+
+def test_device_planes_equal_the_committed_oracle_fixture(api):
+    """The device kernel against an oracle that is NOT product code: tests/golden/planes_real_games.npz holds the
+    planes oracle/features.py computes -- flood fills, simulated moves, whole-position super-ko; made by tests/golden/make_planes.py
+    -- for every 5th position of the three reference games x both colours x eight symmetries.  board_records_kernel builds the same
+    words from 896-byte records."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from oracle import features as F
+    fx = np.load(os.path.join(GOLDEN, "planes_real_games.npz"))
+    wanted = {}
+    for i in range(len(fx["game"])):
+        wanted.setdefault((int(fx["game"][i]), int(fx["stones"][i])), []).append(i)
+    records, order = [], []
+    for g, game in enumerate(json.load(open(os.path.join(GOLDEN, "real_games.json")))["games"]):
+        board = api.Board(7.5)
+        for n, (_, c, p) in enumerate(F.replay(game["moves"])):          # (the oracle's replay only supplies the move list here)
+            board.place(c - 1, p % 19, p // 19)
+            for i in wanted.get((g, n + 1), ()):
+                records.append(board.record(int(fx["color"][i]) - 1, int(fx["symmetry"][i])))
+                order.append(i)
+    n = len(order)
+    assert n == len(fx["game"]) == 2064
+    got = api.board_records_to_packed(np.concatenate(records), n, device=0).reshape(n, api.PACKED_WORDS)
+    masks, komi, color = fx["masks"][order], fx["komi"][order].astype(np.uint32), fx["color"][order]
+    bad = np.argwhere(got[:, :361] != masks)
+    assert bad.size == 0, (len(bad), bad[0], hex(int(got[bad[0][0], bad[0][1]])), hex(int(masks[bad[0][0], bad[0][1]])))
+    assert np.array_equal(got[:, 361], np.where(color == 1, komi, komi << 16))          # the constant of the colour plane, as fp16 bits
+    planes = [int(((masks >> c) & 1).sum()) for c in range(32)]
+    print(f"{n} boards: device planes equal the oracle fixture; set bits per plane {planes}")
+    assert all(count > 0 for count in planes)
