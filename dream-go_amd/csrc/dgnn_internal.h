@@ -167,6 +167,15 @@ void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, f
 void add_valid_candidates(float* dst, const uint16_t* src_f16, const int* indices, int transform);
 void normalize_policy(float* policy, float sum_to);
 
+// Host SIMD: the AVX2 / F16C forms of the hot host loops exist on x86-64 only and are used when the CPU has them; everywhere else --
+// and with DGNN_HOST_SIMD=0 in the environment (read once; the tests compare the two) -- the scalar forms run.  Same bits either way.
+#if defined(__x86_64__)
+#define DGNN_X86_SIMD 1
+#else
+#define DGNN_X86_SIMD 0
+#endif
+bool host_simd(bool need_f16c = false);
+
 // thread-local HIP error detail
 void set_last_hip_error(int code);
 

@@ -1601,9 +1601,14 @@ int dgnn_network_weight_image_reserve(dgnn_network* net, int device, void** d_im
     if (!net) return DGNN_BAD_ARGUMENT;
     Network* n = N(net);
     std::lock_guard<std::mutex> lock(n->mutex);
+    // A receiver is about to be OVERWRITTEN: not while a workspace is checked out (a forward may be reading the range), and from
+    // now until dgnn_network_weight_image_commit the range counts as empty -- also on a device that already held a valid image: a
+    // failed or partial transfer then ends in a fresh upload from the host instead of kernels on a torn image
+    if (n->checked_out > 0) return DGNN_BUSY;
     DeviceState* dev = nullptr;
     const int status = get_device_state(n, device, &dev, /*upload=*/false);
     if (status != DGNN_OK) return status;
+    dev->image_valid = false;
     if (d_image) *d_image = dev->d_image;
     if (num_bytes) *num_bytes = n->image.size();
     return DGNN_OK;

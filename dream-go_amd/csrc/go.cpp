@@ -18,7 +18,9 @@
 // words, with the same observable counts; Fast::consistent() is the from-scratch flood fill they are tested against.
 // Zobrist numbers are this build's own (splitmix64 of a fixed seed): only equality of hashes is observable; the positions
 // of the reference's three real-game tests reproduce its expected hashes under its own table (tests/golden/).
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -790,6 +792,7 @@ void stone_sets_scalar(const Fast& b, StoneSets* s)
         s->visited.w[i] = visited;
     }
 }
+#if DGNN_X86_SIMD
 __attribute__((target("avx2")))
 void stone_sets_avx2(const Fast& b, StoneSets* s)
 {
@@ -808,11 +811,15 @@ void stone_sets_avx2(const Fast& b, StoneSets* s)
         s->visited.w[i] = ((uint64_t)visited[2 * i] | (uint64_t)visited[2 * i + 1] << 32) & kMasks.board.w[i];
     }
 }
-const bool kGoAvx2 = __builtin_cpu_supports("avx2");
+#endif
+const bool kGoAvx2 = host_simd();
 inline StoneSets stone_sets(const Fast& b)
 {
     StoneSets s;
-    if (kGoAvx2) stone_sets_avx2(b, &s); else stone_sets_scalar(b, &s);
+#if DGNN_X86_SIMD
+    if (kGoAvx2) stone_sets_avx2(b, &s); else
+#endif
+    stone_sets_scalar(b, &s);
     s.empty = andnot(kMasks.board, s.stones[0] | s.stones[1]);
     return s;
 }
@@ -824,6 +831,7 @@ BB weak_heads_scalar(const Fast& b)
     for (int p = 0; p < kPoints; ++p) if (b.stone[p] != kEmpty && b.head[p] == p && b.libs[p] < 2) r.set(p);
     return r;
 }
+#if DGNN_X86_SIMD
 __attribute__((target("avx2")))
 BB weak_heads_avx2(const Fast& b)
 {
@@ -846,7 +854,14 @@ BB weak_heads_avx2(const Fast& b)
     }
     return r;
 }
-inline BB weak_heads(const Fast& b) { return kGoAvx2 ? weak_heads_avx2(b) : weak_heads_scalar(b); }
+#endif
+inline BB weak_heads(const Fast& b)
+{
+#if DGNN_X86_SIMD
+    if (kGoAvx2) return weak_heads_avx2(b);
+#endif
+    return weak_heads_scalar(b);
+}
 inline BB block_stones(const Fast& b, int q) { BB r; std::memset(&r, 0, sizeof(r)); int s = q; do { r.set(s); s = b.next[s]; } while (s != q); return r; }
 
 // Benson's unconditional life (utils/benson.rs:62-190), same result as benson_flood above, on bit boards.
@@ -1374,7 +1389,16 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
             };
             // Played::from_mcts (self_play.rs:120-137): C[] = tree::to_pretty, TR[] = the best move of the tree's prior, TV[] = the
             // tree's size, P[] = its visit distribution.
-            auto record_mcts = [&](char* out, size_t capacity, int point, float value, const dgnn_tree_node* tree) {
+            // one move record as a string, sized by what dgnn_sgf_played asks for (a fixed buffer that is too small used to
+            // drop the C[] text -- or the whole move -- silently; the reference always writes both)
+            auto played_text = [&](int color, int point, int rollouts, const float* softmax, int has_value, float value, int prior_index,
+                                   const char* explain) {
+                std::string text(dgnn_sgf_played(nullptr, 0, color, point, rollouts, softmax, has_value, value, prior_index, explain), '\0');
+                dgnn_sgf_played(&text[0], text.size(), color, point, rollouts, softmax, has_value, value, prior_index, explain);
+                text.resize(text.size() - 1);       // (the NUL)
+                return text;
+            };
+            auto record_mcts = [&](std::string& out, int point, float value, const dgnn_tree_node* tree) {
                 float softmax[DGNN_NUM_MOVES], tree_prior[DGNN_NUM_MOVES + 6];
                 dgnn_tree_node_softmax(tree, softmax);
                 dgnn_tree_node_prior(tree, tree_prior);
@@ -1383,27 +1407,26 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                 if (prior_index < 0) prior_index = kPass;                      // Node::prior, tree.rs:1285-1289
                 int total = 0;
                 dgnn_tree_node_info(tree, nullptr, &total, nullptr, nullptr, nullptr);
-                char explain[2048];                                            // tree::to_pretty: eleven lines at most
-                if (dgnn_tree_node_to_pretty(tree, explain, sizeof(explain)) > sizeof(explain)) explain[0] = '\0';
-                dgnn_sgf_played(out, capacity, me, point, total, softmax, 1, value, prior_index, explain);
+                std::string explain(dgnn_tree_node_to_pretty(tree, nullptr, 0), '\0');        // tree::to_pretty: eleven lines, each with its
+                dgnn_tree_node_to_pretty(tree, &explain[0], explain.size());                   // principal variation -- as long as the tree is deep
+                out = played_text(me, point, total, softmax, 1, value, prior_index, explain.c_str());
             };
             // Player::ex_it (self_play.rs:277-305) behind is_good_candidate (:315-319): one move in twenty gets a fresh, full-size
             // search whose visit distribution and value replace the record's; the move that was chosen stays
-            auto expert_iteration = [&](char* out, size_t capacity, int point) -> bool {
+            auto expert_iteration = [&](std::string& out, int point) -> bool {
                 if (num_ex_it_rollouts <= 0 || rng.uniform() >= 0.05) return false;
                 float value;
                 int ignored;
                 dgnn_tree_node* tree = search(num_ex_it_rollouts, nullptr, &value, &ignored);
                 if (!tree) return false;
-                if (std::isfinite(value)) record_mcts(out, capacity, point, value, tree);
+                if (std::isfinite(value)) record_mcts(out, point, value, tree);
                 dgnn_tree_node_free(tree);
                 ex_it_searches.fetch_add(1);
                 return std::isfinite(value);
             };
 
             int played = kPass;
-            char move[4608];
-            move[0] = '\0';
+            std::string move;
             if (limit > 1) {                                                   // Player::predict, self_play.rs:340-368
                 dgnn_tree_node* start = roots[me];
                 roots[me] = nullptr;
@@ -1413,9 +1436,9 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                 if (!root || !std::isfinite(best_value) || played < 0 || (played != kPass && !board.is_valid(me, played))) {
                     played = kPass;                                            // nothing to play: pass (self_play.rs:347-350)
                     dgnn_tree_node_free(root);
-                    dgnn_sgf_played(move, sizeof(move), me, kPass, 0, nullptr, 0, 0.0f, -1, "");
+                    move = played_text(me, kPass, 0, nullptr, 0, 0.0f, -1, "");
                 } else {
-                    if (!expert_iteration(move, sizeof(move), played)) record_mcts(move, sizeof(move), played, best_value, root);
+                    if (!expert_iteration(move, played)) record_mcts(move, played, best_value, root);
                     winrate[me] -= 0.2f * (winrate[me] - best_value);          // MovingAverage::update, self_play.rs:56-58
                     roots[me] = dgnn_tree_node_forward(root, played);
                 }
@@ -1429,7 +1452,7 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                 for (int i = 0; i < DGNN_NUM_MOVES; ++i) scaled[i] = (double)prior[i];
                 if (dgnn_choose_f64(scaled, DGNN_NUM_MOVES, 0.5, 1.0 / 0.8, rng.uniform(), &played, nullptr) != 1) played = kPass;
                 if (played < 0 || (played != kPass && !board.is_valid(me, played))) played = kPass;
-                if (!expert_iteration(move, sizeof(move), played)) dgnn_sgf_played(move, sizeof(move), me, played, 1, prior, 1, value, -1, "");
+                if (!expert_iteration(move, played)) move = played_text(me, played, 1, prior, 1, value, -1, "");
                 if (status.load() != DGNN_OK) break;
                 winrate[me] -= 0.2f * (winrate[me] - value);
                 if (roots[me]) roots[me] = dgnn_tree_node_forward(roots[me], played);

@@ -18,7 +18,9 @@
 // rule-free synthetic game with a synthetic self-play loop for throughput measurements of the host + device pipeline
 // without Go rules.  The synthetic game is NOT Go: every empty point is a legal move, nothing is ever captured, features
 // are pseudo-random bits of the position hash.  The real game is go.cpp.
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -84,18 +86,22 @@ void create_initial_policy(const dgnn_game_ops* ops, void* board, int to_move, f
 
 namespace {
 
+#if DGNN_X86_SIMD
 __attribute__((target("avx2,f16c")))
 void halfs_to_floats_f16c(const uint16_t* src, float* dst, int n)            // n a multiple of 8
 {
     for (int i = 0; i < n; i += 8) _mm256_storeu_ps(dst + i, _mm256_cvtph_ps(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src + i))));
 }
-const bool kHaveF16c = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("f16c");
+#endif
+const bool kHaveF16c = host_simd(true);
 
 // exact conversions either way: the hardware instruction and half_to_float give the same bits
 void halfs_to_floats(const uint16_t* src, float* dst, int n)
 {
     const int vector = kHaveF16c ? n & ~7 : 0;
+#if DGNN_X86_SIMD
     if (vector) halfs_to_floats_f16c(src, dst, vector);
+#endif
     for (int i = vector; i < n; ++i) dst[i] = half_to_float(src[i]);
 }
 
@@ -108,6 +114,7 @@ float sum_finite_lanes_scalar(const float* v, int n)
         for (int l = 0; l < 8; ++l) lane[l] += std::isfinite(v[i + l]) ? v[i + l] : 0.0f;
     return ((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
 }
+#if DGNN_X86_SIMD
 __attribute__((target("avx2")))
 float sum_finite_lanes_avx2(const float* v, int n)
 {
@@ -123,11 +130,31 @@ float sum_finite_lanes_avx2(const float* v, int n)
     _mm256_storeu_ps(lane, acc);
     return ((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
 }
-const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+#endif
+const bool kHaveAvx2 = host_simd();
 
 }  // namespace
 
-float sum_finite(const float* v, int n) { return kHaveAvx2 ? sum_finite_lanes_avx2(v, n) : sum_finite_lanes_scalar(v, n); }
+// dgnn_internal.h: the one switch of the AVX2 / F16C host paths (DGNN_HOST_SIMD=0 forces the scalar forms)
+bool host_simd(bool need_f16c)
+{
+#if DGNN_X86_SIMD
+    static const bool off = [] { const char* e = std::getenv("DGNN_HOST_SIMD"); return e && std::atoi(e) == 0; }();
+    if (off) return false;
+    return __builtin_cpu_supports("avx2") && (!need_f16c || __builtin_cpu_supports("f16c"));
+#else
+    (void)need_f16c;
+    return false;
+#endif
+}
+
+float sum_finite(const float* v, int n)
+{
+#if DGNN_X86_SIMD
+    if (kHaveAvx2) return sum_finite_lanes_avx2(v, n);
+#endif
+    return sum_finite_lanes_scalar(v, n);
+}
 
 // policy_helper.rs:87-103: de-transform the network's policy to the identity orientation and add it
 void add_valid_candidates(float* dst, const uint16_t* src_f16, const int* indices, int transform)

@@ -14,7 +14,9 @@
 // the reference: atomic counters, one spin lock per node around the value update, the "expanding" flag against double
 // expansion; several threads may probe / insert into one tree.
 #include <algorithm>
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 #include <atomic>
 #include <cmath>
@@ -68,6 +70,7 @@ int argmax_f32_scalar(const float* v, int n)
 
 // The same answer with 256-bit vectors (the reference's is AVX2 as well): the running maximum ends as the global maximum
 // M, and the index ends in the last group that holds an element equal to M, at its first such element.
+#if DGNN_X86_SIMD
 __attribute__((target("avx2")))
 int argmax_f32_avx2(const float* v, int n)
 {
@@ -87,9 +90,16 @@ int argmax_f32_avx2(const float* v, int n)
     }
     return argmax_f32_scalar(v, n);
 }
+#endif
 
-const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
-int argmax_f32(const float* v, int n) { return kHaveAvx2 ? argmax_f32_avx2(v, n) : argmax_f32_scalar(v, n); }
+const bool kHaveAvx2 = host_simd();
+int argmax_f32(const float* v, int n)
+{
+#if DGNN_X86_SIMD
+    if (kHaveAvx2) return argmax_f32_avx2(v, n);
+#endif
+    return argmax_f32_scalar(v, n);
+}
 
 struct SpinLock {
     std::atomic_flag flag = ATOMIC_FLAG_INIT;
@@ -159,6 +169,7 @@ void puct_scalar(const TreeNode* node, bool apply_fpu, float fpu_reduce, float u
 // The reference's own formulation (tree.rs:63-115: cmpeq / div / mul / add on 8 lanes, no fused multiply-add), so both
 // variants give the same bits.  The counters are read as plain ints: aligned 32-bit loads, racing with other search
 // threads exactly as the reference's do.
+#if DGNN_X86_SIMD
 __attribute__((target("avx2")))
 void puct_avx2(const TreeNode* node, bool apply_fpu, float fpu_reduce, float uct_exp_sqrt_n, float* value)
 {
@@ -177,6 +188,7 @@ void puct_avx2(const TreeNode* node, bool apply_fpu, float fpu_reduce, float uct
         _mm256_storeu_ps(value + i, _mm256_add_ps(v, _mm256_mul_ps(_mm256_loadu_ps(node->prior + i), bonus)));
     }
 }
+#endif
 
 // tree.rs:1329-1384.  Returns 1 found (index, value filled), 0 no result, -1 conflict.
 int select(TreeNode* node, bool apply_fpu, int* index_out, float* value_out)
@@ -186,8 +198,11 @@ int select(TreeNode* node, bool apply_fpu, int* index_out, float* value_out)
     const float fpu_reduce = apply_fpu ? intp_value(kFpuReduce, 5, n) : 0.0f;  // tree.rs:1342-1348
     const float sqrt_n = std::sqrt((float)(1 + n));                          // tree.rs:86-115
     const float uct_exp_sqrt_n = intp_value(kUctExp, 5, n) * sqrt_n;
+#if DGNN_X86_SIMD
     if (kHaveAvx2) puct_avx2(node, apply_fpu, fpu_reduce, uct_exp_sqrt_n, value);
-    else puct_scalar(node, apply_fpu, fpu_reduce, uct_exp_sqrt_n, value);
+    else
+#endif
+    puct_scalar(node, apply_fpu, fpu_reduce, uct_exp_sqrt_n, value);
     for (int i = kMoves; i < kPadded; ++i) value[i] = -std::numeric_limits<float>::infinity();
 
     const int max_i = argmax_f32(value, kPadded);
