@@ -95,6 +95,7 @@ struct Network {
     std::vector<uint8_t> image;    // packed host weight image
     bool frozen = false;           // set once the first workspace exists
     int checked_out = 0;           // workspaces handed out and not yet released (under `mutex`): weights are not replaced meanwhile
+    bool destroy_pending = false;  // dgnn_network_destroy came while workspaces were checked out: the last release deletes the network
 
     std::mutex mutex;
     std::map<int, std::unique_ptr<DeviceState>> devices;

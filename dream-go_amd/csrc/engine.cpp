@@ -925,7 +925,20 @@ int dgnn_network_load_default(const char* exe_path, dgnn_network** out)
     return DGNN_MISSING_WEIGHTS;
 }
 
-void dgnn_network_destroy(dgnn_network* net) { delete N(net); }
+// A workspace holds a pointer to its network (its weights, its pool): destroying the network under a checked-out workspace would
+// leave dgnn_workspace_release locking a freed mutex.  The reference cannot express that (WorkspaceGuard borrows the Network,
+// network.rs:54-79); a C caller -- or a garbage collector that finalises two objects in an order of its own choosing -- can.  So
+// the destruction is deferred to the release of the last checked-out workspace.
+void dgnn_network_destroy(dgnn_network* net)
+{
+    if (!net) return;
+    Network* n = N(net);
+    {
+        std::lock_guard<std::mutex> lock(n->mutex);
+        if (n->checked_out > 0) { n->destroy_pending = true; return; }
+    }
+    delete n;
+}
 
 int dgnn_network_info(const dgnn_network* net, int* num_blocks, int* num_channels, int* num_samples)
 {
@@ -983,9 +996,14 @@ void dgnn_workspace_release(dgnn_workspace* handle)
         (void)hipStreamSynchronize(ws->stream);
         ws->pending = false;
     }
-    std::lock_guard<std::mutex> lock(ws->net->mutex);
-    ws->dev->idle[ws->batch].push_back(ws);
-    --ws->net->checked_out;
+    Network* net = ws->net;
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lock(net->mutex);
+        ws->dev->idle[ws->batch].push_back(ws);
+        last = --net->checked_out == 0 && net->destroy_pending;
+    }
+    if (last) delete net;      // dgnn_network_destroy was called while this workspace was out
 }
 
 int dgnn_network_synchronize(dgnn_network* net)

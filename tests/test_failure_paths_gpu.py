@@ -225,3 +225,102 @@ def test_a_launch_that_is_not_fully_resident_gives_up_within_milliseconds(api, s
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     ws.release()
     net.destroy()
+
+
+TWO_RANKS_ONE_GPU = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+import __graft_entry__ as graft
+graft.package()
+from dream_go_amd import api, synth
+rank, ident_path = int(sys.argv[1]), sys.argv[2]
+net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 64, seed=700 + rank)))      # different weights per rank
+features = synth.make_features(4, seed=701)
+with net.get_workspace(4) as ws:
+    before = api.forward(ws, features).unwrap()
+before = (before[0].view(np.uint16).copy(), before[1].view(np.uint16).copy())
+checksum = (net.weight_checksum(), net.weight_checksum_device(0))
+if rank == 0:
+    ident = api.Comm.unique_id()
+    with open(ident_path + ".tmp", "wb") as f:
+        f.write(ident)
+    os.replace(ident_path + ".tmp", ident_path)
+else:
+    while not os.path.exists(ident_path):
+        time.sleep(0.05)
+    ident = open(ident_path, "rb").read()
+t0 = time.perf_counter()
+result = {"rank": rank}
+try:
+    comm = api.Comm.create(0, 2, rank, ident)                # BOTH ranks name GPU 0: RCCL refuses a duplicate device
+    result["create"] = "ok"
+    try:
+        net.broadcast_weights(comm, root=0)
+        result["broadcast"] = "ok"
+    except api.Error as e:
+        result["broadcast"] = e.status
+    comm.destroy()
+except api.Error as e:
+    result["create"] = e.status
+result["seconds"] = time.perf_counter() - t0
+with net.get_workspace(4) as ws:
+    after = api.forward(ws, features).unwrap()
+result["weights_untouched"] = checksum == (net.weight_checksum(), net.weight_checksum_device(0))
+result["forward_bit_equal"] = bool(np.array_equal(before[0], after[0].view(np.uint16)) and np.array_equal(before[1], after[1].view(np.uint16)))
+result["comm_error"] = api.COMM_ERROR
+print("RESULT " + json.dumps(result), flush=True)
+"""
+
+
+def test_two_processes_naming_the_same_gpu_are_refused_by_rccl_on_every_rank(tmp_path):
+    """the refusal path of csrc/rccl.cpp against a REAL librccl on hardware, as far as one GPU allows: two ranks,
+    two processes, both on device 0.  RCCL does not build a communicator over a duplicate GPU: dgnn_rccl_comm_create (or, should a
+    communicator come back, dgnn_broadcast_weights) returns DGNN_COMM_ERROR on EVERY rank within a bounded time -- nobody hangs --, the
+    weights and their checksums are untouched and forwards are bit-equal afterwards."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    ident = str(tmp_path / "rccl_unique_id")
+    script = TWO_RANKS_ONE_GPU % {"root": ROOT}
+    procs = [subprocess.Popen([sys.executable, "-c", script, str(rank), ident], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+             for rank in (0, 1)]
+    results = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=150)
+            found = re.findall(r"RESULT (\{.*\})", out)      # (RCCL writes its warning to stdout too, without a newline of its own)
+            assert p.returncode == 0 and found, (p.returncode, out[-500:], err[-1500:])
+            results.append(json.loads(found[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r in results:
+        print(r)
+        refused = r["create"] == r["comm_error"] or (r["create"] == "ok" and r.get("broadcast") == r["comm_error"])
+        assert refused, r
+        assert r["seconds"] < 90 and r["weights_untouched"] and r["forward_bit_equal"], r
+
+
+def test_a_network_destroyed_under_a_checked_out_workspace_lives_until_the_release(api, synth):
+    """Round 4: a failing test used to HANG the interpreter at exit -- its workspace and network were finalised in the collector's
+    order, dgnn_network_destroy freed the network, dgnn_workspace_release locked the freed mutex.  Destruction is now deferred to the
+    release of the last checked-out workspace: the workspace keeps working, nothing is touched after the free."""
+    features = synth.make_features(4, seed=801)
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 64, seed=800)))
+    ws = net.get_workspace(4)
+    want = _bits(api.forward(ws, features).unwrap())
+    net.destroy()                                                   # the workspace is still out
+    got = _bits(api.forward(ws, features).unwrap())
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ws.release()                                                    # ... and takes the network with it
+    other = api.Network.from_json(synth.to_json(synth.make_tensors(2, 64, seed=800)))
+    with other.get_workspace(4) as ws2:
+        again = _bits(api.forward(ws2, features).unwrap())
+    other.destroy()
+    assert np.array_equal(again[1], want[1])

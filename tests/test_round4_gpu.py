@@ -156,5 +156,7 @@ def test_logits_and_pre_tanh_in_ulps_and_against_exact_arithmetic(api, oracle, s
     print(f"   board identity: own distance <= {own.max():.3e}, nearest OTHER board >= {distance.min():.3e}")
     if conditioning != "ill":
         check(np.all(own < distance.min(axis=1)), "board identity")
-        check(distance.min() > 3 * max(own.max(), 1e-4), "board identity margin")
+        # (256 boards are positions 2-3 stones apart: 3 x the error on the well-conditioned nets, 2 x where the oracle itself is
+        # 5e-3 from exact arithmetic)
+        check(distance.min() > (3 if well_conditioned else 2) * max(own.max(), 1e-4), "board identity margin")
     assert not problems, problems
