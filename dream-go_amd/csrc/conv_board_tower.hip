@@ -31,7 +31,7 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 // the hand-off is agent-scope and does not depend on it), so the G workgroups of a board take ids that are congruent
 // mod 8 and share an L2.  All batch * G workgroups must be resident at once (the launcher keeps that <= the CU count).
 template <int NS>
-__global__ __launch_bounds__(Split<NS>::Threads)
+__global__ __launch_bounds__(Split<NS>::Threads, Split<NS>::MinWavesPerSimd)
 void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, int batch, int groups, unsigned base, unsigned* done,
                         unsigned* err, unsigned long long* trace)
 {
@@ -102,13 +102,21 @@ int tower_split_ns(int batch, int channels, int num_cus)
     return ns == slices ? 0 : ns;
 }
 
+// The pair split (Split<24>): a 256-channel board on two four-wave workgroups, both resident on one CU -- 2 x batch workgroups, all
+// of which must be resident: two per CU.  (The switch is the workspace's: DGNN_TOWER_PAIR, engine.cpp.)
+bool tower_pair_supported(int batch, int channels, int num_cus)
+{
+    return channels == 256 && batch >= tower_min_batch() && batch <= num_cus;
+}
+
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
                               size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream, bool inject_missing)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     const int slices = channels / 32;
-    if (ns != 32 && (ns < 1 || ns >= slices || slices % ns != 0)) return hipErrorInvalidValue;
-    const int groups = ns == 32 ? slices * 2 : slices / ns;          // workgroups per board (row split: channel blocks x 2 row halves)
+    if (ns == 24 && slices != 8) return hipErrorInvalidValue;
+    if (ns != 32 && ns != 24 && (ns < 1 || ns >= slices || slices % ns != 0)) return hipErrorInvalidValue;
+    const int groups = ns == 32 ? slices * 2 : ns == 24 ? 2 : slices / ns;          // workgroups per board (row split: channel blocks x 2 row halves)
     if ((size_t)batch * groups > done_words) return hipErrorInvalidValue;
     // The flags are never reset between launches: a launch publishes *base + 1 .. *base + count, the next one counts from
     // above that (whatever batch size or split it uses: every stale word is below its base).  Only a counter about to wrap
@@ -132,6 +140,7 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
         (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
     }
     switch (ns) {
+        case 24: hipLaunchKernelGGL((tower_split_kernel<24>), grid, dim3(Split<24>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
         case 32: hipLaunchKernelGGL((tower_split_kernel<32>), grid, dim3(Split<32>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
         case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
         case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;

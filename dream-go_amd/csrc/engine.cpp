@@ -75,6 +75,7 @@ struct Workspace {
     bool pending = false;                   // a submit without its wait
     bool use_board = false;                 // padded slot-major layout + one-board-per-workgroup kernel (conv_board.hip)
     bool use_tower = false;                 // the residual tower as ONE launch where a workgroup owns a whole board (DGNN_TOWER)
+    bool use_pair = false;                  // 256 channels, 129+ boards: a board on TWO four-wave workgroups that share a CU (DGNN_TOWER_PAIR)
     ConvBoardLaunch* d_tower_layers = nullptr;   // 2 * blocks descriptors for tower_board_kernel, filled on first use
     unsigned long long* d_tower_timing = nullptr;   // measurement only (DGNN_TOWER_TIMING): per-layer s_memtime stamps of a whole-board tower
     int tower_timing_layers = 0;
@@ -252,6 +253,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         // MI355X, 20x256 batch 256: 85.3 us per convolution against 91.3 with one launch per layer.  DGNN_TOWER=0: per layer.
         const char* tower = std::getenv("DGNN_TOWER");
         ws->use_tower = ws->use_board && !(tower && std::atoi(tower) == 0) && t.num_blocks > 0;
+        { const char* pair = std::getenv("DGNN_TOWER_PAIR"); ws->use_pair = pair && std::atoi(pair) != 0; }
         const char* up = std::getenv("DGNN_TOWER_UP");
         ws->up_in_tower = !(up && std::atoi(up) == 0);
         const char* split = std::getenv("DGNN_TOWER_SPLIT");
@@ -339,6 +341,7 @@ int tower_mode(const Workspace* ws)
     if (!(ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero)) return 0;
     const int channels = ws->net->topo.num_channels;
     const bool whole = tower_board_supported(ws->active, channels);
+    if (whole && ws->use_pair && !ws->split_failed && tower_pair_supported(ws->active, channels, ws->dev->num_cus)) return 24;
     if (ws->split_pref != 0 && !ws->split_failed && (!whole || ws->split_pref == 2)) {
         const int ns = tower_split_ns(ws->active, channels, ws->dev->num_cus);
         if (ns > 0) return ns;
@@ -468,7 +471,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
             const int layer_count = 2 * t.num_blocks + (up_in_tower ? 1 : 0);
             const int mode = tower_mode(ws);
             if (mode > 0) {
-                const int groups = mode == 32 ? t.num_channels / 32 * 2 : t.num_channels / 32 / mode;
+                const int groups = mode == 32 ? t.num_channels / 32 * 2 : mode == 24 ? 2 : t.num_channels / 32 / mode;
                 SplitChain* chain = ws->dev->chain;
                 std::lock_guard<std::mutex> chained(chain->mutex);
                 if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));

@@ -107,6 +107,7 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
 // launch if a poll gave up).  tower_split_ns: the slices per workgroup the launcher wants for this batch, 0 = do not split (the
 // workgroups of one launch must all be resident at once: batch * C / (32 * ns) <= num_cus).
 int tower_split_ns(int batch, int channels, int num_cus);
+bool tower_pair_supported(int batch, int channels, int num_cus);
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
                               size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream, bool inject_missing = false);
 // Layout changes at the two ends of the tower: [B][361][C] NHWC <-> [B][C / 8][400][8].  C a multiple of 8.
