@@ -61,10 +61,11 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-midgame", type=int, default=60,
                     help="second self-play leg: the searched stones start after this many stones of policy play (0 = skip that leg)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
-    ap.add_argument("--selfplay-batches", type=int, default=2,
-                    help="device batches the leaf pool keeps alive per GPU (the reference keeps 2, nn.rs:64-67).  A third raises the engine's "
-                         "rate on partial batches (opening leg 75.7 -> 77.1 k evals/s) and LOWERS the moves per second (239 -> 206): more "
-                         "leaves in flight are more duplicate evaluations past the transposition table (hit ratio 0.60 -> 0.53)")
+    ap.add_argument("--selfplay-batches", type=int, default=0,
+                    help="device batches the leaf pool keeps alive per GPU.  The reference keeps 2 (nn.rs:64-67); a third raises the engine's "
+                         "rate on partial batches and puts more leaves in flight (more positions evaluated twice before the first answer "
+                         "reaches the transposition table).  0 (default): ADAPTIVE, 2 or 3 -- the pool measures unique positions per second "
+                         "under both and stays with the better one (dgnn_pool_set_adaptive_batches)")
     ap.add_argument("--selfplay-host-threads", type=int, default=2,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
@@ -263,13 +264,16 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     if job.dry and boards:
         # no GPU: the CPU stand-in behind a stand-in for the device (a batch of n boards takes 500 + 10.8 n us, one at a time: the
         # 20x256 engine's 3.3 ms at 256 boards) -- what is measured is the HOST side alone, rollouts per second and core
-        pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=args.selfplay_batches,
-                                           workers_per_lane=args.selfplay_batches)
+        pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=args.selfplay_batches or 3,
+                                           workers_per_lane=args.selfplay_batches or 3)
     elif job.dry:
         pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
     else:
-        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
-                                        workers_per_device=args.selfplay_batches, boards=boards)
+        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches or 3,
+                                        workers_per_device=args.selfplay_batches or 3, boards=boards)
+    adaptive = args.selfplay_batches == 0 and pool.takes_boards
+    if adaptive:
+        pool.set_adaptive_batches(2, 3)
     opening = None
     if fast_forward > 0:
         ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=fast_forward, num_rollouts=1, threads_per_search=1,
@@ -288,6 +292,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     cpu_cores_busy = cpu_seconds / max(time.perf_counter() - wall0, 1e-9)
     rank_rollouts = out["evals"] + out["cache_hits"]                                          # this rank's own games
     st = pool.stats()
+    adaptive_stats = pool.adaptive_stats() if adaptive else None
     boards = sum(job.gather_int(st["boards"] - before["boards"]))
     batches = sum(job.gather_int(st["batches"] - before["batches"]))
     pool.close()
@@ -300,7 +305,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
                  else f"first {args.selfplay_moves} stones of each") + f", --num-rollout {args.selfplay_rollouts}, "
                 f"1 search thread x {args.selfplay_leaves} leaves per game, games as " +
                 (f"fibers on {args.selfplay_host_threads} host threads" if args.selfplay_host_threads > 0 else "one OS thread each") + ", transposition cache 200001 x 8 shards, through the leaf pool "
-                f"({args.selfplay_batches} device batches alive, PCIe-inclusive); random-init weights; feature planes built on the " +
+                f"({args.selfplay_batches or ('2 or 3 (adaptive)' if adaptive else 3)} device batches alive, PCIe-inclusive); random-init weights; feature planes built on the " +
                 ("DEVICE from 896-byte board records (dgnn_forward_boards)" if boards else "HOST (features::V1, 23 KB of fp16 per leaf)"),
         "seconds": sec, "games": j["games"], "moves": j["moves"],
         "evals_per_sec": j["evals"] / sec,                          # predictor evaluations (cache misses) per second, whole job
@@ -323,6 +328,8 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
         "host_us_per_rollout": 1e6 * cpu_seconds / max(rank_rollouts, 1),
         "host_us_per_eval": 1e6 * cpu_seconds / max(out["evals"], 1),
     }
+    if adaptive_stats is not None:
+        leg["batches_alive"] = adaptive_stats      # rank 0's pool: where the adaptive rule stood at the end, what it measured
     # how many GPUs running THIS leg the box's CPU quota could feed: quota cores / cores one GPU's leg kept busy
     leg["gpus_feedable_at_quota"] = leg["host_cpus"] / max(cpu_cores_busy, 1e-9)
     # the host's capacity: rollouts per second and busy core, this rank and every rank (8 pinned ranks on one box: --gpus 8 --dry)

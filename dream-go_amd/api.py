@@ -225,6 +225,9 @@ SYMBOLS = [
     ("dgnn_cache_generation", ctypes.c_uint64, [_vp]),
     ("dgnn_cache_insert_at", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint16, _u16p]),
     ("dgnn_pool_generation", ctypes.c_uint64, [_vp]),
+    ("dgnn_pool_set_adaptive_batches", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_pool_adaptive_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("dgnn_pool_pause", ctypes.c_int, [_vp]),
     ("dgnn_pool_resume", ctypes.c_int, [_vp]),
     ("dgnn_network_weight_image_commit", ctypes.c_int, [_vp, ctypes.c_int]),
@@ -935,6 +938,19 @@ class LeafPool:
     def generation(self):
         """Completed pauses (weight refreshes) so far."""
         return int(lib.dgnn_pool_generation(self._handle))
+
+    def set_adaptive_batches(self, lo, hi):
+        """Between `lo` and `hi` batches alive per lane, chosen by the pool from the unique positions per second it measures
+        (include/dgnn.h: dgnn_pool_set_adaptive_batches); (0, 0): the constant the pool was created with."""
+        _check(lib.dgnn_pool_set_adaptive_batches(self._handle, int(lo), int(hi)), "LeafPool.set_adaptive_batches")
+
+    def adaptive_stats(self):
+        alive, sw, hashed, rep = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        lo, hi = ctypes.c_double(), ctypes.c_double()
+        _check(lib.dgnn_pool_adaptive_stats(self._handle, ctypes.byref(alive), ctypes.byref(sw), ctypes.byref(hashed), ctypes.byref(rep),
+                                            ctypes.byref(lo), ctypes.byref(hi)), "LeafPool.adaptive_stats")
+        return {"alive_per_lane": alive.value, "switches": sw.value, "boards_hashed": hashed.value, "boards_repeated": rep.value,
+                "unique_per_sec_lo": lo.value, "unique_per_sec_hi": hi.value}
 
     @property
     def takes_boards(self):

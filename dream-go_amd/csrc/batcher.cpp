@@ -145,8 +145,71 @@ struct Batcher {
     std::atomic<uint64_t> boards_evaluated{0}, batches_evaluated{0};
     std::atomic<int> refs{1};       // the handle + every batch split off it: a batch may outlive dgnn_batcher_destroy
 
+    // ---- how many batches may be alive: the reference's rule is a constant, 2 per device (predictors/nn.rs:64-67).  A third keeps a
+    // device supplied when batches are partial (129 .. 200 boards: one workgroup per board leaves CUs idle) -- and
+    // it means more leaves in flight, i.e. more positions evaluated twice before the first answer reaches the transposition table.
+    // Which effect wins depends on the phase of the games (openings share positions, middle games do not), so the rule can be made
+    // ADAPTIVE (dgnn_pool_set_adaptive_batches): the batcher counts the positions it is handed for the first time (a hash of the
+    // stones and the colour to move of every board record against a table of recent ones), measures UNIQUE positions per second under
+    // `lo` and under `hi` batches alive per lane in alternating windows, stays with the better one for a while, and probes again.
+    int lanes = 1;
+    int adaptive_lo = 0, adaptive_hi = 0;                     // per lane; 0 = the constant rule
+    std::atomic<int> limit{0};                               // batches alive allowed right now (== max_batches without the adaptive rule)
+    static constexpr int kRecent = 1 << 15;
+    std::vector<uint64_t> recent;                            // direct-mapped: the last position hash that fell on each slot
+    struct Window { uint64_t pushed = 0, repeated = 0; std::chrono::steady_clock::time_point start; } window;
+    static constexpr uint64_t kWindowBoards = 1 << 15;       // a window: about 0.4 s at 80 k boards per second
+    double rate_at[2] = {0.0, 0.0};                          // unique positions per second last measured under lo / hi
+    int probing = 0;                                         // 0, 1: measuring lo / hi; 2: holding `choice`
+    int choice = 1, hold_windows = 0;
+    std::atomic<uint64_t> switches{0}, boards_repeated{0}, boards_hashed{0};
+
+    int alive_limit() const { return adaptive_hi > 0 ? limit.load(std::memory_order_acquire) : max_batches; }
+    void note_record(const uint16_t* record);                // under `mutex`
     void release() { if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
 };
+
+// position identity of a board record: the colours of the 361 cells (bits 0-1; the block ids next to them depend on the order
+// the stones were played in) and the colour to move -- not the symmetry, not the move history: what the transposition table keys on
+void Batcher::note_record(const uint16_t* record)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < 361; i += 3) {
+        const uint64_t three = (uint64_t)(record[i] & 3u) | (uint64_t)(record[i + 1 < 361 ? i + 1 : 360] & 3u) << 2 | (uint64_t)(record[i + 2 < 361 ? i + 2 : 360] & 3u) << 4;
+        h = (h ^ three) * 1099511628211ull;
+    }
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(record);
+    h = (h ^ bytes[368 * 2 + 3 * 48]) * 1099511628211ull;     // to_move: the first byte behind cell[368] and the three 48-byte masks
+    h ^= h >> 29;
+    uint64_t& slot = recent[h & (kRecent - 1)];
+    const bool repeat = slot == h;
+    slot = h;
+    if (window.pushed == 0) window.start = std::chrono::steady_clock::now();
+    ++window.pushed;
+    window.repeated += repeat ? 1 : 0;
+    if (window.pushed < kWindowBoards) return;
+    // ---- a window is full: unique positions per second under the limit it ran with
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - window.start).count();
+    const double rate = (double)(window.pushed - window.repeated) / (seconds > 1e-6 ? seconds : 1e-6);
+    boards_hashed.fetch_add(window.pushed, std::memory_order_relaxed);
+    boards_repeated.fetch_add(window.repeated, std::memory_order_relaxed);
+    window = Window();
+    int next = choice;
+    if (probing < 2) {
+        rate_at[probing] = rate;
+        if (probing == 0) { probing = 1; next = 1; }                     // lo measured: now hi
+        else {                                                           // both measured: keep the better one for a while (3 % hysteresis)
+            const int better = rate_at[1] > 1.03 * rate_at[0] ? 1 : rate_at[0] > 1.03 * rate_at[1] ? 0 : choice;
+            probing = 2; hold_windows = 12; next = better;
+        }
+    } else {
+        rate_at[choice] = rate;
+        if (--hold_windows <= 0) { probing = 0; next = 0; }             // probe again, lo first
+    }
+    if (next != choice) switches.fetch_add(1, std::memory_order_relaxed);
+    choice = next;
+    limit.store((choice ? adaptive_hi : adaptive_lo) * lanes, std::memory_order_release);
+}
 
 // ------------------------------------------------------------------------------------------------ leaf pool
 //
@@ -196,7 +259,7 @@ struct LeafPool {
     bool ready() const
     {
         return batcher->queued.load(std::memory_order_acquire) > 0 &&
-               batcher->num_batches.load(std::memory_order_acquire) < batcher->max_batches;
+               batcher->num_batches.load(std::memory_order_acquire) < batcher->alive_limit();
     }
     // state the predicate reads changes outside `mutex` (under the batcher's): passing through the mutex before the notify
     // closes the window between a worker's predicate check and its going to sleep
@@ -426,6 +489,7 @@ void dgnn_batcher_destroy(dgnn_batcher* batcher) { if (batcher) reinterpret_cast
 static int batcher_push(Batcher* b, const uint16_t* item, uint64_t tag)
 {
     std::lock_guard<std::mutex> lock(b->mutex);                                 // batch.rs:80-84
+    if (b->adaptive_hi > 0 && b->records) b->note_record(item);
     b->features.insert(b->features.end(), item, item + b->item);
     b->tags.push_back(tag);
     b->queued.store((int)b->tags.size(), std::memory_order_release);
@@ -460,7 +524,7 @@ int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch
     Batcher* b = reinterpret_cast<Batcher*>(batcher);
 
     int current = b->num_batches.load(std::memory_order_acquire);               // batch.rs:93-99
-    if (current >= b->max_batches) return DGNN_OK;
+    if (current >= b->alive_limit()) return DGNN_OK;
 
     std::lock_guard<std::mutex> lock(b->mutex);
     const size_t size = b->tags.size();
@@ -761,6 +825,46 @@ void dgnn_pool_destroy(dgnn_pool* handle)
 // queue up and are served after dgnn_pool_resume -- by the new weights.  The sequence of a refresh inside a running job:
 //   dgnn_pool_pause -> dgnn_broadcast_weights / dgnn_network_set_weight_image -> dgnn_cache_clear -> dgnn_pool_resume
 // (the reference restarts the worker process instead, contrib/distr-env/run_worker.py:66-77).
+// The adaptive rule above for a pool of board records: between `lo` and `hi` batches alive per lane (hi <= what the pool was created
+// with: its workers and the batcher's cap).  lo == hi == 0 switches back to the constant the pool was created with.
+int dgnn_pool_set_adaptive_batches(dgnn_pool* handle, int lo, int hi)
+{
+    if (!handle || lo < 0 || hi < lo) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    Batcher* b = pool->batcher;
+    if (hi > 0 && (!b->records || lo == 0 || hi * pool->num_lanes > b->max_batches || hi * pool->num_lanes > (int)pool->workers.size()))
+        return DGNN_BAD_ARGUMENT;
+    {
+        std::lock_guard<std::mutex> lock(b->mutex);
+        b->lanes = pool->num_lanes;
+        b->adaptive_lo = lo;
+        b->adaptive_hi = hi;
+        if (hi > 0 && b->recent.empty()) b->recent.assign(Batcher::kRecent, 0);
+        b->window = Batcher::Window();
+        b->probing = 0;
+        b->choice = 0;
+        b->limit.store(hi > 0 ? lo * pool->num_lanes : b->max_batches, std::memory_order_release);
+    }
+    pool->work.notify_all();
+    return DGNN_OK;
+}
+
+int dgnn_pool_adaptive_stats(dgnn_pool* handle, int* alive_per_lane, uint64_t* switches, uint64_t* boards_hashed, uint64_t* boards_repeated,
+                             double* unique_rate_lo, double* unique_rate_hi)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    Batcher* b = pool->batcher;
+    std::lock_guard<std::mutex> lock(b->mutex);
+    if (alive_per_lane) *alive_per_lane = b->alive_limit() / (pool->num_lanes > 0 ? pool->num_lanes : 1);
+    if (switches) *switches = b->switches.load();
+    if (boards_hashed) *boards_hashed = b->boards_hashed.load() + b->window.pushed;
+    if (boards_repeated) *boards_repeated = b->boards_repeated.load() + b->window.repeated;
+    if (unique_rate_lo) *unique_rate_lo = b->rate_at[0];
+    if (unique_rate_hi) *unique_rate_hi = b->rate_at[1];
+    return DGNN_OK;
+}
+
 int dgnn_pool_pause(dgnn_pool* handle)
 {
     if (!handle) return DGNN_BAD_ARGUMENT;

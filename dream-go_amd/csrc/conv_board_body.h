@@ -283,7 +283,16 @@ struct Split {
     static constexpr int PPW = (Pieces + WAVES - 1) / WAVES;        // ... per wave (4 at NS = 1, 8 at NS = 2; surplus ones repeat)
     // Chunked: piece j of a wave goes out behind the MFMA of pair piece_pair(j) of tap piece_tap(j) (early in the chunk: it
     // has to land before the chunk barrier)
-    static constexpr int piece_tap(int j) { return SL == 1 ? j : j / 2; }
+    // One slice per workgroup (SL == 1: the smallest-batch splits): kPiecesPerTap pieces of the next chunk go out per tap.  Round 3 sent
+    // ONE (the last of a wave's seven at tap 6, three taps in front of the chunk barrier that waits for it); round 4 measured 2 / 4 / 7
+    // (tools/build_variant.sh, tools/ab_ppt.sh, profiles/r04/ab_pieces_per_tap.txt; same box, evals/s): 9x128 batch 32: 154.4 k ->
+    // 159.4 k / 157.0 k / 155.0 k; 20x256 batch 8 / 16: 13.4 k / 26.6 k -> 14.5 k / 28.6 k with two.  Two it is: the whole chunk in
+    // flight at once (seven) buys nothing -- the K loop of these splits is not waiting for bytes in flight (what bounds it: DESIGN 13.4).
+#ifndef DGNN_PIECES_PER_TAP
+#define DGNN_PIECES_PER_TAP 2
+#endif
+    static constexpr int kPiecesPerTap = DGNN_PIECES_PER_TAP;
+    static constexpr int piece_tap(int j) { return SL == 1 ? j / kPiecesPerTap : j / 2; }
     static constexpr int piece_pair(int j) { return SL == 1 ? 1 : (j % 2 ? 4 : 1); }
     static constexpr int pieces_in_tap(int tap) { int n = 0; for (int j = 0; j < PPW; ++j) n += piece_tap(j) == tap ? 1 : 0; return n; }
     static constexpr int CT2 = 2 * CT;                 // 16-channel MFMA tiles per wave

@@ -434,6 +434,16 @@ int dgnn_pool_create_board_callbacks(dgnn_predict_boards_fn predict, void* predi
 int dgnn_pool_predict_boards(dgnn_pool* pool, const uint8_t* records, int batch_size, uint16_t* value_out, uint16_t* policy_out);
 int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool of board records */
 
+/* How many batches a pool keeps alive per lane.  The reference's rule is the constant 2 per device (predictors/nn.rs:64-67); a third
+ * keeps a device supplied when batches are partial (one workgroup per board: 129 .. 200 boards leave CUs idle) but puts more leaves in
+ * flight, i.e. more positions evaluated twice before the first answer reaches the transposition table.  With lo < hi (a pool of board
+ * records created with at least `hi` batches and workers per lane) the pool measures UNIQUE positions per second -- it hashes the
+ * stones and the colour to move of every record against a table of recent ones -- under both settings in alternating windows of 32 768
+ * boards and stays with the better one, probing again every dozen windows.  lo == hi == 0: back to the constant. */
+int dgnn_pool_set_adaptive_batches(dgnn_pool* pool, int lo, int hi);
+int dgnn_pool_adaptive_stats(dgnn_pool* pool, int* alive_per_lane, uint64_t* switches, uint64_t* boards_hashed, uint64_t* boards_repeated,
+                             double* unique_rate_lo, double* unique_rate_hi);
+
 /* Weight refresh inside a running job (f-4: "closes the RL loop"; the reference restarts the worker process,
  * contrib/distr-env/run_worker.py:66-77):  dgnn_pool_pause -> dgnn_broadcast_weights or dgnn_network_set_weight_image ->
  * dgnn_cache_clear -> dgnn_pool_resume.  pause returns when no worker holds a batch or a workspace any more (so the weights may be

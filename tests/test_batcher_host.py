@@ -280,3 +280,36 @@ def test_idle_pool_workers_sleep(api):
     pool.predict(feats, 1)
     assert time.perf_counter() - t1 < 0.015                  # woken by the push, not by the 20 ms safety timeout
     pool.close()
+
+
+def test_adaptive_batches_alive_follow_the_unique_positions_per_second(api):
+    """Round 4: between 2 and 3 batches alive per lane, chosen by the pool from what it measures.  Here over the
+    CPU stand-in of a device: the rule can only be switched on for a pool of board records that was created with enough batches and
+    workers; it counts repeated positions (same stones, same colour to move, ANY symmetry) and never leaves [lo, hi]."""
+    pool = api.LeafPool.over_dry_device(base_us=50.0, per_board_us=0.5, max_batch_size=64, batches_per_lane=3, workers_per_lane=3)
+    import pytest
+    with pytest.raises(api.Error):
+        pool.set_adaptive_batches(2, 4)                      # more than the pool has workers for
+    with pytest.raises(api.Error):
+        pool.set_adaptive_batches(0, 3)
+    pool.set_adaptive_batches(2, 3)
+    assert pool.adaptive_stats()["alive_per_lane"] == 2
+    board = api.Board(7.5)
+    board.place(0, 3, 3)
+    same = np.concatenate([board.record(1, s) for s in range(8)])               # one position, eight symmetries
+    other = api.Board(7.5)
+    other.place(0, 15, 15)
+    records = np.concatenate([same, other.record(1, 0)])
+    for _ in range(8000):                                                       # 72 000 boards: two windows of 32 768
+        pool.predict_boards(records, 9)
+    stats = pool.adaptive_stats()
+    assert stats["boards_hashed"] == 72000 and stats["boards_repeated"] >= 71990        # everything but the first sighting of each
+    # (the two first sightings fell into the first window, measured under `lo`; the second window saw repeats only)
+    assert stats["alive_per_lane"] in (2, 3) and stats["unique_per_sec_lo"] > 0 and stats["unique_per_sec_hi"] == 0
+    pool.set_adaptive_batches(0, 0)
+    assert pool.adaptive_stats()["alive_per_lane"] == 3
+    pool.close()
+    features_pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=8, batches_per_lane=3, workers_per_lane=3)
+    with pytest.raises(api.Error):
+        features_pool.set_adaptive_batches(2, 3)             # fp16 planes are not hashed: records only
+    features_pool.close()

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
     ap.add_argument("--leaves", type=int, default=1, help="leaves a search thread keeps in flight per predictor call (1 = the reference's worker)")
     ap.add_argument("--max-batch", type=int, default=256)
-    ap.add_argument("--max-batches", type=int, default=2, help="device batches the pool keeps alive (a third costs moves: more duplicate evaluations past the table, DESIGN.md 11.7)")
+    ap.add_argument("--max-batches", type=int, default=0, help="device batches the pool keeps alive: 2 (the reference's rule), 3, or 0 (default) = adaptive, 2 or 3 by the unique positions per second the pool measures (dgnn_pool_set_adaptive_batches, DESIGN.md 13)")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
@@ -64,8 +64,11 @@ def main():
         import bench
         broadcast = bench.broadcast_weights(net, device, torch, dist, replicas)
     import time
-    pool = api.LeafPool.over_devices(net, [device], max_batch_size=args.max_batch, batches_per_device=args.max_batches,
-                                    workers_per_device=args.max_batches, boards=args.planes == "device")
+    pool = api.LeafPool.over_devices(net, [device], max_batch_size=args.max_batch, batches_per_device=args.max_batches or 3,
+                                    workers_per_device=args.max_batches or 3, boards=args.planes == "device")
+    adaptive = args.max_batches == 0 and pool.takes_boards
+    if adaptive:
+        pool.set_adaptive_batches(2, 3)
     api.selfplay_go(2, 1, 16, 2, seed=1, pool=pool)          # warm: workspace, weight upload
     cache = api.LruCache(args.cache, 8) if args.cache > 0 else None
     before = pool.stats()
@@ -76,6 +79,7 @@ def main():
                                       host_threads=args.host_threads)
     host_cpus_busy = (time.process_time() - cpu0) / max(time.perf_counter() - wall0, 1e-9)
     after = pool.stats()
+    adaptive_stats = pool.adaptive_stats() if adaptive else None
     if args.sgf:
         with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
             f.write("\n".join(stats.get("sgf", [])) + "\n")
@@ -96,6 +100,7 @@ def main():
             "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1),
             "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
             "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
+            "batches_alive": adaptive_stats if adaptive else args.max_batches,
             "feature_planes": args.planes, "host_threads": args.host_threads, "host_cpus_busy_rank0": host_cpus_busy,
             "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
             "sharding": "game_id mod world, one engine + batcher + pool + cache per rank, no data-path collective",
