@@ -61,11 +61,14 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-midgame", type=int, default=60,
                     help="second self-play leg: the searched stones start after this many stones of policy play (0 = skip that leg)")
     ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
-    ap.add_argument("--selfplay-batches", type=int, default=0,
+    ap.add_argument("--selfplay-batches", type=int, default=2,
                     help="device batches the leaf pool keeps alive per GPU.  The reference keeps 2 (nn.rs:64-67); a third raises the engine's "
                          "rate on partial batches and puts more leaves in flight (more positions evaluated twice before the first answer "
-                         "reaches the transposition table).  0 (default): ADAPTIVE, 2 or 3 -- the pool measures unique positions per second "
-                         "under both and stays with the better one (dgnn_pool_set_adaptive_batches)")
+                         "reaches the transposition table; measured in DESIGN.md 13).  0: ADAPTIVE, 2 or 3 -- the pool measures unique positions "
+                         "per second under both and stays with the better one (dgnn_pool_set_adaptive_batches)")
+    ap.add_argument("--selfplay-coalesce", type=int, default=1,
+                    help="1 (default): a request for a position that is already queued or on the device follows it instead of being evaluated "
+                         "again (dgnn_pool_set_coalescing: what the shared transposition table does, one evaluation earlier); 0: the reference's behaviour")
     ap.add_argument("--selfplay-host-threads", type=int, default=2,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
@@ -274,6 +277,9 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     adaptive = args.selfplay_batches == 0 and pool.takes_boards
     if adaptive:
         pool.set_adaptive_batches(2, 3)
+    coalesce = bool(args.selfplay_coalesce) and pool.takes_boards          # (the games of this leg share one transposition table)
+    if coalesce:
+        pool.set_coalescing(True)
     opening = None
     if fast_forward > 0:
         ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=fast_forward, num_rollouts=1, threads_per_search=1,
@@ -293,6 +299,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     rank_rollouts = out["evals"] + out["cache_hits"]                                          # this rank's own games
     st = pool.stats()
     adaptive_stats = pool.adaptive_stats() if adaptive else None
+    coalesced = pool.coalesced()
     boards = sum(job.gather_int(st["boards"] - before["boards"]))
     batches = sum(job.gather_int(st["batches"] - before["batches"]))
     pool.close()
@@ -330,6 +337,8 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     }
     if adaptive_stats is not None:
         leg["batches_alive"] = adaptive_stats      # rank 0's pool: where the adaptive rule stood at the end, what it measured
+    leg["coalescing"] = coalesce
+    leg["coalesced_boards_rank0"] = coalesced      # boards that followed a position in flight instead of being evaluated (whole pool lifetime)
     # how many GPUs running THIS leg the box's CPU quota could feed: quota cores / cores one GPU's leg kept busy
     leg["gpus_feedable_at_quota"] = leg["host_cpus"] / max(cpu_cores_busy, 1e-9)
     # the host's capacity: rollouts per second and busy core, this rank and every rank (8 pinned ranks on one box: --gpus 8 --dry)

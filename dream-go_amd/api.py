@@ -226,6 +226,8 @@ SYMBOLS = [
     ("dgnn_cache_insert_at", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_uint16, _u16p]),
     ("dgnn_pool_generation", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_set_adaptive_batches", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_pool_set_coalescing", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("dgnn_pool_coalesced", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_adaptive_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                                ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("dgnn_pool_pause", ctypes.c_int, [_vp]),
@@ -938,6 +940,13 @@ class LeafPool:
     def generation(self):
         """Completed pauses (weight refreshes) so far."""
         return int(lib.dgnn_pool_generation(self._handle))
+
+    def set_coalescing(self, enabled=True):
+        """Requests for a position that is already in flight follow it instead of being evaluated again (include/dgnn.h)."""
+        _check(lib.dgnn_pool_set_coalescing(self._handle, 1 if enabled else 0), "LeafPool.set_coalescing")
+
+    def coalesced(self):
+        return int(lib.dgnn_pool_coalesced(self._handle))
 
     def set_adaptive_batches(self, lo, hi):
         """Between `lo` and `hi` batches alive per lane, chosen by the pool from the unique positions per second it measures

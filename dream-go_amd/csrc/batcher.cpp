@@ -153,7 +153,7 @@ struct Batcher {
     // stones and the colour to move of every board record against a table of recent ones), measures UNIQUE positions per second under
     // `lo` and under `hi` batches alive per lane in alternating windows, stays with the better one for a while, and probes again.
     int lanes = 1;
-    int adaptive_lo = 0, adaptive_hi = 0;                     // per lane; 0 = the constant rule
+    std::atomic<int> adaptive_lo{0}, adaptive_hi{0};          // per lane; 0 = the constant rule (read by the workers without the lock)
     std::atomic<int> limit{0};                               // batches alive allowed right now (== max_batches without the adaptive rule)
     static constexpr int kRecent = 1 << 15;
     std::vector<uint64_t> recent;                            // direct-mapped: the last position hash that fell on each slot
@@ -164,14 +164,14 @@ struct Batcher {
     int choice = 1, hold_windows = 0;
     std::atomic<uint64_t> switches{0}, boards_repeated{0}, boards_hashed{0};
 
-    int alive_limit() const { return adaptive_hi > 0 ? limit.load(std::memory_order_acquire) : max_batches; }
+    int alive_limit() const { return adaptive_hi.load(std::memory_order_acquire) > 0 ? limit.load(std::memory_order_acquire) : max_batches; }
     void note_record(const uint16_t* record);                // under `mutex`
     void release() { if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this; }
 };
 
 // position identity of a board record: the colours of the 361 cells (bits 0-1; the block ids next to them depend on the order
 // the stones were played in) and the colour to move -- not the symmetry, not the move history: what the transposition table keys on
-void Batcher::note_record(const uint16_t* record)
+static uint64_t record_position_hash(const uint16_t* record)
 {
     uint64_t h = 1469598103934665603ull;
     for (int i = 0; i < 361; i += 3) {
@@ -181,6 +181,13 @@ void Batcher::note_record(const uint16_t* record)
     const uint8_t* bytes = reinterpret_cast<const uint8_t*>(record);
     h = (h ^ bytes[368 * 2 + 3 * 48]) * 1099511628211ull;     // to_move: the first byte behind cell[368] and the three 48-byte masks
     h ^= h >> 29;
+    return h;
+}
+static int record_symmetry(const uint16_t* record) { return reinterpret_cast<const uint8_t*>(record)[368 * 2 + 3 * 48 + 1] & 7; }
+
+void Batcher::note_record(const uint16_t* record)
+{
+    const uint64_t h = record_position_hash(record);
     uint64_t& slot = recent[h & (kRecent - 1)];
     const bool repeat = slot == h;
     slot = h;
@@ -208,7 +215,7 @@ void Batcher::note_record(const uint16_t* record)
     }
     if (next != choice) switches.fetch_add(1, std::memory_order_relaxed);
     choice = next;
-    limit.store((choice ? adaptive_hi : adaptive_lo) * lanes, std::memory_order_release);
+    limit.store((choice ? adaptive_hi.load() : adaptive_lo.load()) * lanes, std::memory_order_release);
 }
 
 // ------------------------------------------------------------------------------------------------ leaf pool
@@ -221,6 +228,11 @@ void Batcher::note_record(const uint16_t* record)
 struct LeafSlot {
     struct LeafRequest* request;
     int index;
+    // coalescing (dgnn_pool_set_coalescing): the position this slot asks for and the symmetry it wants the answer in; a slot that was
+    // pushed into the batcher LEADS every later slot for the same position until its answer is delivered
+    uint64_t position = 0;
+    uint8_t symmetry = 0;
+    bool leads = false;
 };
 
 struct LeafRequest {
@@ -254,6 +266,17 @@ struct LeafPool {
     int evaluating = 0;             // workers between get_batch and the end of evaluate (under `mutex`)
     std::condition_variable idle;   // signalled when `evaluating` drops to zero
     std::atomic<uint64_t> generation{0};   // completed pauses: what a game compares per move to drop its PRIVATE table after a refresh
+    // Coalescing of positions IN FLIGHT (records pools; off unless dgnn_pool_set_coalescing): the transposition table only knows
+    // positions whose evaluation has come back; with hundreds of games searching the same opening most "misses" are positions
+    // somebody else has on the device right now (measured: 60 % of the boards a pool is handed in the first six moves of 256 games
+    // repeat a position it was handed within the last half second).  A request for a position that is in flight FOLLOWS the slot
+    // that leads it and receives that answer, re-oriented from the leader's symmetry to its own -- exactly what a table hit returns
+    // (predictors/nn.rs:72-81) -- instead of being evaluated again.
+    std::atomic<bool> coalesce{false};
+    std::mutex inflight_mutex;
+    struct InFlight { const LeafRequest* owner; std::vector<LeafSlot*> followers; };
+    std::unordered_map<uint64_t, InFlight> inflight;                    // position -> who leads it, and the slots that follow
+    std::atomic<uint64_t> coalesced{0};
     std::atomic<uint64_t> calls{0};
 
     bool ready() const
@@ -300,13 +323,11 @@ struct LeafPool {
             const int status = evaluate(lane, batch, n, value.data(), policy.data());
             dgnn_batch_destroy(batch);
             wake();                                 // a batch slot is free again
-            for (int i = 0; i < n; ++i) {
-                LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
+            auto deliver = [&](LeafSlot* slot, uint16_t v, const uint16_t* p) {
                 LeafRequest* r = slot->request;
                 if (status == DGNN_OK) {
-                    r->value_out[slot->index] = value[i];
-                    std::memcpy(r->policy_out + (size_t)slot->index * DGNN_NUM_MOVES, policy.data() + (size_t)i * DGNN_NUM_MOVES,
-                                DGNN_NUM_MOVES * sizeof(uint16_t));
+                    r->value_out[slot->index] = v;
+                    std::memcpy(r->policy_out + (size_t)slot->index * DGNN_NUM_MOVES, p, DGNN_NUM_MOVES * sizeof(uint16_t));
                 }
                 Fiber* resume = nullptr;
                 {
@@ -315,6 +336,28 @@ struct LeafPool {
                     if (--r->remaining == 0) { if (r->fiber) resume = r->fiber; else r->done.notify_one(); }
                 }
                 if (resume) fiber_make_ready(resume);      // (the request lives on the fiber's stack: not touched after this)
+            };
+            std::vector<LeafSlot*> followers;
+            for (int i = 0; i < n; ++i) {
+                LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
+                const uint16_t* p = policy.data() + (size_t)i * DGNN_NUM_MOVES;
+                followers.clear();
+                int leader_symmetry = 0;
+                if (slot->leads) {                         // (read before the leader's request can return and take its slots with it)
+                    leader_symmetry = slot->symmetry;
+                    std::lock_guard<std::mutex> lock(inflight_mutex);
+                    auto it = inflight.find(slot->position);
+                    if (it != inflight.end()) { followers.swap(it->second.followers); inflight.erase(it); }
+                }
+                deliver(slot, value[i], p);
+                if (!followers.empty()) {
+                    uint16_t canonical[DGNN_NUM_MOVES], oriented[DGNN_NUM_MOVES];
+                    if (status == DGNN_OK) with_transform(p, kInverse[leader_symmetry], canonical);        // nn.rs:78-81
+                    for (LeafSlot* f : followers) {
+                        if (status == DGNN_OK) with_transform(canonical, f->symmetry, oriented);           // nn.rs:72-74
+                        deliver(f, value[i], oriented);
+                    }
+                }
             }
             done();     // after the answers are with their requests: a pause returns with no old-weights answer still on its way
         }
@@ -489,7 +532,7 @@ void dgnn_batcher_destroy(dgnn_batcher* batcher) { if (batcher) reinterpret_cast
 static int batcher_push(Batcher* b, const uint16_t* item, uint64_t tag)
 {
     std::lock_guard<std::mutex> lock(b->mutex);                                 // batch.rs:80-84
-    if (b->adaptive_hi > 0 && b->records) b->note_record(item);
+    if (b->adaptive_hi.load(std::memory_order_relaxed) > 0 && b->records) b->note_record(item);
     b->features.insert(b->features.end(), item, item + b->item);
     b->tags.push_back(tag);
     b->queued.store((int)b->tags.size(), std::memory_order_release);
@@ -837,17 +880,30 @@ int dgnn_pool_set_adaptive_batches(dgnn_pool* handle, int lo, int hi)
     {
         std::lock_guard<std::mutex> lock(b->mutex);
         b->lanes = pool->num_lanes;
-        b->adaptive_lo = lo;
-        b->adaptive_hi = hi;
         if (hi > 0 && b->recent.empty()) b->recent.assign(Batcher::kRecent, 0);
         b->window = Batcher::Window();
         b->probing = 0;
         b->choice = 0;
         b->limit.store(hi > 0 ? lo * pool->num_lanes : b->max_batches, std::memory_order_release);
+        b->adaptive_lo.store(lo, std::memory_order_release);
+        b->adaptive_hi.store(hi, std::memory_order_release);
     }
     pool->work.notify_all();
     return DGNN_OK;
 }
+
+int dgnn_pool_set_coalescing(dgnn_pool* handle, int enabled)
+{
+    if (!handle) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    if (enabled && !pool->batcher->records) return DGNN_BAD_ARGUMENT;       // positions are recognised in board records only
+    std::lock_guard<std::mutex> lock(pool->inflight_mutex);
+    if (!pool->inflight.empty()) return DGNN_BUSY;                          // not while leaders are out
+    pool->coalesce = enabled != 0;
+    return DGNN_OK;
+}
+
+uint64_t dgnn_pool_coalesced(const dgnn_pool* handle) { return handle ? reinterpret_cast<const LeafPool*>(handle)->coalesced.load() : 0; }
 
 int dgnn_pool_adaptive_stats(dgnn_pool* handle, int* alive_per_lane, uint64_t* switches, uint64_t* boards_hashed, uint64_t* boards_repeated,
                              double* unique_rate_lo, double* unique_rate_hi)
@@ -941,7 +997,24 @@ static int pool_predict(LeafPool* pool, const uint16_t* features, int batch_size
     for (int i = 0; i < batch_size; ++i) {
         slots[i].request = &request;
         slots[i].index = i;
-        const int status = batcher_push(pool->batcher, features + (size_t)i * pool->batcher->item, (uint64_t)(uintptr_t)&slots[i]);
+        const uint16_t* item = features + (size_t)i * pool->batcher->item;
+        if (pool->coalesce) {
+            slots[i].position = record_position_hash(item);
+            slots[i].symmetry = (uint8_t)record_symmetry(item);
+            std::lock_guard<std::mutex> lock(pool->inflight_mutex);
+            auto found = pool->inflight.find(slots[i].position);
+            if (found == pool->inflight.end()) {
+                pool->inflight.emplace(slots[i].position, LeafPool::InFlight{&request, {}});
+                slots[i].leads = true;
+            } else if (found->second.owner != &request) {   // somebody ELSE has this position on its way: follow
+                found->second.followers.push_back(&slots[i]);
+                pool->coalesced.fetch_add(1, std::memory_order_relaxed);
+                continue;
+            }
+            // (the same position twice in ONE request is the root ensemble of lib.rs:83-130 -- eight symmetries that are meant to be
+            // eight evaluations: the reference's table would not have served them either, it is filled after the predict call)
+        }
+        const int status = batcher_push(pool->batcher, item, (uint64_t)(uintptr_t)&slots[i]);
         if (status != DGNN_OK) {       // cannot happen after the argument checks above; the pushed part still completes
             std::unique_lock<std::mutex> lock(request.mutex);
             request.remaining -= batch_size - i;

@@ -434,6 +434,16 @@ int dgnn_pool_create_board_callbacks(dgnn_predict_boards_fn predict, void* predi
 int dgnn_pool_predict_boards(dgnn_pool* pool, const uint8_t* records, int batch_size, uint16_t* value_out, uint16_t* policy_out);
 int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool of board records */
 
+/* Coalescing of positions that are IN FLIGHT (a pool of board records; off by default).  The transposition table
+ * (NnPredictor::{fetch, cache}, predictors/nn.rs:29-82) knows a position once its evaluation has come back; until then every search
+ * that reaches it evaluates it again -- with hundreds of games in the same opening that is most of the device's work.  With
+ * coalescing a request for a position (same stones, same colour to move) that the pool already has queued or on a device FOLLOWS it
+ * and receives that answer re-oriented from the leader's symmetry to its own: what a table hit would have returned
+ * (nn.rs:72-81), one evaluation earlier.  Like the shared table it makes WHICH evaluation a search sees a matter of timing: games that
+ * must be a function of their seed (cache_entries_per_game > 0) keep it off.  DGNN_BUSY while requests are in flight. */
+int dgnn_pool_set_coalescing(dgnn_pool* pool, int enabled);
+uint64_t dgnn_pool_coalesced(const dgnn_pool* pool);        /* boards that followed instead of being evaluated */
+
 /* How many batches a pool keeps alive per lane.  The reference's rule is the constant 2 per device (predictors/nn.rs:64-67); a third
  * keeps a device supplied when batches are partial (one workgroup per board: 129 .. 200 boards leave CUs idle) but puts more leaves in
  * flight, i.e. more positions evaluated twice before the first answer reaches the transposition table.  With lo < hi (a pool of board

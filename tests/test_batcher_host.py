@@ -313,3 +313,55 @@ def test_adaptive_batches_alive_follow_the_unique_positions_per_second(api):
     with pytest.raises(api.Error):
         features_pool.set_adaptive_batches(2, 3)             # fp16 planes are not hashed: records only
     features_pool.close()
+
+
+def test_requests_for_a_position_in_flight_follow_it(api):
+    """Round 4: dgnn_pool_set_coalescing.  A slow stand-in device; one thread asks for a position in symmetry 0, seven more ask for the
+    SAME position in the other symmetries while it is out: ONE board reaches the device, and every follower receives the leader's
+    answer re-oriented to its own symmetry -- value as is, policy = with_transform(with_transform(p, inverse(leader)), own): what
+    NnPredictor::fetch returns for a table hit (predictors/nn.rs:72-81).  A different position is evaluated on its own."""
+    import threading
+    import time
+    board = api.Board(7.5)
+    for i, (x, y) in enumerate([(3, 3), (15, 15), (3, 15), (16, 3), (9, 10)]):
+        board.place(i % 2, x, y)
+    other = board.clone()
+    other.place(1, 10, 10)
+    plain = api.LeafPool.over_dry_device(base_us=0.0, per_board_us=0.0, max_batch_size=16, batches_per_lane=1, workers_per_lane=1)
+    direct = plain.predict_boards(board.record(1, 0), 1)                       # what the stand-in answers for the leader's record
+    direct_other = plain.predict_boards(other.record(0, 5), 1)
+    plain.close()
+    pool = api.LeafPool.over_dry_device(base_us=150000.0, per_board_us=0.0, max_batch_size=16, batches_per_lane=1, workers_per_lane=1)
+    pool.set_coalescing(True)
+    answers = {}
+
+    def ask(symmetry, rec):
+        answers[symmetry] = pool.predict_boards(rec, 1)
+
+    leader = threading.Thread(target=ask, args=(0, board.record(1, 0)))
+    leader.start()
+    time.sleep(0.03)                                                           # the leader is on the "device" (150 ms) by now
+    rest = [threading.Thread(target=ask, args=(s, board.record(1, s))) for s in range(1, 8)]
+    rest.append(threading.Thread(target=ask, args=("other", other.record(0, 5))))
+    [t.start() for t in rest]
+    [t.join() for t in rest + [leader]]
+    assert pool.coalesced() == 7 and pool.stats()["boards"] == 2               # the position once, the other position once
+    bits = lambda prediction: prediction._policy.view(np.uint16)              # noqa: E731  (the 362 fp16 bit patterns)
+    for s in range(8):                                                         # leader symmetry 0 = the canonical orientation
+        got = answers[s][0]
+        assert float(got.value()) == float(direct[0].value())
+        want = api.Prediction.with_transform(direct[0], s)
+        assert np.array_equal(bits(got), bits(want)), s
+    assert np.array_equal(bits(answers["other"][0]), bits(direct_other[0]))
+    # nothing stays behind: the same position asked again is evaluated again (the table, not the pool, remembers answers)
+    again = pool.predict_boards(board.record(1, 3), 1)
+    assert pool.stats()["boards"] == 3 and pool.coalesced() == 7 and again is not None
+    # the eight symmetries of ONE request are eight evaluations (the root ensemble of lib.rs:83-130), never followers of each other
+    ensemble = pool.predict_boards(np.concatenate([board.record(1, s) for s in range(8)]), 8)
+    assert pool.stats()["boards"] == 11 and pool.coalesced() == 7 and len(ensemble) == 8
+    pool.close()
+    features_pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=8)
+    import pytest
+    with pytest.raises(api.Error):
+        features_pool.set_coalescing(True)
+    features_pool.close()

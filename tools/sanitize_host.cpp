@@ -97,7 +97,9 @@ int main() {
         dgnn_pool* pool = nullptr;
         dgnn_cache* cache = nullptr;
         dgnn_dry_device device{200.0, 2.0};
-        dgnn_pool_create_board_callbacks(dgnn_hash_boards_predictor(), &device, 1, 256, 2, 2, &pool);
+        dgnn_pool_create_board_callbacks(dgnn_hash_boards_predictor(), &device, 1, 256, 3, 3, &pool);
+        dgnn_pool_set_coalescing(pool, 1);              // positions in flight are followed, not evaluated again (shared table below)
+        dgnn_pool_set_adaptive_batches(pool, 2, 3);     // ... and 2 or 3 batches alive by what the pool measures
         dgnn_cache_create(200001, 8, &cache);
         dgnn_selfplay_params p{};
         p.num_games = 256; p.num_parallel = 256; p.game_stride = 1; p.max_moves = 4; p.num_rollouts = 64; p.threads_per_search = 1;
@@ -113,8 +115,9 @@ int main() {
         });
         int rc = dgnn_selfplay_go_boards(dgnn_pool_boards_predictor(), pool, cache, &p, &st, nullptr, nullptr, 0);
         refresher.join();
-        std::printf("fibers: 256 games on 2 host threads rc %d moves %llu evals %llu hits %llu\n", rc, (unsigned long long)st.moves,
-                    (unsigned long long)st.evals, (unsigned long long)st.cache_hits);
+        std::printf("fibers: 256 games on 2 host threads rc %d moves %llu evals %llu hits %llu followed %llu\n", rc, (unsigned long long)st.moves,
+                    (unsigned long long)st.evals, (unsigned long long)st.cache_hits, (unsigned long long)dgnn_pool_coalesced(pool));
+        dgnn_pool_set_coalescing(pool, 0);              // (the private-table job below must stay a function of its seeds)
         // the same with a table per game (the reproducible mode) and games started as others end
         p.num_games = 48; p.num_parallel = 32; p.max_moves = 12; p.cache_entries_per_game = 2000; p.seed = 80; p.host_threads = 3;
         rc = dgnn_selfplay_go_boards(dgnn_pool_boards_predictor(), pool, nullptr, &p, &st, nullptr, nullptr, 0);

@@ -34,7 +34,8 @@ def main():
     ap.add_argument("--threads", type=int, default=8, help="search threads per game (the reference: --num-threads per pool)")
     ap.add_argument("--leaves", type=int, default=1, help="leaves a search thread keeps in flight per predictor call (1 = the reference's worker)")
     ap.add_argument("--max-batch", type=int, default=256)
-    ap.add_argument("--max-batches", type=int, default=0, help="device batches the pool keeps alive: 2 (the reference's rule), 3, or 0 (default) = adaptive, 2 or 3 by the unique positions per second the pool measures (dgnn_pool_set_adaptive_batches, DESIGN.md 13)")
+    ap.add_argument("--coalesce", type=int, default=1, help="1: requests for a position in flight follow it (dgnn_pool_set_coalescing; only with a shared table); 0: off")
+    ap.add_argument("--max-batches", type=int, default=2, help="device batches the pool keeps alive: 2 (the reference's rule, default), 3, or 0 = adaptive, 2 or 3 by the unique positions per second the pool measures (dgnn_pool_set_adaptive_batches, DESIGN.md 13)")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
@@ -69,6 +70,9 @@ def main():
     adaptive = args.max_batches == 0 and pool.takes_boards
     if adaptive:
         pool.set_adaptive_batches(2, 3)
+    coalesce = bool(args.coalesce) and pool.takes_boards and args.cache > 0 and not args.cache_per_game
+    if coalesce:
+        pool.set_coalescing(True)
     api.selfplay_go(2, 1, 16, 2, seed=1, pool=pool)          # warm: workspace, weight upload
     cache = api.LruCache(args.cache, 8) if args.cache > 0 else None
     before = pool.stats()
@@ -80,6 +84,7 @@ def main():
     host_cpus_busy = (time.process_time() - cpu0) / max(time.perf_counter() - wall0, 1e-9)
     after = pool.stats()
     adaptive_stats = pool.adaptive_stats() if adaptive else None
+    coalesced = pool.coalesced()
     if args.sgf:
         with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
             f.write("\n".join(stats.get("sgf", [])) + "\n")
@@ -100,7 +105,7 @@ def main():
             "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1),
             "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
             "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
-            "batches_alive": adaptive_stats if adaptive else args.max_batches,
+            "batches_alive": adaptive_stats if adaptive else args.max_batches, "coalescing": coalesce, "coalesced_boards_rank0": coalesced,
             "feature_planes": args.planes, "host_threads": args.host_threads, "host_cpus_busy_rank0": host_cpus_busy,
             "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
             "sharding": "game_id mod world, one engine + batcher + pool + cache per rank, no data-path collective",
