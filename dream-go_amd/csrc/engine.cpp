@@ -176,6 +176,8 @@ int get_device_state(Network* net, int device, DeviceState** out, bool upload = 
         if (upload && !state->image_valid) {          // reserved for a transfer that never filled it: never run on garbage
             DGNN_HIP(hipSetDevice(device));
             DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
+            DGNN_HIP(hipDeviceSynchronize());         // (a copy from pageable memory may return with the DMA still on its way; the
+                                                      // workspaces' streams are non-blocking and would not wait for it)
             state->image_valid = true;
         }
         *out = state;
@@ -196,6 +198,7 @@ int get_device_state(Network* net, int device, DeviceState** out, bool upload = 
     DGNN_HIP(hipMalloc((void**)&state->d_image, net->image.size()));
     if (upload) {
         DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
+        DGNN_HIP(hipDeviceSynchronize());
         state->image_valid = true;
     }
 
@@ -298,7 +301,14 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
 
     DGNN_HIP(hipMalloc(&ws->arena, total));
     // board path: pad rows 384..399 of every k-slot are never written by the kernels and must read as zero
-    if (ws->use_board) DGNN_HIP(hipMemset(ws->arena, 0, total));
+    if (ws->use_board) {
+        DGNN_HIP(hipMemset(ws->arena, 0, total));
+        // hipMemset is asynchronous to the host and runs on the NULL stream; the workspace's stream is non-blocking and does not wait
+        // for it.  Without this the first pass could run beside (or ahead of) its own arena being zeroed: found in round 4 by two
+        // processes starting on one GPU at the same moment -- the first forward of one of them differed from all its later ones
+        // (tools/diag_two_procs.py: 1 438 policy entries).
+        DGNN_HIP(hipDeviceSynchronize());
+    }
     uint8_t* p = (uint8_t*)ws->arena;
     ws->d_features = (uint16_t*)p; p += sz_features;
     for (int i = 0; i < 3; ++i) { ws->d_act[i] = (uint16_t*)p; p += sz_act; }
@@ -466,6 +476,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     for (size_t l = 0; l + 1 < layers.size(); ++l) { layers[l].w_next = layers[l + 1].w; layers[l + 1].carry_in = 1; }
                 if (!ws->d_tower_layers) DGNN_HIP(hipMalloc((void**)&ws->d_tower_layers, (layers.size() + 1) * sizeof(ConvBoardLaunch)));
                 DGNN_HIP(hipMemcpy(ws->d_tower_layers, layers.data(), layers.size() * sizeof(ConvBoardLaunch), hipMemcpyHostToDevice));
+                DGNN_HIP(hipDeviceSynchronize());      // (pageable source, NULL stream: the launch below is on a non-blocking stream)
                 ws->tower_layers_ready = true;
             }
             const int layer_count = 2 * t.num_blocks + (up_in_tower ? 1 : 0);
@@ -1695,6 +1706,7 @@ int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src
         } else {
             DGNN_HIP(hipMemcpy(d->d_image, n->image.data(), num_bytes, hipMemcpyHostToDevice));
         }
+        DGNN_HIP(hipDeviceSynchronize());            // the copy has LANDED before a (non-blocking) workspace stream may read the image
         d->image_valid = true;
         for (Workspace* ws : d->all) ws->tower_layers_ready = false;   // the cached descriptors hold the old gates
     }

@@ -324,3 +324,23 @@ def test_a_network_destroyed_under_a_checked_out_workspace_lives_until_the_relea
         again = _bits(api.forward(ws2, features).unwrap())
     other.destroy()
     assert np.array_equal(again[1], want[1])
+
+
+def test_first_forward_of_two_processes_starting_together_is_deterministic():
+    """Round 4: two processes that create their workspaces on one GPU at the same moment -- the first forward of a process used to run
+    beside the (asynchronous, NULL-stream) zeroing of its own arena, because the workspace's stream is non-blocking: 1 438 policy entries
+    of a first pass differed from every later one (tools/diag_two_procs.py).  Twelve forwards of the same input in each of two concurrent
+    processes: all bit-equal."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_two_procs.py")], capture_output=True, text=True, timeout=400,
+                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert done.returncode == 0, done.stderr[-1500:]
+    reports = [json.loads(m) for m in re.findall(r"RESULT (\{.*?\})['\"]", done.stdout)]
+    assert len(reports) == 4, done.stdout[-2000:]                  # two modes (plain, with a refused RCCL communicator) x two ranks
+    for r in reports:
+        assert all(dv == 0 and dp == 0 for _, dv, dp in r["diffs_vs_first"]), r

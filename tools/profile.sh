@@ -8,7 +8,9 @@ mkdir -p $out
 cd /tmp
 export TMPDIR=/tmp
 cmd="python $root/bench.py --steps 3 --warmup 1 --lean"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python $root/bench.py --steps 10 --warmup 2 --lean > $out/trace.log 2>&1
+# 40 timed passes (+ 5 warm-up): the AVERAGE launch duration of the dominant kernel in kernel_stats.csv is what the bench line's
+# roofline.launch_us must agree with (12 launches with one outlier did not)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python $root/bench.py --steps 40 --warmup 5 --lean > $out/trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $out/pmc_sq -o p --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- $cmd > $out/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $out/pmc_fetch -o p --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- $cmd > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $out/pmc_write -o p --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $cmd > $out/pmc_write.log 2>&1
