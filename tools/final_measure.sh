@@ -11,6 +11,20 @@ timeout 400 python tools/sweep.py --blocks 20 --channels 256 --batches 1,8,16,32
 timeout 300 python tools/sweep.py --blocks 9 --channels 128 --batches 1,8,16,32,64,128,256 > $out/batch_sweep_9x128.jsonl 2>/dev/null
 timeout 300 python bench.py --lean --blocks 9 --channels 128 --batch 32 --steps 50 > $out/bench_9x128_b32.json 2>/dev/null
 timeout 400 python -m pytest tests/test_round4_gpu.py -q -m gpu -s --timeout 200 -p no:cacheprovider 2>&1 | grep -E "^(sharp|centered)|^   |passed|failed" > $out/parity_ulps.txt
+DGNN_SPLIT_INJECT_GIVEUP=2 timeout 100 python - > $out/giveup_latency.txt 2>&1 <<PY
+import sys, time
+sys.path.insert(0, ".")
+import __graft_entry__ as graft
+graft.package()
+from dream_go_amd import api, synth
+net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 256, seed=650)))
+features = synth.make_features(16, seed=651)
+ws = net.get_workspace(16)
+t0 = time.perf_counter(); api.forward(ws, features); t1 = time.perf_counter()
+api.forward(ws, features); t2 = time.perf_counter()
+print(f"split tower launched without its last eight workgroups (DGNN_SPLIT_INJECT_GIVEUP=2): first pass {1e3 * (t1 - t0):.1f} ms end to end "
+      f"(the give-up after 50 ms of s_memrealtime + the pass repeated per layer), next pass {1e3 * (t2 - t1):.2f} ms")
+PY
 timeout 600 python -m pytest tests -x -q -m gpu --timeout 200 -p no:cacheprovider > $out/gpu_suite.log 2>&1; echo "suite rc $?"; tail -2 $out/gpu_suite.log
 python - <<PY
 import json
