@@ -266,12 +266,14 @@ struct Split {
     static constexpr int WAVES = NS == 1 ? 12 : (NS == 16 || NS == 24) ? 4 : NS == 32 ? 6 : 8;
     static constexpr int MinWavesPerSimd = NS == 24 ? 2 : 1;          // __launch_bounds__: the pair split must leave room for its sibling
     static constexpr int Threads = WAVES * 64;
-    static constexpr int XP = (4 * (NS == 32 ? 5 : kPieces) + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated) or 7
+    static constexpr int XP = (4 * (NS == 32 ? 4 : NS <= 2 ? 6 : kPieces) + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated), 7, 3 (row split), 2 / 3 (twelve / eight waves)
     static constexpr int RG = WAVES / CW;              // row groups of the workgroup
     static constexpr int RT = 12 / RS / RG;            // 32-row MFMA tiles per wave
     // activation pieces (64 rows) per k-slot the workgroup fetches: all seven, or -- a row half needs its 192 rows and 21 above /
-    // below -- pieces 0..4 (upper half) / 2..6 (lower half)
-    static constexpr int XPS = RS == 2 ? 5 : kPieces;
+    // below -- pieces 0..3 (upper half: rows 0..212 of 0..255) / 2..5 (lower half: rows 171..383; what lies below row 383 is the pad row
+    // and beyond, zeros that the workgroup writes into its LDS once per layer instead of fetching them: round 3 fetched five pieces each)
+    // The chunked whole-board splits (NS = 1, 2) fetch six: rows 384..447 of piece 6 are the pad row and what lies behind the board.
+    static constexpr int XPS = RS == 2 ? 4 : (NS <= 2 ? 6 : kPieces);
     static constexpr int first_piece(int rh) { return RS == 2 && rh ? 2 : 0; }
     static constexpr int W = 2 * CT;                   // DMA instructions (1 KiB fragments) per filter slab: (tile, k16)
     static constexpr int SlabBytes = W * 1024;
@@ -279,7 +281,21 @@ struct Split {
     static constexpr int FChunkBytes = 9 * SL * 2048;  // Chunked: the workgroup's filter rows of one chunk, [tap][slice][k16][lane][8]
     static constexpr int BufStride = Chunked ? kXBufBytes + FChunkBytes : kXBufBytes;   // one of the two chunk buffers
     static constexpr int LdsBytes = Chunked ? 2 * BufStride : DirectA ? kWBase : kWBase + WAVES * RingBytes;
-    static constexpr int Pieces = 4 * XPS + 18 * SL;                // Chunked: DMA instructions per chunk, activations then filter
+    // StageF (round 4, the one-slice chunked splits): the workgroup's filter rows of the NEXT chunk do not come by LDS-DMA but by
+    // ordinary 16-byte global loads into registers (FPW per wave, requested at the start of the chunk) that are written to the other
+    // buffer with ds_write_b128 at the chunk boundary.  Why: per-tap stamps (tools/tap_trace.py, 9x128 batch 32) show the taps that
+    // carry no DMA at 125-165 cycles and a 1 000-cycle wait at every chunk boundary for the chunk's 38 KB to land -- 256 workgroups x
+    // 38 KB per 3 180 cycles is 12 B per clock and CU, 6.5 TB/s chip-wide: the rate of the LDS-DMA path itself (the guide's "all-LDS-DMA
+    // prologue: 12-13 B/cyc/CU").  Half of those bytes are the filter, which the vector L1 path can carry instead.
+    // MEASURED (tools/ab_stage.sh, profiles/r04/ab_stage_filter.txt, same box): no gain -- 9x128 batch 32 155.9-158.8 k against 156.1-157.4 k
+    // evals/s, 20x256 batch 32 46.8 k against 49.4 k.  The limit is not the LDS-DMA path but what a CU can pull through the fabric when
+    // all 256 do (11-13 B per clock and CU either way).  Off by default; bit-identical when on.
+#ifndef DGNN_STAGE_FILTER
+#define DGNN_STAGE_FILTER 0
+#endif
+    static constexpr bool StageF = DGNN_STAGE_FILTER != 0 && Chunked && SL == 1;
+    static constexpr int FPW = StageF ? (18 * SL + WAVES - 1) / WAVES : 0;      // staged filter pieces (1 KiB) per wave and chunk: 3 (six waves) / 2 (twelve)
+    static constexpr int Pieces = StageF ? 4 * XPS : 4 * XPS + 18 * SL;          // Chunked: DMA instructions per chunk, activations then (unless staged) filter
     static constexpr int PPW = (Pieces + WAVES - 1) / WAVES;        // ... per wave (4 at NS = 1, 8 at NS = 2; surplus ones repeat)
     // Chunked: piece j of a wave goes out behind the MFMA of pair piece_pair(j) of tap piece_tap(j) (early in the chunk: it
     // has to land before the chunk barrier)
@@ -466,6 +482,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
 
     const bool tracing = a.timing != nullptr || (SPLIT && sync.trace != nullptr);
     const unsigned long long t_start = tracing ? __builtin_amdgcn_s_memtime() : 0;
+#ifdef DGNN_TAP_STAMPS      // measurement builds only (tools/build_variant.sh, tools/tap_trace.py): where the taps of ONE chunk start, per wave
+    unsigned long long tap_stamp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // ---- zero the halo rows of both activation buffers (never touched by the DMA) ----
     if (tid < 2 * 4 * kHalo) {
@@ -474,6 +493,8 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         const int slot = rem / kHalo;
         const int row = rem - slot * kHalo;
         *reinterpret_cast<uint4*>(lds + buf * BUF + slot * kSlotBytes + row * 16) = make_uint4(0, 0, 0, 0);
+        // row split (lower half) and the chunked whole-board splits: rows 384..404 (the pad row and what a tap of row 383 reaches below it) are never fetched
+        if ((RS == 2 && rh == 1) || S::XPS == 6) *reinterpret_cast<uint4*>(lds + buf * BUF + slot * kSlotBytes + (kHalo + 384 + row) * 16) = make_uint4(0, 0, 0, 0);
     }
 
     const uint16_t* const x_board = a.x + (long)b * cin * kRows + lane * 8;
@@ -535,6 +556,28 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         } else {
             issue_f(f_chunk, buf, p - 4 * S::XPS);
         }
+    };
+    // StageF: this wave's FPW filter pieces of `chunk` requested into registers / written to buffer `buf` (piece q = wave + WAVES * k; a
+    // surplus one repeats the previous: same bytes to the same place)
+    u32x4 fstage[S::FPW > 0 ? S::FPW : 1];
+    auto stage_f_load = [&](int chunk) {
+        static_for<S::FPW>([&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            int q = wave + S::WAVES * K;
+            if (q >= 18 * SL) q -= S::WAVES;
+            const int tap = q / (2 * SL), rest = q - tap * (2 * SL);
+            const int st = chunk * 9 + tap;
+            const uint16_t* src = (st >= nsteps_total ? w_next_group : w_group) + (long)st * step_halfs + rest * 512;
+            load_row_asm<false>(fstage[K], src);
+        });
+    };
+    auto stage_f_store = [&](int buf) {       // the caller has waited for the loads (vmcnt) and names the registers
+        static_for<S::FPW>([&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            int q = wave + S::WAVES * K;
+            if (q >= 18 * SL) q -= S::WAVES;
+            *reinterpret_cast<u32x4*>(lds + buf * BUF + kXBufBytes + q * 1024 + lane * 16) = fstage[K];
+        });
     };
     // SPLIT: the flag of the workgroup that produces input chunk c (its channel block is c / SL).  Row split: a channel block has
     // two producers, flags [block][row half]; a consumer needs its own half of the rows and 21 of the other one, so BOTH -- its own
@@ -759,10 +802,18 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             constexpr bool FIRST = TAP == 0, LAST = TAP == 8;
             constexpr int P = PIPE ? (TAP & 1) : 0;
             constexpr int PH = PIPE ? (TAP * NP) % BD : 0;        // where the rotation stands at the start of this step
+#ifdef DGNN_TAP_STAMPS
+            if (chunk == 1) tap_stamp[TAP] = __builtin_amdgcn_s_memtime();
+#endif
 
             if constexpr (!PIPE) {
                 if constexpr (!(ABL & 8)) wait_vmcnt<N>();
                 read_a(std::integral_constant<int, 0>(), std::integral_constant<int, WOFF>(), w_addr);
+            }
+            if constexpr (S::StageF && FIRST) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_f_load(chunk + 1);          // (chunks past the last one: the next layer's first chunk, or padding nobody reads)
+                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (CHUNKED && FIRST) read_a(std::integral_constant<int, 0>(), std::integral_constant<int, WOFF>(), w_addr_c);
             if constexpr (!PIPE || FIRST) {
@@ -891,6 +942,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         step(std::integral_constant<int, 6>());
         step(std::integral_constant<int, 7>());
         step(std::integral_constant<int, 8>());
+#ifdef DGNN_TAP_STAMPS
+        if (chunk == 1) tap_stamp[9] = __builtin_amdgcn_s_memtime();
+#endif
 
         // chunk boundary: this wave's pieces of the next chunk landed at tap 8's wait (issued at taps 0..3, at
         // least 5 slabs ago); its reads of this chunk retired with the MFMAs above.  With seven pieces per wave (taps 0..6)
@@ -898,7 +952,15 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         if constexpr (CHUNKED) {
             // every piece of the next chunk this wave asked for has landed (tap 8 left no LDS read in flight); the barrier
             // below publishes all of them
-            wait_vmcnt<0>();
+            if constexpr (S::StageF) {
+                if constexpr (S::FPW == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(fstage[0]), "+v"(fstage[1]), "+v"(fstage[2]) :: "memory");
+                else if constexpr (S::FPW == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(fstage[0]), "+v"(fstage[1]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fstage[0]) :: "memory");
+                stage_f_store(buf ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the writes are in the LDS before this wave reaches the barrier
+            } else {
+                wait_vmcnt<0>();
+            }
         } else if constexpr (XP > 4) {
             wait_vmcnt<WI * (8 - (XP - 1))>();
         }
@@ -931,6 +993,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
         }
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DGNN_TAP_STAMPS
+        if (chunk == 1) tap_stamp[10] = __builtin_amdgcn_s_memtime();
+#endif
     };
     int first_loop_chunk = 1;
     if constexpr (SKIP == 2) {          // the launcher guarantees nchunks >= 2
@@ -1081,6 +1146,14 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
             unsigned long long* out = sync.trace + (((long)sync.epoch * a.batch + b) * sync.groups + nb * RS + rh) * 4;
             out[0] = t_start; out[1] = t_loop; out[2] = t_epilogue | (x0_next ? 1ull << 63 : 0ull); out[3] = __builtin_amdgcn_s_memtime();
         }
+#ifdef DGNN_TAP_STAMPS
+        if (sync.trace != nullptr && lane == 0 && wave < 12) {      // behind the regular records: [layer][board][group][12 waves][12]
+            unsigned long long* out = sync.trace + (long)gridDim.x * 0 + (long)a.batch * sync.groups * 4 * DGNN_TAP_STAMPS +
+                                      ((((long)sync.epoch * a.batch + b) * sync.groups + nb * RS + rh) * 12 + wave) * 12;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) out[k] = tap_stamp[k];
+        }
+#endif
     }
     return (x0_next ? kX0InFlight : 0) | (hand_over ? kHandedOver : 0) | (buf_next ? kStartBuffer : 0);
 }

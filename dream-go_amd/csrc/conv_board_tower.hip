@@ -134,7 +134,12 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
     // measurement only: DGNN_SPLIT_TRACE=<file> dumps wave 0's stamps of every (layer, board, channel block) of each launch
     static const char* const trace_path = std::getenv("DGNN_SPLIT_TRACE");
     unsigned long long* d_trace = nullptr;
+#ifdef DGNN_TAP_STAMPS      // -DDGNN_TAP_STAMPS=<layers of the launch>: the per-tap stamps sit behind the regular records
+    const size_t trace_words = (size_t)count * batch * groups * 4 + (size_t)count * batch * groups * 12 * 12;
+    if (count != DGNN_TAP_STAMPS) { std::fprintf(stderr, "dgnn: built with DGNN_TAP_STAMPS=%d for a launch of %d layers\n", DGNN_TAP_STAMPS, count); return hipErrorInvalidValue; }
+#else
     const size_t trace_words = (size_t)count * batch * groups * 4;
+#endif
     if (trace_path && *trace_path) {
         if (hipMalloc((void**)&d_trace, trace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
