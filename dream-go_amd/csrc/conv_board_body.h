@@ -404,6 +404,16 @@ __device__ __forceinline__ void load_row_asm(u32x4& dst, const uint16_t* p)
     if constexpr (SPLIT) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");   // "sc1 both sides", like the DMA of the input chunks
     else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+// The same load with the destination TIED ("+v"): for a load that sits under a wave-uniform branch (the skip rows of the splits in which
+// a wave owns only some row tiles).  An "=v" destination is a new value; at the join behind the branch hipcc would have to merge it with
+// the old one and may do so with a copy -- of a register whose data has not landed (tools/asm_lint.py finds such copies).  Tied, old and
+// new value are one register and there is nothing to merge.
+template <bool SPLIT>
+__device__ __forceinline__ void load_row_asm_tied(u32x4& dst, const uint16_t* p)
+{
+    if constexpr (SPLIT) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(p) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_z(u32x4& z0, u32x4& z1)
 {
@@ -641,6 +651,21 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
     const long ep_base = (((long)b * (cout / 8) + co_base / 8 + slot_of_lane) * kRows) * 8;
     auto row_of = [&](int rt16) { return g * (RT * 32) + rt16 * 16 + (lane & 15); };
     u32x4 zl[CT][2];                                  // one 32-row tile of z in flight: per 32-channel tile its two 16-row halves
+    // OwnerZ (round 4): in the splits where a wave owns only SOME of the board's twelve 32-row tiles (RT < 12) a wave used to request
+    // zeros in the slots of tiles it does not own and WAIT for them like for real rows -- a counted vmcnt, which (memory operations
+    // complete in order) also waits for every DMA piece issued before it: per-tap stamps of the row split show 500-860 cycles per tap
+    // in taps 1..6 of a skip layer's first two chunks against 125-350 without (tools/tap_trace.py; a fifth of a skip layer).  Now only
+    // the OWNER of a slot loads, waits and adds (wave-uniform branches); for an output the summation order is what it was (the
+    // zeros the other waves used to add changed nothing: x + 0 = x, and the accumulators never hold -0).
+#ifndef DGNN_OWNER_Z
+#define DGNN_OWNER_Z 1
+#endif
+    // (Chunked splits only: the four-slice split counts its filter loads' vmcnt on the assumption that EVERY wave issued the skip rows.)
+    constexpr bool OWNER_Z = DGNN_OWNER_Z != 0 && SKIP == 2 && RT < 12 && CHUNKED;
+    if constexpr (OWNER_Z) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { zl[ct][0] = u32x4{0, 0, 0, 0}; zl[ct][1] = u32x4{0, 0, 0, 0}; }
+    }
     const uint16_t* const z_lane = a.z + ep_base + row_of(0) * 8;
     // Row tile `rt` (32 rows) of this wave -- or, for a wave that does not own board row tile T (`mine` false), ZEROS: the same
     // k-slots' pad rows 384..399, which no kernel ever writes.  A load either way, never a branch: at the join of a branch hipcc
@@ -654,8 +679,10 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int half = 0; half < 2; ++half)      // rows rt * 32 + half * 16 .., k-slot ct * 4 + sigma(h)
-                load_row_asm<SPLIT>(zl[ct][half], p + (long)(ct * 4 * kRows) * 8 + half * half_stride);
+            for (int half = 0; half < 2; ++half) {    // rows rt * 32 + half * 16 .., k-slot ct * 4 + sigma(h)
+                if constexpr (OWNER_Z) load_row_asm_tied<SPLIT>(zl[ct][half], p + (long)(ct * 4 * kRows) * 8 + half * half_stride);
+                else load_row_asm<SPLIT>(zl[ct][half], p + (long)(ct * 4 * kRows) * 8 + half * half_stride);
+            }
     };
     const float zscale = SKIP == 2 ? a.alpha2 / a.alpha1 : 0.0f;
     auto add_z_tile = [&](auto rt_c, auto ct_c) {
@@ -920,16 +947,30 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                 // the z rows requested at the end of the previous step are this wave's youngest memory operations but for
                 // the DMA instructions this step has issued
                 constexpr int YOUNGER_VM = CHUNKED ? S::pieces_in_tap(TAP) : WI + (TAP < XP);
-                if constexpr (CT == 1) wait_z<YOUNGER_VM>(zl[0][0], zl[0][1]);
-                else wait_z<YOUNGER_VM>(zl[0][0], zl[0][1], zl[CT - 1][0], zl[CT - 1][1]);
-                __builtin_amdgcn_sched_barrier(0);
-                add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>());
+                if constexpr (OWNER_Z) {
+                    // wave-uniform branch: only the owner of this slot has rows in flight, and only the owner adds.  (Every other wave
+                    // used to add zeros here -- exact, and 350 cycles per slot with its two fences: eleven of a wave's twelve slots in
+                    // the row split.)  Inside the branch: the counted wait, the fences around the tile, VALU code; the accumulators
+                    // are tied asm operands on both sides of the join.
+                    if ((ZC * 6 + TAP - 1) / RT == g) {
+                        if constexpr (CT == 1) wait_z<YOUNGER_VM>(zl[0][0], zl[0][1]);
+                        else wait_z<YOUNGER_VM>(zl[0][0], zl[0][1], zl[CT - 1][0], zl[CT - 1][1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>());
+                    }
+                } else {
+                    if constexpr (CT == 1) wait_z<YOUNGER_VM>(zl[0][0], zl[0][1]);
+                    else wait_z<YOUNGER_VM>(zl[0][0], zl[0][1], zl[CT - 1][0], zl[CT - 1][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add_z_unit(std::integral_constant<int, (ZC * 6 + TAP - 1) % RT>());
+                }
             }
             // extra memory operations only make the counted waits above more conservative (they require that many
             // more of the OLDER operations to have completed), never unsafe
             if constexpr (ZC >= 0 && TAP <= 5 && ZC * 6 + TAP < 12) {
                 constexpr int T = ZC * 6 + TAP;
-                load_z_unit(T % RT, RT == 12 || T / RT == g);
+                if constexpr (OWNER_Z) { if (T / RT == g) load_z_unit(T % RT, true); }
+                else load_z_unit(T % RT, RT == 12 || T / RT == g);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
