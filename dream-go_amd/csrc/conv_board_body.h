@@ -660,8 +660,9 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
 #ifndef DGNN_OWNER_Z
 #define DGNN_OWNER_Z 1
 #endif
-    // (Chunked splits only: the four-slice split counts its filter loads' vmcnt on the assumption that EVERY wave issued the skip rows.)
-    constexpr bool OWNER_Z = DGNN_OWNER_Z != 0 && SKIP == 2 && RT < 12 && CHUNKED;
+    // (The four-slice split counts its filter loads' vmcnt with the skip rows of the previous tap among the younger operations: that
+    // count follows the ownership too -- wait_a below.)
+    constexpr bool OWNER_Z = DGNN_OWNER_Z != 0 && SKIP == 2 && RT < 12;
     if constexpr (OWNER_Z) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { zl[ct][0] = u32x4{0, 0, 0, 0}; zl[ct][1] = u32x4{0, 0, 0, 0}; }
@@ -859,7 +860,13 @@ __device__ __forceinline__ int conv_board_body(const ConvBoardLaunch& a, char* c
                         constexpr int PT = (TAP + 8) % 9;                         // the previous tap
                         constexpr bool Z_PREV = ZC >= 0 && TAP >= 1 && PT <= 5 && ZC * 6 + PT < 12;
                         constexpr int N_A = FIRST ? 0 : (PT < XP ? 1 : 0) + (Z_PREV ? 2 * CT : 0);
-                        wait_a<N_A>();
+                        if constexpr (OWNER_Z && Z_PREV) {
+                            // only the owner of the previous tap's slot has skip rows among its younger operations (wave-uniform)
+                            if ((ZC * 6 + PT) / RT == g) wait_a<N_A>();
+                            else wait_a<N_A - 2 * CT>();
+                        } else {
+                            wait_a<N_A>();
+                        }
                         wait_lgkm<YOUNGER>(bf[PH % BD]);
                     }
                     else if constexpr (I == 0) wait_first(std::integral_constant<int, YOUNGER>(), std::integral_constant<int, P>(), bf[PH % BD]);

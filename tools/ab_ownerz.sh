@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r4i
 timeout 500 python -m pytest tests/test_parity_gpu.py tests/test_round2_gpu.py tests/test_round3_gpu.py tests/test_round4_gpu.py -q -m gpu --timeout 200 -p no:cacheprovider 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-160
 for rep in 1 2; do
   for lib in gpurun_libs/libdgnn_noownerz.so ""; do
-    for shape in "9 128 8,16,32,64" "20 256 8,16,32,64" "6 64 16,64"; do
+    for shape in "20 256 65,96,128" "9 128 192,256" "6 64 256"; do
       set -- $shape
       DGNN_LIBRARY=$lib timeout 200 python tools/sweep.py --blocks $1 --channels $2 --batches $3 --steps 50 2>/dev/null | python -c "import sys,json
 for l in sys.stdin:
