@@ -227,6 +227,7 @@ SYMBOLS = [
     ("dgnn_pool_generation", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_set_adaptive_batches", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_set_coalescing", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("dgnn_pool_set_extra_batch_queue", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_coalesced", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_adaptive_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                                ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
@@ -940,6 +941,10 @@ class LeafPool:
     def generation(self):
         """Completed pauses (weight refreshes) so far."""
         return int(lib.dgnn_pool_generation(self._handle))
+
+    def set_extra_batch_queue(self, lo, hi, min_queued):
+        """`lo` batches alive per lane, up to `hi` while at least `min_queued` boards are waiting (include/dgnn.h); min_queued 0: off."""
+        _check(lib.dgnn_pool_set_extra_batch_queue(self._handle, int(lo), int(hi), int(min_queued)), "LeafPool.set_extra_batch_queue")
 
     def set_coalescing(self, enabled=True):
         """Requests for a position that is already in flight follow it instead of being evaluated again (include/dgnn.h)."""

@@ -451,6 +451,10 @@ uint64_t dgnn_pool_coalesced(const dgnn_pool* pool);        /* boards that follo
  * stones and the colour to move of every record against a table of recent ones -- under both settings in alternating windows of 32 768
  * boards and stays with the better one, probing again every dozen windows.  lo == hi == 0: back to the constant. */
 int dgnn_pool_set_adaptive_batches(dgnn_pool* pool, int lo, int hi);
+/* The rule that measured better than both constants: `lo` batches alive per lane, up to `hi` only while at least `min_queued` boards
+ * are waiting -- an extra batch that comes out full keeps the device supplied, one that splits the same few leaves over more batches
+ * only makes every batch smaller.  min_queued == 0: off. */
+int dgnn_pool_set_extra_batch_queue(dgnn_pool* pool, int lo, int hi, int min_queued);
 int dgnn_pool_adaptive_stats(dgnn_pool* pool, int* alive_per_lane, uint64_t* switches, uint64_t* boards_hashed, uint64_t* boards_repeated,
                              double* unique_rate_lo, double* unique_rate_hi);
 

@@ -365,3 +365,22 @@ def test_requests_for_a_position_in_flight_follow_it(api):
     with pytest.raises(api.Error):
         features_pool.set_coalescing(True)
     features_pool.close()
+
+
+def test_a_third_batch_only_while_enough_boards_wait(api):
+    """dgnn_pool_set_extra_batch_queue: two batches alive per lane, a third only while at least `min_queued` boards are waiting."""
+    import pytest
+    pool = api.LeafPool.over_dry_device(base_us=0.0, per_board_us=0.0, max_batch_size=64, batches_per_lane=3, workers_per_lane=3)
+    with pytest.raises(api.Error):
+        pool.set_extra_batch_queue(2, 4, 64)                 # more than the pool has workers for
+    with pytest.raises(api.Error):
+        pool.set_extra_batch_queue(0, 3, 64)
+    pool.set_extra_batch_queue(2, 3, 64)
+    assert pool.adaptive_stats()["alive_per_lane"] == 2     # nothing waits: the reference's rule
+    board = api.Board(7.5)
+    board.place(0, 3, 3)
+    for _ in range(50):
+        assert len(pool.predict_boards(np.concatenate([board.record(1, s) for s in range(8)]), 8)) == 8
+    pool.set_extra_batch_queue(0, 0, 0)
+    assert pool.adaptive_stats()["alive_per_lane"] == 3     # back to the constant the pool was created with
+    pool.close()
