@@ -69,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-coalesce", type=int, default=1,
                     help="1 (default): a request for a position that is already queued or on the device follows it instead of being evaluated "
                          "again (dgnn_pool_set_coalescing: what the shared transposition table does, one evaluation earlier); 0: the reference's behaviour")
-    ap.add_argument("--selfplay-host-threads", type=int, default=2,
+    ap.add_argument("--selfplay-host-threads", type=int, default=4,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
                     help="where the 32 feature planes are built: on the device from 896-byte board records (default), or on the host like the reference")

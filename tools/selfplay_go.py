@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--sgf", default=None)
     ap.add_argument("--planes", choices=["device", "host"], default="device",
                     help="where the feature planes are built: on the device from 896-byte board records (dgnn_forward_boards), or on the host")
-    ap.add_argument("--host-threads", type=int, default=2, help="the games in flight run as fibers on this many host threads (0 = one OS thread per game)")
+    ap.add_argument("--host-threads", type=int, default=4, help="the games in flight run as fibers on this many host threads (0 = one OS thread per game)")
     args = ap.parse_args()
 
     # one process per GPU (python -m torch.distributed.run --nproc-per-node N tools/selfplay_go.py ...): every rank owns an
