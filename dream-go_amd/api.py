@@ -227,6 +227,7 @@ SYMBOLS = [
     ("dgnn_pool_generation", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_set_adaptive_batches", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_set_coalescing", ctypes.c_int, [_vp, ctypes.c_int]),
+    ("dgnn_pool_set_min_fill", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_set_extra_batch_queue", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_coalesced", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_adaptive_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
@@ -945,6 +946,10 @@ class LeafPool:
     def set_extra_batch_queue(self, lo, hi, min_queued):
         """`lo` batches alive per lane, up to `hi` while at least `min_queued` boards are waiting (include/dgnn.h); min_queued 0: off."""
         _check(lib.dgnn_pool_set_extra_batch_queue(self._handle, int(lo), int(hi), int(min_queued)), "LeafPool.set_extra_batch_queue")
+
+    def set_min_fill(self, min_boards, max_wait_us):
+        """While another batch keeps the device busy a free slot waits for `min_boards` (or `max_wait_us`); 0: off (include/dgnn.h)."""
+        _check(lib.dgnn_pool_set_min_fill(self._handle, int(min_boards), int(max_wait_us)), "LeafPool.set_min_fill")
 
     def set_coalescing(self, enabled=True):
         """Requests for a position that is already in flight follow it instead of being evaluated again (include/dgnn.h)."""

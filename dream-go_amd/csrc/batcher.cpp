@@ -142,6 +142,7 @@ struct Batcher {
     std::vector<std::vector<uint64_t>> spare_tags;       // (and fault its pages in) under the lock after every hand-over
     std::atomic<int> num_batches{0};
     std::atomic<int> queued{0};     // == tags.size(), readable without the lock (the pool workers' wake-up predicate)
+    std::atomic<long long> first_queued_us{0};   // when the oldest board now waiting was queued (steady clock; LeafPool::min_fill)
     std::atomic<uint64_t> boards_evaluated{0}, batches_evaluated{0};
     std::atomic<int> refs{1};       // the handle + every batch split off it: a batch may outlive dgnn_batcher_destroy
 
@@ -287,11 +288,26 @@ struct LeafPool {
     std::unordered_map<uint64_t, InFlight> inflight;                    // position -> who leads it, and the slots that follow
     std::atomic<uint64_t> coalesced{0};
     std::atomic<uint64_t> calls{0};
+    // Minimum fill (dgnn_pool_set_min_fill): a workgroup per board makes a batch of 130 boards take as long as one of 256, so while
+    // ANOTHER batch keeps the device busy a free slot is not filled with whatever happens to be queued the moment it frees (a handful
+    // of boards: the games the finished batch woke have not produced their next leaves yet) but waits until `min_fill` boards are
+    // there -- or `max_wait_us` have passed since the oldest of them was queued, or nothing else is alive.
+    std::atomic<int> min_fill{0};
+    std::atomic<int> max_wait_us{0};
 
     bool ready() const
     {
-        return batcher->queued.load(std::memory_order_acquire) > 0 &&
-               batcher->num_batches.load(std::memory_order_acquire) < batcher->alive_limit();
+        const int queued = batcher->queued.load(std::memory_order_acquire);
+        const int alive = batcher->num_batches.load(std::memory_order_acquire);
+        if (queued <= 0 || alive >= batcher->alive_limit()) return false;
+        const int fill = min_fill.load(std::memory_order_relaxed);
+        if (fill <= 0 || alive == 0 || queued >= fill) return true;
+        const long long waited = now_us() - batcher->first_queued_us.load(std::memory_order_acquire);
+        return waited >= max_wait_us.load(std::memory_order_relaxed);
+    }
+    static long long now_us()
+    {
+        return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
     // state the predicate reads changes outside `mutex` (under the batcher's): passing through the mutex before the notify
     // closes the window between a worker's predicate check and its going to sleep
@@ -312,9 +328,12 @@ struct LeafPool {
                 // sleep until there is something queued AND a batch slot free (signalled by dgnn_pool_predict and by every
                 // batch that retires); the timeout only covers boards pushed into the batcher behind the pool's back
                 std::unique_lock<std::mutex> lock(mutex);
-                work.wait_for(lock, std::chrono::milliseconds(20), [&] { return stopping || (!paused && ready()); });
+                // (with a minimum fill the predicate also turns true by the clock: short naps while boards are waiting for company)
+                const bool holding = min_fill.load(std::memory_order_relaxed) > 0 && batcher->queued.load(std::memory_order_acquire) > 0;
+                work.wait_for(lock, holding ? std::chrono::microseconds(100) : std::chrono::microseconds(20000),
+                              [&] { return stopping || (!paused && ready()); });
                 if (stopping) return;
-                if (paused) continue;
+                if (paused || !ready()) continue;
                 ++evaluating;       // from here to done(): a pause waits for us
             }
             auto done = [&] {
@@ -542,6 +561,9 @@ static int batcher_push(Batcher* b, const uint16_t* item, uint64_t tag)
 {
     std::lock_guard<std::mutex> lock(b->mutex);                                 // batch.rs:80-84
     if (b->adaptive_hi.load(std::memory_order_relaxed) > 0 && b->records) b->note_record(item);
+    if (b->tags.empty())
+        b->first_queued_us.store(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
+                                 std::memory_order_release);
     b->features.insert(b->features.end(), item, item + b->item);
     b->tags.push_back(tag);
     b->queued.store((int)b->tags.size(), std::memory_order_release);
@@ -915,6 +937,17 @@ int dgnn_pool_set_extra_batch_queue(dgnn_pool* handle, int lo, int hi, int min_q
         b->extra_hi.store(hi);
         b->extra_min_queued.store(min_queued, std::memory_order_release);
     }
+    pool->work.notify_all();
+    return DGNN_OK;
+}
+
+int dgnn_pool_set_min_fill(dgnn_pool* handle, int min_boards, int max_wait_us)
+{
+    if (!handle || min_boards < 0 || max_wait_us < 0) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    if (min_boards > pool->batcher->max_batch_size) min_boards = pool->batcher->max_batch_size;
+    pool->max_wait_us.store(max_wait_us, std::memory_order_relaxed);
+    pool->min_fill.store(min_boards, std::memory_order_release);
     pool->work.notify_all();
     return DGNN_OK;
 }

@@ -442,6 +442,11 @@ int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool
  * (nn.rs:72-81), one evaluation earlier.  Like the shared table it makes WHICH evaluation a search sees a matter of timing: games that
  * must be a function of their seed (cache_entries_per_game > 0) keep it off.  DGNN_BUSY while requests are in flight. */
 int dgnn_pool_set_coalescing(dgnn_pool* pool, int enabled);
+/* Minimum fill: while ANOTHER batch keeps a device busy, a free batch slot waits until `min_boards` are queued -- or `max_wait_us` have
+ * passed since the oldest waiting board was queued -- instead of taking the handful that is there the moment the slot frees.  A
+ * workgroup per board makes 130 boards take as long as 256, so fuller batches are more evaluations per second.  0: off (the reference
+ * takes whatever is queued, batch.rs:93-121). */
+int dgnn_pool_set_min_fill(dgnn_pool* pool, int min_boards, int max_wait_us);
 uint64_t dgnn_pool_coalesced(const dgnn_pool* pool);        /* boards that followed instead of being evaluated */
 
 /* How many batches a pool keeps alive per lane.  The reference's rule is the constant 2 per device (predictors/nn.rs:64-67); a third
