@@ -326,7 +326,10 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
         "games_per_hour": moves_per_sec * 3600.0 / 250.0,
         "note": "games_per_hour = measured moves/s x 3600 / 250 stones (a trained net's game length; a random-init net plays to the "
                 "722-stone cap: whole games measured in profiles/, DESIGN.md section 8). " +
-                ("Mid-game stones." if fast_forward else "Opening moves only: games in flight share their first positions in the table."),
+                ("Mid-game stones." if fast_forward else "Opening moves only: games in flight share their first positions; with coalescing most "
+                 "requests FOLLOW a position that is already in flight (device batches of ~25 boards), so this leg is bound by the host threads "
+                 "and its host_cpus_busy / gpus_feedable_at_quota describe the first moves of a game, not a game: whole games keep 1.8 cores "
+                 "per GPU busy (profiles/r04_final/selfplay_full_games_*.json, DESIGN.md 13.5); the mid-game leg is the steady state."),
         "host_cpus": effective_cpus(),
         "host_cpu_affinity": f"{min(os.sched_getaffinity(0))}-{max(os.sched_getaffinity(0))} ({len(os.sched_getaffinity(0))} CPUs)",
         "host_cpus_busy": cpu_cores_busy,          # CPU time of rank 0's process over the leg / its wall time: cores kept busy
