@@ -60,7 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-rollouts", type=int, default=800, help="--num-rollout of the self-play leg (BASELINE.json: 800)")
     ap.add_argument("--selfplay-midgame", type=int, default=60,
                     help="second self-play leg: the searched stones start after this many stones of policy play (0 = skip that leg)")
-    ap.add_argument("--selfplay-leaves", type=int, default=8, help="leaves a search thread keeps on the device (dgnn_search_run_batched)")
+    ap.add_argument("--selfplay-leaves", type=int, default=16,
+                    help="leaves a search thread keeps on the device (dgnn_search_run_batched): one thread x 16 leaves = the reference's default of 16 "
+                         "parallel probes per search tree (--num-threads, libdg_utils/config.rs:143-149; rounds 1-3 ran 8)")
     ap.add_argument("--selfplay-batches", type=int, default=2,
                     help="device batches the leaf pool keeps alive per GPU.  The reference keeps 2 (nn.rs:64-67); a third raises the engine's "
                          "rate on partial batches and puts more leaves in flight (more positions evaluated twice before the first answer "
