@@ -325,7 +325,9 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
         "probe_conflicts": j["conflicts"],
         "moves_per_sec": moves_per_sec,
         "assumed_stones_per_game": 250,
-        "games_per_hour": moves_per_sec * 3600.0 / 250.0,
+        # the opening leg's moves per second are those of the first stones only (with coalescing: host-bound, tiny device batches); only the
+        # mid-game leg is extrapolated to games per hour
+        "games_per_hour": moves_per_sec * 3600.0 / 250.0 if fast_forward else None,
         "note": "games_per_hour = measured moves/s x 3600 / 250 stones (a trained net's game length; a random-init net plays to the "
                 "722-stone cap: whole games measured in profiles/, DESIGN.md section 8). " +
                 ("Mid-game stones." if fast_forward else "Opening moves only: games in flight share their first positions; with coalescing most "
@@ -607,6 +609,18 @@ def main():
             out["selfplay_midgame"] = selfplay_mid
         if selfplay is not None:
             out["selfplay"] = selfplay
+            # WHOLE games are too long for this line (6-8 minutes): the committed, builder-run measurement is quoted with its file
+            whole = os.path.join(ROOT, "profiles", "r04_final", "selfplay_full_games_96g_coalesce_b2_h4.json")
+            if os.path.exists(whole):
+                try:
+                    w = json.load(open(whole))
+                    out["whole_games_committed"] = {
+                        "games_per_hour_measured": w["games_per_hour_measured"], "moves_per_sec": w["moves_per_sec"], "games": w["games"],
+                        "mean_stones_per_game": w["mean_stones_per_game"], "host_cpus_busy": w["host_cpus_busy_rank0"],
+                        "source": "profiles/r04_final/selfplay_full_games_96g_coalesce_b2_h4.json (tools/selfplay_go.py --games 96 --moves 0; NOT measured in this run)",
+                    }
+                except Exception:   # noqa: BLE001
+                    pass
             out["derived"] = {
                 "games_per_hour_upper_bound": value * 3600.0 / (250 * max(selfplay["evals_per_move"], 1e-9)),
                 "what": "engine evals/s (inputs resident) x 3600 / (250 stones x the MEASURED evals per move of the selfplay leg): what the "

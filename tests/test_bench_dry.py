@@ -32,7 +32,8 @@ def test_bare_invocation_spawns_the_ranks_it_reports():
     assert b["ranks"] == 2 and b["checksums_agree"] is True and b["distinct_images_before"] == 2 and b["bytes"] > 0
     s = line["selfplay"]
     assert s["games"] == 4 and s["moves"] == 12 and s["evals_per_move"] > 0 and 0 <= s["cache_hit_ratio"] < 1
-    assert s["games_per_hour"] > 0 and line["derived"]["games_per_hour_upper_bound"] > 0
+    assert s["games_per_hour"] is None and s["moves_per_sec"] > 0        # the opening leg is not extrapolated to games per hour
+    assert line["selfplay_midgame"]["games_per_hour"] > 0 and line["derived"]["games_per_hour_upper_bound"] > 0
     assert "roofline" not in line and "cpu_baseline" not in line      # a dry run measures nothing and claims nothing
 
 
