@@ -611,7 +611,7 @@ def main():
             out["selfplay"] = selfplay
             # WHOLE games are too long for this line (6-8 minutes): the committed, builder-run measurement is quoted with its file
             whole = os.path.join(ROOT, "profiles", "r04_final", "selfplay_full_games_96g_coalesce_b2_h4.json")
-            if os.path.exists(whole):
+            if os.path.exists(whole) and not job.dry:
                 try:
                     w = json.load(open(whole))
                     out["whole_games_committed"] = {
