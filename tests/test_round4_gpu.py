@@ -188,3 +188,58 @@ def test_pair_split_tower_equals_one_launch_per_layer(api, synth, blocks, batch,
                 assert np.array_equal(value.view(np.uint16), reference[i][0].view(np.uint16)), (rep, i)
                 assert np.array_equal(policy.view(np.uint16), reference[i][1].view(np.uint16)), (rep, i)
     net.destroy()
+
+
+def test_coalescing_on_the_device_answers_with_the_evaluation_of_some_symmetry(api, synth):
+    """dgnn_pool_set_coalescing on the real engine: sixteen threads ask for six positions in random symmetries at once.  Whatever the
+    timing made of it -- evaluated on its own, or answered by following a request for the same position that was in flight -- every
+    answer, brought back to the canonical orientation, must be bit for bit the canonical form of the DIRECT evaluation of that position
+    under one of its eight symmetries (with that evaluation's value): exactly what a transposition-table hit may return
+    (predictors/nn.rs:72-81), nothing else."""
+    import threading
+    net = api.Network.from_json(synth.to_json(synth.make_sharp_tensors(2, 64, seed=930, policy_gain=8.0, value_gain=4.0)))
+    board = api.Board(7.5)
+    positions = []
+    for i, (x, y) in enumerate([(3, 3), (15, 15), (3, 15), (16, 3), (9, 10), (10, 10), (2, 9)]):
+        board.place(i % 2, x, y)
+        if i >= 1:
+            positions.append((board.clone(), (i + 1) % 2))
+    # the eight direct evaluations of every position, canonical form
+    candidates = []
+    with net.get_workspace(8) as ws:
+        for b, to_move in positions:
+            records = np.concatenate([b.record(to_move, s) for s in range(8)])
+            out = api.forward_boards(ws, records, 8)
+            value, policy = out.value.view(np.uint16), out.policy.view(np.uint16).reshape(8, 362)
+            forms = []
+            for s in range(8):
+                canon = api.Prediction.with_transform(api.Prediction(value[s:s + 1].view(np.float16)[0], policy[s].view(np.float16)), api.Transform.inverse(s))
+                forms.append((int(value[s]), canon._policy.view(np.uint16).tobytes()))
+            assert len({f[1] for f in forms}) >= 4                 # the network is not symmetric: the eight evaluations differ
+            candidates.append(forms)
+    pool = api.LeafPool.over_devices(net, [0], max_batch_size=64, batches_per_device=2, workers_per_device=2, boards=True)
+    pool.set_coalescing(True)
+    problems, lock = [], threading.Lock()
+
+    def caller(seed):
+        rng = np.random.default_rng(seed)
+        for _ in range(60):
+            k = int(rng.integers(0, len(positions)))
+            s = int(rng.integers(0, 8))
+            b, to_move = positions[k]
+            got = pool.predict_boards(b.record(to_move, s), 1)[0]
+            canon = api.Prediction.with_transform(got, api.Transform.inverse(s))
+            key = (int(np.asarray(got._value).view(np.uint16)), canon._policy.view(np.uint16).tobytes())
+            if key not in candidates[k]:
+                with lock:
+                    problems.append((k, s))
+
+    threads = [threading.Thread(target=caller, args=(1000 + t,)) for t in range(16)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    followed, boards = pool.coalesced(), pool.stats()["boards"]
+    pool.close()
+    net.destroy()
+    print(f"960 requests: {boards} boards evaluated, {followed} followed a position in flight")
+    assert not problems, problems[:5]
+    assert followed > 0 and boards + followed == 960
