@@ -1,7 +1,10 @@
 // Scope row f-2 (first part): the Monte-Carlo search tree of dream-go's libdg_mcts as a C++ library behind the C ABI.
 //
-//   Node, Child           src/libdg_mcts/tree.rs:259-360,1027-1095 (dense children here; the reference's sparse "small"
-//                         children are a memory optimisation with the same observable values)
+//   Node, Child           src/libdg_mcts/tree.rs:259-360,1027-1095.  Children are SPARSE: a node holds its prior (368 floats) and
+//                         a slot per child that has ever been selected or disqualified -- the reference's "small" children
+//                         (tree.rs:633-770, SMALL_SIZE 8) taken to its end: a child without a slot has the values of
+//                         Child::with_value (tree.rs:276-285), so nothing observable changes and a node is 1.8 KB instead of
+//                         10.7 KB (one node per rollout; 256 trees of dense nodes were 2 GB and every select a cache miss)
 //   select                tree.rs:1329-1384: child values, first-play urgency (tree.rs:180-254), PUCT (tree.rs:41-178), argmax
 //                         (asm/argmax.rs:24-78, including which index wins a tie), "expanding" flag, virtual loss
 //   probe / undo / insert tree.rs:1397-1510;  UCT::update (incremental mean and sum of squares) tree.rs:125-160
@@ -109,109 +112,216 @@ struct SpinLock {
 
 }  // namespace
 
+struct TreeNode;
+
+// One child that has been touched: selected by a probe (set_expanding creates the slot), or disqualified.  Slots never move and
+// never go away while the node lives, so a trace may keep a pointer to one.
+struct ChildSlot {
+    std::atomic<int> count{0};
+    std::atomic<int> vcount{0};
+    float value = 0.0f;
+    float value_s = 0.0f;
+    std::atomic<TreeNode*> ptr{nullptr};
+    uint16_t index = 0;
+    std::atomic<unsigned char> expanding{0};
+};
+
 struct TreeNode {
-    SpinLock lock;
+    static constexpr int kInline = 8;          // SMALL_SIZE, tree.rs:633: the slots that live inside the node
+    static constexpr int kChunks = 5;          // further slots in chunks of 16, 32, 64, 128, 256 (8 + 496 >= 362), allocated on demand
+    static constexpr int kMapFrom = 16;        // from this many slots on a node keeps an index -> slot map (a root: hundreds of children)
+
+    SpinLock lock;                             // the value update of a child (UCT::update) and the creation of a slot
     int to_move;
     float initial_value;
     int pass_count = 0;
     std::atomic<int> total_count{0};
     std::atomic<int> vtotal_count{0};
+    std::atomic<int> num_slots{0};             // slots 0 .. num_slots-1 are initialised and visible (release / acquire)
+    std::atomic<std::atomic<uint16_t>*> slot_of{nullptr};   // [362]: slot number + 1, 0 = no slot
+    std::atomic<ChildSlot*> chunk[kChunks];
+    ChildSlot first[kInline];
     float prior[kPadded];
-
-    std::atomic<int> count[kPadded];
-    std::atomic<int> vcount[kPadded];
-    std::atomic<unsigned char> expanding[kPadded];
-    std::atomic<TreeNode*> ptr[kPadded];
-    float value[kPadded];
-    float value_s[kPadded];
 
     TreeNode(int color, float v, const float* p) : to_move(color), initial_value(v)
     {
-        // 10.7 KB per node and one node per rollout: block operations instead of 368 x 7 element stores.  The node is not
-        // visible to any other thread before the constructor returns (dgnn_tree_insert publishes it with a CAS).
-        static_assert(sizeof(std::atomic<int>) == sizeof(int) && sizeof(std::atomic<unsigned char>) == 1 &&
-                      sizeof(std::atomic<TreeNode*>) == sizeof(TreeNode*), "plain layouts");
+        // one node per rollout: 1.5 KB of prior and nothing else to write (the node is not visible to any other thread before the
+        // constructor returns -- dgnn_tree_insert publishes it with a CAS)
+        for (auto& c : chunk) c.store(nullptr, std::memory_order_relaxed);
         std::memcpy(prior, p, kMoves * sizeof(float));
         for (int i = kMoves; i < kPadded; ++i) prior[i] = -std::numeric_limits<float>::infinity();   // tree.rs:1075-1076
-        std::memset(static_cast<void*>(count), 0, sizeof(count));
-        std::memset(static_cast<void*>(vcount), 0, sizeof(vcount));
-        std::memset(static_cast<void*>(expanding), 0, sizeof(expanding));
-        std::memset(static_cast<void*>(ptr), 0, sizeof(ptr));
-        std::fill(value, value + kPadded, v);                                           // Child::with_value, tree.rs:276-285
-        std::memset(value_s, 0, sizeof(value_s));
     }
 
     ~TreeNode()
     {
-        for (int i = 0; i < kMoves; ++i) delete ptr[i].load(std::memory_order_relaxed);
+        const int n = num_slots.load(std::memory_order_relaxed);
+        for (int k = 0; k < n; ++k) delete slot(k)->ptr.load(std::memory_order_relaxed);
+        for (auto& c : chunk) delete[] c.load(std::memory_order_relaxed);
+        delete[] slot_of.load(std::memory_order_relaxed);
     }
 
-    int total(int i) const { return count[i].load(std::memory_order_relaxed) + vcount[i].load(std::memory_order_relaxed); }
+    // slot number -> its place: 0..7 inside the node, 8..23 chunk 0, 24..55 chunk 1, 56..119, 120..247, 248..503
+    static int chunk_of(int k) { return 31 - __builtin_clz((unsigned)(k / kInline + 1)) - 1; }
+    static int chunk_base(int j) { return kInline * ((2 << j) - 1); }
+    static int chunk_size(int j) { return kInline * (2 << j); }
+    ChildSlot* slot(int k)
+    {
+        if (k < kInline) return &first[k];
+        const int j = chunk_of(k);
+        return chunk[j].load(std::memory_order_acquire) + (k - chunk_base(j));
+    }
+    const ChildSlot* slot(int k) const { return const_cast<TreeNode*>(this)->slot(k); }
+
+    // the slot of child `index`, or NULL: such a child is Child::with_value(initial_value) -- no visits, no virtual loss, not
+    // expanding, no sub-tree (tree.rs:901-927)
+    ChildSlot* find(int index)
+    {
+        if (const std::atomic<uint16_t>* map = slot_of.load(std::memory_order_acquire)) {
+            const int k = map[index].load(std::memory_order_acquire);
+            return k ? slot(k - 1) : nullptr;
+        }
+        const int n = num_slots.load(std::memory_order_acquire);
+        for (int k = 0; k < n && k < kInline; ++k)
+            if (first[k].index == index) return &first[k];
+        for (int k = kInline; k < n; ++k) {
+            ChildSlot* s = slot(k);
+            if (s->index == index) return s;
+        }
+        return nullptr;
+    }
+    const ChildSlot* find(int index) const { return const_cast<TreeNode*>(this)->find(index); }
+
+    // tree.rs:929-995 (with_mut: a child that is written to gets a slot).  NULL only when memory is exhausted.
+    ChildSlot* find_or_create(int index)
+    {
+        if (ChildSlot* s = find(index)) return s;
+        lock.lock();
+        ChildSlot* s = find(index);                      // (another search thread may have created it meanwhile)
+        if (!s) {
+            const int n = num_slots.load(std::memory_order_relaxed);
+            if (n >= kInline) {
+                const int j = chunk_of(n);
+                if (!chunk[j].load(std::memory_order_relaxed)) {
+                    ChildSlot* fresh = new (std::nothrow) ChildSlot[chunk_size(j)];
+                    if (!fresh) { lock.unlock(); return nullptr; }
+                    chunk[j].store(fresh, std::memory_order_release);
+                }
+            }
+            std::atomic<uint16_t>* map = slot_of.load(std::memory_order_relaxed);
+            if (!map && n + 1 >= kMapFrom) {
+                map = new (std::nothrow) std::atomic<uint16_t>[kMoves];
+                if (map) {
+                    for (int i = 0; i < kMoves; ++i) map[i].store(0, std::memory_order_relaxed);
+                    for (int k = 0; k < n; ++k) map[slot(k)->index].store((uint16_t)(k + 1), std::memory_order_relaxed);
+                }
+            }
+            s = slot(n);
+            s->index = (uint16_t)index;
+            s->value = initial_value;
+            if (map) map[index].store((uint16_t)(n + 1), std::memory_order_release);
+            num_slots.store(n + 1, std::memory_order_release);
+            if (map && !slot_of.load(std::memory_order_relaxed)) slot_of.store(map, std::memory_order_release);
+        }
+        lock.unlock();
+        return s;
+    }
 };
 
-struct TraceEntry { TreeNode* node; int color; int index; };
+// A node's children by move index, for the walks that happen once per move (best, softmax, to_pretty): NULL = no slot.
+struct ChildView {
+    const TreeNode* node;
+    const ChildSlot* at[kMoves];
+    explicit ChildView(const TreeNode* n) : node(n)
+    {
+        std::memset(at, 0, sizeof(at));
+        const int slots = n->num_slots.load(std::memory_order_acquire);
+        for (int k = 0; k < slots; ++k) { const ChildSlot* s = n->slot(k); at[s->index] = s; }
+    }
+    int count(int i) const { return at[i] ? at[i]->count.load(std::memory_order_relaxed) : 0; }
+    float value(int i) const { return at[i] ? at[i]->value : node->initial_value; }
+    float value_s(int i) const { return at[i] ? at[i]->value_s : 0.0f; }
+    const TreeNode* ptr(int i) const { return at[i] ? at[i]->ptr.load(std::memory_order_acquire) : nullptr; }
+};
+
+struct TraceEntry { TreeNode* node; ChildSlot* slot; int color; int index; };
 struct Trace { std::vector<TraceEntry> entries; };
 
 namespace {
 
-// FPU::apply + UCT::get (tree.rs:180-254, 86-115): value[i] <- fpu(value[i]) + prior[i] * bonus(total[i])
-void puct_scalar(const TreeNode* node, bool apply_fpu, float fpu_reduce, float uct_exp_sqrt_n, float* value)
+// FPU::apply + UCT::get (tree.rs:180-254, 86-115): value[i] <- fpu(value[i]) + prior[i] * bonus(total[i]).  A child without a
+// slot has value = the node's initial value and no visits, so the whole array starts as fpu(initial) + prior[i] * bonus(0) -- the
+// same operations on the same operands as the per-child form -- and the few children with a slot are then computed on their own.
+struct PuctTerms { bool apply_fpu; float fpu_reduce, uct_exp_sqrt_n; };
+
+void puct_scalar(const TreeNode* node, const PuctTerms& t, float* value)
 {
-    for (int i = 0; i < kPadded; ++i) {
-        const int c = node->total(i);
-        float v = node->value[i];
-        if (apply_fpu && c == 0) v = std::max(v - fpu_reduce, 0.0f);
-        const float bonus = c == 0 ? uct_exp_sqrt_n : uct_exp_sqrt_n / (float)(1 + c);
-        value[i] = v + node->prior[i] * bonus;
+    float v0 = node->initial_value;
+    if (t.apply_fpu) v0 = std::max(v0 - t.fpu_reduce, 0.0f);
+    for (int i = 0; i < kPadded; ++i) value[i] = v0 + node->prior[i] * t.uct_exp_sqrt_n;
+    const int n = node->num_slots.load(std::memory_order_acquire);
+    for (int k = 0; k < n; ++k) {
+        const ChildSlot* s = node->slot(k);
+        const int c = s->count.load(std::memory_order_relaxed) + s->vcount.load(std::memory_order_relaxed);
+        float v = s->value;
+        if (t.apply_fpu && c == 0) v = std::max(v - t.fpu_reduce, 0.0f);
+        const float bonus = c == 0 ? t.uct_exp_sqrt_n : t.uct_exp_sqrt_n / (float)(1 + c);
+        value[s->index] = v + node->prior[s->index] * bonus;
     }
 }
 
 // The reference's own formulation (tree.rs:63-115: cmpeq / div / mul / add on 8 lanes, no fused multiply-add), so both
-// variants give the same bits.  The counters are read as plain ints: aligned 32-bit loads, racing with other search
-// threads exactly as the reference's do.
+// variants give the same bits; the children with a slot go through the same instructions, one lane at a time (max_ss, div_ss:
+// what a lane of the reference's vectors computes, including which operand a NaN leaves behind).  The counters are read as plain
+// loads, racing with other search threads exactly as the reference's do.
 #if DGNN_X86_SIMD
 __attribute__((target("avx2")))
-void puct_avx2(const TreeNode* node, bool apply_fpu, float fpu_reduce, float uct_exp_sqrt_n, float* value)
+void puct_avx2(const TreeNode* node, const PuctTerms& t, float* value)
 {
-    static_assert(sizeof(std::atomic<int>) == sizeof(int), "atomic<int> must be a plain int");
-    const int* count = reinterpret_cast<const int*>(&node->count[0]);
-    const int* vcount = reinterpret_cast<const int*>(&node->vcount[0]);
-    const __m256 u = _mm256_set1_ps(uct_exp_sqrt_n), fpu = _mm256_set1_ps(fpu_reduce), zero_ps = _mm256_setzero_ps();
-    const __m256i zero = _mm256_setzero_si256(), one = _mm256_set1_epi32(1);
-    for (int i = 0; i < kPadded; i += 8) {
-        const __m256i c = _mm256_add_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(count + i)),
-                                           _mm256_loadu_si256(reinterpret_cast<const __m256i*>(vcount + i)));
-        const __m256 is_zero = _mm256_castsi256_ps(_mm256_cmpeq_epi32(c, zero));
-        __m256 v = _mm256_loadu_ps(node->value + i);
-        if (apply_fpu) v = _mm256_blendv_ps(v, _mm256_max_ps(_mm256_sub_ps(v, fpu), zero_ps), is_zero);
-        const __m256 bonus = _mm256_blendv_ps(_mm256_div_ps(u, _mm256_cvtepi32_ps(_mm256_add_epi32(c, one))), u, is_zero);
-        _mm256_storeu_ps(value + i, _mm256_add_ps(v, _mm256_mul_ps(_mm256_loadu_ps(node->prior + i), bonus)));
+    const __m256 u = _mm256_set1_ps(t.uct_exp_sqrt_n);
+    __m256 v0 = _mm256_set1_ps(node->initial_value);
+    if (t.apply_fpu) v0 = _mm256_max_ps(_mm256_sub_ps(v0, _mm256_set1_ps(t.fpu_reduce)), _mm256_setzero_ps());
+    for (int i = 0; i < kPadded; i += 8)
+        _mm256_storeu_ps(value + i, _mm256_add_ps(v0, _mm256_mul_ps(_mm256_loadu_ps(node->prior + i), u)));
+    const int n = node->num_slots.load(std::memory_order_acquire);
+    const __m128 u1 = _mm_set_ss(t.uct_exp_sqrt_n), fpu1 = _mm_set_ss(t.fpu_reduce), zero1 = _mm_setzero_ps();
+    for (int k = 0; k < n; ++k) {
+        const ChildSlot* s = node->slot(k);
+        const int c = s->count.load(std::memory_order_relaxed) + s->vcount.load(std::memory_order_relaxed);
+        __m128 v = _mm_set_ss(s->value);
+        if (t.apply_fpu && c == 0) v = _mm_max_ss(_mm_sub_ss(v, fpu1), zero1);
+        const __m128 bonus = c == 0 ? u1 : _mm_div_ss(u1, _mm_cvtsi32_ss(zero1, 1 + c));
+        value[s->index] = _mm_cvtss_f32(_mm_add_ss(v, _mm_mul_ss(_mm_set_ss(node->prior[s->index]), bonus)));
     }
 }
 #endif
 
-// tree.rs:1329-1384.  Returns 1 found (index, value filled), 0 no result, -1 conflict.
-int select(TreeNode* node, bool apply_fpu, int* index_out, float* value_out)
+// tree.rs:1329-1384.  Returns 1 found (index, slot, value filled), 0 no result, -1 conflict, -2 out of memory.
+int select(TreeNode* node, bool apply_fpu, int* index_out, ChildSlot** slot_out, float* value_out)
 {
     float value[kPadded];
     const int n = node->total_count.load(std::memory_order_relaxed) + node->vtotal_count.load(std::memory_order_relaxed);
-    const float fpu_reduce = apply_fpu ? intp_value(kFpuReduce, 5, n) : 0.0f;  // tree.rs:1342-1348
+    PuctTerms t;
+    t.apply_fpu = apply_fpu;
+    t.fpu_reduce = apply_fpu ? intp_value(kFpuReduce, 5, n) : 0.0f;          // tree.rs:1342-1348
     const float sqrt_n = std::sqrt((float)(1 + n));                          // tree.rs:86-115
-    const float uct_exp_sqrt_n = intp_value(kUctExp, 5, n) * sqrt_n;
+    t.uct_exp_sqrt_n = intp_value(kUctExp, 5, n) * sqrt_n;
 #if DGNN_X86_SIMD
-    if (kHaveAvx2) puct_avx2(node, apply_fpu, fpu_reduce, uct_exp_sqrt_n, value);
+    if (kHaveAvx2) puct_avx2(node, t, value);
     else
 #endif
-    puct_scalar(node, apply_fpu, fpu_reduce, uct_exp_sqrt_n, value);
+    puct_scalar(node, t, value);
     for (int i = kMoves; i < kPadded; ++i) value[i] = -std::numeric_limits<float>::infinity();
 
     const int max_i = argmax_f32(value, kPadded);
     if (max_i < 0) return 0;
-    const bool was_expanding = node->expanding[max_i].exchange(1, std::memory_order_acq_rel) != 0;   // set_expanding, tree.rs:445-449
-    if (was_expanding && node->ptr[max_i].load(std::memory_order_acquire) == nullptr) return -1;
-    node->vcount[max_i].fetch_add(kVlossCnt, std::memory_order_relaxed);
+    ChildSlot* slot = node->find_or_create(max_i);
+    if (!slot) return -2;
+    const bool was_expanding = slot->expanding.exchange(1, std::memory_order_acq_rel) != 0;   // set_expanding, tree.rs:445-449
+    if (was_expanding && slot->ptr.load(std::memory_order_acquire) == nullptr) return -1;
+    slot->vcount.fetch_add(kVlossCnt, std::memory_order_relaxed);
     node->vtotal_count.fetch_add(kVlossCnt, std::memory_order_relaxed);
     *index_out = max_i;
+    *slot_out = slot;
     *value_out = value[max_i];
     return 1;
 }
@@ -220,15 +330,15 @@ void undo(const Trace& trace, bool undo_expanding)                          // t
 {
     for (const TraceEntry& e : trace.entries) {
         e.node->vtotal_count.fetch_sub(kVlossCnt, std::memory_order_relaxed);
-        e.node->vcount[e.index].fetch_sub(kVlossCnt, std::memory_order_relaxed);
-        if (undo_expanding && e.node->ptr[e.index].load(std::memory_order_acquire) == nullptr)
-            e.node->expanding[e.index].store(0, std::memory_order_release);
+        e.slot->vcount.fetch_sub(kVlossCnt, std::memory_order_relaxed);
+        if (undo_expanding && e.slot->ptr.load(std::memory_order_acquire) == nullptr)
+            e.slot->expanding.store(0, std::memory_order_release);
     }
 }
 
-float value_std(const TreeNode* node, int i)                                 // tree.rs:351-358
+float value_std(float value_s, int count)                                    // tree.rs:351-358
 {
-    return std::sqrt(node->value_s[i] / ((float)node->count[i].load(std::memory_order_relaxed) + 1e-5f));
+    return std::sqrt(value_s / ((float)count + 1e-5f));
 }
 
 float normal_lcb_m(float p_hat, float p_std, int n, int m)                  // lcb.rs:28-37
@@ -238,18 +348,19 @@ float normal_lcb_m(float p_hat, float p_std, int n, int m)                  // l
 }
 
 // compare_children, tree.rs:1524-1560: < 0 when a is the worse candidate
-int compare_children(const TreeNode* node, int a, int b)
+int compare_children(const ChildView& view, int a, int b)
 {
-    const int ac = node->count[a].load(std::memory_order_relaxed), bc = node->count[b].load(std::memory_order_relaxed);
+    const TreeNode* node = view.node;
+    const int ac = view.count(a), bc = view.count(b);
     if (ac >= kMinLcbVisits && bc >= kMinLcbVisits) {
         const int m = node->total_count.load(std::memory_order_relaxed);
-        const float al = normal_lcb_m(node->value[a], value_std(node, a), ac, m);
-        const float bl = normal_lcb_m(node->value[b], value_std(node, b), bc, m);
+        const float al = normal_lcb_m(view.value(a), value_std(view.value_s(a), ac), ac, m);
+        const float bl = normal_lcb_m(view.value(b), value_std(view.value_s(b), bc), bc, m);
         if (al != bl) return al < bl ? -1 : 1;
     }
     if (ac != bc) return ac < bc ? -1 : 1;
     if (node->prior[a] != node->prior[b]) return node->prior[a] < node->prior[b] ? -1 : 1;
-    if (node->value[a] != node->value[b]) return node->value[a] < node->value[b] ? -1 : 1;
+    if (view.value(a) != view.value(b)) return view.value(a) < view.value(b) ? -1 : 1;
     return 0;
 }
 
@@ -299,16 +410,18 @@ int dgnn_tree_probe(dgnn_tree_node* root, const dgnn_board_ops* ops, void* board
     for (;;) {                                                               // tree.rs:1421-1470
         int next_child = 0;
         float next_value = 0.0f;
-        const int r = select(current, !trace->entries.empty(), &next_child, &next_value);
+        ChildSlot* slot = nullptr;
+        const int r = select(current, !trace->entries.empty(), &next_child, &slot, &next_value);
+        if (r == -2) { undo(*trace, false); delete trace; return DGNN_OUT_OF_MEMORY; }
         if (r < 0) { undo(*trace, false); delete trace; return DGNN_PROBE_CONFLICT; }   // (select's own -1, not the ABI's value)
         if (r == 0) { delete trace; return DGNN_PROBE_NO_RESULT; }            // (the reference leaks the partial trace's virtual loss here too)
-        trace->entries.push_back({current, current->to_move, next_child});
+        trace->entries.push_back({current, slot, current->to_move, next_child});
         if (next_child != kMoves - 1) {
             if (ops && ops->place) ops->place(board, current->to_move, next_child);
         } else if (current->pass_count >= 1) {
             break;                                                           // at least two consecutive passes
         }
-        TreeNode* child = current->ptr[next_child].load(std::memory_order_acquire);
+        TreeNode* child = slot->ptr.load(std::memory_order_acquire);
         if (!child) break;
         current = child;
     }
@@ -348,7 +461,7 @@ int dgnn_tree_insert(const dgnn_trace* handle, int color, float value, const flo
         if (!next) return DGNN_OUT_OF_MEMORY;
         if (last.index == kMoves - 1) next->pass_count = last.node->pass_count + 1;
         TreeNode* expected = nullptr;
-        if (!last.node->ptr[last.index].compare_exchange_strong(expected, next, std::memory_order_acq_rel))
+        if (!last.slot->ptr.compare_exchange_strong(expected, next, std::memory_order_acq_rel))
             delete next;                                                     // double expansion behind two passes
     }
     for (const TraceEntry& e : trace->entries) {                              // UCT::update, tree.rs:125-160
@@ -356,14 +469,15 @@ int dgnn_tree_insert(const dgnn_trace* handle, int color, float value, const flo
         const float v = color == node->to_move ? value : 1.0f - value;
         node->total_count.fetch_add(1, std::memory_order_relaxed);
         node->vtotal_count.fetch_sub(kVlossCnt, std::memory_order_relaxed);
+        ChildSlot* slot = e.slot;
         node->lock.lock();
-        const float prev_value = node->value[e.index];
-        const float prev_value_s = node->value_s[e.index];
-        const int prev_count = node->count[e.index].fetch_add(1, std::memory_order_relaxed);
+        const float prev_value = slot->value;
+        const float prev_value_s = slot->value_s;
+        const int prev_count = slot->count.fetch_add(1, std::memory_order_relaxed);
         const float next_value = prev_value + (v - prev_value) / (float)(prev_count + 1);
-        node->value[e.index] = next_value;
-        node->value_s[e.index] = prev_value_s + (v - prev_value) * (v - next_value);
-        node->vcount[e.index].fetch_sub(kVlossCnt, std::memory_order_relaxed);
+        slot->value = next_value;
+        slot->value_s = prev_value_s + (v - prev_value) * (v - next_value);
+        slot->vcount.fetch_sub(kVlossCnt, std::memory_order_relaxed);
         node->lock.unlock();
     }
     return DGNN_OK;
@@ -374,11 +488,13 @@ int dgnn_tree_node_child(const dgnn_tree_node* handle, int index, int* count, in
 {
     if (!handle || index < 0 || index >= kMoves) return DGNN_BAD_ARGUMENT;
     const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
-    if (count) *count = node->count[index].load();
-    if (vcount) *vcount = node->vcount[index].load();
-    if (value) *value = node->value[index];
-    if (value_std_out) *value_std_out = value_std(node, index);
-    if (has_child) *has_child = node->ptr[index].load() != nullptr;
+    const ChildSlot* slot = node->find(index);                                // none: Child::with_value, tree.rs:276-285
+    const int visits = slot ? slot->count.load() : 0;
+    if (count) *count = visits;
+    if (vcount) *vcount = slot ? slot->vcount.load() : 0;
+    if (value) *value = slot ? slot->value : node->initial_value;
+    if (value_std_out) *value_std_out = value_std(slot ? slot->value_s : 0.0f, visits);
+    if (has_child) *has_child = slot && slot->ptr.load() != nullptr;
     return DGNN_OK;
 }
 
@@ -408,7 +524,8 @@ dgnn_tree_node* dgnn_tree_node_forward(dgnn_tree_node* handle, int index)
 {
     if (!handle || index < 0 || index >= kMoves) return nullptr;
     TreeNode* node = reinterpret_cast<TreeNode*>(handle);
-    TreeNode* next = node->ptr[index].exchange(nullptr);
+    ChildSlot* slot = node->find(index);
+    TreeNode* next = slot ? slot->ptr.exchange(nullptr) : nullptr;
     if (!next && index == kMoves - 1) {
         float prior[kMoves];
         for (float& v : prior) v = 0.0f;
@@ -424,14 +541,13 @@ int dgnn_tree_node_min_promote(const dgnn_tree_node* handle)
 {
     if (!handle) return DGNN_BAD_ARGUMENT;
     const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
-    int top = 0, count_1 = -1, count_2 = 0;
-    for (int i = 0; i < kMoves; ++i) {
-        const int c = node->count[i].load(std::memory_order_relaxed);
-        if (c > count_1) { count_1 = c; top = i; }
-    }
-    for (int i = 0; i < kMoves; ++i) {
-        const int c = node->count[i].load(std::memory_order_relaxed);
-        if (i != top && c > count_2) count_2 = c;
+    // the largest count and the largest among the OTHER children (a child without a slot counts 0, and so does the floor)
+    int count_1 = 0, count_2 = 0;
+    const int n = node->num_slots.load(std::memory_order_acquire);
+    for (int k = 0; k < n; ++k) {
+        const int c = node->slot(k)->count.load(std::memory_order_relaxed);
+        if (c > count_1) { count_2 = count_1; count_1 = c; }
+        else if (c > count_2) count_2 = c;
     }
     return count_1 > count_2 ? count_1 - count_2 : 0;
 }
@@ -458,19 +574,21 @@ int dgnn_tree_node_disqualify(dgnn_tree_node* handle, int index)             // 
 {
     if (!handle || index < 0 || index >= kMoves) return DGNN_BAD_ARGUMENT;
     TreeNode* node = reinterpret_cast<TreeNode*>(handle);
-    node->value[index] = -std::numeric_limits<float>::infinity();
-    node->count[index].store(0);
+    ChildSlot* slot = node->find_or_create(index);
+    if (!slot) return DGNN_OUT_OF_MEMORY;
+    slot->value = -std::numeric_limits<float>::infinity();
+    slot->count.store(0);
     return DGNN_OK;
 }
 
 int dgnn_tree_node_softmax(const dgnn_tree_node* handle, float* out)         // tree.rs:1293-1307
 {
     if (!handle || !out) return DGNN_BAD_ARGUMENT;
-    const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
+    const ChildView view(reinterpret_cast<const TreeNode*>(handle));
     float total = 0.0f;
-    for (int i = 0; i < kMoves; ++i) total += (float)node->count[i].load();
+    for (int i = 0; i < kMoves; ++i) total += (float)view.count(i);
     for (int i = 0; i < kMoves; ++i) {
-        const int c = node->count[i].load();
+        const int c = view.count(i);
         out[i] = c != 0 ? (float)c / total : 0.0f;
     }
     return DGNN_OK;
@@ -530,12 +648,12 @@ std::string pretty_vertex(int i)                                             // 
     static const char letters[] = "abcdefghjklmnopqrst";
     return std::string(1, letters[i % 19]) + std::to_string(i / 19 + 1);
 }
-int greedy_child(const TreeNode* node)                                       // GreedyPath::next, tree.rs:1659-1662
+int greedy_child(const ChildView& view)                                      // GreedyPath::next, tree.rs:1659-1662
 {
     int best = -1;
     for (int i = 0; i < kMoves; ++i) {
-        if (node->count[i].load(std::memory_order_relaxed) == 0) continue;
-        if (best < 0 || compare_children(node, best, i) <= 0) best = i;      // max_by keeps the last maximum
+        if (view.count(i) == 0) continue;
+        if (best < 0 || compare_children(view, best, i) <= 0) best = i;      // max_by keeps the last maximum
     }
     return best < 0 ? kMoves - 1 : best;
 }
@@ -543,11 +661,12 @@ std::string greedy_path(const TreeNode* node)                                // 
 {
     std::string out;
     while (node) {
-        const int i = greedy_child(node);
-        if (node->count[i].load(std::memory_order_relaxed) < 1) break;
+        const ChildView view(node);
+        const int i = greedy_child(view);
+        if (view.count(i) < 1) break;
         if (!out.empty()) out += ' ';
         out += pretty_vertex(i);
-        node = node->ptr[i].load(std::memory_order_acquire);
+        node = view.ptr(i);
     }
     return out;
 }
@@ -557,13 +676,14 @@ size_t dgnn_tree_node_to_pretty(const dgnn_tree_node* handle, char* out, size_t 
 {
     if (!handle) return 0;
     const TreeNode* root = reinterpret_cast<const TreeNode*>(handle);
+    const ChildView view(root);
     std::vector<int> children;
-    for (int i = 0; i < kMoves; ++i) if (root->count[i].load(std::memory_order_relaxed) != 0) children.push_back(i);
-    std::stable_sort(children.begin(), children.end(), [&](int a, int b) { return compare_children(root, b, a) < 0; });   // best first
+    for (int i = 0; i < kMoves; ++i) if (view.count(i) != 0) children.push_back(i);
+    std::stable_sort(children.begin(), children.end(), [&](int a, int b) { return compare_children(view, b, a) < 0; });   // best first
     if (children.size() > 10) children.resize(10);
     float total_value = 0.0f;
     for (int i = 0; i < kMoves; ++i) {
-        const float v = (float)root->count[i].load(std::memory_order_relaxed) * root->value[i];
+        const float v = (float)view.count(i) * view.value(i);
         if (std::isfinite(v)) total_value += v;
     }
     const int total = root->total_count.load(std::memory_order_relaxed);
@@ -571,11 +691,11 @@ size_t dgnn_tree_node_to_pretty(const dgnn_tree_node* handle, char* out, size_t 
     std::snprintf(line, sizeof(line), "Nodes: %d, Win: %.1f%%, PV: ", total, (double)(100.0f * (total_value / ((float)total + 1e-5f))));
     std::string text = line + greedy_path(root) + "\n";
     for (int i : children) {
-        const TreeNode* child = root->ptr[i].load(std::memory_order_acquire);
+        const TreeNode* child = view.ptr(i);
         const std::string vertex = pretty_vertex(i);
         std::snprintf(line, sizeof(line), "%5s -> %7d (W: %5.2f%% / %5.2f%%) (N: %5.2f%%) PV: %s ", vertex.c_str(),
-                      child ? child->total_count.load(std::memory_order_relaxed) : 0, (double)(100.0f * root->value[i]),
-                      (double)(100.0f * normal_lcb_m(root->value[i], value_std(root, i), root->count[i].load(std::memory_order_relaxed), total)),
+                      child ? child->total_count.load(std::memory_order_relaxed) : 0, (double)(100.0f * view.value(i)),
+                      (double)(100.0f * normal_lcb_m(view.value(i), value_std(view.value_s(i), view.count(i)), view.count(i), total)),
                       (double)(100.0f * root->prior[i]), vertex.c_str());
         text += line + (child ? greedy_path(child) : std::string()) + "\n";
     }
@@ -587,23 +707,24 @@ int dgnn_tree_node_best(const dgnn_tree_node* handle, float temperature, double 
 {
     if (!handle || !value_out || !index_out) return DGNN_BAD_ARGUMENT;
     const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
+    const ChildView view(node);
     if (temperature <= 9e-2f) {                                              // greedy, tree.rs:1263-1268
         int best = -1;
         for (int i = 0; i < kMoves; ++i) {
-            if (node->count[i].load() == 0) continue;                        // children.nonzero()
-            if (best < 0 || compare_children(node, best, i) <= 0) best = i;  // Iterator::max_by keeps the LAST maximum
+            if (view.count(i) == 0) continue;                                // children.nonzero()
+            if (best < 0 || compare_children(view, best, i) <= 0) best = i;  // Iterator::max_by keeps the LAST maximum
         }
         if (best < 0) best = kMoves - 1;
         *index_out = best;
-        *value_out = node->value[best];
+        *value_out = view.value(best);
         return DGNN_OK;
     }
     int visits[kMoves];
-    for (int i = 0; i < kMoves; ++i) visits[i] = node->count[i].load();
+    for (int i = 0; i < kMoves; ++i) visits[i] = view.count(i);
     int chosen = 0;
     if (dgnn_choose(visits, kMoves, 0.5, 1.0 / (double)temperature, at, &chosen, nullptr) == 1) {
         *index_out = chosen;
-        *value_out = node->value[chosen];
+        *value_out = view.value(chosen);
     } else {
         *index_out = kMoves - 1;                                             // no valid moves, tree.rs:1279
         *value_out = node->initial_value;
