@@ -34,6 +34,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "dgnn_internal.h"
@@ -483,39 +484,7 @@ struct BoardRecord {
 };
 static_assert(sizeof(BoardRecord) == DGNN_BOARD_RECORD_BYTES, "BoardRecord layout");
 
-void board_record(const GoBoard& b, int to_move, int symmetry, BoardRecord* out)
-{
-    const Fast& f = b.inner;
-    std::memset(out, 0, sizeof(*out));
-    for (int p = 0; p < kPoints; ++p) out->cell[p] = (uint16_t)(f.stone[p] | (f.stone[p] != kEmpty ? f.head[p] << 2 : 0));
-    out->to_move = (uint8_t)to_move;
-    out->symmetry = (uint8_t)symmetry;
-    out->komi = float_to_half(std::max(0.0f, std::min(1.0f, 0.5f + (0.5f * b.komi) / 7.5f)));
-    for (int i = 0; i < 2; ++i) out->last[i] = (int16_t)((b.history[i] >= 0 && b.history[i] < kPoints) ? b.history[i] : -1);
-
-    auto set = [](uint32_t* mask, int p) { mask[p >> 5] |= 1u << (p & 31); };
-    // super-ko can only strike on a point that has held a stone (board.rs:121)
-    for (int p = 0; p < kPoints; ++p)
-        if (f.visited[p] && f.stone[p] == kEmpty && f.is_valid(to_move, p) && b.is_ko(to_move, p)) set(out->ko, p);
-    // the ladder readers answer "no" unless an opponent block with exactly two liberties (capture, may_start_ladder) or an own
-    // block with fewer than two (escape, ladder.rs:146-151) is adjacent: only the liberties of such blocks are ever read out
-    const unsigned char mine = (unsigned char)(to_move + 1), theirs = (unsigned char)(2 - to_move);
-    for (int h = 0; h < kPoints; ++h) {
-        if (f.stone[h] == kEmpty || f.head[h] != h) continue;
-        const bool capture = f.stone[h] == theirs && f.libs[h] == 2, escape = f.stone[h] == mine && f.libs[h] < 2;
-        if (!capture && !escape) continue;
-        int s = h;
-        do {
-            for (int d = 0; d < 4; ++d) {
-                const int q = neighbour(s, d);
-                if (q < 0 || f.stone[q] != kEmpty) continue;
-                if (capture && !((out->ladder_capture[q >> 5] >> (q & 31)) & 1u) && f.is_valid(to_move, q) && ladder_capture(f, to_move, q)) set(out->ladder_capture, q);
-                if (escape && !((out->ladder_escape[q >> 5] >> (q & 31)) & 1u) && f.is_valid(to_move, q) && ladder_escape(f, to_move, q)) set(out->ladder_escape, q);
-            }
-            s = f.next[s];
-        } while (s != h);
-    }
-}
+void board_record(const GoBoard& b, int to_move, int symmetry, BoardRecord* out);    // (below, behind the bit-set scans it uses)
 
 // The planes from a record alone: the host statement of csrc/features.hip (same steps, same order), producing the packed
 // form of dgnn_forward_packed (361 plane masks + the komi word).  Used by the CPU tests (against features_v1 on every position of
@@ -823,21 +792,21 @@ inline StoneSets stone_sets(const Fast& b)
     s.empty = andnot(kMasks.board, s.stones[0] | s.stones[1]);
     return s;
 }
-// the heads of the blocks with fewer than two liberties, as a bit set (rarely any)
-BB weak_heads_scalar(const Fast& b)
+// the heads of the blocks with fewer than `limit` liberties, as a bit set (limit 2, the weak blocks: rarely any)
+BB weak_heads_scalar(const Fast& b, int limit)
 {
     BB r;
     std::memset(&r, 0, sizeof(r));
-    for (int p = 0; p < kPoints; ++p) if (b.stone[p] != kEmpty && b.head[p] == p && b.libs[p] < 2) r.set(p);
+    for (int p = 0; p < kPoints; ++p) if (b.stone[p] != kEmpty && b.head[p] == p && b.libs[p] < limit) r.set(p);
     return r;
 }
 #if DGNN_X86_SIMD
 __attribute__((target("avx2")))
-BB weak_heads_avx2(const Fast& b)
+BB weak_heads_avx2(const Fast& b, int limit)
 {
     BB r;
     std::memset(&r, 0, sizeof(r));
-    const __m256i step = _mm256_set1_epi16(16), two = _mm256_set1_epi16(2), zero = _mm256_setzero_si256();
+    const __m256i step = _mm256_set1_epi16(16), two = _mm256_set1_epi16((short)limit), zero = _mm256_setzero_si256();
     __m256i index = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     for (int k = 0; k < 23; ++k, index = _mm256_add_epi16(index, step)) {
         const __m256i head = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b.head + 16 * k));
@@ -855,13 +824,75 @@ BB weak_heads_avx2(const Fast& b)
     return r;
 }
 #endif
-inline BB weak_heads(const Fast& b)
+inline BB weak_heads(const Fast& b, int limit = 2)
 {
 #if DGNN_X86_SIMD
-    if (kGoAvx2) return weak_heads_avx2(b);
+    if (kGoAvx2) return weak_heads_avx2(b, limit);
 #endif
-    return weak_heads_scalar(b);
+    return weak_heads_scalar(b, limit);
 }
+// stone | block id << 2 per point (BoardRecord::cell); points 361..367 of the array stay zero
+void record_cells_scalar(const Fast& f, uint16_t* cell)
+{
+    for (int p = 0; p < kPoints; ++p) cell[p] = (uint16_t)(f.stone[p] | (f.stone[p] != kEmpty ? f.head[p] << 2 : 0));
+}
+#if DGNN_X86_SIMD
+__attribute__((target("avx2")))
+void record_cells_avx2(const Fast& f, uint16_t* cell)
+{
+    const __m256i zero = _mm256_setzero_si256();
+    int p = 0;
+    for (; p + 16 <= kPoints; p += 16) {
+        const __m256i stone = _mm256_cvtepu8_epi16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(f.stone + p)));
+        const __m256i head = _mm256_slli_epi16(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(f.head + p)), 2);
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(cell + p), _mm256_or_si256(stone, _mm256_andnot_si256(_mm256_cmpeq_epi16(stone, zero), head)));
+    }
+    for (; p < kPoints; ++p) cell[p] = (uint16_t)(f.stone[p] | (f.stone[p] != kEmpty ? f.head[p] << 2 : 0));
+}
+#endif
+
+void board_record(const GoBoard& b, int to_move, int symmetry, BoardRecord* out)
+{
+    const Fast& f = b.inner;
+    std::memset(out, 0, sizeof(*out));
+#if DGNN_X86_SIMD
+    if (kGoAvx2) record_cells_avx2(f, out->cell); else
+#endif
+    record_cells_scalar(f, out->cell);
+    out->to_move = (uint8_t)to_move;
+    out->symmetry = (uint8_t)symmetry;
+    out->komi = float_to_half(std::max(0.0f, std::min(1.0f, 0.5f + (0.5f * b.komi) / 7.5f)));
+    for (int i = 0; i < 2; ++i) out->last[i] = (int16_t)((b.history[i] >= 0 && b.history[i] < kPoints) ? b.history[i] : -1);
+
+    auto set = [](uint32_t* mask, int p) { mask[p >> 5] |= 1u << (p & 31); };
+    // super-ko can only strike on a point that has held a stone (board.rs:121): the empty ones among them, from the bit sets
+    const StoneSets sets = stone_sets(f);
+    for (BB ko = sets.visited & sets.empty; ko.any();) {
+        const int p = ko.lowest();
+        ko.w[p >> 6] &= ~(1ull << (p & 63));
+        if (f.is_valid(to_move, p) && b.is_ko(to_move, p)) set(out->ko, p);
+    }
+    // the ladder readers answer "no" unless an opponent block with exactly two liberties (capture, may_start_ladder) or an own
+    // block with fewer than two (escape, ladder.rs:146-151) is adjacent: only the liberties of such blocks are ever read out
+    const unsigned char mine = (unsigned char)(to_move + 1), theirs = (unsigned char)(2 - to_move);
+    for (BB heads = weak_heads(f, 3); heads.any();) {                         // the blocks with at most two liberties, lowest head first
+        const int h = heads.lowest();
+        heads.w[h >> 6] &= ~(1ull << (h & 63));
+        const bool capture = f.stone[h] == theirs && f.libs[h] == 2, escape = f.stone[h] == mine && f.libs[h] < 2;
+        if (!capture && !escape) continue;
+        int s = h;
+        do {
+            for (int d = 0; d < 4; ++d) {
+                const int q = neighbour(s, d);
+                if (q < 0 || f.stone[q] != kEmpty) continue;
+                if (capture && !((out->ladder_capture[q >> 5] >> (q & 31)) & 1u) && f.is_valid(to_move, q) && ladder_capture(f, to_move, q)) set(out->ladder_capture, q);
+                if (escape && !((out->ladder_escape[q >> 5] >> (q & 31)) & 1u) && f.is_valid(to_move, q) && ladder_escape(f, to_move, q)) set(out->ladder_escape, q);
+            }
+            s = f.next[s];
+        } while (s != h);
+    }
+}
+
 inline BB block_stones(const Fast& b, int q) { BB r; std::memset(&r, 0, sizeof(r)); int s = q; do { r.set(s); s = b.next[s]; } while (s != q); return r; }
 
 // Benson's unconditional life (utils/benson.rs:62-190), same result as benson_flood above, on bit boards.
@@ -1043,8 +1074,17 @@ bool is_simple_eye(const Fast& b, int color, int p)
 }
 
 // ---- game callbacks for the search driver ----
-void* go_clone(void* b) { return new GoBoard(*static_cast<GoBoard*>(b)); }
-void go_destroy(void* b) { delete static_cast<GoBoard*>(b); }
+// (every leaf of a search plays on its own copy of the board, pool/event.rs:44-46: dgnn_internal.h BlockPool; GoBoard is trivially
+// destructible, a copy is its bytes)
+using GoBoardPool = BlockPool<sizeof(GoBoard), 1024>;
+static_assert(std::is_trivially_destructible<GoBoard>::value && std::is_trivially_copyable<GoBoard>::value, "go_clone copies bytes");
+void* go_clone(void* b)
+{
+    void* copy = GoBoardPool::get();
+    if (copy) std::memcpy(copy, b, sizeof(GoBoard));
+    return copy;
+}
+void go_destroy(void* b) { GoBoardPool::put(b); }
 void go_place(void* b, int color, int index) { if (index >= 0 && index < kPoints) static_cast<GoBoard*>(b)->place(color, index); }
 void go_features(void* b, int to_move, int symmetry, uint16_t* out) { features_v1(*static_cast<GoBoard*>(b), to_move, symmetry, out); }
 // Board::is_valid for every point at once (board_fast.rs:213-241 + board.rs:120-145): an empty point next to an empty point, to

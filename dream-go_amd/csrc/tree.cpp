@@ -160,6 +160,10 @@ struct TreeNode {
         delete[] slot_of.load(std::memory_order_relaxed);
     }
 
+    // (one node per rollout, freed by the thousand when a root moves on: dgnn_internal.h BlockPool)
+    static void* operator new(size_t, const std::nothrow_t&) noexcept;
+    static void operator delete(void* p) noexcept;
+
     // slot number -> its place: 0..7 inside the node, 8..23 chunk 0, 24..55 chunk 1, 56..119, 120..247, 248..503
     static int chunk_of(int k) { return 31 - __builtin_clz((unsigned)(k / kInline + 1)) - 1; }
     static int chunk_base(int j) { return kInline * ((2 << j) - 1); }
@@ -172,6 +176,19 @@ struct TreeNode {
     }
     const ChildSlot* slot(int k) const { return const_cast<TreeNode*>(this)->slot(k); }
 
+    // every visible slot, in slot order: the eight inside the node, then chunk after chunk (no per-slot address arithmetic)
+    template <typename F>
+    void for_each_slot(F&& f) const
+    {
+        const int n = num_slots.load(std::memory_order_acquire);
+        for (int k = 0; k < n && k < kInline; ++k) f(first[k]);
+        for (int j = 0, base = kInline; base < n; base += chunk_size(j), ++j) {
+            const ChildSlot* c = chunk[j].load(std::memory_order_acquire);
+            const int m = std::min(n - base, chunk_size(j));
+            for (int k = 0; k < m; ++k) f(c[k]);
+        }
+    }
+
     // the slot of child `index`, or NULL: such a child is Child::with_value(initial_value) -- no visits, no virtual loss, not
     // expanding, no sub-tree (tree.rs:901-927)
     ChildSlot* find(int index)
@@ -180,12 +197,13 @@ struct TreeNode {
             const int k = map[index].load(std::memory_order_acquire);
             return k ? slot(k - 1) : nullptr;
         }
-        const int n = num_slots.load(std::memory_order_acquire);
+        const int n = num_slots.load(std::memory_order_acquire);      // (fewer than kMapFrom: the inline slots and at most chunk 0)
         for (int k = 0; k < n && k < kInline; ++k)
             if (first[k].index == index) return &first[k];
-        for (int k = kInline; k < n; ++k) {
-            ChildSlot* s = slot(k);
-            if (s->index == index) return s;
+        if (n > kInline) {
+            ChildSlot* c = chunk[0].load(std::memory_order_acquire);
+            for (int k = 0; k < n - kInline; ++k)
+                if (c[k].index == index) return &c[k];
         }
         return nullptr;
     }
@@ -210,10 +228,9 @@ struct TreeNode {
             std::atomic<uint16_t>* map = slot_of.load(std::memory_order_relaxed);
             if (!map && n + 1 >= kMapFrom) {
                 map = new (std::nothrow) std::atomic<uint16_t>[kMoves];
-                if (map) {
-                    for (int i = 0; i < kMoves; ++i) map[i].store(0, std::memory_order_relaxed);
-                    for (int k = 0; k < n; ++k) map[slot(k)->index].store((uint16_t)(k + 1), std::memory_order_relaxed);
-                }
+                if (!map) { lock.unlock(); return nullptr; }            // (find() scans no further than chunk 0 without the map)
+                for (int i = 0; i < kMoves; ++i) map[i].store(0, std::memory_order_relaxed);
+                for (int k = 0; k < n; ++k) map[slot(k)->index].store((uint16_t)(k + 1), std::memory_order_relaxed);
             }
             s = slot(n);
             s->index = (uint16_t)index;
@@ -227,6 +244,10 @@ struct TreeNode {
     }
 };
 
+using TreeNodePool = BlockPool<sizeof(TreeNode), 8192>;
+void* TreeNode::operator new(size_t, const std::nothrow_t&) noexcept { return TreeNodePool::get(); }
+void TreeNode::operator delete(void* p) noexcept { TreeNodePool::put(p); }
+
 // A node's children by move index, for the walks that happen once per move (best, softmax, to_pretty): NULL = no slot.
 struct ChildView {
     const TreeNode* node;
@@ -234,8 +255,7 @@ struct ChildView {
     explicit ChildView(const TreeNode* n) : node(n)
     {
         std::memset(at, 0, sizeof(at));
-        const int slots = n->num_slots.load(std::memory_order_acquire);
-        for (int k = 0; k < slots; ++k) { const ChildSlot* s = n->slot(k); at[s->index] = s; }
+        n->for_each_slot([&](const ChildSlot& s) { at[s.index] = &s; });
     }
     int count(int i) const { return at[i] ? at[i]->count.load(std::memory_order_relaxed) : 0; }
     float value(int i) const { return at[i] ? at[i]->value : node->initial_value; }
@@ -258,15 +278,13 @@ void puct_scalar(const TreeNode* node, const PuctTerms& t, float* value)
     float v0 = node->initial_value;
     if (t.apply_fpu) v0 = std::max(v0 - t.fpu_reduce, 0.0f);
     for (int i = 0; i < kPadded; ++i) value[i] = v0 + node->prior[i] * t.uct_exp_sqrt_n;
-    const int n = node->num_slots.load(std::memory_order_acquire);
-    for (int k = 0; k < n; ++k) {
-        const ChildSlot* s = node->slot(k);
-        const int c = s->count.load(std::memory_order_relaxed) + s->vcount.load(std::memory_order_relaxed);
-        float v = s->value;
+    node->for_each_slot([&](const ChildSlot& s) {
+        const int c = s.count.load(std::memory_order_relaxed) + s.vcount.load(std::memory_order_relaxed);
+        float v = s.value;
         if (t.apply_fpu && c == 0) v = std::max(v - t.fpu_reduce, 0.0f);
         const float bonus = c == 0 ? t.uct_exp_sqrt_n : t.uct_exp_sqrt_n / (float)(1 + c);
-        value[s->index] = v + node->prior[s->index] * bonus;
-    }
+        value[s.index] = v + node->prior[s.index] * bonus;
+    });
 }
 
 // The reference's own formulation (tree.rs:63-115: cmpeq / div / mul / add on 8 lanes, no fused multiply-add), so both
@@ -282,16 +300,15 @@ void puct_avx2(const TreeNode* node, const PuctTerms& t, float* value)
     if (t.apply_fpu) v0 = _mm256_max_ps(_mm256_sub_ps(v0, _mm256_set1_ps(t.fpu_reduce)), _mm256_setzero_ps());
     for (int i = 0; i < kPadded; i += 8)
         _mm256_storeu_ps(value + i, _mm256_add_ps(v0, _mm256_mul_ps(_mm256_loadu_ps(node->prior + i), u)));
-    const int n = node->num_slots.load(std::memory_order_acquire);
     const __m128 u1 = _mm_set_ss(t.uct_exp_sqrt_n), fpu1 = _mm_set_ss(t.fpu_reduce), zero1 = _mm_setzero_ps();
-    for (int k = 0; k < n; ++k) {
-        const ChildSlot* s = node->slot(k);
-        const int c = s->count.load(std::memory_order_relaxed) + s->vcount.load(std::memory_order_relaxed);
-        __m128 v = _mm_set_ss(s->value);
-        if (t.apply_fpu && c == 0) v = _mm_max_ss(_mm_sub_ss(v, fpu1), zero1);
+    const bool apply_fpu = t.apply_fpu;
+    node->for_each_slot([&](const ChildSlot& s) __attribute__((target("avx2"))) {
+        const int c = s.count.load(std::memory_order_relaxed) + s.vcount.load(std::memory_order_relaxed);
+        __m128 v = _mm_set_ss(s.value);
+        if (apply_fpu && c == 0) v = _mm_max_ss(_mm_sub_ss(v, fpu1), zero1);
         const __m128 bonus = c == 0 ? u1 : _mm_div_ss(u1, _mm_cvtsi32_ss(zero1, 1 + c));
-        value[s->index] = _mm_cvtss_f32(_mm_add_ss(v, _mm_mul_ss(_mm_set_ss(node->prior[s->index]), bonus)));
-    }
+        value[s.index] = _mm_cvtss_f32(_mm_add_ss(v, _mm_mul_ss(_mm_set_ss(node->prior[s.index]), bonus)));
+    });
 }
 #endif
 
@@ -543,12 +560,11 @@ int dgnn_tree_node_min_promote(const dgnn_tree_node* handle)
     const TreeNode* node = reinterpret_cast<const TreeNode*>(handle);
     // the largest count and the largest among the OTHER children (a child without a slot counts 0, and so does the floor)
     int count_1 = 0, count_2 = 0;
-    const int n = node->num_slots.load(std::memory_order_acquire);
-    for (int k = 0; k < n; ++k) {
-        const int c = node->slot(k)->count.load(std::memory_order_relaxed);
+    node->for_each_slot([&](const ChildSlot& s) {
+        const int c = s.count.load(std::memory_order_relaxed);
         if (c > count_1) { count_2 = count_1; count_1 = c; }
         else if (c > count_2) count_2 = c;
-    }
+    });
     return count_1 > count_2 ? count_1 - count_2 : 0;
 }
 
