@@ -384,3 +384,38 @@ def test_a_third_batch_only_while_enough_boards_wait(api):
     pool.set_extra_batch_queue(0, 0, 0)
     assert pool.adaptive_stats()["alive_per_lane"] == 3     # back to the constant the pool was created with
     pool.close()
+
+
+def test_the_table_behaves_like_a_textbook_lru_under_random_traffic(api):
+    """The arena / open-addressing form of the table (batcher.cpp CacheShard) against an OrderedDict that restates
+    lru_cache.rs:95-147 -- get moves an entry to the front, an insert of a present key changes nothing, an insert into a full
+    table drops the least recently used entry -- over 60 000 random operations on few enough keys that buckets collide, entries
+    are evicted and re-inserted, and deletions shift probe chains; then a clear, and the same again on the re-used arena."""
+    from collections import OrderedDict
+    rng = np.random.default_rng(11)
+    for capacity, keys in ((7, 40), (64, 400), (500, 1200)):
+        lru = api.LruCache(capacity=capacity, num_shards=1)
+        for _round in range(2):
+            model = OrderedDict()
+            for _ in range(15000 if capacity < 500 else 30000):
+                key, colour = int(rng.integers(keys)) * 0x9E3779B97F4A7C15 % (1 << 64), int(rng.integers(2))
+                if rng.random() < 0.5:
+                    got = lru.fetch(key, colour, 0)
+                    want = model.get((key, colour))
+                    assert (got is None) == (want is None)
+                    if want is not None:
+                        assert got.value() == want
+                        model.move_to_end((key, colour))
+                else:
+                    value = float(np.float16(rng.integers(-64, 64) / 64))
+                    lru.cache(key, colour, 0, api.Prediction(value, np.zeros(362)))
+                    if (key, colour) not in model:
+                        model[(key, colour)] = value
+                        if len(model) > capacity:
+                            model.popitem(last=False)
+                assert len(lru) == len(model)
+            # every survivor is there with its value, nothing else is (checked from the oldest: the fetches re-order both alike)
+            for (key, colour), value in list(model.items()):
+                assert lru.fetch(key, colour, 0).value() == value
+            lru.clear()
+            assert len(lru) == 0 and lru.fetch(next(iter(model))[0], 0, 0) is None and lru.fetch(next(iter(model))[0], 1, 0) is None

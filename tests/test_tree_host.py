@@ -341,3 +341,60 @@ def test_to_pretty_summarises_a_search_like_the_reference(api):
     vertex = "pass" if best == 361 else "abcdefghjklmnopqrst"[best % 19] + str(best // 19 + 1)
     assert first.group(1) == vertex == first.group(3) and lines[0].split("PV: ")[1].split(" ")[0] == vertex
     assert "i" not in "".join(l.split("PV:")[1] for l in lines).replace("pass", "")
+
+
+def test_sparse_children_answer_like_a_dense_node(api):
+    """tree.cpp keeps a slot per child that was ever selected (eight in the node, chunks of 16 .. 256 beyond, an index map from
+    the sixteenth on); a child without a slot must read as Child::with_value (tree.rs:276-285).  A root is driven across every
+    one of those boundaries -- probes that each pick a new child (the "expanding" flag keeps them apart), inserts in a shuffled
+    order, undos -- and after every step all 362 children, the totals, softmax, best and the early-termination lead are compared
+    with a dense restatement kept in numpy."""
+    rng = np.random.default_rng(5)
+    vloss = api.config.VLOSS_CNT
+    prior = _prior_distribution(rng)
+    root = api.Node(api.BLACK, 0.5, prior)
+    count, vcount, value = np.zeros(362, dtype=np.int64), np.zeros(362, dtype=np.int64), np.full(362, np.float32(0.5))
+
+    def check():
+        for i in range(362):
+            child = root.with_(i)
+            assert (child.count(), child.vcount()) == (count[i], vcount[i]), i
+            assert child.value() == value[i], i
+        assert root.total_count == count.sum() and root.vtotal_count == vcount.sum()
+        visits = count.astype(np.float32)
+        expected = np.where(count != 0, visits / np.float32(visits.sum()), 0.0) if count.sum() else np.zeros(362)
+        assert np.array_equal(root.softmax(), expected.astype(np.float32))
+        top = np.sort(count)[::-1]
+        assert root.min_promote_rollouts() == max(int(top[0] - top[1]), 0)
+
+    check()
+    touched, steps = set(), iter((3, 5, 1, 7, 9, 31, 64) + (130,) * 40)
+    while len(touched) < 260:                            # slot counts around 8, 16, 24, 56, 120, 248: every chunk and the map
+        traces = []
+        for _ in range(next(steps)):
+            trace = api.probe(root)
+            if not isinstance(trace, api.Trace):
+                assert trace == api.PROBE_CONFLICT       # (the best child is still being expanded: nothing was changed)
+                continue
+            i = trace[0][2]                              # (a visited child may be chosen again and the probe go on below it)
+            touched.add(i)
+            vcount[i] += vloss
+            traces.append(trace)
+        check()
+        order = rng.permutation(len(traces))
+        for k in order[: len(order) // 4]:               # a quarter is undone: the slot stays, the child reads as untouched
+            vcount[traces[k][0][2]] -= vloss
+            api.undo(traces[k], True)
+        for k in order[len(order) // 4:]:
+            i, v = traces[k][0][2], np.float32(0.4 * rng.random())   # (below the 0.5 of an unvisited child: the search keeps widening)
+            api.insert(traces[k], api.BLACK, float(v), _prior_distribution(rng))
+            vcount[i] -= vloss
+            count[i] += 1
+            value[i] = value[i] + (v - value[i]) / np.float32(count[i])
+        check()
+    assert int((count > 0).sum()) > 150
+    _, best = root.best(0.0)
+    assert count[best] > 0 and root.with_(best).has_node()
+    # a child that never got a slot has no sub-tree and reads as Child::with_value
+    untouched = int(np.flatnonzero((count == 0) & (vcount == 0))[-1])
+    assert not root.with_(untouched).has_node() and root.with_(untouched).value() == np.float32(0.5)
