@@ -71,6 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-coalesce", type=int, default=1,
                     help="1 (default): a request for a position that is already queued or on the device follows it instead of being evaluated "
                          "again (dgnn_pool_set_coalescing: what the shared transposition table does, one evaluation earlier); 0: the reference's behaviour")
+    ap.add_argument("--selfplay-back-to-back", type=int, default=300, metavar="LEAD_US",
+                    help="> 0 (default 300): while a batch occupies the device a PARTIAL batch waits until this many microseconds before that batch "
+                         "is expected to finish and leaves with what has queued up meanwhile (dgnn_pool_set_back_to_back; a full batch goes at "
+                         "once); 0: the reference's rule, whatever is queued the moment a slot is free")
     ap.add_argument("--selfplay-host-threads", type=int, default=4,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
@@ -282,6 +286,8 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     coalesce = bool(args.selfplay_coalesce) and pool.takes_boards          # (the games of this leg share one transposition table)
     if coalesce:
         pool.set_coalescing(True)
+    if args.selfplay_back_to_back > 0:
+        pool.set_back_to_back(args.selfplay_back_to_back)
     opening = None
     if fast_forward > 0:
         ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=fast_forward, num_rollouts=1, threads_per_search=1,
@@ -314,7 +320,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
                  else f"first {args.selfplay_moves} stones of each") + f", --num-rollout {args.selfplay_rollouts}, "
                 f"1 search thread x {args.selfplay_leaves} leaves per game, games as " +
                 (f"fibers on {args.selfplay_host_threads} host threads" if args.selfplay_host_threads > 0 else "one OS thread each") + ", transposition cache 200001 x 8 shards, through the leaf pool "
-                f"({args.selfplay_batches or ('2 or 3 (adaptive)' if adaptive else 3)} device batches alive, PCIe-inclusive); random-init weights; feature planes built on the " +
+                f"({args.selfplay_batches or ('2 or 3 (adaptive)' if adaptive else 3)} device batches alive" + (f", partial batches back to back (lead {args.selfplay_back_to_back} us)" if args.selfplay_back_to_back > 0 else "") + f", PCIe-inclusive); random-init weights; feature planes built on the " +
                 ("DEVICE from 896-byte board records (dgnn_forward_boards)" if boards else "HOST (features::V1, 23 KB of fp16 per leaf)"),
         "seconds": sec, "games": j["games"], "moves": j["moves"],
         "evals_per_sec": j["evals"] / sec,                          # predictor evaluations (cache misses) per second, whole job

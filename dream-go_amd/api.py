@@ -228,6 +228,7 @@ SYMBOLS = [
     ("dgnn_pool_set_adaptive_batches", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_set_coalescing", ctypes.c_int, [_vp, ctypes.c_int]),
     ("dgnn_pool_set_min_fill", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_pool_set_back_to_back", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_set_extra_batch_queue", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_coalesced", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_adaptive_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
@@ -950,6 +951,11 @@ class LeafPool:
     def set_min_fill(self, min_boards, max_wait_us):
         """While another batch keeps the device busy a free slot waits for `min_boards` (or `max_wait_us`); 0: off (include/dgnn.h)."""
         _check(lib.dgnn_pool_set_min_fill(self._handle, int(min_boards), int(max_wait_us)), "LeafPool.set_min_fill")
+
+    def set_back_to_back(self, lead_us, snap_lo=0, snap_hi=0):
+        """A partial batch waits until `lead_us` before the batch on the device is expected to finish; with snap_lo a batch of
+        snap_lo < n < snap_hi boards is cut to its snap_lo oldest (include/dgnn.h).  (0, 0): off."""
+        _check(lib.dgnn_pool_set_back_to_back(self._handle, int(lead_us), int(snap_lo), int(snap_hi)), "LeafPool.set_back_to_back")
 
     def set_coalescing(self, enabled=True):
         """Requests for a position that is already in flight follow it instead of being evaluated again (include/dgnn.h)."""

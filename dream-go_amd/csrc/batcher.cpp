@@ -318,6 +318,8 @@ struct LeafRequest {
     std::condition_variable done;
 };
 
+static int batcher_get_batch(struct Batcher* b, int min_batch_size, int cap, dgnn_batch** out);
+
 struct LeafPool {
     Batcher* batcher = nullptr;     // holds a reference (Batcher::refs) for the pool's lifetime
     bool owns_batcher = false;      // created by dgnn_pool_create_devices / _callbacks: nobody else has a handle
@@ -357,12 +359,30 @@ struct LeafPool {
     // there -- or `max_wait_us` have passed since the oldest of them was queued, or nothing else is alive.
     std::atomic<int> min_fill{0};
     std::atomic<int> max_wait_us{0};
+    // Back to back (dgnn_pool_set_back_to_back; pools of one lane): a partial batch is not sent to run BESIDE the batch that occupies
+    // the device -- a workgroup per board makes 120 boards take what 128 take and 190 what 256 take -- but `lead_us` before that batch
+    // is expected to finish (how long a batch of its size took lately), so that its upload and its first kernels fall into the
+    // other's tail and the device is never idle, with everything that has queued up until then.  A FULL batch still goes at once.
+    // With snapping a batch of snap_lo < n < snap_hi boards is cut to its snap_lo OLDEST (the rest follows a moment later): alone on
+    // the device 129 .. 200 boards on whole-board workgroups are the worst sizes there are.
+    static constexpr long long kMaxHoldUs = 5000;
+    std::atomic<int> lead_us{0}, snap_lo{0}, snap_hi{0};
+    std::atomic<long long> expected_done_us{0};      // of the batch most recently sent to the device
+    std::atomic<int> took_us[17] = {};                  // by size / 16: moving average of evaluate()'s wall time, 0 = not seen yet
 
     bool ready() const
     {
         const int queued = batcher->queued.load(std::memory_order_acquire);
         const int alive = batcher->num_batches.load(std::memory_order_acquire);
         if (queued <= 0 || alive >= batcher->alive_limit()) return false;
+        const int lead = lead_us.load(std::memory_order_relaxed);
+        if (lead > 0 && alive > 0 && queued < batcher->max_batch_size) {
+            // (never longer than kMaxHoldUs behind the oldest board waiting: an estimate spoilt by a first batch that created its
+            // workspace must not stall the games)
+            const long long now = now_us();
+            return now >= expected_done_us.load(std::memory_order_acquire) - lead ||
+                   now - batcher->first_queued_us.load(std::memory_order_acquire) >= kMaxHoldUs;
+        }
         const int fill = min_fill.load(std::memory_order_relaxed);
         if (fill <= 0 || alive == 0 || queued >= fill) return true;
         const long long waited = now_us() - batcher->first_queued_us.load(std::memory_order_acquire);
@@ -392,7 +412,8 @@ struct LeafPool {
                 // batch that retires); the timeout only covers boards pushed into the batcher behind the pool's back
                 std::unique_lock<std::mutex> lock(mutex);
                 // (with a minimum fill the predicate also turns true by the clock: short naps while boards are waiting for company)
-                const bool holding = min_fill.load(std::memory_order_relaxed) > 0 && batcher->queued.load(std::memory_order_acquire) > 0;
+                const bool holding = (min_fill.load(std::memory_order_relaxed) > 0 || lead_us.load(std::memory_order_relaxed) > 0) &&
+                                     batcher->queued.load(std::memory_order_acquire) > 0;
                 work.wait_for(lock, holding ? std::chrono::microseconds(100) : std::chrono::microseconds(20000),
                               [&] { return stopping || (!paused && ready()); });
                 if (stopping) return;
@@ -406,12 +427,24 @@ struct LeafPool {
             dgnn_batch* batch = nullptr;
             // take whatever is queued as soon as a batch slot is free: with max_batches batches in flight the queue
             // fills up behind them, which is what makes the batches large under load and keeps latency low when idle
-            (void)dgnn_batcher_get_batch(reinterpret_cast<dgnn_batcher*>(batcher), 1, &batch);
+            int cap = 0;
+            if (const int lo = snap_lo.load(std::memory_order_relaxed)) {
+                const int waiting = batcher->queued.load(std::memory_order_acquire);
+                if (waiting > lo && waiting < snap_hi.load(std::memory_order_relaxed)) cap = lo;
+            }
+            (void)batcher_get_batch(batcher, 1, cap, &batch);
             if (!batch) { done(); continue; }
-            if (ready()) work.notify_one();         // more than one batch was queued: the next idle worker takes the rest
             const int n = dgnn_batch_size(batch);
+            const long long sent = now_us();
+            if (lead_us.load(std::memory_order_relaxed) > 0)
+                expected_done_us.store(sent + took_us[n >> 4].load(std::memory_order_relaxed), std::memory_order_release);
+            if (ready()) work.notify_one();         // more than one batch was queued: the next idle worker takes the rest
             (void)dgnn_batch_tags(batch, tags.data());
             const int status = evaluate(lane, batch, n, value.data(), policy.data());
+            {
+                const int took = (int)std::min<long long>(now_us() - sent, 20000), before = took_us[n >> 4].load(std::memory_order_relaxed);
+                took_us[n >> 4].store(before ? (3 * before + took) / 4 : took, std::memory_order_relaxed);
+            }
             dgnn_batch_destroy(batch);
             wake();                                 // a batch slot is free again
             auto deliver = [&](LeafSlot* slot, uint16_t v, const uint16_t* p) {
@@ -672,8 +705,13 @@ int dgnn_batcher_pending(dgnn_batcher* batcher, int* queued, int* batches_alive)
 int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch** out)
 {
     if (!batcher || !out) return DGNN_BAD_ARGUMENT;
+    return batcher_get_batch(reinterpret_cast<Batcher*>(batcher), min_batch_size, 0, out);
+}
+
+// get_batch with a cap below the batcher's own: the `cap` OLDEST entries go (cap <= 0: the reference's rule)
+int dgnn::batcher_get_batch(Batcher* b, int min_batch_size, int cap, dgnn_batch** out)
+{
     *out = nullptr;
-    Batcher* b = reinterpret_cast<Batcher*>(batcher);
 
     int current = b->num_batches.load(std::memory_order_acquire);               // batch.rs:93-99
     if (current >= b->alive_limit()) return DGNN_OK;
@@ -689,7 +727,14 @@ int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch
     const size_t split = size >= (size_t)b->max_batch_size ? size - b->max_batch_size : 0;     // batch.rs:106
     batch->owner = b;
     b->refs.fetch_add(1, std::memory_order_relaxed);
-    if (split == 0) {                                                           // everything goes: hand the buffers over, no copy under the lock
+    if (cap > 0 && (size_t)cap < size && cap < b->max_batch_size) {             // a cut batch: the entries that have waited longest
+        batch->features.assign(b->features.begin(), b->features.begin() + (size_t)cap * b->item);
+        batch->tags.assign(b->tags.begin(), b->tags.begin() + cap);
+        b->features.erase(b->features.begin(), b->features.begin() + (size_t)cap * b->item);
+        b->tags.erase(b->tags.begin(), b->tags.begin() + cap);
+        b->first_queued_us.store(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
+                                 std::memory_order_release);
+    } else if (split == 0) {                                                           // everything goes: hand the buffers over, no copy under the lock
         batch->features.swap(b->features);
         batch->tags.swap(b->tags);
         if (!b->spare_features.empty()) { b->features.swap(b->spare_features.back()); b->spare_features.pop_back(); }
@@ -1026,6 +1071,19 @@ int dgnn_pool_set_min_fill(dgnn_pool* handle, int min_boards, int max_wait_us)
     if (min_boards > pool->batcher->max_batch_size) min_boards = pool->batcher->max_batch_size;
     pool->max_wait_us.store(max_wait_us, std::memory_order_relaxed);
     pool->min_fill.store(min_boards, std::memory_order_release);
+    pool->work.notify_all();
+    return DGNN_OK;
+}
+
+int dgnn_pool_set_back_to_back(dgnn_pool* handle, int lead_us, int snap_lo, int snap_hi)
+{
+    if (!handle || lead_us < 0 || snap_lo < 0 || (snap_lo > 0 && snap_hi <= snap_lo)) return DGNN_BAD_ARGUMENT;
+    LeafPool* pool = reinterpret_cast<LeafPool*>(handle);
+    if ((lead_us > 0 || snap_lo > 0) && pool->num_lanes != 1) return DGNN_BAD_ARGUMENT;     // one device: the clock is that device's
+    if (snap_lo >= pool->batcher->max_batch_size) snap_lo = 0;
+    pool->snap_hi.store(snap_hi, std::memory_order_relaxed);
+    pool->snap_lo.store(snap_lo, std::memory_order_relaxed);
+    pool->lead_us.store(lead_us, std::memory_order_release);
     pool->work.notify_all();
     return DGNN_OK;
 }

@@ -442,6 +442,15 @@ int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool
  * (nn.rs:72-81), one evaluation earlier.  Like the shared table it makes WHICH evaluation a search sees a matter of timing: games that
  * must be a function of their seed (cache_entries_per_game > 0) keep it off.  DGNN_BUSY while requests are in flight. */
 int dgnn_pool_set_coalescing(dgnn_pool* pool, int enabled);
+/* Back to back (pools of ONE lane; off by default): while a batch occupies the device, a PARTIAL batch is held back until
+ * `lead_us` before that batch is expected to finish (the pool keeps a moving average of how long a batch of each size took) and
+ * then goes with everything that has queued up meanwhile -- its upload and first kernels fall into the other's tail, the device is
+ * never idle, and the batches come out as full as the leaves in flight allow (a workgroup per board makes 120 boards take what 128
+ * take, and 190 what 256 take).  A full batch is sent at once, as before.  snap_lo > 0: a batch of snap_lo < n < snap_hi boards is
+ * cut to its snap_lo OLDEST boards, the rest goes with the next batch (alone on the device, 129 .. 200 boards are the least
+ * efficient sizes).  lead_us 0 and snap_lo 0 switch both off.  The reference sends what is queued the moment a slot is free
+ * (pool/worker_thread.rs:131-140, predictors/nn.rs:64-67). */
+int dgnn_pool_set_back_to_back(dgnn_pool* pool, int lead_us, int snap_lo, int snap_hi);
 /* Minimum fill: while ANOTHER batch keeps a device busy, a free batch slot waits until `min_boards` are queued -- or `max_wait_us` have
  * passed since the oldest waiting board was queued -- instead of taking the handful that is there the moment the slot frees.  A
  * workgroup per board makes 130 boards take as long as 256, so fuller batches are more evaluations per second.  0: off (the reference

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--extra-batch-queue", type=int, default=0, metavar="BOARDS", help="> 0: two batches alive, a third only while at least this many boards are waiting (dgnn_pool_set_extra_batch_queue)")
     ap.add_argument("--min-fill", type=int, default=0, metavar="BOARDS", help="> 0: a free batch slot waits for this many boards while another batch keeps the device busy (dgnn_pool_set_min_fill)")
     ap.add_argument("--min-fill-wait-us", type=int, default=1000)
+    ap.add_argument("--back-to-back", type=int, default=300, metavar="LEAD_US", help="> 0 (default 300): a partial batch waits until this long before the batch on the device is expected to finish (dgnn_pool_set_back_to_back)")
+    ap.add_argument("--snap", default="", metavar="LO,HI", help="with --back-to-back: a batch of LO < n < HI boards is cut to its LO oldest, e.g. 128,208")
     ap.add_argument("--coalesce", type=int, default=1, help="1: requests for a position in flight follow it (dgnn_pool_set_coalescing; only with a shared table); 0: off")
     ap.add_argument("--max-batches", type=int, default=2, help="device batches the pool keeps alive: 2 (the reference's rule, default), 3, or 0 = adaptive, 2 or 3 by the unique positions per second the pool measures (dgnn_pool_set_adaptive_batches, DESIGN.md 13)")
     ap.add_argument("--blocks", type=int, default=20)
@@ -75,6 +77,9 @@ def main():
         pool.set_extra_batch_queue(2, 3, args.extra_batch_queue)
     if args.min_fill > 0:
         pool.set_min_fill(args.min_fill, args.min_fill_wait_us)
+    snap = [int(v) for v in args.snap.split(",")] if args.snap else [0, 0]
+    if args.back_to_back > 0 or snap[0] > 0:
+        pool.set_back_to_back(args.back_to_back, snap[0], snap[1])
     adaptive = args.max_batches == 0 and pool.takes_boards and args.extra_batch_queue == 0
     if adaptive:
         pool.set_adaptive_batches(2, 3)
@@ -113,7 +118,7 @@ def main():
             "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1),
             "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
             "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
-            "batches_alive": adaptive_stats if adaptive else (f"2, a third while >= {args.extra_batch_queue} boards wait" if args.extra_batch_queue > 0 else args.max_batches), "coalescing": coalesce, "min_fill": [args.min_fill, args.min_fill_wait_us] if args.min_fill > 0 else None, "coalesced_boards_rank0": coalesced,
+            "batches_alive": adaptive_stats if adaptive else (f"2, a third while >= {args.extra_batch_queue} boards wait" if args.extra_batch_queue > 0 else args.max_batches), "coalescing": coalesce, "min_fill": [args.min_fill, args.min_fill_wait_us] if args.min_fill > 0 else None, "back_to_back": [args.back_to_back] + snap if (args.back_to_back > 0 or snap[0] > 0) else None, "coalesced_boards_rank0": coalesced,
             "feature_planes": args.planes, "host_threads": args.host_threads, "host_cpus_busy_rank0": host_cpus_busy,
             "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
             "sharding": "game_id mod world, one engine + batcher + pool + cache per rank, no data-path collective",
