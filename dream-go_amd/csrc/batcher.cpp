@@ -488,6 +488,48 @@ struct LeafPool {
     }
 };
 
+// get_batch with a cap below the batcher's own: the `cap` OLDEST entries go (cap <= 0: the reference's rule)
+static int batcher_get_batch(Batcher* b, int min_batch_size, int cap, dgnn_batch** out)
+{
+    *out = nullptr;
+
+    int current = b->num_batches.load(std::memory_order_acquire);               // batch.rs:93-99
+    if (current >= b->alive_limit()) return DGNN_OK;
+
+    std::lock_guard<std::mutex> lock(b->mutex);
+    const size_t size = b->tags.size();
+    if (size == 0 || size < (size_t)(min_batch_size > 0 ? min_batch_size : 0)) return DGNN_OK;   // an empty batch is never useful
+    if (!b->num_batches.compare_exchange_strong(current, current + 1, std::memory_order_acquire, std::memory_order_relaxed))
+        return DGNN_OK;                                                         // batch.rs:105: lost the race, try again later
+
+    std::unique_ptr<Batch> batch(new (std::nothrow) Batch());
+    if (!batch) { b->num_batches.fetch_sub(1); return DGNN_OUT_OF_MEMORY; }
+    const size_t split = size >= (size_t)b->max_batch_size ? size - b->max_batch_size : 0;     // batch.rs:106
+    batch->owner = b;
+    b->refs.fetch_add(1, std::memory_order_relaxed);
+    if (cap > 0 && (size_t)cap < size && cap < b->max_batch_size) {             // a cut batch: the entries that have waited longest
+        batch->features.assign(b->features.begin(), b->features.begin() + (size_t)cap * b->item);
+        batch->tags.assign(b->tags.begin(), b->tags.begin() + cap);
+        b->features.erase(b->features.begin(), b->features.begin() + (size_t)cap * b->item);
+        b->tags.erase(b->tags.begin(), b->tags.begin() + cap);
+        b->first_queued_us.store(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
+                                 std::memory_order_release);
+    } else if (split == 0) {                                                           // everything goes: hand the buffers over, no copy under the lock
+        batch->features.swap(b->features);
+        batch->tags.swap(b->tags);
+        if (!b->spare_features.empty()) { b->features.swap(b->spare_features.back()); b->spare_features.pop_back(); }
+        if (!b->spare_tags.empty()) { b->tags.swap(b->spare_tags.back()); b->spare_tags.pop_back(); }
+    } else {
+        batch->features.assign(b->features.begin() + split * b->item, b->features.end());   // split_off: the NEWEST entries
+        batch->tags.assign(b->tags.begin() + split, b->tags.end());
+        b->features.resize(split * b->item);
+        b->tags.resize(split);
+    }
+    b->queued.store((int)b->tags.size(), std::memory_order_release);
+    *out = reinterpret_cast<dgnn_batch*>(batch.release());
+    return DGNN_OK;
+}
+
 }  // namespace dgnn
 
 const uint16_t* dgnn::symmetry_map(int transform) { return tables().map[transform & 7]; }
@@ -706,48 +748,6 @@ int dgnn_batcher_get_batch(dgnn_batcher* batcher, int min_batch_size, dgnn_batch
 {
     if (!batcher || !out) return DGNN_BAD_ARGUMENT;
     return batcher_get_batch(reinterpret_cast<Batcher*>(batcher), min_batch_size, 0, out);
-}
-
-// get_batch with a cap below the batcher's own: the `cap` OLDEST entries go (cap <= 0: the reference's rule)
-int dgnn::batcher_get_batch(Batcher* b, int min_batch_size, int cap, dgnn_batch** out)
-{
-    *out = nullptr;
-
-    int current = b->num_batches.load(std::memory_order_acquire);               // batch.rs:93-99
-    if (current >= b->alive_limit()) return DGNN_OK;
-
-    std::lock_guard<std::mutex> lock(b->mutex);
-    const size_t size = b->tags.size();
-    if (size == 0 || size < (size_t)(min_batch_size > 0 ? min_batch_size : 0)) return DGNN_OK;   // an empty batch is never useful
-    if (!b->num_batches.compare_exchange_strong(current, current + 1, std::memory_order_acquire, std::memory_order_relaxed))
-        return DGNN_OK;                                                         // batch.rs:105: lost the race, try again later
-
-    std::unique_ptr<Batch> batch(new (std::nothrow) Batch());
-    if (!batch) { b->num_batches.fetch_sub(1); return DGNN_OUT_OF_MEMORY; }
-    const size_t split = size >= (size_t)b->max_batch_size ? size - b->max_batch_size : 0;     // batch.rs:106
-    batch->owner = b;
-    b->refs.fetch_add(1, std::memory_order_relaxed);
-    if (cap > 0 && (size_t)cap < size && cap < b->max_batch_size) {             // a cut batch: the entries that have waited longest
-        batch->features.assign(b->features.begin(), b->features.begin() + (size_t)cap * b->item);
-        batch->tags.assign(b->tags.begin(), b->tags.begin() + cap);
-        b->features.erase(b->features.begin(), b->features.begin() + (size_t)cap * b->item);
-        b->tags.erase(b->tags.begin(), b->tags.begin() + cap);
-        b->first_queued_us.store(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
-                                 std::memory_order_release);
-    } else if (split == 0) {                                                           // everything goes: hand the buffers over, no copy under the lock
-        batch->features.swap(b->features);
-        batch->tags.swap(b->tags);
-        if (!b->spare_features.empty()) { b->features.swap(b->spare_features.back()); b->spare_features.pop_back(); }
-        if (!b->spare_tags.empty()) { b->tags.swap(b->spare_tags.back()); b->spare_tags.pop_back(); }
-    } else {
-        batch->features.assign(b->features.begin() + split * b->item, b->features.end());   // split_off: the NEWEST entries
-        batch->tags.assign(b->tags.begin() + split, b->tags.end());
-        b->features.resize(split * b->item);
-        b->tags.resize(split);
-    }
-    b->queued.store((int)b->tags.size(), std::memory_order_release);
-    *out = reinterpret_cast<dgnn_batch*>(batch.release());
-    return DGNN_OK;
 }
 
 int dgnn_batcher_push_and_get_batch(dgnn_batcher* batcher, const uint16_t* features, uint64_t tag, dgnn_batch** out)
