@@ -616,7 +616,7 @@ def main():
         if selfplay is not None:
             out["selfplay"] = selfplay
             # WHOLE games are too long for this line (6-8 minutes): the committed, builder-run measurement is quoted with its file
-            whole = os.path.join(ROOT, "profiles", "r04_final", "selfplay_full_games_96g_l16_h4_sparse.json")
+            whole = os.path.join(ROOT, "profiles", "r04_final", "selfplay_full_games_96g_l16_h4_sparse_b2b300.json")
             if os.path.exists(whole) and not job.dry:
                 try:
                     w = json.load(open(whole))
