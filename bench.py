@@ -623,7 +623,7 @@ def main():
                     out["whole_games_committed"] = {
                         "games_per_hour_measured": w["games_per_hour_measured"], "moves_per_sec": w["moves_per_sec"], "games": w["games"],
                         "mean_stones_per_game": w["mean_stones_per_game"], "host_cpus_busy": w["host_cpus_busy_rank0"],
-                        "source": "profiles/r04_final/selfplay_full_games_96g_l16_h4_sparse.json (tools/selfplay_go.py --games 96 --moves 0 --threads 1 --leaves 16 --host-threads 4: the legs' own setting; NOT measured in this run)",
+                        "source": "profiles/r04_final/selfplay_full_games_96g_l16_h4_sparse_b2b300.json (tools/selfplay_go.py --games 96 --moves 0 --threads 1 --leaves 16 --host-threads 4 --back-to-back 300: the legs' own setting; NOT measured in this run)",
                     }
                 except Exception:   # noqa: BLE001
                     pass
