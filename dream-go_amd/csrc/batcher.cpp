@@ -616,9 +616,9 @@ static int cache_insert(Cache* c, bool checked, uint64_t generation, uint64_t bo
     } else {
         id = (uint32_t)s.size++;
         if ((id >> CacheShard::kBlockBits) >= s.blocks.size()) {
-            CacheEntry* block = new (std::nothrow) CacheEntry[1u << CacheShard::kBlockBits];
-            if (!block) { --s.size; return DGNN_OUT_OF_MEMORY; }
-            s.blocks.emplace_back(block);
+            std::unique_ptr<CacheEntry[]> block(new (std::nothrow) CacheEntry[1u << CacheShard::kBlockBits]);
+            if (block) { try { s.blocks.push_back(std::move(block)); } catch (const std::bad_alloc&) { block.reset(); } }
+            if ((id >> CacheShard::kBlockBits) >= s.blocks.size()) { --s.size; return DGNN_OUT_OF_MEMORY; }
         }
     }
     CacheEntry& e = s.entry(id);

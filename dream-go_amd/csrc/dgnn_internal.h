@@ -196,7 +196,7 @@ struct BlockPool {
     struct List {
         Free* head = nullptr;
         int count = 0;
-        ~List() { while (head) { Free* next = head->next; ::operator delete(head); head = next; } }
+        ~List() { while (head) { Free* next = head->next; ::operator delete(head); head = next; } count = 0; }   // (usable after it: empty)
     };
     static List& list() { static thread_local List l; return l; }
     static void* get()
