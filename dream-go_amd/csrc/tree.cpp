@@ -657,6 +657,7 @@ int dgnn_choose_f64(const double* items, int n, double cutoff_percentile, double
 //   "Nodes: <visits>, Win: <visit-weighted value>%, PV: <greedy path>" and, for the ten best children in compare_children order,
 //   "<vertex> -> <child visits> (W: <value>% / <lower confidence bound>%) (N: <prior>%) PV: <vertex> <greedy path below it>".
 // Vertices are GTP style (no i column, row 1 at packed y = 0), "pass" for 361.
+extern "C++" {
 namespace {
 std::string pretty_vertex(int i)                                             // PrettyVertex, tree.rs:1620-1640
 {
@@ -687,6 +688,7 @@ std::string greedy_path(const TreeNode* node)                                // 
     return out;
 }
 }  // namespace
+}  // extern "C++"
 
 size_t dgnn_tree_node_to_pretty(const dgnn_tree_node* handle, char* out, size_t capacity)
 {
