@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <sys/resource.h>
 #include <sys/time.h>
 #include <ucontext.h>
 #include <vector>
@@ -39,6 +40,9 @@ int main(int argc, char** argv) {
     rc = dgnn_selfplay_go_boards(dgnn_hash_boards_predictor(), nullptr, cache, &p, &st, nullptr, nullptr, 0);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     it = itimerval{}; setitimer(ITIMER_PROF, &it, nullptr);
+    rusage ru{}; getrusage(RUSAGE_SELF, &ru);
+    const double cpu = ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec + ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec;
+    std::printf("CPU %.2f us per rollout (user + system, every thread); ", 1e6 * cpu / (double)(st.evals + st.cache_hits));
     std::printf("rc %d games %llu moves %llu evals %llu hits %llu: %.2f s, %.2f us per rollout\n", rc, (unsigned long long)st.games, (unsigned long long)st.moves,
                 (unsigned long long)st.evals, (unsigned long long)st.cache_hits, sec, 1e6 * sec / (double)(st.evals + st.cache_hits));
     { FILE* m = fopen("/proc/self/maps", "r"); FILE* o = fopen("maps.txt", "w"); char line[512]; while (fgets(line, sizeof line, m)) fputs(line, o); fclose(m); fclose(o); }
