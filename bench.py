@@ -308,6 +308,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     st = pool.stats()
     adaptive_stats = pool.adaptive_stats() if adaptive else None
     coalesced = pool.coalesced()
+    batch_times = pool.batch_times()
     boards = sum(job.gather_int(st["boards"] - before["boards"]))
     batches = sum(job.gather_int(st["batches"] - before["batches"]))
     pool.close()
@@ -326,6 +327,9 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
         "evals_per_sec": j["evals"] / sec,                          # predictor evaluations (cache misses) per second, whole job
         "device_boards_per_sec": boards / sec,
         "mean_device_batch": boards / max(batches, 1),
+        # what a batch took lately by size (first size of each 16-board bucket -> microseconds from hand-over to answers, moving average,
+        # including what the batch shared the device with): the pool's own figures (dgnn_pool_batch_times)
+        "device_batch_us_by_size": {str(k): v for k, v in batch_times.items()},
         "evals_per_move": j["evals"] / max(j["moves"], 1),          # MEASURED: what one move costs the engine
         "cache_hit_ratio": j["cache_hits"] / max(j["cache_hits"] + j["evals"], 1),
         "probe_conflicts": j["conflicts"],

@@ -229,6 +229,7 @@ SYMBOLS = [
     ("dgnn_pool_set_coalescing", ctypes.c_int, [_vp, ctypes.c_int]),
     ("dgnn_pool_set_min_fill", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_set_back_to_back", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("dgnn_pool_batch_times", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int)]),
     ("dgnn_pool_set_extra_batch_queue", ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("dgnn_pool_coalesced", ctypes.c_uint64, [_vp]),
     ("dgnn_pool_adaptive_stats", ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
@@ -956,6 +957,12 @@ class LeafPool:
         """A partial batch waits until `lead_us` before the batch on the device is expected to finish; with snap_lo a batch of
         snap_lo < n < snap_hi boards is cut to its snap_lo oldest (include/dgnn.h).  (0, 0): off."""
         _check(lib.dgnn_pool_set_back_to_back(self._handle, int(lead_us), int(snap_lo), int(snap_hi)), "LeafPool.set_back_to_back")
+
+    def batch_times(self):
+        """{first size of the bucket: microseconds a batch of that size took lately} for the sizes seen (include/dgnn.h)."""
+        took = (ctypes.c_int * 17)()
+        _check(lib.dgnn_pool_batch_times(self._handle, took), "LeafPool.batch_times")
+        return {16 * k: int(took[k]) for k in range(17) if took[k] > 0}
 
     def set_coalescing(self, enabled=True):
         """Requests for a position that is already in flight follow it instead of being evaluated again (include/dgnn.h)."""

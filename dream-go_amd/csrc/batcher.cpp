@@ -437,13 +437,13 @@ struct LeafPool {
             const int n = dgnn_batch_size(batch);
             const long long sent = now_us();
             if (lead_us.load(std::memory_order_relaxed) > 0)
-                expected_done_us.store(sent + took_us[n >> 4].load(std::memory_order_relaxed), std::memory_order_release);
+                expected_done_us.store(sent + took_us[std::min(n >> 4, 16)].load(std::memory_order_relaxed), std::memory_order_release);
             if (ready()) work.notify_one();         // more than one batch was queued: the next idle worker takes the rest
             (void)dgnn_batch_tags(batch, tags.data());
             const int status = evaluate(lane, batch, n, value.data(), policy.data());
             {
-                const int took = (int)std::min<long long>(now_us() - sent, 20000), before = took_us[n >> 4].load(std::memory_order_relaxed);
-                took_us[n >> 4].store(before ? (3 * before + took) / 4 : took, std::memory_order_relaxed);
+                const int took = (int)std::min<long long>(now_us() - sent, 20000), before = took_us[std::min(n >> 4, 16)].load(std::memory_order_relaxed);
+                took_us[std::min(n >> 4, 16)].store(before ? (3 * before + took) / 4 : took, std::memory_order_relaxed);
             }
             dgnn_batch_destroy(batch);
             wake();                                 // a batch slot is free again
@@ -1085,6 +1085,17 @@ int dgnn_pool_set_back_to_back(dgnn_pool* handle, int lead_us, int snap_lo, int 
     pool->snap_lo.store(snap_lo, std::memory_order_relaxed);
     pool->lead_us.store(lead_us, std::memory_order_release);
     pool->work.notify_all();
+    return DGNN_OK;
+}
+
+// What evaluate() took lately, by batch size: took_us[k] is the moving average over batches of 16 k .. 16 k + 15 boards (k = 16: 256 and
+// more), 0 = none seen.  Wall time of the worker from handing the batch to the device to having the answers, i.e. including what it
+// shared the device with.
+int dgnn_pool_batch_times(const dgnn_pool* handle, int* took_us)
+{
+    if (!handle || !took_us) return DGNN_BAD_ARGUMENT;
+    const LeafPool* pool = reinterpret_cast<const LeafPool*>(handle);
+    for (int k = 0; k < 17; ++k) took_us[k] = pool->took_us[k].load(std::memory_order_relaxed);
     return DGNN_OK;
 }
 

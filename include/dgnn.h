@@ -451,6 +451,10 @@ int dgnn_pool_set_coalescing(dgnn_pool* pool, int enabled);
  * efficient sizes).  lead_us 0 and snap_lo 0 switch both off.  The reference sends what is queued the moment a slot is free
  * (pool/worker_thread.rs:131-140, predictors/nn.rs:64-67). */
 int dgnn_pool_set_back_to_back(dgnn_pool* pool, int lead_us, int snap_lo, int snap_hi);
+/* What a batch took lately, by size: took_us[k] = moving average (microseconds, wall time of the worker from handing the batch over to
+ * having its answers) over batches of 16 k .. 16 k + 15 boards, k = 0 .. 16 (16: 256 and more); 0 = no such batch yet.  The estimate
+ * back-to-back batching runs on, and a measured handle on the fixed cost per batch. */
+int dgnn_pool_batch_times(const dgnn_pool* pool, int* took_us /* 17 */);
 /* Minimum fill: while ANOTHER batch keeps a device busy, a free batch slot waits until `min_boards` are queued -- or `max_wait_us` have
  * passed since the oldest waiting board was queued -- instead of taking the handful that is there the moment the slot frees.  A
  * workgroup per board makes 130 boards take as long as 256, so fuller batches are more evaluations per second.  0: off (the reference

@@ -98,6 +98,7 @@ def main():
     after = pool.stats()
     adaptive_stats = pool.adaptive_stats() if adaptive else None
     coalesced = pool.coalesced()
+    batch_times = pool.batch_times()
     if args.sgf:
         with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
             f.write("\n".join(stats.get("sgf", [])) + "\n")
@@ -115,7 +116,7 @@ def main():
             "games_ended_by_passes": job["games_ended"], "mean_stones_per_game": job["moves"] / max(job["games"], 1),
             "games_per_hour_measured": (job["games"] * 3600 / job["seconds"]) if args.moves == 0 else None,
             "evals_per_move": job["evals"] / max(job["moves"], 1),
-            "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1),
+            "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1), "device_batch_us_by_size": {str(k): v for k, v in batch_times.items()},
             "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
             "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
             "batches_alive": adaptive_stats if adaptive else (f"2, a third while >= {args.extra_batch_queue} boards wait" if args.extra_batch_queue > 0 else args.max_batches), "coalescing": coalesce, "min_fill": [args.min_fill, args.min_fill_wait_us] if args.min_fill > 0 else None, "back_to_back": [args.back_to_back] + snap if (args.back_to_back > 0 or snap[0] > 0) else None, "coalesced_boards_rank0": coalesced,
