@@ -199,7 +199,9 @@ struct BlockPool {
         ~List() { while (head) { Free* next = head->next; ::operator delete(head); head = next; } count = 0; }   // (usable after it: empty)
     };
     static List& list() { static thread_local List l; return l; }
-    static void* get()
+    // (never inlined: games run as fibers that may resume on another host thread, and a caller that contained a switch point could
+    // otherwise keep the address of its OLD thread's list across it -- the sanitizer builds, which bypass the pool, would not see it)
+    __attribute__((noinline)) static void* get()
     {
         List& l = list();
         if (!l.head) return ::operator new(Bytes, std::nothrow);
@@ -208,7 +210,7 @@ struct BlockPool {
         --l.count;
         return f;
     }
-    static void put(void* p)
+    __attribute__((noinline)) static void put(void* p)
     {
         if (!p) return;
         List& l = list();
