@@ -468,6 +468,8 @@ def test_back_to_back_holds_partial_batches_until_the_device_is_about_to_be_free
     mean, total = drive(pool)
     print(f"mean batch {plain_mean:.1f} -> {mean:.1f} boards, {plain_boards} -> {total} boards evaluated in 0.6 s")
     assert mean > 1.15 * plain_mean and total > 0.8 * plain_boards          # (measured: 22.5 -> 31.5 boards, 4 300 -> 6 100 in 0.6 s; the same under full CPU load)
+    times = pool.batch_times()                               # the pool's own clock: a batch of the stand-in takes 3 ms (+ the wait for its turn)
+    assert times and all(3000 <= t <= 20000 for t in times.values()) and max(times) <= 64
     pool.set_back_to_back(0, 0, 0)
     drive(pool, 0.1)
     pool.close()
