@@ -68,6 +68,9 @@ def parse_args(argv=None):
                          "rate on partial batches and puts more leaves in flight (more positions evaluated twice before the first answer "
                          "reaches the transposition table; measured in DESIGN.md 13).  0: ADAPTIVE, 2 or 3 -- the pool measures unique positions "
                          "per second under both and stays with the better one (dgnn_pool_set_adaptive_batches)")
+    ap.add_argument("--selfplay-workers", type=int, default=0,
+                    help="pool worker threads per GPU; 0 (default) = as many as batches alive.  One more lets a free worker take the next batch while "
+                         "another is still handing 256 answers to their games (about a millisecond per cycle, DESIGN.md 13.10 / 13.11: not measured yet)")
     ap.add_argument("--selfplay-coalesce", type=int, default=1,
                     help="1 (default): a request for a position that is already queued or on the device follows it instead of being evaluated "
                          "again (dgnn_pool_set_coalescing: what the shared transposition table does, one evaluation earlier); 0: the reference's behaviour")
@@ -274,12 +277,12 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
         # no GPU: the CPU stand-in behind a stand-in for the device (a batch of n boards takes 500 + 10.8 n us, one at a time: the
         # 20x256 engine's 3.3 ms at 256 boards) -- what is measured is the HOST side alone, rollouts per second and core
         pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=args.selfplay_batches or 3,
-                                           workers_per_lane=args.selfplay_batches or 3)
+                                           workers_per_lane=max(args.selfplay_workers, args.selfplay_batches or 3))
     elif job.dry:
         pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
     else:
         pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches or 3,
-                                        workers_per_device=args.selfplay_batches or 3, boards=boards)
+                                        workers_per_device=max(args.selfplay_workers, args.selfplay_batches or 3), boards=boards)
     adaptive = args.selfplay_batches == 0 and pool.takes_boards
     if adaptive:
         pool.set_adaptive_batches(2, 3)
