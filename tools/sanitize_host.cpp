@@ -118,11 +118,15 @@ int main() {
         std::printf("fibers: 256 games on 2 host threads rc %d moves %llu evals %llu hits %llu followed %llu\n", rc, (unsigned long long)st.moves,
                     (unsigned long long)st.evals, (unsigned long long)st.cache_hits, (unsigned long long)dgnn_pool_coalesced(pool));
         dgnn_pool_set_coalescing(pool, 0);              // (the private-table job below must stay a function of its seeds)
+        dgnn_pool_set_adaptive_batches(pool, 0, 0);
+        dgnn_pool_set_back_to_back(pool, 300, 16, 48);  // partial batches held until the running one is due, 17 .. 47 boards cut to 16
         // the same with a table per game (the reproducible mode) and games started as others end
         p.num_games = 48; p.num_parallel = 32; p.max_moves = 12; p.cache_entries_per_game = 2000; p.seed = 80; p.host_threads = 3;
         rc = dgnn_selfplay_go_boards(dgnn_pool_boards_predictor(), pool, nullptr, &p, &st, nullptr, nullptr, 0);
         std::printf("fibers: 48 games (32 in flight) on 3 host threads, private tables rc %d moves %llu evals %llu\n", rc,
                     (unsigned long long)st.moves, (unsigned long long)st.evals);
+        int took[17];
+        dgnn_pool_batch_times(pool, took);
         dgnn_pool_destroy(pool);
         dgnn_cache_destroy(cache);
     }
