@@ -82,13 +82,24 @@ def parse_args(argv=None):
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
                     help="where the 32 feature planes are built: on the device from 896-byte board records (default), or on the host like the reference")
+    ap.add_argument("--whole-games", type=int, default=96,
+                    help="games in flight PER GPU, with replacement, in the steady-state WHOLE-GAME leg (the setting of tools/selfplay_go.py; 0 = skip the leg)")
+    ap.add_argument("--whole-games-seconds", type=float, default=90.0, help="the timed window of the whole-game leg")
+    ap.add_argument("--whole-games-ramp", type=float, default=20.0, help="untimed seconds in front of that window")
+    ap.add_argument("--policy-play-games", type=int, default=1024,
+                    help="games in flight PER GPU in the policy-play leg (BASELINE.json configs[4]: --num-rollout 1; 0 = skip the leg)")
+    ap.add_argument("--policy-play-seconds", type=float, default=10.0, help="the timed window of the policy-play leg (after 2 untimed seconds)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0, help="`value_sustained`: the passes of `value` repeated for at least this long (0 = skip)")
+    ap.add_argument("--reference-rule-leg", type=int, default=1,
+                    help="1 (default): the mid-game leg is run a second time under the REFERENCE's batching rule -- no coalescing, whatever is queued "
+                         "the moment a slot is free (worker_thread.rs:131-140) -- and reported beside the tuned one; 0: skip")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the weight broadcast even with one rank (self-test of the N > 1 path)")
     ap.add_argument("--lean", action="store_true", help="only the engine measurement (profiling passes): no PCIe-inclusive, reference-style or self-play legs")
     ap.add_argument("--dry", action="store_true", help="no GPU: gloo + the CPU hash predictor behind the leaf pool (CPU tests of the N > 1 path)")
     args = ap.parse_args(argv)
     if args.lean:
-        args.selfplay_games, args.cpu_sample = 0, 0
+        args.selfplay_games, args.cpu_sample, args.whole_games, args.policy_play_games, args.sustained_seconds = 0, 0, 0, 0, 0.0
     return args
 
 
@@ -264,14 +275,9 @@ def broadcast_weights(job, api, net):
             "distinct_images_before": len(set(before)), "seconds_incl_comm_setup": seconds}
 
 
-def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
-    """Whole pipeline, measured: Go boards -> board records (planes on the device) -> search (1 thread x K leaves per game) ->
-    transposition cache -> leaf pool -> engine, `selfplay_games` games in flight per GPU for `selfplay_moves` searched stones each
-    (self_play.rs:423-459; rollouts per move follow the win rate, :234-241).  Games are sharded `id mod world`.
-    fast_forward > 0: every game is first played that many stones deep by policy play (--num-rollout 1, self_play.rs:369-405; not
-    timed) and the searched stones start from there: a MID-GAME leg (fewer table hits, narrower trees, more ladders and captures)."""
-    games = args.selfplay_games * job.world
-    cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
+def selfplay_pool(job, api, net, args, coalesce=None, back_to_back=None):
+    """The leaf pool of every self-play leg: one device (or its stand-in), `--selfplay-batches` batches alive, coalescing and
+    back-to-back batching as the arguments say (coalesce / back_to_back override them: the reference-rule leg)."""
     boards = args.selfplay_planes == "device"
     if job.dry and boards:
         # no GPU: the CPU stand-in behind a stand-in for the device (a batch of n boards takes 500 + 10.8 n us, one at a time: the
@@ -286,11 +292,138 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
     adaptive = args.selfplay_batches == 0 and pool.takes_boards
     if adaptive:
         pool.set_adaptive_batches(2, 3)
-    coalesce = bool(args.selfplay_coalesce) and pool.takes_boards          # (the games of this leg share one transposition table)
+    coalesce = (bool(args.selfplay_coalesce) if coalesce is None else coalesce) and pool.takes_boards   # (the games of a leg share one transposition table)
     if coalesce:
         pool.set_coalescing(True)
-    if args.selfplay_back_to_back > 0:
-        pool.set_back_to_back(args.selfplay_back_to_back)
+    lead = args.selfplay_back_to_back if back_to_back is None else back_to_back
+    if lead > 0:
+        pool.set_back_to_back(lead)
+    return pool, {"adaptive": adaptive, "coalesce": coalesce, "back_to_back": lead, "boards": boards}
+
+
+def pool_rule_text(args, rule):
+    return (f"{args.selfplay_batches or ('2 or 3 (adaptive)' if rule['adaptive'] else 3)} device batches alive" +
+            (f", partial batches back to back (lead {rule['back_to_back']} us)" if rule["back_to_back"] > 0 else ", a free slot takes what is queued (the reference's rule)") +
+            (", positions in flight coalesced" if rule["coalesce"] else ", no coalescing (the reference: every miss is evaluated)"))
+
+
+class EdgeProbe:
+    """What the library does not count, read at the two edges of a dgnn_selfplay_window (from the watcher thread): the pool's device
+    boards / batches / followers, the process's CPU time, the wall clock."""
+
+    def __init__(self, pool):
+        self.pool, self.edges = pool, {}
+
+    def __call__(self, edge):
+        st = self.pool.stats()
+        self.edges[edge] = {"boards": st["boards"], "batches": st["batches"], "coalesced": self.pool.coalesced(),
+                            "cpu": time.process_time(), "wall": time.perf_counter()}
+
+    def delta(self, key):
+        return self.edges[1][key] - self.edges[0][key] if 0 in self.edges and 1 in self.edges else 0
+
+
+def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds, staggered, seed):
+    """`in_flight` games per GPU WITH REPLACEMENT (self_play.rs:478-495) for a fixed wall time: `ramp` untimed seconds, then a
+    window of `seconds` whose counters the library notes itself (dgnn_selfplay_window), then the job stops.  staggered: game i of a
+    rank's first `in_flight` starts i / in_flight of the way into a game that policy play (--num-rollout 1, not timed) has played to
+    its end, so that from the first second on the games in flight are at every stage of a game -- the steady state of a long job --
+    and whole games END inside the window at the rate they would in hour six."""
+    pool, rule = selfplay_pool(job, api, net, args)
+    cache = api.LruCache(200_001, num_shards=8)
+    opening, prep_seconds = None, 0.0
+    if staggered:
+        t0 = time.perf_counter()
+        ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=in_flight * job.world, num_moves=0, num_rollouts=1, threads_per_search=1,
+                                          seed=seed, pool=pool, cache=api.LruCache(50_001, num_shards=8), device=job.tensor_device,
+                                          host_threads=args.selfplay_host_threads, return_moves=True)
+        opening = np.array(ahead["record"], copy=True)
+        for i in range(opening.shape[0]):
+            stones = int((opening[i] >= 0).sum())
+            opening[i, stones * i // opening.shape[0]:] = -1
+        prep_seconds = time.perf_counter() - t0
+    probe = EdgeProbe(pool)
+    out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=4096 * job.world, num_moves=0, num_rollouts=rollouts, threads_per_search=1,
+                                    seed=seed + 1, pool=pool, cache=cache, device=job.tensor_device, leaves_per_thread=args.selfplay_leaves,
+                                    host_threads=args.selfplay_host_threads, opening=opening, num_parallel=in_flight, window=(ramp, seconds, probe))
+    batch_times = pool.batch_times()
+    pool.close()
+    w = out["job"]["window"]
+    sec = max(w["seconds"], 1e-9)
+    boards = sum(job.gather_int(probe.delta("boards")))
+    batches = sum(job.gather_int(probe.delta("batches")))
+    followers = sum(job.gather_int(probe.delta("coalesced")))
+    cores = job.gather_float(probe.delta("cpu") / max(probe.delta("wall"), 1e-9))
+    stones = w["stones_completed"] / max(w["games_completed"], 1)
+    leg = {
+        "seconds": sec, "ramp_seconds": ramp, "preparation_seconds": prep_seconds, "games_in_flight_per_gpu": in_flight,
+        "moves": w["moves"], "moves_per_sec": w["moves"] / sec,
+        "games_completed": w["games_completed"], "games_ended_by_passes": w["games_ended"], "games_started": w["games_started"],
+        "mean_stones_per_completed_game": stones if w["games_completed"] else None,
+        # whole games that ENDED inside the window, per hour of window -- and the same figure from the window's moves (less noisy: a
+        # window sees a few dozen endings): moves per second x 3600 / the mean stones of the games that ended
+        "games_per_hour_measured": w["games_completed"] * 3600.0 / sec,
+        "games_per_hour_from_moves": (w["moves"] / sec) * 3600.0 / stones if w["games_completed"] else None,
+        "answers_per_sec": w["evals"] / sec,                          # what the searches were answered (table misses; followers of positions in flight included)
+        "rollouts_per_sec": (w["evals"] + w["cache_hits"]) / sec,
+        "evals_per_move": w["evals"] / max(w["moves"], 1),
+        "cache_hit_ratio": w["cache_hits"] / max(w["cache_hits"] + w["evals"], 1),
+        "device_boards_per_sec": boards / sec, "mean_device_batch": boards / max(batches, 1),
+        "followers_per_sec": followers / sec,                         # boards that followed a position in flight instead of being evaluated
+        "device_batch_us_by_size": {str(k): v for k, v in batch_times.items()},
+        "host_cpus_busy": cores[0], "per_rank_host_cpus_busy": cores, "host_cpus": effective_cpus(), "host_threads": args.selfplay_host_threads,
+        "probe_conflicts": w["conflicts"],
+    }
+    return leg, rule
+
+
+def whole_games_leg(job, api, replicas, net, args):
+    """BASELINE.json's first metric on this run's own clock: self-play games per hour, whole games (self_play.rs:423-499)."""
+    leg, rule = window_leg(job, api, replicas, net, args, args.whole_games, args.selfplay_rollouts, args.whole_games_ramp, args.whole_games_seconds,
+                           staggered=True, seed=20261001)
+    leg["what"] = (f"steady state of WHOLE games: {args.whole_games} games in flight per GPU with replacement, --num-rollout {args.selfplay_rollouts}, 1 search thread x "
+                   f"{args.selfplay_leaves} leaves per game, games as fibers on {args.selfplay_host_threads} host threads, shared transposition table 200001 x 8, "
+                   f"{pool_rule_text(args, rule)}; game i of the first {args.whole_games} starts i / {args.whole_games} of the way into a game played to its end by policy play "
+                   f"(not timed), so games at every stage are in flight from the start and END inside the window; {args.whole_games_ramp:.0f} s ramp, then the timed window; "
+                   "random-init weights (such a net plays 600-700 stones per game: games_per_hour_at_250_stones is the same moves per second at a trained net's game length)")
+    leg["games_per_hour_at_250_stones"] = leg["moves_per_sec"] * 3600.0 / 250.0
+    cross = os.path.join(ROOT, "profiles", "r04_final", "selfplay_full_games_96g_l16_h4_sparse_b2b300.json")
+    if os.path.exists(cross) and not job.dry:
+        try:
+            c = json.load(open(cross))
+            leg["cross_check_committed"] = {"games_per_hour_measured": c["games_per_hour_measured"], "moves_per_sec": c["moves_per_sec"],
+                                            "mean_stones_per_game": c["mean_stones_per_game"],
+                                            "source": "profiles/r04_final/selfplay_full_games_96g_l16_h4_sparse_b2b300.json: 96 games from the empty board to their end, no "
+                                                      "replacement (tools/selfplay_go.py --games 96 --moves 0), a builder-run file -- a label beside the measurement, not the measurement"}
+        except Exception:   # noqa: BLE001
+            pass
+    return leg
+
+
+def policy_play_leg(job, api, replicas, net, args):
+    """BASELINE.json configs[4]: --num-rollout 1 (self_play.rs:370-405), a thousand games in flight, every move one 8-symmetry
+    evaluation through the pool."""
+    leg, rule = window_leg(job, api, replicas, net, args, args.policy_play_games, 1, 2.0, args.policy_play_seconds, staggered=False, seed=20261003)
+    leg["what"] = (f"policy play (configs[4], --num-rollout 1): {args.policy_play_games} games in flight per GPU with replacement from the empty board, every move the "
+                   f"8-symmetry evaluation of one position, games as fibers on {args.selfplay_host_threads} host threads, {pool_rule_text(args, rule)}; 2 s ramp, then the timed window "
+                   "(games of 500-700 stones take about a minute here: few END inside a 10 s window, the rate is moves per second)")
+    leg["games_per_hour_at_250_stones"] = leg["moves_per_sec"] * 3600.0 / 250.0
+    return leg
+
+
+def selfplay_leg(job, api, replicas, net, args, fast_forward=0, reference_rule=False):
+    """Whole pipeline, measured: Go boards -> board records (planes on the device) -> search (1 thread x K leaves per game) ->
+    transposition cache -> leaf pool -> engine, `selfplay_games` games in flight per GPU for `selfplay_moves` searched stones each
+    (self_play.rs:423-459; rollouts per move follow the win rate, :234-241).  Games are sharded `id mod world`.
+    fast_forward > 0: every game is first played that many stones deep by policy play (--num-rollout 1, self_play.rs:369-405; not
+    timed) and the searched stones start from there: a MID-GAME leg (fewer table hits, narrower trees, more ladders and captures).
+    reference_rule: the pool batches like the reference's -- no coalescing of positions in flight, a free slot takes whatever is
+    queued (pool/worker_thread.rs:131-140, predictors/nn.rs:64-67) -- so the figure is comparable with rounds 1-3 and with the
+    reference's own behaviour."""
+    games = args.selfplay_games * job.world
+    cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
+    pool, rule = selfplay_pool(job, api, net, args, coalesce=False if reference_rule else None, back_to_back=0 if reference_rule else None)
+    adaptive, coalesce, boards = rule["adaptive"], rule["coalesce"], rule["boards"]
     opening = None
     if fast_forward > 0:
         ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=fast_forward, num_rollouts=1, threads_per_search=1,
@@ -324,10 +457,12 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
                  else f"first {args.selfplay_moves} stones of each") + f", --num-rollout {args.selfplay_rollouts}, "
                 f"1 search thread x {args.selfplay_leaves} leaves per game, games as " +
                 (f"fibers on {args.selfplay_host_threads} host threads" if args.selfplay_host_threads > 0 else "one OS thread each") + ", transposition cache 200001 x 8 shards, through the leaf pool "
-                f"({args.selfplay_batches or ('2 or 3 (adaptive)' if adaptive else 3)} device batches alive" + (f", partial batches back to back (lead {args.selfplay_back_to_back} us)" if args.selfplay_back_to_back > 0 else "") + f", PCIe-inclusive); random-init weights; feature planes built on the " +
+                f"({pool_rule_text(args, rule)}, PCIe-inclusive); random-init weights; feature planes built on the " +
                 ("DEVICE from 896-byte board records (dgnn_forward_boards)" if boards else "HOST (features::V1, 23 KB of fp16 per leaf)"),
         "seconds": sec, "games": j["games"], "moves": j["moves"],
-        "evals_per_sec": j["evals"] / sec,                          # predictor evaluations (cache misses) per second, whole job
+        # what the searches were ANSWERED per second (table misses): with coalescing most of an opening leg's answers follow a position in
+        # flight and cost no evaluation -- the device's own rate is device_boards_per_sec (rounds 1-4 called this field evals_per_sec)
+        "answers_per_sec": j["evals"] / sec,
         "device_boards_per_sec": boards / sec,
         "mean_device_batch": boards / max(batches, 1),
         # what a batch took lately by size (first size of each 16-board bucket -> microseconds from hand-over to answers, moving average,
@@ -354,6 +489,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0):
         # what one rollout (probe, board, record, cache, prior, insert, queueing) costs this rank's host: CPU seconds / rollouts
         "host_us_per_rollout": 1e6 * cpu_seconds / max(rank_rollouts, 1),
         "host_us_per_eval": 1e6 * cpu_seconds / max(out["evals"], 1),
+        "batching_rule": "reference (no coalescing, a free slot takes what is queued)" if reference_rule else "tuned (see `what`)",
     }
     if adaptive_stats is not None:
         leg["batches_alive"] = adaptive_stats      # rank 0's pool: where the adaptive rule stood at the end, what it measured
@@ -556,6 +692,22 @@ def main():
 
     per_rank_elapsed = job.gather_float(elapsed)
     elapsed = max(per_rank_elapsed)                      # the job's clock is the slowest rank's
+
+    # ---- the same passes for seconds instead of milliseconds: `value` times K passes (61 ms at the driver's K = 20), which says nothing about
+    # what the part sustains once its power management has settled
+    sustained = None
+    if not job.dry and args.sustained_seconds > 0:
+        job.barrier(ws)
+        s_total = s_tower = 0.0
+        s_launches = s_steps = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.sustained_seconds:
+            a, b, n = ws.forward_timed(100)
+            s_total, s_tower, s_launches, s_steps = s_total + a, s_tower + b, s_launches + n, s_steps + 100
+        job.barrier(ws)
+        s_elapsed = max(job.gather_float(time.perf_counter() - t0))
+        sustained = {"seconds": s_elapsed, "steps": s_steps, "evals_per_sec": job.world * args.batch * s_steps / s_elapsed,
+                     "gpu_ms_per_step": s_total / max(s_steps, 1), "tower_launch_us": 1e3 * s_tower / max(s_launches, 1), "tower_launches": s_launches}
     evals = world * args.batch * args.steps
     value = evals / elapsed
 
@@ -585,11 +737,17 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
 
-    selfplay = selfplay_mid = None
+    selfplay = selfplay_mid = selfplay_mid_ref = whole_games = policy_play = None
     if args.selfplay_games > 0:
         selfplay = selfplay_leg(job, api, replicas, net, args)
         if args.selfplay_midgame > 0:
             selfplay_mid = selfplay_leg(job, api, replicas, net, args, fast_forward=args.selfplay_midgame)
+            if args.reference_rule_leg:
+                selfplay_mid_ref = selfplay_leg(job, api, replicas, net, args, fast_forward=args.selfplay_midgame, reference_rule=True)
+    if args.whole_games > 0:
+        whole_games = whole_games_leg(job, api, replicas, net, args)
+    if args.policy_play_games > 0:
+        policy_play = policy_play_leg(job, api, replicas, net, args)
 
     out = None
     if rank == 0:
@@ -618,22 +776,21 @@ def main():
                 "frac_of_mfma_peak": flops_eval * args.batch * args.steps / (total_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
                 "gpu_ms_per_step": total_ms / args.steps, "flops_per_eval": flops_eval,
             }
+            if sustained is not None:
+                sustained["roofline_frac"] = roofline["flops_per_launch"] / (sustained["tower_launch_us"] * 1e-6) / 1e12 / PEAK_FP16_MFMA_TFLOPS
+                sustained["what"] = (f"the passes of `value` (same kernel, same resident batch) back to back for {sustained['seconds']:.1f} s instead of "
+                                     f"{elapsed * 1e3:.0f} ms; roofline_frac from HIP events around every tower launch of those seconds")
+                out["value_sustained"] = sustained
+        if whole_games is not None:
+            out["whole_games"] = whole_games
+        if policy_play is not None:
+            out["policy_play"] = policy_play
         if selfplay_mid is not None:
             out["selfplay_midgame"] = selfplay_mid
+        if selfplay_mid_ref is not None:
+            out["selfplay_midgame_reference_rule"] = selfplay_mid_ref
         if selfplay is not None:
             out["selfplay"] = selfplay
-            # WHOLE games are too long for this line (6-8 minutes): the committed, builder-run measurement is quoted with its file
-            whole = os.path.join(ROOT, "profiles", "r04_final", "selfplay_full_games_96g_l16_h4_sparse_b2b300.json")
-            if os.path.exists(whole) and not job.dry:
-                try:
-                    w = json.load(open(whole))
-                    out["whole_games_committed"] = {
-                        "games_per_hour_measured": w["games_per_hour_measured"], "moves_per_sec": w["moves_per_sec"], "games": w["games"],
-                        "mean_stones_per_game": w["mean_stones_per_game"], "host_cpus_busy": w["host_cpus_busy_rank0"],
-                        "source": "profiles/r04_final/selfplay_full_games_96g_l16_h4_sparse_b2b300.json (tools/selfplay_go.py --games 96 --moves 0 --threads 1 --leaves 16 --host-threads 4 --back-to-back 300: the legs' own setting; NOT measured in this run)",
-                    }
-                except Exception:   # noqa: BLE001
-                    pass
             out["derived"] = {
                 "games_per_hour_upper_bound": value * 3600.0 / (250 * max(selfplay["evals_per_move"], 1e-9)),
                 "what": "engine evals/s (inputs resident) x 3600 / (250 stones x the MEASURED evals per move of the selfplay leg): what the "

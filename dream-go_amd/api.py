@@ -1259,7 +1259,19 @@ class SelfplayParams(ctypes.Structure):
     _fields_ = [("num_games", ctypes.c_int), ("num_parallel", ctypes.c_int), ("first_game", ctypes.c_int), ("game_stride", ctypes.c_int),
                 ("max_moves", ctypes.c_int), ("num_rollouts", ctypes.c_int), ("num_ex_it_rollouts", ctypes.c_int),
                 ("threads_per_search", ctypes.c_int), ("leaves_per_thread", ctypes.c_int), ("cache_entries_per_game", ctypes.c_int),
-                ("seed", ctypes.c_uint64), ("host_threads", ctypes.c_int), ("opening_len", ctypes.c_int), ("opening", ctypes.c_void_p)]
+                ("seed", ctypes.c_uint64), ("host_threads", ctypes.c_int), ("opening_len", ctypes.c_int), ("opening", ctypes.c_void_p),
+                ("opening_games", ctypes.c_int), ("window", ctypes.c_void_p)]
+
+
+WINDOW_EDGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
+
+
+class SelfplayWindow(ctypes.Structure):
+    """dgnn_selfplay_window (include/dgnn.h): a timed window over a steady state of games in flight."""
+    _fields_ = [("ramp_seconds", ctypes.c_double), ("seconds", ctypes.c_double), ("on_edge", WINDOW_EDGE_FN), ("ctx", ctypes.c_void_p),
+                ("measured_seconds", ctypes.c_double), ("moves", ctypes.c_uint64), ("evals", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64),
+                ("conflicts", ctypes.c_uint64), ("games_started", ctypes.c_uint64), ("games_completed", ctypes.c_uint64),
+                ("games_ended", ctypes.c_uint64), ("stones_completed", ctypes.c_uint64)]
 
 
 class SelfplayStats(ctypes.Structure):
@@ -1492,10 +1504,13 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
                 return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1, cache_per_game=0,
-                host_threads=0, opening=None):
+                host_threads=0, opening=None, window=None):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
     (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
-    num_parallel of them run at a time (0 = all); host_threads > 0 runs them as fibers on that many OS threads (csrc/fiber.h)."""
+    num_parallel of them run at a time (0 = all); host_threads > 0 runs them as fibers on that many OS threads (csrc/fiber.h).
+    opening: [rows][len] packed indices, -1 ends a row; fewer rows than games: the later games start from the empty board.
+    window = (ramp_seconds, seconds[, on_edge(edge)]): the job runs num_parallel games WITH REPLACEMENT (num_games bounds how many may
+    be started) and is stopped at the end of a timed window; out["window"] holds what happened inside it (dgnn_selfplay_window)."""
     fn, ctx = _predictor(pool)
     stats = SelfplayStats()
     if num_moves <= 0 or num_moves > 722:
@@ -1504,16 +1519,30 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 2600 + 4 * 722 * 6 + 2048)) if return_sgf else None
     params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
                             int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed),
-                            int(host_threads), 0, None)
-    if opening is not None:                                    # [num_games][opening_len] packed indices: every game starts from that position
-        opening = np.ascontiguousarray(opening, dtype=np.int32).reshape(num_games, -1)
+                            int(host_threads), 0, None, 0, None)
+    if opening is not None:                                    # [rows][opening_len] packed indices: game g < rows starts from the position of row g
+        opening = np.ascontiguousarray(opening, dtype=np.int32)
+        opening = opening.reshape(opening.shape[0] if opening.ndim == 2 else num_games, -1)
+        if opening.shape[0] > num_games:
+            opening = np.ascontiguousarray(opening[:num_games])
         params.opening_len = opening.shape[1]
         params.opening = opening.ctypes.data_as(ctypes.c_void_p)
+        params.opening_games = opening.shape[0]
+    win = None
+    if window is not None:
+        on_edge = window[2] if len(window) > 2 and window[2] is not None else None
+        thunk = WINDOW_EDGE_FN((lambda _ctx, edge: on_edge(int(edge))) if on_edge else (lambda _ctx, edge: None))
+        win = SelfplayWindow(float(window[0]), float(window[1]), thunk, None)
+        params.window = ctypes.addressof(win)
     play = lib.dgnn_selfplay_go_boards if _takes_boards(pool) else lib.dgnn_selfplay_go
     _check(play(fn, ctx, cache._handle if cache is not None else None, ctypes.byref(params), ctypes.byref(stats),
                 moves.ctypes.data_as(_ip) if moves is not None else None, sgf, len(sgf) if sgf is not None else 0), "selfplay_go")
     out = {"seconds": stats.seconds, "games": stats.games, "moves": stats.moves, "evals": stats.evals, "conflicts": stats.conflicts,
            "cache_hits": stats.cache_hits, "games_ended": stats.games_ended, "ex_it_searches": stats.ex_it_searches}
+    if win is not None:
+        out["window"] = {"seconds": win.measured_seconds, "moves": win.moves, "evals": win.evals, "cache_hits": win.cache_hits,
+                         "conflicts": win.conflicts, "games_started": win.games_started, "games_completed": win.games_completed,
+                         "games_ended": win.games_ended, "stones_completed": win.stones_completed}
     if return_moves:
         out["record"] = moves.reshape(num_games, num_moves)
     if return_sgf:

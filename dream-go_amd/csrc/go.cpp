@@ -30,7 +30,9 @@
 #include <cmath>
 #include <cstdio>
 #include <ctime>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -1349,9 +1351,11 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
     if (num_games <= 0 || first_game < 0 || max_moves < 0 || num_rollouts <= 0 || leaves_per_thread > 64) return DGNN_BAD_ARGUMENT;
     if (num_parallel <= 0 || num_parallel > num_games) num_parallel = num_games;
     if (max_moves == 0 || max_moves > 722) max_moves = 722;
-    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0}, ex_it_searches{0};
+    std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0}, ex_it_searches{0}, started{0}, completed{0}, stones_completed{0};
     std::atomic<int> status{DGNN_OK};
+    std::atomic<bool> stop{false};                                              // set at the end of a measurement window (params->window)
     std::vector<std::string> records((size_t)num_games);
+    const int opening_games = params->opening_games > 0 ? std::min(params->opening_games, num_games) : num_games;
     const auto t0 = std::chrono::steady_clock::now();
 
     auto game = [&](int g) {
@@ -1371,7 +1375,8 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
         bool finished = false;
         if (moves_out) for (int m = 0; m < max_moves; ++m) moves_out[(size_t)g * max_moves + m] = -1;
         int first_turn = 0;
-        if (params->opening && params->opening_len > 0) {                       // start from a given position (alternating colours, black first)
+        started.fetch_add(1);
+        if (params->opening && params->opening_len > 0 && g < opening_games) {  // start from a given position (alternating colours, black first)
             for (int m = 0; m < params->opening_len && m < max_moves; ++m) {
                 const int p = params->opening[(size_t)g * params->opening_len + m];
                 if (p < 0 || p >= kPoints || !board.is_valid(m & 1, p)) break;
@@ -1387,7 +1392,7 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
         // one turn per iteration, black first; the turn cap only guards against two players passing for ever on a board
         // that never becomes scorable (the reference would spin there)
         uint64_t weights_seen = predictor.generation();
-        for (int turn = first_turn; board.count < max_moves && turn < 4 * 722 && status.load() == DGNN_OK; ++turn) {
+        for (int turn = first_turn; board.count < max_moves && turn < 4 * 722 && status.load() == DGNN_OK && !stop.load(std::memory_order_relaxed); ++turn) {
             const int me = turn & 1;
             // a weight refresh of the pool (dgnn_pool_pause ... resume) cannot reach a table that is the game's own: the game
             // drops it itself, before the first search that could be served the replaced network's outputs
@@ -1510,6 +1515,10 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
             if (roots[1 - me]) roots[1 - me] = dgnn_tree_node_forward(roots[1 - me], played);   // players[1].forward, self_play.rs:453
         }
         if (finished) ended.fetch_add(1);
+        if ((finished || board.count >= max_moves) && status.load() == DGNN_OK) {   // a whole game: two passes on a scorable board, or the stone cap
+            stones_completed.fetch_add((uint64_t)board.count);                  // (before `completed`: a window edge between the two counts a game without its stones at worst)
+            completed.fetch_add(1);
+        }
         dgnn_tree_node_free(roots[0]);
         dgnn_tree_node_free(roots[1]);
         if (private_cache > 0) dgnn_cache_destroy(cache);
@@ -1525,7 +1534,42 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
         records[(size_t)g] = header + sgf + territory_sgf(point_status) + ")";
     };
     std::atomic<int> next_game{0};
-    auto play = [&](int) { for (int g; (g = next_game.fetch_add(1)) < num_games && status.load() == DGNN_OK;) game(g); };
+    auto play = [&](int) { for (int g; !stop.load(std::memory_order_relaxed) && (g = next_game.fetch_add(1)) < num_games && status.load() == DGNN_OK;) game(g); };
+    // A measurement window over a job that is already running (games per hour on the driver's clock): a watcher thread
+    // notes the job's counters `ramp_seconds` after the start and again `seconds` later, then stops the job -- every game finishes the
+    // move it is searching and leaves.  With num_parallel games in flight and num_games larger than the window can consume, games that
+    // end inside the window are replaced at once (self_play.rs:478-495), so the window sees a steady number of games.
+    dgnn_selfplay_window* window = params->window;
+    std::thread watcher;
+    std::mutex watch_mutex;
+    std::condition_variable watch_cv;
+    bool job_over = false;
+    if (window && window->seconds > 0.0) {
+        watcher = std::thread([&] {
+            struct Snapshot { uint64_t moves, evals, hits, conflicts, started, completed, ended, stones; std::chrono::steady_clock::time_point at; };
+            auto snapshot = [&] { return Snapshot{moves.load(), evals.load(), hits.load(), conflicts.load(), started.load(), completed.load(), ended.load(), stones_completed.load(), std::chrono::steady_clock::now()}; };
+            auto sleep_until = [&](double seconds_after_start) {              // false: the job ended before that
+                std::unique_lock<std::mutex> lock(watch_mutex);
+                return !watch_cv.wait_until(lock, t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds_after_start)), [&] { return job_over; });
+            };
+            sleep_until(std::max(0.0, window->ramp_seconds));
+            if (window->on_edge) window->on_edge(window->ctx, 0);
+            const Snapshot a = snapshot();
+            sleep_until(std::max(0.0, window->ramp_seconds) + window->seconds);
+            const Snapshot b = snapshot();
+            if (window->on_edge) window->on_edge(window->ctx, 1);
+            stop.store(true);
+            window->measured_seconds = std::chrono::duration<double>(b.at - a.at).count();
+            window->moves = b.moves - a.moves;
+            window->evals = b.evals - a.evals;
+            window->cache_hits = b.hits - a.hits;
+            window->conflicts = b.conflicts - a.conflicts;
+            window->games_started = b.started - a.started;
+            window->games_completed = b.completed - a.completed;
+            window->games_ended = b.ended - a.ended;
+            window->stones_completed = b.stones - a.stones;
+        });
+    }
     if (params->host_threads > 0 && fibers_available()) {
         run_fibers(num_parallel, params->host_threads, play);             // num_parallel games in flight on host_threads OS threads
     } else {
@@ -1533,8 +1577,13 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
         for (int t = 0; t < num_parallel; ++t) threads.emplace_back(play, t);
         for (std::thread& t : threads) t.join();
     }
+    if (watcher.joinable()) {
+        { std::lock_guard<std::mutex> lock(watch_mutex); job_over = true; }
+        watch_cv.notify_all();
+        watcher.join();
+    }
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    stats->games = (uint64_t)num_games;
+    stats->games = window && window->seconds > 0.0 ? started.load() : (uint64_t)num_games;
     stats->moves = moves.load();
     stats->evals = evals.load();
     stats->conflicts = conflicts.load();

@@ -711,6 +711,7 @@ int dgnn_go_result_sgf(const dgnn_go_board* board, char* winner_out, size_t winn
  * (seed, game id, network outputs) for any leaves_per_thread: deterministic self-play with many leaves on the device --
  * provided the games do not share a transposition table (cache == NULL or cache_entries_per_game > 0): the table is keyed
  * like the reference's, by stones and colour only, while the feature planes also hold the last moves and the ko state. */
+struct dgnn_selfplay_window;
 typedef struct dgnn_selfplay_params {     /* zero the whole struct first: fields are appended between versions and 0 means "off" */
     int num_games;            /* games this call plays */
     int num_parallel;         /* games in flight (--num-games of the reference); <= 0: all at once */
@@ -732,7 +733,25 @@ typedef struct dgnn_selfplay_params {     /* zero the whole struct first: fields
     int opening_len;          /* > 0: every game starts from a given position: the first opening_len entries of its row of `opening` are
                                  placed, black first, before the first move is searched (a -1 ends a row early) */
     const int* opening;       /* [num_games][opening_len] packed indices, e.g. the moves_out of an earlier call; NULL = empty boards */
+    int opening_games;        /* > 0: `opening` holds rows for the first opening_games games only, later games start from the empty board */
+    struct dgnn_selfplay_window* window;   /* non-NULL with seconds > 0: a timed window over a steady state of num_parallel games, see below */
 } dgnn_selfplay_params;
+/* A measurement window over a running self-play job: games per hour on somebody's clock needs whole games, and a whole game is
+ * minutes.  The job starts num_parallel games (each from its row of `opening`, so that the games in flight can be at EVERY stage of
+ * a game from the first second on), replaces every game that ends (self_play.rs:478-495) -- num_games is then only the upper bound
+ * on the games that may be started -- and a watcher thread notes the counters `ramp_seconds` after the start and `seconds` later;
+ * then the job stops: every game finishes the move it is searching and leaves, unfinished.  on_edge (may be NULL) is called from
+ * the watcher thread at the window's start (edge 0) and end (edge 1): the place to read what the library does not count (the leaf
+ * pool's device boards and batches, the process's CPU time).  A game COMPLETED when two passes ended it on a scorable board or
+ * when it reached the stone cap (self_play.rs:437-450); stones_completed sums the stones on the boards of those games, the stones
+ * of their openings included. */
+typedef struct dgnn_selfplay_window {
+    double ramp_seconds, seconds;                               /* in */
+    void (*on_edge)(void* ctx, int edge);                       /* in */
+    void* ctx;                                                  /* in */
+    double measured_seconds;                                    /* out: the window as the watcher's clock saw it */
+    uint64_t moves, evals, cache_hits, conflicts, games_started, games_completed, games_ended, stones_completed;   /* out: inside the window */
+} dgnn_selfplay_window;
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
 

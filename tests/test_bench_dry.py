@@ -11,7 +11,8 @@ import sys
 from conftest import ROOT
 
 SMALL = ["--steps", "3", "--warmup", "1", "--blocks", "1", "--channels", "32", "--batch", "8",
-         "--selfplay-games", "2", "--selfplay-moves", "3", "--selfplay-rollouts", "16"]
+         "--selfplay-games", "2", "--selfplay-moves", "3", "--selfplay-rollouts", "16",
+         "--whole-games", "4", "--whole-games-seconds", "3", "--whole-games-ramp", "1", "--policy-play-games", "8", "--policy-play-seconds", "2"]
 
 
 def _clean_env():
@@ -35,6 +36,46 @@ def test_bare_invocation_spawns_the_ranks_it_reports():
     assert s["games_per_hour"] is None and s["moves_per_sec"] > 0        # the opening leg is not extrapolated to games per hour
     assert line["selfplay_midgame"]["games_per_hour"] > 0 and line["derived"]["games_per_hour_upper_bound"] > 0
     assert "roofline" not in line and "cpu_baseline" not in line      # a dry run measures nothing and claims nothing
+    _check_window_legs(line, world=2)
+
+
+def _check_window_legs(line, world):
+    """The legs that put games per hour on the run's own clock: a steady state of whole games with replacement
+    and a policy-play window, both timed by the library's watcher (dgnn_selfplay_window), aggregated over the ranks."""
+    w = line["whole_games"]
+    assert 2.5 < w["seconds"] < 4.0 and w["ramp_seconds"] == 1.0 and w["games_in_flight_per_gpu"] == 4
+    assert w["moves"] > 0 and abs(w["moves_per_sec"] - w["moves"] / w["seconds"]) < 1e-6
+    # game i of a rank starts i / 4 of the way into a finished policy-play game: whole games END inside even a 3 s window of the stand-in
+    assert w["games_completed"] >= 1 and 100 < w["mean_stones_per_completed_game"] <= 722
+    assert abs(w["games_per_hour_measured"] - w["games_completed"] * 3600 / w["seconds"]) < 1e-6
+    assert w["games_per_hour_from_moves"] > 0 and w["device_boards_per_sec"] > 0 and 0 < w["mean_device_batch"] <= 8
+    assert len(w["per_rank_host_cpus_busy"]) == world and all(c > 0 for c in w["per_rank_host_cpus_busy"])
+    p = line["policy_play"]
+    assert 1.5 < p["seconds"] < 3.0 and p["moves"] > 0 and 7.0 < p["evals_per_move"] + 8 * p["cache_hit_ratio"] < 9.5   # one 8-symmetry evaluation per move
+    r, t = line["selfplay_midgame_reference_rule"], line["selfplay_midgame"]
+    assert r["coalescing"] is False and "reference" in r["batching_rule"] and r["moves"] == t["moves"]
+    assert "answers_per_sec" in line["selfplay"] and "evals_per_sec" not in line["selfplay"]
+
+
+def test_eight_ranks_dry_aggregate_like_one_job():
+    """configs[3]'s shape without the hardware: eight ranks, games `id mod 8`, one JSON line whose per-rank
+    lists have eight entries, whose job clock is the slowest rank's and whose counters are the ranks' sums."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry", *SMALL],
+                         capture_output=True, text=True, timeout=900, env=_clean_env(), cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["dry"] is True and line["n_gpus"] == 8 and line["config"]["global_batch"] == 64
+    rates = line["per_rank_evals_per_sec"]
+    assert len(rates) == 8 and all(v > 0 for v in rates)
+    # value = the units all ranks processed / the SLOWEST rank's clock: never more than the sum of the ranks' own rates, never less than 8 x the slowest
+    assert 8 * min(rates) * 0.999 <= line["value"] <= sum(rates) * 1.001
+    b = line["weight_broadcast"]
+    assert b["ranks"] == 8 and b["checksums_agree"] is True and b["distinct_images_before"] == 8
+    s = line["selfplay"]
+    assert s["games"] == 16 and s["moves"] == 48                       # 2 games per rank x 8 ranks, 3 stones each: every game id mod 8 was played by somebody
+    assert len(s["per_rank_rollouts_per_sec_per_core"]) == 8 and len(s["per_rank_host_cpus_busy"]) == 8
+    _check_window_legs(line, world=8)
+    assert line["whole_games"]["games_in_flight_per_gpu"] == 4 and line["whole_games"]["games_started"] >= 0
 
 
 def test_refuses_a_world_that_is_not_the_one_asked_for():
