@@ -255,6 +255,9 @@ SYMBOLS = [
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("dgnn_full_forward_boards", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _fp, _fp]),
     ("dgnn_selfplay_go_boards", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _ip, ctypes.c_char_p, ctypes.c_size_t]),
+    # round 5
+    ("dgnn_test_fail_push_after", None, [ctypes.c_int]),
+    ("dgnn_forward_stage_times", ctypes.c_int, [_vpp, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_int, _fp, ctypes.POINTER(ctypes.c_double)]),
 ]
 
 
@@ -649,6 +652,21 @@ def forward_pipelined_timed_n(workspaces, form, data, count, steps):
     _check(lib.dgnn_forward_pipelined_timed_n(handles, len(workspaces), code, a.ctypes.data_as(ctypes.c_void_p), int(count), int(steps),
                                               ctypes.byref(seconds)), "forward_pipelined_timed_n")
     return count * steps / seconds.value
+
+
+STAGES = ("h2d_records", "planes_kernel", "tower", "head_conv", "policy_gemm", "softmax_value", "d2h_outputs")
+
+
+def forward_stage_times(workspaces, records, count, steps):
+    """dgnn_forward_stage_times -> {stage: microseconds, ..., "host": {...}}: where one device batch's wall time goes."""
+    handles = (ctypes.c_void_p * len(workspaces))(*[w.handle for w in workspaces])
+    r = _as_records(records, count)
+    stage = (ctypes.c_float * 7)()
+    host = (ctypes.c_double * 4)()
+    _check(lib.dgnn_forward_stage_times(handles, len(workspaces), r.ctypes.data_as(_u8p), int(count), int(steps), stage, host), "forward_stage_times")
+    out = {name: float(stage[i]) for i, name in enumerate(STAGES)}
+    out["host"] = {"submit_call_us": host[0], "submit_to_answers_us": host[1], "device_span_us": host[2], "host_on_top_us": host[3]}
+    return out
 
 
 def layer_dense(x, batch, k_in, w_in_out, bias, n_out, alpha=1.0, relu=False, device=0):

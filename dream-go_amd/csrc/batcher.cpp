@@ -31,6 +31,8 @@
 #include "fiber.h"
 
 namespace dgnn {
+
+std::atomic<int> g_fail_push_countdown{-1};
 namespace {
 
 // ------------------------------------------------------------------------------------------------ symmetry
@@ -320,6 +322,23 @@ struct LeafRequest {
 
 static int batcher_get_batch(struct Batcher* b, int min_batch_size, int cap, dgnn_batch** out);
 
+// One slot's answer (or the status that stands in for it) reaches its request; the last slot of a request wakes the caller.
+static void complete_slot(LeafSlot* slot, int status, uint16_t v, const uint16_t* p)
+{
+    LeafRequest* r = slot->request;
+    if (status == DGNN_OK) {
+        r->value_out[slot->index] = v;
+        std::memcpy(r->policy_out + (size_t)slot->index * DGNN_NUM_MOVES, p, DGNN_NUM_MOVES * sizeof(uint16_t));
+    }
+    Fiber* resume = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(r->mutex);
+        if (status != DGNN_OK) r->status = status;
+        if (--r->remaining == 0) { if (r->fiber) resume = r->fiber; else r->done.notify_one(); }
+    }
+    if (resume) fiber_make_ready(resume);      // (the request lives on the fiber's stack: not touched after this)
+}
+
 struct LeafPool {
     Batcher* batcher = nullptr;     // holds a reference (Batcher::refs) for the pool's lifetime
     bool owns_batcher = false;      // created by dgnn_pool_create_devices / _callbacks: nobody else has a handle
@@ -447,20 +466,7 @@ struct LeafPool {
             }
             dgnn_batch_destroy(batch);
             wake();                                 // a batch slot is free again
-            auto deliver = [&](LeafSlot* slot, uint16_t v, const uint16_t* p) {
-                LeafRequest* r = slot->request;
-                if (status == DGNN_OK) {
-                    r->value_out[slot->index] = v;
-                    std::memcpy(r->policy_out + (size_t)slot->index * DGNN_NUM_MOVES, p, DGNN_NUM_MOVES * sizeof(uint16_t));
-                }
-                Fiber* resume = nullptr;
-                {
-                    std::lock_guard<std::mutex> lock(r->mutex);
-                    if (status != DGNN_OK) r->status = status;
-                    if (--r->remaining == 0) { if (r->fiber) resume = r->fiber; else r->done.notify_one(); }
-                }
-                if (resume) fiber_make_ready(resume);      // (the request lives on the fiber's stack: not touched after this)
-            };
+            auto deliver = [&](LeafSlot* slot, uint16_t v, const uint16_t* p) { complete_slot(slot, status, v, p); };
             std::vector<LeafSlot*> followers;
             for (int i = 0; i < n; ++i) {
                 LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
@@ -712,13 +718,21 @@ void dgnn_batcher_destroy(dgnn_batcher* batcher) { if (batcher) reinterpret_cast
 
 static int batcher_push(Batcher* b, const uint16_t* item, uint64_t tag)
 {
+    // test hook (dgnn_test_fail_push_after, include/dgnn_test.h): the n-th push from now fails like an allocation that failed
+    if (g_fail_push_countdown.load(std::memory_order_relaxed) >= 0 && g_fail_push_countdown.fetch_sub(1, std::memory_order_relaxed) == 0)
+        return DGNN_OUT_OF_MEMORY;
     std::lock_guard<std::mutex> lock(b->mutex);                                 // batch.rs:80-84
     if (b->adaptive_hi.load(std::memory_order_relaxed) > 0 && b->records) b->note_record(item);
-    if (b->tags.empty())
+    try {
+        b->features.insert(b->features.end(), item, item + b->item);
+        b->tags.push_back(tag);
+    } catch (const std::bad_alloc&) {
+        b->features.resize(b->tags.size() * b->item);                           // (the board without its tag goes again)
+        return DGNN_OUT_OF_MEMORY;
+    }
+    if (b->tags.size() == 1)
         b->first_queued_us.store(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
                                  std::memory_order_release);
-    b->features.insert(b->features.end(), item, item + b->item);
-    b->tags.push_back(tag);
     b->queued.store((int)b->tags.size(), std::memory_order_release);
     return DGNN_OK;
 }
@@ -1205,28 +1219,46 @@ static int pool_predict(LeafPool* pool, const uint16_t* features, int batch_size
         slots[i].request = &request;
         slots[i].index = i;
         const uint16_t* item = features + (size_t)i * pool->batcher->item;
-        if (pool->coalesce) {
-            slots[i].position = record_position_hash(item);
-            slots[i].symmetry = (uint8_t)record_symmetry(item);
-            std::lock_guard<std::mutex> lock(pool->inflight_mutex);
-            auto found = pool->inflight.find(slots[i].position);
-            if (found == pool->inflight.end()) {
-                pool->inflight.emplace(slots[i].position, LeafPool::InFlight{&request, {}});
-                slots[i].leads = true;
-            } else if (found->second.owner != &request) {   // somebody ELSE has this position on its way: follow
-                found->second.followers.push_back(&slots[i]);
-                pool->coalesced.fetch_add(1, std::memory_order_relaxed);
-                continue;
+        int status = DGNN_OK;
+        bool follows = false;
+        try {
+            if (pool->coalesce) {
+                slots[i].position = record_position_hash(item);
+                slots[i].symmetry = (uint8_t)record_symmetry(item);
+                std::lock_guard<std::mutex> lock(pool->inflight_mutex);
+                auto found = pool->inflight.find(slots[i].position);
+                if (found == pool->inflight.end()) {
+                    pool->inflight.emplace(slots[i].position, LeafPool::InFlight{&request, {}});
+                    slots[i].leads = true;
+                } else if (found->second.owner != &request) {   // somebody ELSE has this position on its way: follow
+                    found->second.followers.push_back(&slots[i]);
+                    pool->coalesced.fetch_add(1, std::memory_order_relaxed);
+                    follows = true;
+                }
+                // (the same position twice in ONE request is the root ensemble of lib.rs:83-130 -- eight symmetries that are meant to be
+                // eight evaluations: the reference's table would not have served them either, it is filled after the predict call)
             }
-            // (the same position twice in ONE request is the root ensemble of lib.rs:83-130 -- eight symmetries that are meant to be
-            // eight evaluations: the reference's table would not have served them either, it is filled after the predict call)
+        } catch (const std::bad_alloc&) {
+            status = DGNN_OUT_OF_MEMORY;
         }
-        const int status = batcher_push(pool->batcher, item, (uint64_t)(uintptr_t)&slots[i]);
-        if (status != DGNN_OK) {       // cannot happen after the argument checks above; the pushed part still completes
+        if (follows) continue;
+        if (status == DGNN_OK) status = batcher_push(pool->batcher, item, (uint64_t)(uintptr_t)&slots[i]);
+        if (status != DGNN_OK) {       // an allocation failed: slots i.. never reach a device; the part that was pushed or follows still completes
+            // A slot that registered as the LEADER of its position and then was not pushed would leave an entry nobody ever answers:
+            // every later request for that position would follow it and wait for ever.  Take the entry back and hand the
+            // status to whoever followed it meanwhile.
+            std::vector<LeafSlot*> orphans;
+            if (slots[i].leads) {
+                std::lock_guard<std::mutex> lock(pool->inflight_mutex);
+                auto it = pool->inflight.find(slots[i].position);
+                if (it != pool->inflight.end() && it->second.owner == &request) { orphans.swap(it->second.followers); pool->inflight.erase(it); }
+                slots[i].leads = false;
+            }
+            for (LeafSlot* f : orphans) complete_slot(f, status, 0, nullptr);
             std::unique_lock<std::mutex> lock(request.mutex);
             request.remaining -= batch_size - i;
             request.status = status;
-            if (i == 0) return status;
+            if (request.remaining == 0) return status;     // nothing of this request is on its way
             break;
         }
     }
@@ -1241,6 +1273,8 @@ static int pool_predict(LeafPool* pool, const uint16_t* features, int batch_size
     request.done.wait(lock, [&] { return request.remaining == 0; });
     return request.status;
 }
+
+void dgnn_test_fail_push_after(int n) { g_fail_push_countdown.store(n, std::memory_order_relaxed); }
 
 int dgnn_batcher_stats(dgnn_batcher* batcher, uint64_t* boards, uint64_t* batches)
 {

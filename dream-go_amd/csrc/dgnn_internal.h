@@ -1,6 +1,7 @@
 // Internal declarations shared by the host side of libdgnn_hip.so.
 #pragma once
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <map>
@@ -181,11 +182,18 @@ bool host_simd(bool need_f16c = false);
 // thread-local HIP error detail
 void set_last_hip_error(int code);
 
+// Test hook (include/dgnn_test.h: dgnn_test_fail_push_after): >= 0 counts down with every board pushed into a batcher's queue; the
+// push that finds it at 0 fails with DGNN_OUT_OF_MEMORY, as an allocation that failed would.  -1 (always, outside the tests): off.
+extern std::atomic<int> g_fail_push_countdown;
+
 // A per-thread free list of blocks of ONE size, for the two objects the search allocates per rollout that are too large for
 // glibc's per-thread cache (it stops at 1 KB): a tree node (1.8 KB) and the leaf's copy of the board (3 KB) went through the
 // arena lock and the bins on every rollout -- a seventh of the host's time with 256 games in flight.  A block freed on another
-// thread than the one that allocated it simply changes lists; a list keeps at most `Keep` blocks and returns the rest.  The
-// sanitizer builds allocate directly, so that ASan sees every node's lifetime.
+// thread than the one that allocated it simply changes lists; a list keeps at most `Keep` blocks and returns the rest (games run
+// as fibers that migrate between host threads and pool workers free what search threads allocated, so a consumer thread's list
+// fills to Keep and stays there: Keep is what ONE search of a game turns over, not more -- ADVICE r04).  A thread that has ended
+// took its list with it: a block freed there later goes back to the heap.  The sanitizer builds allocate directly, so that ASan
+// sees every node's lifetime; tests/test_tree_host.py runs the pooled path across threads in the shipped build.
 template <size_t Bytes, int Keep>
 struct BlockPool {
 #if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__)
@@ -196,7 +204,8 @@ struct BlockPool {
     struct List {
         Free* head = nullptr;
         int count = 0;
-        ~List() { while (head) { Free* next = head->next; ::operator delete(head); head = next; } count = 0; }   // (usable after it: empty)
+        bool dead = false;
+        ~List() { while (head) { Free* next = head->next; ::operator delete(head); head = next; } count = 0; dead = true; }   // (after it: pass-through)
     };
     static List& list() { static thread_local List l; return l; }
     // (never inlined: games run as fibers that may resume on another host thread, and a caller that contained a switch point could
@@ -214,7 +223,7 @@ struct BlockPool {
     {
         if (!p) return;
         List& l = list();
-        if (l.count >= Keep) { ::operator delete(p); return; }
+        if (l.dead || l.count >= Keep) { ::operator delete(p); return; }
         Free* f = static_cast<Free*>(p);
         f->next = l.head;
         l.head = f;

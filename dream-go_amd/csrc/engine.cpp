@@ -49,6 +49,10 @@ struct Workspace {
     double wait_last = 0.0;                 // ... the most recent one (wait_submission)
     int wait_boards = 0;
     std::vector<hipEvent_t> tower_events;   // pairs, grown on demand by dgnn_forward_timed
+    // measurement only (dgnn_forward_stage_times): events between the stages of a submission of board records, on this stream
+    enum { kStages = 8 };                   // start | H2D | planes kernel | tower | head convolution | policy GEMM | soft-max + value | D2H
+    hipEvent_t stage_ev[kStages] = {};
+    bool stage_on = false;
 
     void* arena = nullptr;                  // one allocation, carved below
     uint16_t* d_features = nullptr;         // [batch][361][32]
@@ -121,6 +125,7 @@ Workspace::~Workspace()
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (hipEvent_t e : tower_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : stage_ev) if (e) (void)hipEventDestroy(e);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (ev_done) (void)hipEventDestroy(ev_done);
@@ -429,8 +434,10 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
 
     int cur = 0;
     const uint16_t* tower = nullptr;   // NHWC tower output for the heads
+    auto stamp = [&](int stage) -> hipError_t { return ws->stage_on ? hipEventRecord(ws->stage_ev[stage], ws->stream) : hipSuccess; };
     // compact board records: the planes are built on the device (features.hip), straight into the up-layer's input on the board path
     if (input_form == kInputRecords) DGNN_HIP(launch_board_records(ws->d_records, ws->d_packed, ws->use_board ? ws->d_features_board : nullptr, ws->active, ws->stream));
+    DGNN_HIP(stamp(2));
     if ((packed_input || input_form == kInputRecords) && !ws->use_board) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features, ws->active, false, ws->stream));
     if (ws->use_board) {
         // features.rs:52-60 HWC fp16, or the packed form: either way the up-layer reads the padded slot-major layout
@@ -522,6 +529,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
             }
         }
         if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
+        DGNN_HIP(stamp(3));
         if (t.head_w_board_offset != 0) {
             HeadConvLaunch hc;                                                      // value_head.rs:76 + policy_head.rs:92
             hc.x = ws->d_act[cur];
@@ -549,6 +557,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     }
     if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
     tower = ws->d_act[cur];
+    DGNN_HIP(stamp(3));
     }
 
     if (tower != nullptr) {
@@ -556,6 +565,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
         DGNN_HIP(conv(t.policy_conv, tower, nullptr, ws->d_policy_features));      // policy_head.rs:92
     }
 
+    DGNN_HIP(stamp(4));
     PolicyGemmLaunch pg;                                                           // policy_head.rs:95
     pg.features = ws->d_policy_features;
     pg.wt = (const uint16_t*)(image + t.policy_wt_offset);
@@ -566,6 +576,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     pg.k_pad = t.policy_k_pad;
     pg.tau = 1.0f / t.softmax_temperature;
     DGNN_HIP(launch_policy_gemm(pg, ws->stream));
+    DGNN_HIP(stamp(5));
 
     SoftmaxValueLaunch sv;                                                         // policy_head.rs:98-100, value_head.rs:80-81
     sv.logits = ws->d_logits;
@@ -577,6 +588,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     sv.value_pre_out = ws->d_value_pre;
     sv.batch = ws->active;
     DGNN_HIP(launch_softmax_value(sv, ws->stream));
+    DGNN_HIP(stamp(6));
     return DGNN_OK;
 }
 
@@ -1162,7 +1174,9 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
 
     DGNN_HIP(hipSetDevice(ws->device));
     if (records != ws->h_records) std::memcpy(ws->h_records, records, in_bytes);
+    if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[0], ws->stream));
     DGNN_HIP(hipMemcpyAsync(ws->d_records, ws->h_records, in_bytes, hipMemcpyHostToDevice, ws->stream));
+    if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[1], ws->stream));
 
     int status = enqueue_forward(ws, -1, kInputRecords);
     if (status != DGNN_OK) return status;
@@ -1170,6 +1184,7 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
     if (status != DGNN_OK) return status;
 
     DGNN_HIP(enqueue_outputs(ws));
+    if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[7], ws->stream));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
     ws->pending = true;
     return DGNN_OK;
@@ -1426,6 +1441,67 @@ int dgnn_forward_pipelined_timed_n(dgnn_workspace* const* ws, int in_flight, int
     }
     *seconds = (double)(now_ns() - t0) * 1e-9;
     return status;
+}
+
+// Where the wall time of ONE device batch goes: `steps` submissions of `count` board records with HIP events
+// between the stages on the workspace's own stream, `in_flight` workspaces kept busy like a leaf pool keeps batches alive.
+//   stage_us[7]: mean microseconds between consecutive stamps -- H2D of the records | planes kernel | tower | head convolution |
+//                policy GEMM | soft-max + value | D2H of the outputs.  A stage that has to WAIT for compute units another
+//                submission's tower holds shows here as long (a whole-board tower workgroup owns its CU's whole register file).
+//   host_us[4]:  mean microseconds of (0) the submit call itself, (1) submit call -> answers in the caller's hands, (2) the device's
+//                span first stamp -> last stamp, (3) what (1) has on top of (2): enqueue latency and the host noticing the end.
+int dgnn_forward_stage_times(dgnn_workspace* const* ws, int in_flight, const uint8_t* records, int count, int steps, float* stage_us, double* host_us)
+{
+    if (!ws || in_flight < 1 || in_flight > 8 || !records || count <= 0 || steps <= 0 || !stage_us || !host_us) return DGNN_BAD_ARGUMENT;
+    for (int i = 0; i < in_flight; ++i) {
+        if (!ws[i] || count > W(ws[i])->batch) return DGNN_BAD_ARGUMENT;
+        for (int j = 0; j < i; ++j) if (ws[i] == ws[j]) return DGNN_BAD_ARGUMENT;
+    }
+    std::vector<uint16_t> value((size_t)count), policy((size_t)count * DGNN_NUM_MOVES);
+    int status = DGNN_OK;
+    for (int i = 0; i < in_flight && status == DGNN_OK; ++i) {
+        Workspace* w = W(ws[i]);
+        DGNN_HIP(hipSetDevice(w->device));
+        for (hipEvent_t& e : w->stage_ev) if (!e) DGNN_HIP(hipEventCreate(&e));
+        status = dgnn_forward_boards(ws[i], records, count, value.data(), policy.data());      // warm, unstamped
+        w->stage_on = true;
+    }
+    double stage_sum[Workspace::kStages - 1] = {}, host_sum[4] = {};
+    long long submitted_at[8] = {}, submit_took[8] = {};
+    int submitted = 0, waited = 0;
+    auto off = [&] { for (int i = 0; i < in_flight; ++i) W(ws[i])->stage_on = false; };
+    while (waited < steps + in_flight && status == DGNN_OK) {                                  // (the first round of submissions is not counted)
+        while (submitted < steps + in_flight && submitted - waited < in_flight && status == DGNN_OK) {
+            const int k = submitted++ % in_flight;
+            submitted_at[k] = now_ns();
+            status = dgnn_forward_submit_boards(ws[k], records, count);
+            submit_took[k] = now_ns() - submitted_at[k];
+        }
+        if (status != DGNN_OK) break;
+        const int k = waited % in_flight;
+        status = dgnn_forward_wait(ws[k], value.data(), policy.data());
+        const long long back = now_ns();
+        if (status != DGNN_OK) break;
+        if (waited++ < in_flight) continue;
+        Workspace* w = W(ws[k]);
+        float span = 0.0f;
+        for (int s = 0; s + 1 < Workspace::kStages; ++s) {
+            float ms = 0.0f;
+            const hipError_t e = hipEventElapsedTime(&ms, w->stage_ev[s], w->stage_ev[s + 1]);
+            if (e != hipSuccess) { off(); set_last_hip_error((int)e); return DGNN_HIP_ERROR; }
+            stage_sum[s] += 1e3 * ms;
+            span += 1e3f * ms;
+        }
+        host_sum[0] += 1e-3 * (double)submit_took[k];
+        host_sum[1] += 1e-3 * (double)(back - submitted_at[k]);
+        host_sum[2] += span;
+        host_sum[3] += 1e-3 * (double)(back - submitted_at[k]) - span;
+    }
+    off();
+    if (status != DGNN_OK) return status;
+    for (int s = 0; s + 1 < Workspace::kStages; ++s) stage_us[s] = (float)(stage_sum[s] / steps);
+    for (int i = 0; i < 4; ++i) host_us[i] = host_sum[i] / steps;
+    return DGNN_OK;
 }
 
 int dgnn_forward_pipelined_timed(dgnn_workspace* wa, dgnn_workspace* wb, int form, const void* input, int count, int steps, double* seconds)

@@ -1078,7 +1078,7 @@ bool is_simple_eye(const Fast& b, int color, int p)
 // ---- game callbacks for the search driver ----
 // (every leaf of a search plays on its own copy of the board, pool/event.rs:44-46: dgnn_internal.h BlockPool; GoBoard is trivially
 // destructible, a copy is its bytes)
-using GoBoardPool = BlockPool<sizeof(GoBoard), 1024>;
+using GoBoardPool = BlockPool<sizeof(GoBoard), 512>;
 static_assert(std::is_trivially_destructible<GoBoard>::value && std::is_trivially_copyable<GoBoard>::value, "go_clone copies bytes");
 void* go_clone(void* b)
 {

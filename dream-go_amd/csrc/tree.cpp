@@ -119,8 +119,11 @@ struct TreeNode;
 struct ChildSlot {
     std::atomic<int> count{0};
     std::atomic<int> vcount{0};
-    float value = 0.0f;
-    float value_s = 0.0f;
+    // the running mean and sum of squares (UCT::update, tree.rs:125-160): written under the node's lock, read by every select() of
+    // every search thread without it, as in the reference (tree.rs:63-115 reads the arrays plainly).  Relaxed atomics: the same
+    // loads and stores on x86, and a race detector has nothing to report
+    std::atomic<float> value{0.0f};
+    std::atomic<float> value_s{0.0f};
     std::atomic<TreeNode*> ptr{nullptr};
     uint16_t index = 0;
     std::atomic<unsigned char> expanding{0};
@@ -197,8 +200,15 @@ struct TreeNode {
             const int k = map[index].load(std::memory_order_acquire);
             return k ? slot(k - 1) : nullptr;
         }
-        const int n = num_slots.load(std::memory_order_acquire);      // (fewer than kMapFrom: the inline slots and at most chunk 0)
-        for (int k = 0; k < n && k < kInline; ++k)
+        const int n = num_slots.load(std::memory_order_acquire);
+        if (n >= kMapFrom) {
+            // another search thread added slots between the two loads above.  The map is published BEFORE the slot count that needs it
+            // (find_or_create), so it is visible now; scanning on would run past chunk 0's sixteen slots
+            const std::atomic<uint16_t>* map = slot_of.load(std::memory_order_acquire);
+            const int k = map[index].load(std::memory_order_acquire);
+            return k ? slot(k - 1) : nullptr;
+        }
+        for (int k = 0; k < n && k < kInline; ++k)                    // fewer than kMapFrom slots: the inline ones and at most 7 of chunk 0
             if (first[k].index == index) return &first[k];
         if (n > kInline) {
             ChildSlot* c = chunk[0].load(std::memory_order_acquire);
@@ -234,17 +244,19 @@ struct TreeNode {
             }
             s = slot(n);
             s->index = (uint16_t)index;
-            s->value = initial_value;
+            s->value.store(initial_value, std::memory_order_relaxed);
+            // order of publication: the slot's fields, its map entry, the map itself, THEN the count -- a reader that sees
+            // num_slots >= kMapFrom thereby sees the map, and a reader that finds the slot through the map sees its fields
             if (map) map[index].store((uint16_t)(n + 1), std::memory_order_release);
-            num_slots.store(n + 1, std::memory_order_release);
             if (map && !slot_of.load(std::memory_order_relaxed)) slot_of.store(map, std::memory_order_release);
+            num_slots.store(n + 1, std::memory_order_release);
         }
         lock.unlock();
         return s;
     }
 };
 
-using TreeNodePool = BlockPool<sizeof(TreeNode), 8192>;
+using TreeNodePool = BlockPool<sizeof(TreeNode), 2048>;
 void* TreeNode::operator new(size_t, const std::nothrow_t&) noexcept { return TreeNodePool::get(); }
 void TreeNode::operator delete(void* p) noexcept { TreeNodePool::put(p); }
 
@@ -258,8 +270,8 @@ struct ChildView {
         n->for_each_slot([&](const ChildSlot& s) { at[s.index] = &s; });
     }
     int count(int i) const { return at[i] ? at[i]->count.load(std::memory_order_relaxed) : 0; }
-    float value(int i) const { return at[i] ? at[i]->value : node->initial_value; }
-    float value_s(int i) const { return at[i] ? at[i]->value_s : 0.0f; }
+    float value(int i) const { return at[i] ? at[i]->value.load(std::memory_order_relaxed) : node->initial_value; }
+    float value_s(int i) const { return at[i] ? at[i]->value_s.load(std::memory_order_relaxed) : 0.0f; }
     const TreeNode* ptr(int i) const { return at[i] ? at[i]->ptr.load(std::memory_order_acquire) : nullptr; }
 };
 
@@ -280,7 +292,7 @@ void puct_scalar(const TreeNode* node, const PuctTerms& t, float* value)
     for (int i = 0; i < kPadded; ++i) value[i] = v0 + node->prior[i] * t.uct_exp_sqrt_n;
     node->for_each_slot([&](const ChildSlot& s) {
         const int c = s.count.load(std::memory_order_relaxed) + s.vcount.load(std::memory_order_relaxed);
-        float v = s.value;
+        float v = s.value.load(std::memory_order_relaxed);
         if (t.apply_fpu && c == 0) v = std::max(v - t.fpu_reduce, 0.0f);
         const float bonus = c == 0 ? t.uct_exp_sqrt_n : t.uct_exp_sqrt_n / (float)(1 + c);
         value[s.index] = v + node->prior[s.index] * bonus;
@@ -304,7 +316,7 @@ void puct_avx2(const TreeNode* node, const PuctTerms& t, float* value)
     const bool apply_fpu = t.apply_fpu;
     node->for_each_slot([&](const ChildSlot& s) __attribute__((target("avx2"))) {
         const int c = s.count.load(std::memory_order_relaxed) + s.vcount.load(std::memory_order_relaxed);
-        __m128 v = _mm_set_ss(s.value);
+        __m128 v = _mm_set_ss(s.value.load(std::memory_order_relaxed));
         if (apply_fpu && c == 0) v = _mm_max_ss(_mm_sub_ss(v, fpu1), zero1);
         const __m128 bonus = c == 0 ? u1 : _mm_div_ss(u1, _mm_cvtsi32_ss(zero1, 1 + c));
         value[s.index] = _mm_cvtss_f32(_mm_add_ss(v, _mm_mul_ss(_mm_set_ss(node->prior[s.index]), bonus)));
@@ -488,12 +500,12 @@ int dgnn_tree_insert(const dgnn_trace* handle, int color, float value, const flo
         node->vtotal_count.fetch_sub(kVlossCnt, std::memory_order_relaxed);
         ChildSlot* slot = e.slot;
         node->lock.lock();
-        const float prev_value = slot->value;
-        const float prev_value_s = slot->value_s;
+        const float prev_value = slot->value.load(std::memory_order_relaxed);
+        const float prev_value_s = slot->value_s.load(std::memory_order_relaxed);
         const int prev_count = slot->count.fetch_add(1, std::memory_order_relaxed);
         const float next_value = prev_value + (v - prev_value) / (float)(prev_count + 1);
-        slot->value = next_value;
-        slot->value_s = prev_value_s + (v - prev_value) * (v - next_value);
+        slot->value.store(next_value, std::memory_order_relaxed);
+        slot->value_s.store(prev_value_s + (v - prev_value) * (v - next_value), std::memory_order_relaxed);
         slot->vcount.fetch_sub(kVlossCnt, std::memory_order_relaxed);
         node->lock.unlock();
     }
@@ -509,8 +521,8 @@ int dgnn_tree_node_child(const dgnn_tree_node* handle, int index, int* count, in
     const int visits = slot ? slot->count.load() : 0;
     if (count) *count = visits;
     if (vcount) *vcount = slot ? slot->vcount.load() : 0;
-    if (value) *value = slot ? slot->value : node->initial_value;
-    if (value_std_out) *value_std_out = value_std(slot ? slot->value_s : 0.0f, visits);
+    if (value) *value = slot ? slot->value.load(std::memory_order_relaxed) : node->initial_value;
+    if (value_std_out) *value_std_out = value_std(slot ? slot->value_s.load(std::memory_order_relaxed) : 0.0f, visits);
     if (has_child) *has_child = slot && slot->ptr.load() != nullptr;
     return DGNN_OK;
 }
@@ -592,7 +604,7 @@ int dgnn_tree_node_disqualify(dgnn_tree_node* handle, int index)             // 
     TreeNode* node = reinterpret_cast<TreeNode*>(handle);
     ChildSlot* slot = node->find_or_create(index);
     if (!slot) return DGNN_OUT_OF_MEMORY;
-    slot->value = -std::numeric_limits<float>::infinity();
+    slot->value.store(-std::numeric_limits<float>::infinity(), std::memory_order_relaxed);
     slot->count.store(0);
     return DGNN_OK;
 }

@@ -221,6 +221,14 @@ int dgnn_forward_pipelined_timed(dgnn_workspace* a, dgnn_workspace* b, int form,
 int dgnn_forward_pipelined_timed_n(dgnn_workspace* const* workspaces, int in_flight, int form, const void* input, int count, int steps,
                                    double* seconds);
 
+/* Where the wall time of one device batch goes: `steps` submissions of `count` board records with HIP events between the stages of a
+ * submission on the workspace's stream, `in_flight` (1..8) distinct workspaces kept busy the way a leaf pool keeps batches alive.
+ * stage_us[7]: mean microseconds per stage -- H2D of the records, planes kernel, tower, head convolution, policy GEMM, soft-max +
+ * value, D2H of the outputs (a stage that waits for compute units held by another submission's tower shows as long);  host_us[4]:
+ * the submit call, submit -> answers with the caller, the device's span first -> last stamp, and the difference of the last two. */
+int dgnn_forward_stage_times(dgnn_workspace* const* workspaces, int in_flight, const uint8_t* records, int count, int steps,
+                             float* stage_us /* 7 */, double* host_us /* 4 */);
+
 /* ---- layer-level entry point (parity tests) --------------------------------------------------- */
 
 /* One Conv2d::forward / forward_skip (src/libdg_nn/layers/conv2d.rs:171-220) on host buffers, for the
@@ -757,6 +765,10 @@ int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cac
 
 int dgnn_selfplay_go_boards(dgnn_predict_boards_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                             dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);
+
+/* Test hook: the n-th board pushed into any batcher's queue from now on (n = 0: the next one) is refused with DGNN_OUT_OF_MEMORY, as if
+ * the queue's allocation had failed; n < 0 switches the hook off (its state at load). */
+void dgnn_test_fail_push_after(int n);
 
 /* Library version / build info string (static). */
 const char* dgnn_version(void);

@@ -477,3 +477,41 @@ def test_back_to_back_holds_partial_batches_until_the_device_is_about_to_be_free
     with pytest.raises(api.Error):
         lanes.set_back_to_back(300)                          # one device, one clock
     lanes.close()
+
+
+def test_a_leader_that_could_not_be_queued_leaves_no_position_behind(api):
+    """with coalescing a slot registers as the LEADER of its position before it is pushed into the queue.  A push that
+    fails (an allocation) used to leave the entry: every later request for the position followed a leader nobody would ever answer
+    and blocked for ever.  The hook makes one push fail like a failed allocation: the call reports it, the boards of the request
+    that WERE queued are still evaluated, and the position can be asked for again."""
+    import threading
+    board = api.Board(7.5)
+    for i, (x, y) in enumerate([(3, 3), (15, 15), (3, 15), (16, 3)]):
+        board.place(i % 2, x, y)
+    others = []
+    for k in range(3):
+        b = board.clone()
+        b.place(0, 9 + k, 9)
+        others.append(b)
+    pool = api.LeafPool.over_dry_device(base_us=2000.0, per_board_us=0.0, max_batch_size=16, batches_per_lane=1, workers_per_lane=1)
+    pool.set_coalescing(True)
+    try:
+        api.lib.dgnn_test_fail_push_after(0)                       # the very next push
+        with pytest.raises(api.Error) as failed:
+            pool.predict_boards(board.record(0, 0), 1)
+        assert failed.value.status == api.OUT_OF_MEMORY
+        # three boards, the THIRD push fails: the call reports the failure after the two queued boards have come back
+        api.lib.dgnn_test_fail_push_after(2)
+        before = pool.stats()["boards"]
+        with pytest.raises(api.Error):
+            pool.predict_boards(np.concatenate([b.record(1, 0) for b in others]), 3)
+        assert pool.stats()["boards"] - before == 2
+    finally:
+        api.lib.dgnn_test_fail_push_after(-1)
+    # every position involved can be asked for again and is EVALUATED (a stale leader entry would make these calls wait for ever)
+    answers = []
+    worker = threading.Thread(target=lambda: answers.extend([pool.predict_boards(board.record(0, 3), 1), pool.predict_boards(others[2].record(1, 1), 1)]))
+    worker.start()
+    worker.join(timeout=20.0)
+    assert not worker.is_alive() and len(answers) == 2 and pool.coalesced() == 0
+    pool.close()

@@ -398,3 +398,58 @@ def test_sparse_children_answer_like_a_dense_node(api):
     # a child that never got a slot has no sub-tree and reads as Child::with_value
     untouched = int(np.flatnonzero((count == 0) & (vcount == 0))[-1])
     assert not root.with_(untouched).has_node() and root.with_(untouched).value() == np.float32(0.5)
+
+
+def test_many_threads_in_one_root_cross_the_slot_map_boundary_safely(api):
+    """a node keeps its first 15 child slots in the node and in one 16-slot chunk, and an index -> slot map from the
+    sixteenth on.  A reader that saw "no map yet" and THEN a slot count past 23 (other threads adding slots in between) scanned
+    past the chunk.  Now the map is published before the count that needs it and the reader switches to it.  Sixteen search
+    threads probing fresh roots with a flat prior (every probe's virtual loss sends the next one to a new child) cross that
+    boundary in every attempt; the tree must come out consistent every time (ASan / TSan run the same stress in tools/sanitize_host.sh)."""
+    import threading
+    prior = np.full(362, 1.0 / 362, dtype=np.float32)
+    for attempt in range(20):
+        root = api.Node(api.BLACK, 0.5, prior)
+        start = threading.Barrier(16)
+        inserted = []
+
+        def work():
+            start.wait()
+            mine = 0
+            for _ in range(6):                                             # (ctypes releases the GIL: the probes run side by side)
+                trace = api.probe(root)
+                if isinstance(trace, int):
+                    continue
+                api.insert(trace, 1 - trace[len(trace) - 1][1], 0.5, prior)
+                mine += 1
+            inserted.append(mine)
+
+        threads = [threading.Thread(target=work) for _ in range(16)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert root.total_count == sum(inserted) and root.vtotal_count == 0
+        counts = _visit_counts(root)
+        assert counts.sum() == root.total_count and int((counts > 0).sum()) > 24        # well past the first chunk: the map is in use
+
+
+def test_nodes_freed_on_another_thread_than_the_one_that_made_them(api):
+    """tree nodes and leaf boards come from per-thread free lists (dgnn_internal.h BlockPool); the sanitizer builds bypass
+    them.  The shipped path: trees built on one thread and freed on another (what pool workers and migrating fibers do), more nodes
+    than a list keeps, and a thread that ends with blocks in its list."""
+    import threading
+    trees = []
+
+    def build():
+        for seed in range(6):
+            root = _fresh_root(api)
+            api.search_run(root, api.SyntheticBoard(7 + seed), num_rollouts=900, num_threads=1, seed=seed)
+            trees.append(root)
+
+    t = threading.Thread(target=build)
+    t.start()
+    t.join()
+    assert all(r.total_count > 0 and r.is_done(900) for r in trees)
+    trees.clear()                                                         # their nodes go to THIS thread's list (it keeps 2 048, the rest goes to the heap)
+    root = _fresh_root(api)                                               # ... and are handed out again here
+    evals, _ = api.search_run(root, api.SyntheticBoard(3), num_rollouts=3000, num_threads=4, seed=9)
+    assert root.total_count == evals and root.is_done(3000) and root.vtotal_count == 0
