@@ -594,6 +594,9 @@ def parity_entry(ws, features, n, ref_value, ref_policy, what):
     rp = np.asarray(ref_policy).view(np.float16).astype(np.float32)[:n * 362].reshape(n, 362)
     entry = {"what": what, "boards": n, "inputs_crc32": zlib.crc32(f[:n * 11552].tobytes()),
              "max_abs_value_diff": float(np.abs(gv - rv).max()), "max_abs_policy_diff": float(np.abs(gp - rp).max()), "tolerance": 1e-3}
+    # north_star names both: value abs-diff and policy KL(checker || HIP), per board, on the fp16 probabilities promoted to fp64
+    kl = np.sum(rp.astype(np.float64) * (np.log(rp.astype(np.float64) + 1e-12) - np.log(gp.astype(np.float64) + 1e-12)), axis=1)
+    entry["policy_kl_max"], entry["policy_kl_mean"] = float(kl.max()), float(kl.mean())
     # board identity: board i's output is nearer to the checker's output of board i than to that of any other board
     hip = np.concatenate([gp, gv[:, None]], axis=1).astype(np.float64)
     ref = np.concatenate([rp, rv[:, None]], axis=1).astype(np.float64)
@@ -654,6 +657,15 @@ def main():
     from dream_go_amd import api, synth
 
     rank, world, device = job.rank, job.world, job.device
+    gpu_bus = None
+    if not job.dry:
+        # the device this rank's library opens IS the device torch (and so the launcher's LOCAL_RANK) means: same physical GPU
+        gpu_bus = api.Device(device).pci_bus_id().lower()
+        props = job.torch.cuda.get_device_properties(device)
+        if hasattr(props, "pci_bus_id"):
+            torch_bus = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+            if gpu_bus[-7:] != torch_bus[-7:]:
+                raise SystemExit(f"rank {rank}: the library's device {device} is {gpu_bus}, torch's cuda:{device} is {torch_bus}")
 
     # ---- synthetic network + inputs in the reference's formats (no network access for real weights).  Rank r > 0 starts from
     # DIFFERENT weights (seed 1 + r): only the broadcast can make the replicas agree
@@ -763,6 +775,7 @@ def main():
                 "blocks": info["num_blocks"], "channels": c, "samples": info["num_samples"],
                 "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                 "parallelism": f"replicas x{world} (independent leaf batches, no data-path collective)",
+                "rank0_gpu": {"pci_bus_id": gpu_bus, "numa_node": replicas.gpu_numa_node(job.local_rank), "cpus_pinned": f"{min(pinned)}-{max(pinned)}" if pinned else None},
             },
             "per_rank_evals_per_sec": [args.batch * args.steps / t for t in per_rank_elapsed],
         }

@@ -256,6 +256,7 @@ SYMBOLS = [
     ("dgnn_full_forward_boards", ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _fp, _fp]),
     ("dgnn_selfplay_go_boards", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _ip, ctypes.c_char_p, ctypes.c_size_t]),
     # round 5
+    ("dgnn_device_pci_bus_id", ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
     ("dgnn_test_fail_push_after", None, [ctypes.c_int]),
     ("dgnn_forward_stage_times", ctypes.c_int, [_vpp, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_int, _fp, ctypes.POINTER(ctypes.c_double)]),
 ]
@@ -331,6 +332,12 @@ class Device:
     @staticmethod
     def all():
         return [Device(i) for i in range(Device.len())]
+
+    def pci_bus_id(self):
+        """The physical GPU behind this runtime index ("0000:c1:00.0")."""
+        out = ctypes.create_string_buffer(32)
+        _check(lib.dgnn_device_pci_bus_id(int(self.device_id), out, len(out)), "Device::pci_bus_id")
+        return out.value.decode("ascii")
 
 
 class OutputMap:

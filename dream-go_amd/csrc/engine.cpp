@@ -168,6 +168,62 @@ SplitChain* split_chain(int device)
     return chain;
 }
 
+// Submissions of one device finish IN ORDER, a tower apart (round 5).  A whole-board tower workgroup owns its compute unit's whole
+// register file, so while submission B's tower holds every CU nothing of submission A's tail -- head convolution, policy GEMM,
+// soft-max, the output copy's blit kernel -- can start: A's answers arrive when B's tower ends, together with B's, and a leaf pool
+// with two batches alive sees both come back at once and then nothing for a host turn-around.  With the chain a submission's first
+// command waits for the previous submission's last one whenever the two cannot share the device anyway (their boards together
+// exceed the CUs): A's tail runs on an idle device for some tens of microseconds, B's tower follows, and the answers of the two
+// arrive a tower apart -- the host works on A's while the device works on B.  DGNN_CHAIN=0 switches it off, 1 chains always.
+struct OrderChain {
+    std::mutex mutex;
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+    int last_active = 0;
+};
+OrderChain* order_chain(int device)
+{
+    static std::mutex table_mutex;
+    static std::map<int, OrderChain*> table;     // never freed: a few bytes per device for the life of the process
+    std::lock_guard<std::mutex> lock(table_mutex);
+    OrderChain*& chain = table[device];
+    if (!chain) {
+        chain = new OrderChain();
+        if (hipEventCreateWithFlags(&chain->done, hipEventDisableTiming) != hipSuccess) chain->done = nullptr;
+    }
+    return chain;
+}
+int chain_mode_from_env()
+{
+    const char* m = std::getenv("DGNN_CHAIN");
+    return m && *m ? std::atoi(m) : 0;
+}
+const int kChainMode = chain_mode_from_env();
+
+// Held by a submit call from its first command to mark_submission: the (wait, record) pairs of two threads must not interleave.
+struct OrderScope {
+    OrderChain* chain = nullptr;
+    std::unique_lock<std::mutex> lock;
+    int begin(Workspace* ws)
+    {
+        if (kChainMode == 0) return DGNN_OK;
+        chain = order_chain(ws->device);
+        if (!chain->done) { chain = nullptr; return DGNN_OK; }
+        lock = std::unique_lock<std::mutex>(chain->mutex);
+        if (chain->recorded && (kChainMode == 1 || chain->last_active + ws->active > ws->dev->num_cus))
+            DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
+        return DGNN_OK;
+    }
+    int end(Workspace* ws)
+    {
+        if (!chain) return DGNN_OK;
+        DGNN_HIP(hipEventRecord(chain->done, ws->stream));
+        chain->recorded = true;
+        chain->last_active = ws->active;
+        return DGNN_OK;
+    }
+};
+
 namespace {
 
 size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
@@ -901,6 +957,16 @@ int dgnn_device_count(int* count)
     return DGNN_OK;
 }
 
+int dgnn_device_pci_bus_id(int device, char* out, size_t capacity)
+{
+    if (!out || capacity < 16) return DGNN_BAD_ARGUMENT;
+    int count = 0;
+    DGNN_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
+    DGNN_HIP(hipDeviceGetPCIBusId(out, (int)capacity, device));
+    return DGNN_OK;
+}
+
 int dgnn_network_load(const char* json_path, dgnn_network** out)
 {
     if (!json_path || !out) return DGNN_BAD_ARGUMENT;
@@ -1080,6 +1146,8 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
     DGNN_HIP(hipSetDevice(ws->device));
     const size_t in_bytes = num_features * sizeof(uint16_t);
     if (features != ws->h_features) std::memcpy(ws->h_features, features, in_bytes);
+    OrderScope order;
+    { const int began = order.begin(ws); if (began != DGNN_OK) return began; }
     DGNN_HIP(hipMemcpyAsync(ws->d_features, ws->h_features, in_bytes, hipMemcpyHostToDevice, ws->stream));   // graph.rs:130-131
 
     int status = enqueue_forward(ws, -1);
@@ -1089,6 +1157,7 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
 
     DGNN_HIP(enqueue_outputs(ws));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
+    { const int ended = order.end(ws); if (ended != DGNN_OK) return ended; }
     ws->pending = true;
     return DGNN_OK;
 }
@@ -1141,6 +1210,8 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
 
     DGNN_HIP(hipSetDevice(ws->device));
     if (packed != ws->h_packed) std::memcpy(ws->h_packed, packed, in_bytes);
+    OrderScope order;
+    { const int began = order.begin(ws); if (began != DGNN_OK) return began; }
     DGNN_HIP(hipMemcpyAsync(ws->d_packed, ws->h_packed, in_bytes, hipMemcpyHostToDevice, ws->stream));
 
     int status = enqueue_forward(ws, -1, kInputPacked);
@@ -1150,6 +1221,7 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
 
     DGNN_HIP(enqueue_outputs(ws));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
+    { const int ended = order.end(ws); if (ended != DGNN_OK) return ended; }
     ws->pending = true;
     return DGNN_OK;
 }
@@ -1174,6 +1246,8 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
 
     DGNN_HIP(hipSetDevice(ws->device));
     if (records != ws->h_records) std::memcpy(ws->h_records, records, in_bytes);
+    OrderScope order;
+    { const int began = order.begin(ws); if (began != DGNN_OK) return began; }
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[0], ws->stream));
     DGNN_HIP(hipMemcpyAsync(ws->d_records, ws->h_records, in_bytes, hipMemcpyHostToDevice, ws->stream));
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[1], ws->stream));
@@ -1186,6 +1260,7 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
     DGNN_HIP(enqueue_outputs(ws));
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[7], ws->stream));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
+    { const int ended = order.end(ws); if (ended != DGNN_OK) return ended; }
     ws->pending = true;
     return DGNN_OK;
 }

@@ -118,7 +118,80 @@ def selfplay_sharded(api, dist, torch, num_games, num_moves, num_rollouts, threa
     return out
 
 
-def pin_to_compact_cpus(local_rank=0, quota=None):
+def _parse_cpulist(text):
+    """"0-15,128-143" -> [0, ..., 15, 128, ..., 143]."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def visible_gpu_index(local_rank):
+    """The PHYSICAL GPU (its position in the KFD topology, the order ROCr / HIP enumerate devices in) behind device `local_rank` of
+    this process: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES re-number the devices a process sees (a list of
+    physical indices; ROCR is applied first, HIP on top of it).  UUID entries ("GPU-...") cannot be resolved here: None."""
+    import os
+    index = int(local_rank)
+    for name in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):      # innermost re-numbering first
+        value = os.environ.get(name)
+        if value is None or value.strip() == "":
+            continue
+        if name == "CUDA_VISIBLE_DEVICES" and os.environ.get("HIP_VISIBLE_DEVICES"):
+            continue                                                                           # (HIP_ takes precedence over CUDA_)
+        entries = [e.strip() for e in value.split(",")]
+        if index >= len(entries) or not entries[index].lstrip("-").isdigit():
+            return None
+        index = int(entries[index])
+        if index < 0:
+            return None
+    return index
+
+
+def gpu_numa_node(local_rank=0, sysfs_root="/sys"):
+    """NUMA node of the GPU this rank opens, from the KFD topology (the nodes with SIMDs are the GPUs, in the runtime's order; each
+    names its DRM render node, whose PCI device carries `numa_node`) -- the figure `rocm-smi --showtoponuma` prints.  None when the
+    tree is not there (no GPU, a container without /sys/class/kfd) or says -1."""
+    import os
+    gpu = visible_gpu_index(local_rank)
+    if gpu is None:
+        return None
+    nodes_dir = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        names = sorted(os.listdir(nodes_dir), key=lambda n: int(n) if n.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    gpus = []
+    for name in names:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(nodes_dir, name, "properties")) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            gpus.append(props)
+    if gpu >= len(gpus):
+        return None
+    minor = gpus[gpu].get("drm_render_minor")
+    if minor is None:
+        return None
+    try:
+        node = int(open(os.path.join(sysfs_root, "class", "drm", f"renderD{minor}", "device", "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None
+    return node if node >= 0 else None
+
+
+def numa_node_cpus(node, sysfs_root="/sys"):
+    import os
+    try:
+        return _parse_cpulist(open(os.path.join(sysfs_root, "devices", "system", "node", f"node{int(node)}", "cpulist")).read())
+    except (OSError, ValueError):
+        return []
+
+
+def pin_to_compact_cpus(local_rank=0, quota=None, sysfs_root="/sys"):
     """Keeps this process's threads on a compact set of CPUs, as many as its CPU-time quota pays for.
 
     The GPU boxes of the pool show 256 logical CPUs (2 sockets x 64 cores x 2) and grant a container 16 CPUs of TIME
@@ -127,11 +200,23 @@ def pin_to_compact_cpus(local_rank=0, quota=None):
     143 k rollouts/s unpinned, 6.0 cores for 195 k rollouts/s on CPUs 0-15 (tools/affinity_probe.sh).  Rank r of a node takes
     the r-th slice of the allowed CPUs (in their numeric order: on these boxes the first half is socket 0, where GPUs 0-3
     hang, and a slice of 16 is 16 physical cores of two neighbouring CCDs).  Returns the chosen CPUs, or None when the process
-    is not oversubscribed (quota >= allowed CPUs) or the platform has no affinity call.  DGNN_PIN_CPUS=0 switches it off."""
+    is not oversubscribed (quota >= allowed CPUs) or the platform has no affinity call.  DGNN_PIN_CPUS=0 switches it off.
+    NUMA (round 5): where the KFD topology says which NUMA node the rank's GPU hangs on (gpu_numa_node: HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES honoured), the slices are cut from THAT node's CPUs, and the ranks whose GPUs share a node take its
+    slices in rank order -- the pinned host buffers, the records a rank uploads and the answers it downloads then stay on the
+    socket the GPU's PCIe root is on.  Without the topology the numeric order stands in for it, as before."""
     import os
     if os.environ.get("DGNN_PIN_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     allowed = sorted(os.sched_getaffinity(0))
+    node = gpu_numa_node(local_rank, sysfs_root)
+    if node is not None:
+        local = [c for c in numa_node_cpus(node, sysfs_root) if c in set(allowed)]
+        if local:
+            # my turn among the node's ranks: the lower local ranks whose GPU sits on the same node
+            world_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+            turn = sum(1 for r in range(min(int(local_rank), world_local)) if gpu_numa_node(r, sysfs_root) == node)
+            allowed, local_rank = local, turn
     if quota is None:
         quota = len(allowed)
         try:

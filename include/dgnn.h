@@ -61,6 +61,10 @@ int dgnn_last_hip_error(void);
 
 /* Device::len() -- number of visible GPUs. */
 int dgnn_device_count(int* count);
+/* Which physical GPU device `device` of THIS process is ("0000:c1:00.0"): HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES re-number the
+ * devices a process sees, and a launcher that binds rank -> GPU wants to see that the library opens the GPU it means
+ * (dg_cuda::Device::set_current takes the same runtime index, src/libdg_cuda/devices.rs:62-73).  capacity >= 16. */
+int dgnn_device_pci_bus_id(int device, char* out, size_t capacity);
 
 /* ---- network: dg_nn::Network + loader ------------------------------------------------------ */
 

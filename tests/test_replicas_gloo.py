@@ -142,6 +142,60 @@ def test_pin_to_compact_cpus_takes_a_slice_per_rank(monkeypatch):
     assert replicas.pin_to_compact_cpus(0, quota=16) is None
 
 
+def _fake_sysfs(root, gpu_nodes, cpus_per_node=64):
+    """A /sys with a KFD topology of one CPU node per NUMA node followed by the GPUs (gpu_nodes[i] = NUMA node of GPU i), their
+    render nodes and the nodes' cpulists -- the files replicas.gpu_numa_node / numa_node_cpus read."""
+    numa = sorted(set(gpu_nodes))
+    topo = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    for i, n in enumerate(numa):                                                     # CPU agents come first, no SIMDs
+        os.makedirs(os.path.join(topo, str(i)))
+        open(os.path.join(topo, str(i), "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+        os.makedirs(os.path.join(root, "devices", "system", "node", f"node{n}"))
+        open(os.path.join(root, "devices", "system", "node", f"node{n}", "cpulist"), "w").write(f"{n * cpus_per_node}-{(n + 1) * cpus_per_node - 1}\n")
+    for g, n in enumerate(gpu_nodes):
+        d = os.path.join(topo, str(len(numa) + g))
+        os.makedirs(d)
+        open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + g}\n")
+        dev = os.path.join(root, "class", "drm", f"renderD{128 + g}", "device")
+        os.makedirs(dev)
+        open(os.path.join(dev, "numa_node"), "w").write(f"{n}\n")
+
+
+def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(monkeypatch, tmp_path):
+    """a rank's CPUs come from the NUMA node its GPU hangs on (KFD topology -> render node -> numa_node), the ranks
+    of one node take that node's slices in rank order, HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES re-numbering is honoured."""
+    from dream_go_amd import replicas
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no scheduler affinity on this platform")
+    root = str(tmp_path)
+    _fake_sysfs(root, [0, 0, 0, 0, 1, 1, 1, 1])                                      # an 8-GPU box: GPUs 0-3 on socket 0, 4-7 on socket 1
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: None)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    for name in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(name, raising=False)
+    assert [replicas.gpu_numa_node(r, root) for r in range(8)] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert replicas.numa_node_cpus(1, root) == list(range(64, 128))
+    # 16 CPUs of quota per rank: ranks 0-3 take socket 0's four slices, ranks 4-7 socket 1's
+    got = [replicas.pin_to_compact_cpus(r, quota=16, sysfs_root=root) for r in range(8)]
+    assert got[0] == list(range(0, 16)) and got[3] == list(range(48, 64))
+    assert got[4] == list(range(64, 80)) and got[7] == list(range(112, 128))
+    # the launcher hands every rank ONE visible device: rank 5 sees physical GPU 5 as its device 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5")
+    assert replicas.visible_gpu_index(0) == 5 and replicas.gpu_numa_node(0, root) == 1
+    # ROCR re-numbers first, HIP on top of it: HIP device 1 -> ROCR entry 1 -> physical GPU 6
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4,6")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+    assert replicas.visible_gpu_index(1) == 6 and replicas.gpu_numa_node(1, root) == 1
+    assert replicas.visible_gpu_index(2) is None and replicas.gpu_numa_node(2, root) is None      # not a visible device
+    # no topology (this container): the numeric slices, as before
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert replicas.gpu_numa_node(0, os.path.join(root, "nowhere")) is None
+    assert replicas.pin_to_compact_cpus(3, quota=16, sysfs_root=os.path.join(root, "nowhere")) == list(range(48, 64))
+
+
 def _mismatch_worker(rank, world, port, results):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

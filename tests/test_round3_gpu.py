@@ -16,24 +16,19 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, f16_to_f32, policy_kl
+from parity_bounds import allowances
 
 pytestmark = pytest.mark.gpu
 
 VALUE_TOL = 1e-3     # north_star: |dvalue| <= 1e-3
 POLICY_TOL = 1e-3    # north_star: max |dpolicy| <= 1e-3
-# Peaked outputs.  Both sides store every tensor as fp16 (layers/common.rs:61-98) and differ only in the order of their fp32
-# sums, i.e. by single-ulp flips of fp16 values.  In front of the soft-max sit fp16 LOGITS: at the magnitudes a peaked policy needs
-# (8 ... 16) one ulp is 2^-7, and one flipped logit moves a probability by p (1 - p) 2^-7 <= 2e-3 -- twice the 1e-3 that holds on flat
-# outputs, whatever the implementation.  An fp16 value near +-1 has an ulp of 4.9e-4, so 1e-3 is two ulps there.  The bounds below
-# are those two effects (two logit ulps relative, 4e-3 absolute); the same networks with their dense gains divided by four stay
-# within 1e-3 (second parametrisation), and board identity holds with a margin of more than 3x in both
-# (the 256 boards are positions 2-3 stones apart of only three games).
-# Round 4: tests/test_round4_gpu.py bounds the same workloads WHERE the error lives -- one fp16 ulp on the logits and on the pre-tanh
-# value, against an exact-arithmetic statement of the oracle -- and derives a per-entry probability tolerance from that; the blanket
-# figures below stay as this file's (older, looser) net.
-PEAKED_POLICY_TOL = 4e-3
-PEAKED_VALUE_TOL = 2.5e-3
-PEAKED_RELATIVE_TOL = 2.0 ** -6
+# Peaked outputs.  Both sides store every tensor as fp16 (layers/common.rs:61-98) and differ only in the order of their fp32 sums,
+# i.e. by single-ulp flips of fp16 values.  In front of the soft-max sit fp16 LOGITS: at the magnitudes a peaked policy needs (8 ... 32)
+# one ulp is 2^-7 ... 2^-6, and one flipped logit moves a probability by p (1 - p) ulp -- more than the 1e-3 that holds on flat
+# outputs, whatever the implementation.  The contract on peaked outputs is therefore "ONE fp16 ulp in front of the soft-max / tanh",
+# and what it allows per probability / value is derived per entry (tests/parity_bounds.py, the helper tests/test_round4_gpu.py
+# measures the bound with): round 3's blanket 4e-3 / 2.5e-3 widening is gone.  The same networks with their dense gains divided by
+# four stay within north_star's 1e-3 outright (second parametrisation); board identity holds with a margin of more than 3x in both.
 
 
 def real_game_positions(api):
@@ -58,9 +53,14 @@ def real_game_features(api, batch, first=3):
     return np.concatenate(planes).view(np.uint16)
 
 
-def oracle_outputs(oracle, text, features, batch):
+def oracle_outputs(oracle, text, features, batch, pre=False):
+    """-> value [B], policy [B, 362] (and, with pre=True, the logits [B, 362] and the pre-tanh value [B]) of the fp32 oracle."""
     tensors, _ = oracle.load_weights(text)
-    rv, rp = oracle.OracleNetwork(tensors).forward(np.ascontiguousarray(features).view(np.uint16).reshape(-1), batch)
+    f = np.ascontiguousarray(features).view(np.uint16).reshape(-1)
+    if pre:
+        rv, rp, rl, rpre = oracle.OracleNetwork(tensors).forward_ex(f, batch)
+        return f16_to_f32(rv), f16_to_f32(rp).reshape(batch, 362), f16_to_f32(rl).reshape(batch, 362), f16_to_f32(rpre)
+    rv, rp = oracle.OracleNetwork(tensors).forward(f, batch)
     return f16_to_f32(rv), f16_to_f32(rp).reshape(batch, 362)
 
 
@@ -80,7 +80,7 @@ def test_sharpened_network_on_real_positions_board_identity(api, oracle, synth, 
         assert ws.conv_kernel() == kernel
         value, policy = api.forward(ws, features).unwrap()
     net.destroy()
-    rv, rp = oracle_outputs(oracle, text, features, batch)
+    rv, rp, rl, rpre = oracle_outputs(oracle, text, features, batch, pre=True)
     gv, gp = value.astype(np.float32), policy.astype(np.float32).reshape(batch, 362)
 
     # the workload discriminates: peaked AND flat soft-maxes, many different best moves, saturated AND small values
@@ -99,7 +99,10 @@ def test_sharpened_network_on_real_positions_board_identity(api, oracle, synth, 
     rel = (np.abs(gp - rp)[big] / rp[big]).max()
     print(f"   max|dvalue| {dv.max():.3e}  max|dpolicy| {dp.max():.3e}  max KL {kl.max():.3e}  max relative error on entries > 0.01: {rel:.3e}")
     if peaked:
-        assert dv.max() <= PEAKED_VALUE_TOL and dp.max() <= PEAKED_POLICY_TOL and rel <= PEAKED_RELATIVE_TOL and kl.max() <= 1e-3
+        # one fp16 ulp in front of the soft-max / tanh, and what that allows per entry (parity_bounds.allowances)
+        allowed_p, allowed_v, held = allowances(rp, rv, rl, rpre)
+        print(f"   {100 * held.mean():.2f} % of the probabilities held to 1e-3, the rest to 2 p (1 - p) x one logit ulp (largest allowance {allowed_p.max():.2e})")
+        assert np.all(np.abs(gp - rp) <= allowed_p) and np.all(dv <= allowed_v) and kl.max() <= 1e-3
     else:
         assert dv.max() <= VALUE_TOL and dp.max() <= POLICY_TOL
 
@@ -133,10 +136,11 @@ def test_every_symmetry_and_colour_of_a_position_is_told_apart(api, oracle, synt
     with net.get_workspace(batch) as ws:
         value, policy = api.forward(ws, features).unwrap()
     net.destroy()
-    rv, rp = oracle_outputs(oracle, text, features, batch)
+    rv, rp, rl, rpre = oracle_outputs(oracle, text, features, batch, pre=True)
     gv, gp = value.astype(np.float32), policy.astype(np.float32).reshape(batch, 362)
     print(f"max|dvalue| {np.abs(gv - rv).max():.3e} max|dpolicy| {np.abs(gp - rp).max():.3e}; oracle policy max {rp.max(axis=1).min():.3f} ... {rp.max():.3f}")
-    assert np.abs(gv - rv).max() <= PEAKED_VALUE_TOL and np.abs(gp - rp).max() <= PEAKED_POLICY_TOL
+    allowed_p, allowed_v, _ = allowances(rp, rv, rl, rpre)
+    assert np.all(np.abs(gv - rv) <= allowed_v) and np.all(np.abs(gp - rp) <= allowed_p)
     hip = np.concatenate([gp, gv[:, None]], axis=1)
     ref = np.concatenate([rp, rv[:, None]], axis=1)
     distance = np.abs(hip[:, None, :] - ref[None, :, :]).max(axis=2)

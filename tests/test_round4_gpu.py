@@ -17,25 +17,17 @@ import numpy as np
 import pytest
 
 from conftest import f16_to_f32
+from parity_bounds import MAX_LOGIT_ULPS, MAX_PRE_TANH_ULPS, NORTH_STAR_TOL, allowances, logit_unit as board_logit_unit, pre_tanh_unit, ulp16
 from test_round3_gpu import real_game_features
 
 pytestmark = pytest.mark.gpu
 
-NORTH_STAR_TOL = 1e-3
 # The unit: one fp16 ulp AT THE SCALE OF THE SUM.  A logit is a sum of 2 888 products whose partial sums are as large as the board's
 # largest logit; one that happens to cancel to 0.01 still carries the absolute error of that scale, so "ulps of its own value" would
 # be meaningless (measured: up to 12 817 of those on a logit of 3e-4).  Logits are measured in ulps of the board's largest |logit|,
-# the pre-tanh value in ulps of the batch's largest |pre-tanh|.
+# the pre-tanh value in ulps of the batch's largest |pre-tanh| (tests/parity_bounds.py, shared with test_round3_gpu.py).
 # Measured (profiles/r04_final/parity_ulps.txt), then fixed, on the WELL-CONDITIONED workloads (gate 0.1): the largest difference
-# HIP vs oracle.
-MAX_LOGIT_ULPS = 1.0           # measured: exactly 1.00 at 20x256 B=256 and at 9x128 B=32 (the oracle itself is up to 1.5 from exact arithmetic)
-MAX_PRE_TANH_ULPS = 1.0
-
-
-def ulp16(x):
-    """Spacing of fp16 at |x| (fp32 array): 2^(floor(log2 |x|) - 10), 2^-24 in the subnormal range."""
-    a = np.maximum(np.abs(np.asarray(x, dtype=np.float64)), 2.0 ** -14)
-    return 2.0 ** (np.floor(np.log2(a)) - 10)
+# HIP vs oracle is exactly 1.00 ulp at 20x256 B=256 and at 9x128 B=32 (the oracle itself is up to 1.5 from exact arithmetic).
 
 
 def build(synth, kind, blocks, channels, gains):
@@ -98,8 +90,8 @@ def test_logits_and_pre_tanh_in_ulps_and_against_exact_arithmetic(api, oracle, s
         if not ok:
             problems.append(what)
 
-    logit_unit = ulp16(np.abs(rl).max(axis=1, keepdims=True))        # [B, 1]
-    pre_unit = ulp16(np.abs(rpre).max())
+    logit_unit = board_logit_unit(rl)                                # [B, 1]
+    pre_unit = pre_tanh_unit(rpre)
     well_conditioned = conditioning == "well"
 
     # ---- ulps at the scale of the sums, HIP vs oracle
@@ -129,14 +121,11 @@ def test_logits_and_pre_tanh_in_ulps_and_against_exact_arithmetic(api, oracle, s
         # probabilities and values: tolerance PER ENTRY from the bound above.  dp_i = p_i (d_i - sum_j p_j d_j) <= 2 p_i (1 - p_i) D with D
         # the largest allowed logit difference on that board, plus an ulp of the fp16 probability; wherever that is below north_star's
         # 1e-3 the entry is held to 1e-3.
-        derived = 2.0 * rp * (1.0 - rp) * MAX_LOGIT_ULPS * logit_unit + ulp16(rp)
-        allowed_p = np.maximum(NORTH_STAR_TOL, derived)
-        held = derived <= NORTH_STAR_TOL
+        allowed_p, allowed_v, held = allowances(rp, rv, rl, rpre)
         print(f"   policy: max |dp| {dp.max():.2e}; {100 * held.mean():.2f} % of the entries are held to 1e-3 by the logit bound (max |dp| there "
               f"{dp[held].max():.2e}), the rest to 2 p (1 - p) D (largest allowance {allowed_p.max():.2e})")
         check(np.all(dp <= allowed_p), f"{int(np.sum(dp > allowed_p))} probabilities beyond their allowance")
         # dv = (1 - v^2) d + an ulp of the fp16 value
-        allowed_v = np.maximum(NORTH_STAR_TOL, (1.0 - rv * rv) * MAX_PRE_TANH_ULPS * pre_unit + ulp16(rv))
         print(f"   value: max |dv| {dv.max():.2e}; allowance from the pre-tanh bound up to {allowed_v.max():.2e}, "
               f"{100 * (allowed_v <= NORTH_STAR_TOL).mean():.1f} % of the boards held to 1e-3")
         check(np.all(dv <= allowed_v), f"{int(np.sum(dv > allowed_v))} values beyond their allowance")
