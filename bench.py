@@ -66,8 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-batches", type=int, default=2,
                     help="device batches the leaf pool keeps alive per GPU.  The reference keeps 2 (nn.rs:64-67); a third raises the engine's "
                          "rate on partial batches and puts more leaves in flight (more positions evaluated twice before the first answer "
-                         "reaches the transposition table; measured in DESIGN.md 13).  0: ADAPTIVE, 2 or 3 -- the pool measures unique positions "
-                         "per second under both and stays with the better one (dgnn_pool_set_adaptive_batches)")
+                         "reaches the transposition table; measured in DESIGN.md 11.7, 13.5)")
     ap.add_argument("--selfplay-workers", type=int, default=0,
                     help="pool worker threads per GPU; 0 (default) = as many as batches alive.  One more lets a free worker take the next batch while "
                          "another is still handing 256 answers to their games (about a millisecond per cycle, DESIGN.md 13.10 / 13.11: not measured yet)")
@@ -98,6 +97,7 @@ def parse_args(argv=None):
     ap.add_argument("--lean", action="store_true", help="only the engine measurement (profiling passes): no PCIe-inclusive, reference-style or self-play legs")
     ap.add_argument("--dry", action="store_true", help="no GPU: gloo + the CPU hash predictor behind the leaf pool (CPU tests of the N > 1 path)")
     args = ap.parse_args(argv)
+    args.selfplay_batches = max(1, args.selfplay_batches)
     if args.lean:
         args.selfplay_games, args.cpu_sample, args.whole_games, args.policy_play_games, args.sustained_seconds = 0, 0, 0, 0, 0.0
     return args
@@ -282,27 +282,24 @@ def selfplay_pool(job, api, net, args, coalesce=None, back_to_back=None):
     if job.dry and boards:
         # no GPU: the CPU stand-in behind a stand-in for the device (a batch of n boards takes 500 + 10.8 n us, one at a time: the
         # 20x256 engine's 3.3 ms at 256 boards) -- what is measured is the HOST side alone, rollouts per second and core
-        pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=args.selfplay_batches or 3,
-                                           workers_per_lane=max(args.selfplay_workers, args.selfplay_batches or 3))
+        pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=args.selfplay_batches,
+                                           workers_per_lane=max(args.selfplay_workers, args.selfplay_batches))
     elif job.dry:
         pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
     else:
-        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches or 3,
-                                        workers_per_device=max(args.selfplay_workers, args.selfplay_batches or 3), boards=boards)
-    adaptive = args.selfplay_batches == 0 and pool.takes_boards
-    if adaptive:
-        pool.set_adaptive_batches(2, 3)
+        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
+                                        workers_per_device=max(args.selfplay_workers, args.selfplay_batches), boards=boards)
     coalesce = (bool(args.selfplay_coalesce) if coalesce is None else coalesce) and pool.takes_boards   # (the games of a leg share one transposition table)
     if coalesce:
         pool.set_coalescing(True)
     lead = args.selfplay_back_to_back if back_to_back is None else back_to_back
     if lead > 0:
         pool.set_back_to_back(lead)
-    return pool, {"adaptive": adaptive, "coalesce": coalesce, "back_to_back": lead, "boards": boards}
+    return pool, {"coalesce": coalesce, "back_to_back": lead, "boards": boards}
 
 
 def pool_rule_text(args, rule):
-    return (f"{args.selfplay_batches or ('2 or 3 (adaptive)' if rule['adaptive'] else 3)} device batches alive" +
+    return (f"{args.selfplay_batches} device batches alive" +
             (f", partial batches back to back (lead {rule['back_to_back']} us)" if rule["back_to_back"] > 0 else ", a free slot takes what is queued (the reference's rule)") +
             (", positions in flight coalesced" if rule["coalesce"] else ", no coalescing (the reference: every miss is evaluated)"))
 
@@ -423,7 +420,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0, reference_rule=F
     games = args.selfplay_games * job.world
     cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
     pool, rule = selfplay_pool(job, api, net, args, coalesce=False if reference_rule else None, back_to_back=0 if reference_rule else None)
-    adaptive, coalesce, boards = rule["adaptive"], rule["coalesce"], rule["boards"]
+    coalesce, boards = rule["coalesce"], rule["boards"]
     opening = None
     if fast_forward > 0:
         ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=games, num_moves=fast_forward, num_rollouts=1, threads_per_search=1,
@@ -442,7 +439,6 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0, reference_rule=F
     cpu_cores_busy = cpu_seconds / max(time.perf_counter() - wall0, 1e-9)
     rank_rollouts = out["evals"] + out["cache_hits"]                                          # this rank's own games
     st = pool.stats()
-    adaptive_stats = pool.adaptive_stats() if adaptive else None
     coalesced = pool.coalesced()
     batch_times = pool.batch_times()
     boards = sum(job.gather_int(st["boards"] - before["boards"]))
@@ -491,8 +487,6 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0, reference_rule=F
         "host_us_per_eval": 1e6 * cpu_seconds / max(out["evals"], 1),
         "batching_rule": "reference (no coalescing, a free slot takes what is queued)" if reference_rule else "tuned (see `what`)",
     }
-    if adaptive_stats is not None:
-        leg["batches_alive"] = adaptive_stats      # rank 0's pool: where the adaptive rule stood at the end, what it measured
     leg["coalescing"] = coalesce
     leg["coalesced_boards_rank0"] = coalesced      # boards that followed a position in flight instead of being evaluated (whole pool lifetime)
     # how many GPUs running THIS leg the box's CPU quota could feed: quota cores / cores one GPU's leg kept busy
@@ -823,10 +817,10 @@ def main():
                 reps = max(10, args.steps)
                 out["value_pcie_inclusive"] = {
                     "what": "evals/s with host buffers in and out, two workspaces in flight (dgnn_forward_submit_* / dgnn_forward_wait inside "
-                            "dgnn_forward_pipelined_timed: no interpreter in the loop), same network and batch as `value`",
-                    "board_records": api.forward_pipelined_timed(ws, ws2, "records", records, args.batch, reps),     # 896 B per board, planes on the device
-                    "packed_planes": api.forward_pipelined_timed(ws, ws2, "packed", packed, args.batch, reps),       # 1.5 KB per board
-                    "fp16_planes": api.forward_pipelined_timed(ws, ws2, "planes", features, args.batch, reps),       # 23 KB per board: the reference's form
+                            "dgnn_forward_pipelined_timed_n: no interpreter in the loop), same network and batch as `value`",
+                    "board_records": api.forward_pipelined_timed_n([ws, ws2], "records", records, args.batch, reps),     # 896 B per board, planes on the device
+                    "packed_planes": api.forward_pipelined_timed_n([ws, ws2], "packed", packed, args.batch, reps),       # 1.5 KB per board
+                    "fp16_planes": api.forward_pipelined_timed_n([ws, ws2], "planes", features, args.batch, reps),       # 23 KB per board: the reference's form
                     "steps": reps,
                 }
                 out["value_pcie_inclusive"]["records_vs_resident"] = out["value_pcie_inclusive"]["board_records"] / value

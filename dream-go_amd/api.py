@@ -26,8 +26,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DGNN_LIBRARY=<path>: another build of the same library (A/B measurements of two builds on one box); default: the in-tree one
-LIB_PATH = os.environ.get("DGNN_LIBRARY") or os.path.join(_HERE, "lib", "libdgnn_hip.so")
+# Which build of the library this module binds.  Default: the SHIPPED one, lib/libdgnn_hip.so (exports include/dgnn.h + dgnn_host.h).
+# DGNN_LIBRARY=<path>: another build (A/B measurements of two builds on one box; the ablations build).  load_full() returns a second
+# instance of this module bound to lib/libdgnn_hip_test.so, the same kernel objects with the test-only entry points of
+# include/dgnn_test.h exported as well (tests/conftest.py: api_full).
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "libdgnn_hip_test.so")
+LIB_PATH = globals().get("_FORCED_LIB_PATH") or os.environ.get("DGNN_LIBRARY") or os.path.join(_HERE, "lib", "libdgnn_hip.so")
 
 OK = 0
 MISSING_WEIGHTS = -1
@@ -262,6 +266,26 @@ SYMBOLS = [
 ]
 
 
+# include/dgnn_test.h: exported by the test build (and the ablations build) only; calling one of them through a binding of the shipped
+# library raises AttributeError -- loudly, at the call
+TEST_ONLY = frozenset('dgnn_pool_create_callbacks_boards dgnn_go_count dgnn_argmax_f32 dgnn_batch_destroy dgnn_batch_features dgnn_batch_forward dgnn_batch_forward_on dgnn_batch_records dgnn_batch_size dgnn_batch_tags dgnn_batcher_create dgnn_batcher_create_boards dgnn_batcher_destroy dgnn_batcher_get_batch dgnn_batcher_pending dgnn_batcher_push dgnn_batcher_push_and_get_batch dgnn_batcher_push_board dgnn_batcher_stats dgnn_board_records_to_packed_device dgnn_cache_fetch dgnn_cache_generation dgnn_cache_insert dgnn_cache_insert_at dgnn_choose dgnn_choose_f64 dgnn_config_fpu_reduce dgnn_config_lcb_critical_value dgnn_config_uct_exp dgnn_config_vloss_cnt dgnn_dirichlet_add dgnn_forward_pipelined_timed dgnn_full_forward dgnn_full_forward_boards dgnn_go_at dgnn_go_benson dgnn_go_benson_flood dgnn_go_candidates dgnn_go_check dgnn_go_hash dgnn_go_is_ladder_capture dgnn_go_is_ladder_escape dgnn_go_is_scorable dgnn_go_is_symmetric dgnn_go_n_liberty dgnn_go_n_liberty_if dgnn_go_result_sgf dgnn_go_score dgnn_go_stone_status dgnn_go_to_move dgnn_intp_value dgnn_layer_conv3x3 dgnn_layer_dense dgnn_layer_heads dgnn_policy_with_transform dgnn_pool_adaptive_stats dgnn_pool_create dgnn_pool_set_adaptive_batches dgnn_pool_set_extra_batch_queue dgnn_pool_set_min_fill dgnn_rollout_limit_is_done dgnn_search_run dgnn_search_run_cached dgnn_selfplay_synthetic dgnn_symmetry_apply dgnn_symmetry_inverse dgnn_synthetic_board_free dgnn_synthetic_board_new dgnn_synthetic_game_ops dgnn_test_fail_push_after dgnn_trace_get dgnn_trace_len dgnn_tree_node_child dgnn_tree_node_disqualify dgnn_tree_node_min_promote dgnn_tree_node_prior dgnn_tree_undo dgnn_workspace_download_pre'.split())
+
+
+def load_full():
+    """A second instance of this module bound to the test build of the library (every symbol of the three headers)."""
+    import importlib.util
+    import sys
+    name = __name__ + "_full"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.abspath(__file__))
+    module = importlib.util.module_from_spec(spec)
+    module.__dict__["_FORCED_LIB_PATH"] = os.environ.get("DGNN_LIBRARY") or TEST_LIB_PATH
+    sys.modules[name] = module
+    spec.loader.exec_module(module)
+    return module
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python dream-go_amd/build.py` (hipcc, gfx950). "
@@ -275,8 +299,13 @@ def _load():
             import torch  # noqa: F401
         except ImportError:
             pass
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)     # (local: the shipped and the test build may live in one process)
+    full = hasattr(lib, "dgnn_layer_conv3x3")               # the test or the ablations build
     for name, restype, argtypes in SYMBOLS:
+        if name in TEST_ONLY and not full:
+            if hasattr(lib, name):
+                raise ImportError(f"{LIB_PATH} exports {name}, which include/dgnn_test.h reserves for the test build")
+            continue
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
@@ -1103,7 +1132,7 @@ PROBE_FOUND, PROBE_NO_RESULT, PROBE_CONFLICT = 1, 0, 2
 
 class config:
     """dg_utils::config accessors used by the tree (src/libdg_utils/config.rs:181-195, 289-330)."""
-    VLOSS_CNT = lib.dgnn_config_vloss_cnt()
+    VLOSS_CNT = lib.dgnn_config_vloss_cnt() if hasattr(lib, "dgnn_config_vloss_cnt") else 32      # (config.rs:187; the accessor is a test-build export)
     get_uct_exp = staticmethod(lambda visits: lib.dgnn_config_uct_exp(int(visits)))
     get_fpu_reduce = staticmethod(lambda visits: lib.dgnn_config_fpu_reduce(int(visits)))
     get_lcb_critical_value = staticmethod(lambda visits: lib.dgnn_config_lcb_critical_value(int(visits)))

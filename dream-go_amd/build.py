@@ -1,8 +1,15 @@
-"""Builds libdgnn_hip.so (the C-ABI library, include/dgnn.h) for gfx950 with hipcc, in-tree.
+"""Builds the C-ABI library for gfx950 with hipcc, in-tree.
 
     python dream-go_amd/build.py [--force]
 
-The library depends only on the HIP runtime (libamdhip64); it does not link torch.
+    lib/libdgnn_hip.so        the shipped library: exports what include/dgnn.h and include/dgnn_host.h declare, nothing else
+    lib/libdgnn_hip_test.so   the SAME kernel objects + the host sources compiled with -DDGNN_TEST_ENTRIES: additionally exports the
+                              test-only entry points of include/dgnn_test.h (layer-level calls, accessors the reference's unit tests
+                              look at, fault injection).  The tests that need them load this one (tests/conftest.py: api_full).
+    DGNN_ABLATIONS=1          one library (lib/ablations/libdgnn_hip.so) with the experiments that were measured and lost -- the NHWC
+                              tile kernels, the pair split, the staged filter, the timing-only ablated kernels -- and every test entry
+
+Both depend only on the HIP runtime (libamdhip64); neither links torch.
 """
 import os
 import subprocess
@@ -10,14 +17,19 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_DIR = os.path.join(HERE, "lib")
+ABLATIONS = os.environ.get("DGNN_ABLATIONS", "0") == "1"
+LIB_DIR = os.path.join(HERE, "lib", "ablations") if ABLATIONS else os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdgnn_hip.so")
+TEST_LIB_PATH = LIB_PATH if ABLATIONS else os.path.join(LIB_DIR, "libdgnn_hip_test.so")
 
-SOURCES = ["loader.cpp", "network.cpp", "engine.cpp", "rccl.cpp", "batcher.cpp", "formats.cpp", "tree.cpp", "search.cpp", "go.cpp", "fiber.cpp", "kernels.hip", "conv_board.hip", "conv_board_tower.hip", "heads.hip", "features.hip"]
+HOST_SOURCES = ["loader.cpp", "network.cpp", "engine.cpp", "rccl.cpp", "batcher.cpp", "formats.cpp", "tree.cpp", "search.cpp", "go.cpp", "fiber.cpp"]
+KERNEL_SOURCES = ["kernels.hip", "conv_board.hip", "conv_board_tower.hip", "heads.hip", "features.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
-if os.environ.get("DGNN_ABLATIONS", "0") == "1":        # the timing-only ablated kernels of tools/ablate*.sh and the NHWC tile kernels of
-    FLAGS.append("-DDGNN_ABLATIONS")                    # round 1 (conv_tile.hip): A/B baselines, not part of the shipped library
-    SOURCES.append("conv_tile.hip")
+if ABLATIONS:
+    FLAGS.append("-DDGNN_ABLATIONS")
+    KERNEL_SOURCES.append("conv_tile.hip")
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions"]    # calls inside the library bind inside it: the shipped
+                                                                                           # and the test library may live in one process
 
 
 def hipcc():
@@ -31,13 +43,12 @@ STAMP_PATH = os.path.join(LIB_DIR, "build.stamp")
 
 
 def _stamp():
-    """What an object file depends on besides its sources: the flags and the compiler.  Toggling DGNN_ABLATIONS=1 (or any flag)
-    must not link objects built for the other setting."""
+    """What an object file depends on besides its sources: the flags and the compiler."""
     try:
         version = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout.strip().splitlines()[0]
     except Exception:   # noqa: BLE001
         version = "unknown hipcc"
-    return " ".join(FLAGS) + "\n" + version + "\n"
+    return " ".join(FLAGS + LINK_FLAGS) + "\n" + version + "\n"
 
 
 def _stamp_matches():
@@ -47,51 +58,73 @@ def _stamp_matches():
         return False
 
 
+def _headers():
+    inc = os.path.join(HERE, "..", "include")
+    return [os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith(".h")] + [os.path.join(inc, n) for n in os.listdir(inc)]
+
+
+def _kernel_headers():
+    """The kernel translation units include the csrc headers only (kernels.h, conv_board_body.h ...), never the public ones: a change of
+    include/*.h recompiles the host sources (seconds), not the kernels (minutes)."""
+    return [os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith(".h") and n != "dgnn_internal.h"]
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH) or not _stamp_matches():
+    if not os.path.exists(LIB_PATH) or not os.path.exists(TEST_LIB_PATH) or not _stamp_matches():
         return True
-    built = os.path.getmtime(LIB_PATH)
-    for root in (CSRC, os.path.join(HERE, "..", "include")):
-        for name in os.listdir(root):
-            if os.path.getmtime(os.path.join(root, name)) > built:
-                return True
-    return False
+    built = min(os.path.getmtime(LIB_PATH), os.path.getmtime(TEST_LIB_PATH))
+    return any(os.path.getmtime(d) > built for d in _headers() + [os.path.join(CSRC, n) for n in HOST_SOURCES + KERNEL_SOURCES])
 
 
-def _stale(src_path, obj):
-    """An object is rebuilt when its source, any header beside it or the public header is newer."""
+def _stale(src_path, obj, headers):
     if not os.path.exists(obj):
         return True
     built = os.path.getmtime(obj)
-    deps = [src_path] + [os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith(".h")]
-    inc = os.path.join(HERE, "..", "include")
-    deps += [os.path.join(inc, n) for n in os.listdir(inc)]
-    return any(os.path.getmtime(d) > built for d in deps)
+    return any(os.path.getmtime(d) > built for d in [src_path] + headers)
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(os.path.join(LIB_DIR, "test"), exist_ok=True)
     if not _stamp_matches():
         force = True                                       # other flags or another compiler: every object is stale
-    objects, running = [], []
-    for src in SOURCES:
+    if not ABLATIONS:
+        stale = os.path.join(LIB_DIR, "conv_tile.o")       # (an object of an ablations build of rounds 1-4 that used to share this directory)
+        if os.path.exists(stale):
+            os.remove(stale)
+    jobs, running = [], []
+    kernel_objects, host_objects, test_objects = [], [], []
+    for src in KERNEL_SOURCES:
         obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
-        objects.append(obj)
-        if not force and not _stale(os.path.join(CSRC, src), obj):
+        kernel_objects.append(obj)
+        jobs.append((src, obj, [], _kernel_headers()))
+    for src in HOST_SOURCES:
+        obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
+        host_objects.append(obj)
+        jobs.append((src, obj, [], _headers()))
+        if not ABLATIONS:
+            tobj = os.path.join(LIB_DIR, "test", src.rsplit(".", 1)[0] + ".o")
+            test_objects.append(tobj)
+            jobs.append((src, tobj, ["-DDGNN_TEST_ENTRIES"], _headers()))
+    for src, obj, extra, headers in jobs:
+        if not force and not _stale(os.path.join(CSRC, src), obj, headers):
             continue
-        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc(), *FLAGS, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         running.append((cmd, subprocess.Popen(cmd)))      # the translation units are independent: compile them side by side
     for cmd, proc in running:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objects]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    links = [(LIB_PATH, host_objects + kernel_objects)]
+    if not ABLATIONS:
+        links.append((TEST_LIB_PATH, test_objects + kernel_objects))
+    for path, objects in links:
+        cmd = [hipcc(), *LINK_FLAGS, "-o", path, *objects]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     with open(STAMP_PATH, "w") as f:
         f.write(_stamp())
     return LIB_PATH

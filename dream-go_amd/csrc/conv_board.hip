@@ -163,7 +163,7 @@ BoardSwitches read_board_switches()
     BoardSwitches s;
     if (const char* v = std::getenv("DGNN_BOARD_NS")) s.ns = std::atoi(v);
     if (const char* v = std::getenv("DGNN_BOARD_SKIP")) s.epilogue_skip = std::atoi(v) == 1;   // =1: keep the skip in the epilogue (A/B, tests)
-    if (const char* v = std::getenv("DGNN_CONV_ABLATE")) s.ablate = std::atoi(v);
+    if (const char* v = ablation_env("DGNN_CONV_ABLATE")) s.ablate = std::atoi(v);
     return s;
 }
 

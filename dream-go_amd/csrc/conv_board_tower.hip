@@ -33,15 +33,40 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 template <int NS>
 __global__ __launch_bounds__(Split<NS>::Threads, Split<NS>::MinWavesPerSimd)
 void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, int batch, int groups, unsigned base, unsigned* done,
-                        unsigned* err, unsigned long long* trace)
+                        unsigned* err, unsigned long long* trace, unsigned* arrive, unsigned arrive_base)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes + 16];    // + one word of workgroup-wide agreement
+    __shared__ unsigned resident;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     constexpr int RS = Split<NS>::RS;                 // `groups` = workgroups per board = channel blocks x row halves
     const int nb = (q % groups) / RS;
     const int rh = (q % groups) % RS;
     const int b = (q / groups) * 8 + xcd;
     if (b >= batch) return;
+    // Co-residency as a PRECONDITION (round 5): the hand-offs below spin on flags of other workgroups of this
+    // launch, which is only safe when every one of them holds a compute unit.  Each workgroup announces itself and waits -- at most
+    // kArriveTicks of wall time -- until all batch * groups have: a launch that shares the device with something that keeps it from
+    // becoming resident (another process's kernels, a launch that lost workgroups) gives up HERE, in well under a millisecond and
+    // before any work is done, and the host repeats the pass per layer; a launch that passes cannot starve later.  The flag waits'
+    // own 50 ms limit (wait_published) stays as the second line.
+    if (threadIdx.x == 0) {
+        unsigned ok = 1;
+        const unsigned want = arrive_base + (unsigned)(batch * groups);
+        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kArriveTicks) {
+                __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        resident = ok;
+    }
+    __syncthreads();
+    if (!resident) return;
     int carry = 0;
     half8 af[2][Split<NS>::CT][2];
     for (int i = 0; i < count; ++i) {
@@ -59,7 +84,7 @@ void tower_split_kernel(const ConvBoardLaunch* __restrict__ layers, int count, i
 // smallest batch for which a workgroup per board is preferred at 128 / 256 channels (DGNN_TOWER_MIN_BATCH, read once)
 static int tower_min_batch()
 {
-    static const int v = [] { const char* e = std::getenv("DGNN_TOWER_MIN_BATCH"); return e && std::atoi(e) > 0 ? std::atoi(e) : 129; }();
+    static const int v = [] { const char* e = ablation_env("DGNN_TOWER_MIN_BATCH"); return e && std::atoi(e) > 0 ? std::atoi(e) : 129; }();
     return v;
 }
 
@@ -97,7 +122,7 @@ int tower_split_ns(int batch, int channels, int num_cus)
     int ns = slices;
     while (ns > 1 && (long)batch * (slices / ns) < 192 && (long)batch * (slices / ns) * 2 <= num_cus) ns /= 2;
     // one slice per workgroup and still room for twice the workgroups: split the rows too (Split<32>; DGNN_TOWER_ROWSPLIT=0: never)
-    static const int rowsplit = [] { const char* e = std::getenv("DGNN_TOWER_ROWSPLIT"); return e ? std::atoi(e) : 1; }();
+    static const int rowsplit = [] { const char* e = ablation_env("DGNN_TOWER_ROWSPLIT"); return e ? std::atoi(e) : 1; }();
     if (ns == 1 && slices >= 4 && rowsplit != 0 && (long)batch * slices * 2 <= num_cus) return 32;
     return ns == slices ? 0 : ns;
 }
@@ -106,11 +131,17 @@ int tower_split_ns(int batch, int channels, int num_cus)
 // of which must be resident: two per CU.  (The switch is the workspace's: DGNN_TOWER_PAIR, engine.cpp.)
 bool tower_pair_supported(int batch, int channels, int num_cus)
 {
+#ifdef DGNN_ABLATIONS     // measured and lost to the power cap: instantiated in the ablations build only
     return channels == 256 && batch >= tower_min_batch() && batch <= num_cus;
+#else
+    (void)batch; (void)channels; (void)num_cus;
+    return false;
+#endif
 }
 
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
-                              size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream, bool inject_missing)
+                              size_t done_words, unsigned* d_err, unsigned* base, unsigned* d_arrive, unsigned* arrive_base, hipStream_t stream,
+                              bool inject_missing)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     const int slices = channels / 32;
@@ -128,11 +159,14 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
     }
     const unsigned launch_base = *base;
     *base += (unsigned)count + 1u;
+    // the arrival counter runs on like the flags: every workgroup of a launch adds one (engine.cpp zeroes it after a launch that gave up)
+    const unsigned launch_arrive = *arrive_base;
+    *arrive_base += (unsigned)(batch * groups);
     // inject_missing (fault injection, tests): the last eight workgroups of the launch never start -- what a launch that is not fully
     // resident looks like to the others: their consumers poll a flag nobody publishes and give up after kGiveUpTicks
     const dim3 grid((batch + 7) / 8 * 8 * groups - (inject_missing ? 8 : 0));
     // measurement only: DGNN_SPLIT_TRACE=<file> dumps wave 0's stamps of every (layer, board, channel block) of each launch
-    static const char* const trace_path = std::getenv("DGNN_SPLIT_TRACE");
+    static const char* const trace_path = ablation_env("DGNN_SPLIT_TRACE");
     unsigned long long* d_trace = nullptr;
 #ifdef DGNN_TAP_STAMPS      // -DDGNN_TAP_STAMPS=<layers of the launch>: the per-tap stamps sit behind the regular records
     const size_t trace_words = (size_t)count * batch * groups * 4 + (size_t)count * batch * groups * 12 * 12;
@@ -145,11 +179,15 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
         (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
     }
     switch (ns) {
-        case 24: hipLaunchKernelGGL((tower_split_kernel<24>), grid, dim3(Split<24>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
-        case 32: hipLaunchKernelGGL((tower_split_kernel<32>), grid, dim3(Split<32>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
-        case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
-        case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
-        default: hipLaunchKernelGGL((tower_split_kernel<1>), grid, dim3(Split<1>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace); break;
+#ifdef DGNN_ABLATIONS
+        case 24: hipLaunchKernelGGL((tower_split_kernel<24>), grid, dim3(Split<24>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_arrive, launch_arrive); break;
+#else
+        case 24: return hipErrorInvalidValue;
+#endif
+        case 32: hipLaunchKernelGGL((tower_split_kernel<32>), grid, dim3(Split<32>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_arrive, launch_arrive); break;
+        case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_arrive, launch_arrive); break;
+        case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_arrive, launch_arrive); break;
+        default: hipLaunchKernelGGL((tower_split_kernel<1>), grid, dim3(Split<1>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_arrive, launch_arrive); break;
     }
     const hipError_t launched = hipGetLastError();
     if (d_trace) {

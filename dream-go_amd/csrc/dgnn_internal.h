@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/dgnn.h"
+#include "../../include/dgnn_test.h"   // dgnn.h + dgnn_host.h + the test-only entry points (exported by the test build only)
 
 namespace dgnn {
 

@@ -75,6 +75,8 @@ struct Workspace {
     uint16_t* h_value = nullptr;
     uint16_t* h_policy = nullptr;
 
+    bool host_io = false;                   // the submission being enqueued reads its records from / writes its outputs to the PINNED HOST buffers
+                                            // themselves (zero copy: no H2D / D2H blit kernels around the compute, see kZeroCopy)
     int active = 0;                         // boards of the submission in flight / being enqueued (<= batch, the capacity)
     bool pending = false;                   // a submit without its wait
     bool use_board = false;                 // padded slot-major layout + one-board-per-workgroup kernel (conv_board.hip)
@@ -96,6 +98,8 @@ struct Workspace {
     bool injected = false;                  // ... and it has fired
     unsigned* d_split_sync = nullptr;       // [batch * kSplitWordsPerBoard] layers published per (board, channel block, row half), then the give-up word
     unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
+    unsigned* d_split_arrive = nullptr;     // one word behind the flags: workgroups of split launches that have become resident (running count)
+    unsigned split_arrive_base = 0;         // ... its value before the next launch
     unsigned* d_split_err = nullptr;        // the give-up word: the last four bytes of the value block
     unsigned* h_split_err = nullptr;        // pinned copy of that word: it arrives with the outputs (one copy for value, word and policy)
     bool split_pending = false;             // the submission in flight used tower_split_kernel
@@ -168,62 +172,6 @@ SplitChain* split_chain(int device)
     return chain;
 }
 
-// Submissions of one device finish IN ORDER, a tower apart (round 5).  A whole-board tower workgroup owns its compute unit's whole
-// register file, so while submission B's tower holds every CU nothing of submission A's tail -- head convolution, policy GEMM,
-// soft-max, the output copy's blit kernel -- can start: A's answers arrive when B's tower ends, together with B's, and a leaf pool
-// with two batches alive sees both come back at once and then nothing for a host turn-around.  With the chain a submission's first
-// command waits for the previous submission's last one whenever the two cannot share the device anyway (their boards together
-// exceed the CUs): A's tail runs on an idle device for some tens of microseconds, B's tower follows, and the answers of the two
-// arrive a tower apart -- the host works on A's while the device works on B.  DGNN_CHAIN=0 switches it off, 1 chains always.
-struct OrderChain {
-    std::mutex mutex;
-    hipEvent_t done = nullptr;
-    bool recorded = false;
-    int last_active = 0;
-};
-OrderChain* order_chain(int device)
-{
-    static std::mutex table_mutex;
-    static std::map<int, OrderChain*> table;     // never freed: a few bytes per device for the life of the process
-    std::lock_guard<std::mutex> lock(table_mutex);
-    OrderChain*& chain = table[device];
-    if (!chain) {
-        chain = new OrderChain();
-        if (hipEventCreateWithFlags(&chain->done, hipEventDisableTiming) != hipSuccess) chain->done = nullptr;
-    }
-    return chain;
-}
-int chain_mode_from_env()
-{
-    const char* m = std::getenv("DGNN_CHAIN");
-    return m && *m ? std::atoi(m) : 0;
-}
-const int kChainMode = chain_mode_from_env();
-
-// Held by a submit call from its first command to mark_submission: the (wait, record) pairs of two threads must not interleave.
-struct OrderScope {
-    OrderChain* chain = nullptr;
-    std::unique_lock<std::mutex> lock;
-    int begin(Workspace* ws)
-    {
-        if (kChainMode == 0) return DGNN_OK;
-        chain = order_chain(ws->device);
-        if (!chain->done) { chain = nullptr; return DGNN_OK; }
-        lock = std::unique_lock<std::mutex>(chain->mutex);
-        if (chain->recorded && (kChainMode == 1 || chain->last_active + ws->active > ws->dev->num_cus))
-            DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
-        return DGNN_OK;
-    }
-    int end(Workspace* ws)
-    {
-        if (!chain) return DGNN_OK;
-        DGNN_HIP(hipEventRecord(chain->done, ws->stream));
-        chain->recorded = true;
-        chain->last_active = ws->active;
-        return DGNN_OK;
-    }
-};
-
 namespace {
 
 size_t align_up(size_t n, size_t a) { return (n + a - 1) / a * a; }
@@ -294,7 +242,7 @@ void conv_impl_from_env(int num_pos, int cout, bool* use_tile, int* fm, int* var
     if (impl && std::strcmp(impl, "tile1") == 0) *variant = 1;
     if (impl && std::strcmp(impl, "tile3") == 0) *variant = 3;
     *fm = conv_tile_pick_fm(num_pos, cout >= 256 ? cout : 256);
-    const char* f = std::getenv("DGNN_CONV_FM");
+    const char* f = ablation_env("DGNN_CONV_FM");
     if (f && (std::atoi(f) == 4 || std::atoi(f) == 6 || std::atoi(f) == 8)) *fm = std::atoi(f);
 }
 
@@ -317,12 +265,12 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         // MI355X, 20x256 batch 256: 85.3 us per convolution against 91.3 with one launch per layer.  DGNN_TOWER=0: per layer.
         const char* tower = std::getenv("DGNN_TOWER");
         ws->use_tower = ws->use_board && !(tower && std::atoi(tower) == 0) && t.num_blocks > 0;
-        { const char* pair = std::getenv("DGNN_TOWER_PAIR"); ws->use_pair = pair && std::atoi(pair) != 0; }
-        const char* up = std::getenv("DGNN_TOWER_UP");
+        { const char* pair = ablation_env("DGNN_TOWER_PAIR"); ws->use_pair = pair && std::atoi(pair) != 0; }
+        const char* up = ablation_env("DGNN_TOWER_UP");
         ws->up_in_tower = !(up && std::atoi(up) == 0);
         const char* split = std::getenv("DGNN_TOWER_SPLIT");
         if (split && *split) ws->split_pref = std::atoi(split);
-        const char* inject = std::getenv("DGNN_SPLIT_INJECT_GIVEUP");
+        const char* inject = test_env("DGNN_SPLIT_INJECT_GIVEUP");
         ws->inject_giveup = inject ? std::atoi(inject) : 0;
     }
 
@@ -355,7 +303,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
     const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
     const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
-    const size_t sz_split = align_up((size_t)batch * kSplitWordsPerBoard * sizeof(unsigned), 256);
+    const size_t sz_split = align_up((size_t)batch * kSplitWordsPerBoard * sizeof(unsigned) + sizeof(unsigned), 256);   // + the arrival counter
     const size_t sz_records = align_up((size_t)batch * DGNN_BOARD_RECORD_BYTES, 256);
     const size_t sz_vpre = align_up((size_t)batch * 2, 256);
     const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split + sz_records + sz_vpre;
@@ -381,6 +329,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_logits = (uint16_t*)p; p += sz_logits;
     ws->d_packed = (uint32_t*)p; p += sz_packed;
     ws->d_split_sync = (unsigned*)p; p += sz_split;
+    ws->d_split_arrive = ws->d_split_sync + (size_t)batch * kSplitWordsPerBoard;
     ws->d_records = p; p += sz_records;
     ws->d_value_pre = (uint16_t*)p; p += sz_vpre;
     if (ws->use_board) {
@@ -492,7 +441,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     const uint16_t* tower = nullptr;   // NHWC tower output for the heads
     auto stamp = [&](int stage) -> hipError_t { return ws->stage_on ? hipEventRecord(ws->stage_ev[stage], ws->stream) : hipSuccess; };
     // compact board records: the planes are built on the device (features.hip), straight into the up-layer's input on the board path
-    if (input_form == kInputRecords) DGNN_HIP(launch_board_records(ws->d_records, ws->d_packed, ws->use_board ? ws->d_features_board : nullptr, ws->active, ws->stream));
+    if (input_form == kInputRecords) DGNN_HIP(launch_board_records(ws->host_io ? ws->h_records : ws->d_records, ws->d_packed, ws->use_board ? ws->d_features_board : nullptr, ws->active, ws->stream));
     DGNN_HIP(stamp(2));
     if ((packed_input || input_form == kInputRecords) && !ws->use_board) DGNN_HIP(launch_packed_features(ws->d_packed, ws->d_features, ws->active, false, ws->stream));
     if (ws->use_board) {
@@ -526,7 +475,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 }
                 // measurement only (tools/tower_trace.py): DGNN_TOWER_TIMING=<file> gives every layer of a whole-board tower its own
                 // block of s_memtime stamps [workgroup][wave][start, K loop, epilogue, end]; dumped after every launch
-                static const char* const timing_path = std::getenv("DGNN_TOWER_TIMING");
+                static const char* const timing_path = ablation_env("DGNN_TOWER_TIMING");
                 if (timing_path && *timing_path && tower_mode(ws) < 0) {
                     const size_t words = (size_t)layers.size() * ws->batch * 8 * 4;
                     if (!ws->d_tower_timing) DGNN_HIP(hipMalloc((void**)&ws->d_tower_timing, words * 8));
@@ -534,7 +483,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     for (size_t l = 0; l < layers.size(); ++l) layers[l].timing = ws->d_tower_timing + l * ws->batch * 8 * 4;
                     ws->tower_timing_layers = (int)layers.size();
                 }
-                const char* carry = std::getenv("DGNN_TOWER_CARRY");          // =0: no hand-over between the layers (A/B)
+                const char* carry = ablation_env("DGNN_TOWER_CARRY");          // =0: no hand-over between the layers (A/B)
                 if (!(carry && std::atoi(carry) == 0))
                     for (size_t l = 0; l + 1 < layers.size(); ++l) { layers[l].w_next = layers[l + 1].w; layers[l + 1].carry_in = 1; }
                 if (!ws->d_tower_layers) DGNN_HIP(hipMalloc((void**)&ws->d_tower_layers, (layers.size() + 1) * sizeof(ConvBoardLaunch)));
@@ -557,7 +506,8 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     else missing = true;
                 }
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
-                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->stream, missing));
+                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->d_split_arrive,
+                                            &ws->split_arrive_base, ws->stream, missing));
                 DGNN_HIP(hipEventRecord(chain->done, ws->stream));
                 chain->recorded = true;
             } else {
@@ -567,7 +517,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     const size_t words = (size_t)ws->tower_timing_layers * ws->batch * 8 * 4;
                     std::vector<unsigned long long> h(words);
                     DGNN_HIP(hipMemcpy(h.data(), ws->d_tower_timing, words * 8, hipMemcpyDeviceToHost));
-                    if (FILE* f = std::fopen(std::getenv("DGNN_TOWER_TIMING"), "wb")) {
+                    if (FILE* f = std::fopen(ablation_env("DGNN_TOWER_TIMING"), "wb")) {
                         const int header[4] = {ws->tower_timing_layers, ws->batch, 8, 4};
                         std::fwrite(header, sizeof(int), 4, f);
                         std::fwrite(h.data(), 8, words, f);
@@ -639,8 +589,8 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     sv.value_features = ws->d_value_features;
     sv.value_w = (const uint16_t*)(image + t.value_w_offset);
     sv.value_b = (const uint16_t*)(image + t.value_b_offset);
-    sv.policy_out = ws->d_policy;
-    sv.value_out = ws->d_value;
+    sv.policy_out = ws->host_io ? ws->h_policy : ws->d_policy;
+    sv.value_out = ws->host_io ? ws->h_value : ws->d_value;
     sv.value_pre_out = ws->d_value_pre;
     sv.batch = ws->active;
     DGNN_HIP(launch_softmax_value(sv, ws->stream));
@@ -653,10 +603,17 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
 // a leaf pool keeps two such waiters per device, more host CPU than the whole search.  So the waiter SLEEPS: for most of the time
 // the last submissions of this size took, then in 30 us naps between hipEventQuery calls (0.03 cores per waiter; the late wake-up
 // is hidden by the second batch in flight).  DGNN_WAIT=spin restores hipStreamSynchronize, DGNN_WAIT=event the blocking event.
+// Zero copy (round 5): a submission's 896-byte records are read by the planes kernel straight from the pinned host buffer, and the
+// soft-max kernel writes value and policy straight into the pinned host buffers -- 0.2 MB each way per 256 boards across PCIe by the
+// kernels' own loads and stores instead of two blit kernels (22 + 19 us of the ~120 us a device batch spends outside its tower,
+// profiles/r05/stage_times_20x256.jsonl), each of which also had to wait for a compute unit the other batch's tower holds.
+// DGNN_ZEROCOPY=0 restores the copies (A/B).
+const bool kZeroCopy = [] { const char* e = ablation_env("DGNN_ZEROCOPY"); return !(e && std::atoi(e) == 0); }();
+
 enum WaitMode { kWaitPoll = 0, kWaitSpin = 1, kWaitEvent = 2 };
 WaitMode wait_mode_from_env()
 {
-    const char* m = std::getenv("DGNN_WAIT");
+    const char* m = ablation_env("DGNN_WAIT");
     if (m && std::strcmp(m, "spin") == 0) return kWaitSpin;
     if (m && std::strcmp(m, "event") == 0) return kWaitEvent;
     return kWaitPoll;
@@ -689,6 +646,12 @@ int mark_submission(Workspace* ws)      // behind the last copy of a submission
 // two of them were 5 % of a 9x128 batch-32 pass.
 hipError_t enqueue_outputs(Workspace* ws)
 {
+    if (ws->host_io) {
+        // the soft-max kernel wrote value and policy into the pinned host buffers itself; only a split tower's give-up word is
+        // still on the device (its workgroups poll it: it cannot live across PCIe)
+        if (tower_mode(ws) > 0) return hipMemcpyAsync(ws->h_split_err, ws->d_split_err, sizeof(unsigned), hipMemcpyDeviceToHost, ws->stream);
+        return hipSuccess;
+    }
     const size_t value_block = (size_t)((const uint8_t*)ws->d_policy - (const uint8_t*)ws->d_value);
     if ((size_t)((const uint8_t*)ws->h_policy - (const uint8_t*)ws->h_value) != value_block) return hipErrorInvalidValue;
     return hipMemcpyAsync(ws->h_value, ws->d_value, value_block + (size_t)ws->active * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream);
@@ -764,6 +727,8 @@ int note_split_failure(Workspace* ws)
     std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer %s\n", ws->device,
                  ws->split_failures >= kSplitMaxFailures ? "from now on" : "for the next passes");
     DGNN_HIP(hipMemsetAsync(ws->d_split_err, 0, sizeof(unsigned), ws->stream));   // the word is sticky on the device
+    DGNN_HIP(hipMemsetAsync(ws->d_split_arrive, 0, sizeof(unsigned), ws->stream)); // (a launch that gave up leaves the arrival count anywhere)
+    ws->split_arrive_base = 0;
     return DGNN_OK;
 }
 
@@ -873,7 +838,7 @@ static int layer_conv3x3_board(const uint16_t* x, int batch, int cin, const uint
         a.batch = batch; a.cin = cin; a.cout = cout; a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
         a.timing = nullptr; a.w_next = nullptr; a.carry_in = 0;
         // instrumentation: DGNN_CONV_TIMING=1 prints where the workgroups spend their cycles (s_memtime stamps)
-        const char* ab = std::getenv("DGNN_CONV_TIMING");
+        const char* ab = ablation_env("DGNN_CONV_TIMING");
         const size_t num_wg = (size_t)batch * (cout / 256);
         unsigned long long* d_timing = nullptr;
         if (ab && std::atoi(ab) == 1 && hipMalloc((void**)&d_timing, num_wg * 8 * 4 * sizeof(unsigned long long)) == hipSuccess) {
@@ -1146,9 +1111,8 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
     DGNN_HIP(hipSetDevice(ws->device));
     const size_t in_bytes = num_features * sizeof(uint16_t);
     if (features != ws->h_features) std::memcpy(ws->h_features, features, in_bytes);
-    OrderScope order;
-    { const int began = order.begin(ws); if (began != DGNN_OK) return began; }
     DGNN_HIP(hipMemcpyAsync(ws->d_features, ws->h_features, in_bytes, hipMemcpyHostToDevice, ws->stream));   // graph.rs:130-131
+    ws->host_io = kZeroCopy;                // (the planes go by copy: 23 KB per board are read more than once; the outputs are written in place)
 
     int status = enqueue_forward(ws, -1);
     if (status != DGNN_OK) return status;
@@ -1157,7 +1121,6 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
 
     DGNN_HIP(enqueue_outputs(ws));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
-    { const int ended = order.end(ws); if (ended != DGNN_OK) return ended; }
     ws->pending = true;
     return DGNN_OK;
 }
@@ -1210,9 +1173,8 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
 
     DGNN_HIP(hipSetDevice(ws->device));
     if (packed != ws->h_packed) std::memcpy(ws->h_packed, packed, in_bytes);
-    OrderScope order;
-    { const int began = order.begin(ws); if (began != DGNN_OK) return began; }
     DGNN_HIP(hipMemcpyAsync(ws->d_packed, ws->h_packed, in_bytes, hipMemcpyHostToDevice, ws->stream));
+    ws->host_io = kZeroCopy;
 
     int status = enqueue_forward(ws, -1, kInputPacked);
     if (status != DGNN_OK) return status;
@@ -1221,7 +1183,6 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
 
     DGNN_HIP(enqueue_outputs(ws));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
-    { const int ended = order.end(ws); if (ended != DGNN_OK) return ended; }
     ws->pending = true;
     return DGNN_OK;
 }
@@ -1246,10 +1207,9 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
 
     DGNN_HIP(hipSetDevice(ws->device));
     if (records != ws->h_records) std::memcpy(ws->h_records, records, in_bytes);
-    OrderScope order;
-    { const int began = order.begin(ws); if (began != DGNN_OK) return began; }
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[0], ws->stream));
-    DGNN_HIP(hipMemcpyAsync(ws->d_records, ws->h_records, in_bytes, hipMemcpyHostToDevice, ws->stream));
+    ws->host_io = kZeroCopy;
+    if (!ws->host_io) DGNN_HIP(hipMemcpyAsync(ws->d_records, ws->h_records, in_bytes, hipMemcpyHostToDevice, ws->stream));
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[1], ws->stream));
 
     int status = enqueue_forward(ws, -1, kInputRecords);
@@ -1260,7 +1220,6 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
     DGNN_HIP(enqueue_outputs(ws));
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[7], ws->stream));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
-    { const int ended = order.end(ws); if (ended != DGNN_OK) return ended; }
     ws->pending = true;
     return DGNN_OK;
 }
@@ -1440,6 +1399,7 @@ int dgnn_forward_resident(dgnn_workspace* handle)
     if (!handle) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
     DGNN_HIP(hipSetDevice(ws->device));
+    ws->host_io = false;                    // resident inputs, outputs left in HBM (dgnn_workspace_download)
     return enqueue_forward(ws, -1);
 }
 
@@ -1466,6 +1426,7 @@ int dgnn_forward_timed(dgnn_workspace* handle, int steps, float* total_ms, float
 
     DGNN_HIP(hipEventRecord(ws->ev_begin, ws->stream));
     for (int i = 0; i < steps; ++i) {
+        ws->host_io = false;
         const int status = enqueue_forward(ws, i);
         if (status != DGNN_OK) return status;
     }
@@ -1644,7 +1605,7 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
         a.alpha1 = alpha1; a.alpha2 = alpha2; a.relu = relu;
         a.timing = nullptr;
         // instrumentation: DGNN_CONV_ABLATE=8 makes the staggered kernel accumulate s_memtime per pipeline segment
-        const char* ab = std::getenv("DGNN_CONV_ABLATE");
+        const char* ab = ablation_env("DGNN_CONV_ABLATE");
         const bool timing = ab && std::atoi(ab) == 8 && fm == 6 && variant >= 2;
         const size_t num_wg = ((num_pos + 32 * fm - 1) / (32 * fm)) * (cout / 256);
         unsigned long long* d_timing = nullptr;

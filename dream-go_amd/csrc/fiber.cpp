@@ -39,6 +39,7 @@
 asm(R"(
 .text
 .globl dgnn_fiber_switch
+.hidden dgnn_fiber_switch
 .type dgnn_fiber_switch,@function
 dgnn_fiber_switch:
     pushq %rbp

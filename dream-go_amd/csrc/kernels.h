@@ -4,6 +4,32 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <cstdlib>
+
+// Environment switches.  The SHIPPED library reads eight: SOFTMAX_TEMPERATURE (the reference's own, config.rs:176-177), DGNN_CONV
+// (v1 / board: which convolution kernel), DGNN_TOWER (0: one launch per layer), DGNN_TOWER_SPLIT (0: never split a board inside the tower
+// launch), DGNN_BOARD_NS and DGNN_BOARD_SKIP (work split / where the skip input is added: the parity tests walk every variant),
+// DGNN_HOST_SIMD (0: the scalar host loops), DGNN_RCCL_DISABLE (tests: as if librccl were not installed).  Everything else --
+// switches of experiments that were measured and lost, measurement hooks (stamps, traces), A/B toggles -- is read by the
+// DGNN_ABLATIONS build only (ablation_env), fault injection by the test and ablations builds (test_env).
+inline const char* ablation_env(const char* name)
+{
+#ifdef DGNN_ABLATIONS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+inline const char* test_env(const char* name)
+{
+#if defined(DGNN_ABLATIONS) || defined(DGNN_TEST_ENTRIES)
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 namespace dgnn {
 
@@ -109,7 +135,8 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
 int tower_split_ns(int batch, int channels, int num_cus);
 bool tower_pair_supported(int batch, int channels, int num_cus);
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
-                              size_t done_words, unsigned* d_err, unsigned* base, hipStream_t stream, bool inject_missing = false);
+                              size_t done_words, unsigned* d_err, unsigned* base, unsigned* d_arrive, unsigned* arrive_base, hipStream_t stream,
+                              bool inject_missing = false);
 // Layout changes at the two ends of the tower: [B][361][C] NHWC <-> [B][C / 8][400][8].  C a multiple of 8.
 hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);
 hipError_t launch_board_to_nhwc(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);

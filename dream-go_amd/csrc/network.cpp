@@ -148,7 +148,7 @@ std::string scope(int index, const char* suffix)
 // (A/B measurements that switch kernels per workspace).  20 x 256: 52 MB instead of 148 MB.
 unsigned pack_layouts_from_env(int channels)
 {
-    const char* all = std::getenv("DGNN_PACK");
+    const char* all = test_env("DGNN_PACK");
     if (all && std::strcmp(all, "all") == 0) return kPackGeneric | kPackTile | kPackBoard;
     const char* impl = std::getenv("DGNN_CONV");
     const bool board_ok = channels >= 64 && channels % 64 == 0;

@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "dgnn.h"
+#include "dgnn_host.h"
 
 int main(int argc, char** argv)
 {

@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "dgnn.h"
+#include "dgnn_host.h"
 
 int main(int argc, char** argv)
 {
@@ -17,7 +17,6 @@ int main(int argc, char** argv)
     dgnn_selfplay_params params;
     dgnn_selfplay_stats stats;
     dgnn_network* net = NULL;
-    dgnn_batcher* batcher = NULL;
     dgnn_pool* pool = NULL;
     dgnn_predict_fn predict = dgnn_hash_predictor();
     void* predict_ctx = NULL;
@@ -35,13 +34,12 @@ int main(int argc, char** argv)
     params.num_ex_it_rollouts = 0;
     params.threads_per_search = 1;             /* one thread with several leaves in flight: reproducible for a fixed seed */
     params.leaves_per_thread = 8;
-    params.cache_entries_per_game = 20001;     /* a table per game, not a shared one: see dgnn_selfplay_go in dgnn.h */
+    params.cache_entries_per_game = 20001;     /* a table per game, not a shared one: see dgnn_selfplay_go in dgnn_host.h */
     params.seed = 2024;
 
     if (path) {
         if ((status = dgnn_network_load(path, &net)) != DGNN_OK) { fprintf(stderr, "%s: %s\n", path, dgnn_status_string(status)); return 1; }
-        if ((status = dgnn_batcher_create(net, 0, 256, 3, &batcher)) != DGNN_OK ||
-            (status = dgnn_pool_create(batcher, 3, &pool)) != DGNN_OK) {
+        if ((status = dgnn_pool_create_devices(net, NULL, 0, 256, 2, 2, &pool)) != DGNN_OK) {      /* every visible GPU, two batches alive on each */
             fprintf(stderr, "pool: %s (hip %d)\n", dgnn_status_string(status), dgnn_last_hip_error());
             return 1;
         }
@@ -59,7 +57,6 @@ int main(int argc, char** argv)
 
     free(sgf);
     if (pool) dgnn_pool_destroy(pool);
-    if (batcher) dgnn_batcher_destroy(batcher);
     if (net) dgnn_network_destroy(net);
     return 0;
 }

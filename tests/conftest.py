@@ -36,6 +36,14 @@ def api():
 
 
 @pytest.fixture(scope="session")
+def api_full(api):
+    """The same bindings over the TEST build of the library (lib/libdgnn_hip_test.so: the shipped library's kernel objects, the host
+    sources with the entry points of include/dgnn_test.h exported as well).  Tests that pin single layers, the tree's / board's
+    accessors or fault paths take this fixture; everything that only needs the product surface takes `api`."""
+    return api.load_full()
+
+
+@pytest.fixture(scope="session")
 def synth():
     from dream_go_amd import synth as module
     return module

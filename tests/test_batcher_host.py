@@ -35,7 +35,8 @@ REFERENCE_TABLES = [                                   # symmetry.rs:39-62, orde
 ]
 
 
-def test_symmetry_tables_and_inverses(api):
+def test_symmetry_tables_and_inverses(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     T = api.Transform
     for t in T.ALL:
         got = np.array([T.apply(t, i) for i in range(362)])
@@ -46,8 +47,9 @@ def test_symmetry_tables_and_inverses(api):
     assert T.apply(8, 0) == -1 and T.apply(0, 362) == -1 and T.inverse(-1) == -1
 
 
-def test_check_with_transform(api):
+def test_check_with_transform(api_full):
     """predictor.rs:98-108, verbatim."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     original = api.Prediction(0.0, np.arange(362, dtype=np.float32))
     T = api.Transform
     assert original.policy()[0] == api.Prediction.with_transform(original, T.Identity).policy()[0]
@@ -60,8 +62,9 @@ def test_check_with_transform(api):
         assert np.array_equal(p[REFERENCE_TABLES[t]], original.policy())        # out[t(i)] = in[i]
 
 
-def test_lru_insert_only_20000(api):
+def test_lru_insert_only_20000(api_full):
     """lru_cache.rs:157-165."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     lru = api.LruCache(capacity=1000, num_shards=1)
     p = api.Prediction(0.5, np.zeros(362))
     for i in range(20000):
@@ -69,8 +72,9 @@ def test_lru_insert_only_20000(api):
     assert len(lru) == 1000
 
 
-def test_lru_mixed_insert(api):
+def test_lru_mixed_insert(api_full):
     """lru_cache.rs:167-182: a get refreshes an entry, the least recently used ones are dropped."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     lru = api.LruCache(capacity=10, num_shards=1)
     p = api.Prediction(0.25, np.zeros(362))
     for i in range(10):
@@ -85,8 +89,9 @@ def test_lru_mixed_insert(api):
         assert lru.fetch(i, 0, 0) is None, i
 
 
-def test_cache_is_keyed_by_colour_and_canonicalises_the_symmetry(api):
+def test_cache_is_keyed_by_colour_and_canonicalises_the_symmetry(api_full):
     """nn.rs:69-82: cache() stores with_transform(response, symmetry.inverse()), fetch() returns with_transform(entry, symmetry)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     T = api.Transform
     lru = api.LruCache(capacity=100)
     rng = np.random.default_rng(3)
@@ -105,7 +110,8 @@ def test_cache_is_keyed_by_colour_and_canonicalises_the_symmetry(api):
     assert lru.stats()["hits"] >= 9 and lru.stats()["misses"] == 1
 
 
-def test_sharded_cache_keeps_its_capacity_under_threads(api):
+def test_sharded_cache_keeps_its_capacity_under_threads(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     lru = api.LruCache(capacity=4096, num_shards=16)
     p = api.Prediction(0.0, np.zeros(362))
 
@@ -126,8 +132,9 @@ def _board(tag):
     return f
 
 
-def test_batcher_hands_out_the_newest_entries(api):
+def test_batcher_hands_out_the_newest_entries(api_full):
     """batch.rs:91-121 with max_batch_size 4: the split index is size - max when size >= max, else 0."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Batcher(None, max_batch_size=4, max_batches=2)
     assert b.get_batch(1) is None                                               # nothing queued
     for tag in range(10):
@@ -149,8 +156,9 @@ def test_batcher_hands_out_the_newest_entries(api):
         third.forward()
 
 
-def test_push_and_get_batch_triggers_at_max_batch_size(api):
+def test_push_and_get_batch_triggers_at_max_batch_size(api_full):
     """batch.rs:86-89: push_and_get_batch(event) == push + get_batch(max_batch_size)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Batcher(None, max_batch_size=3, max_batches=4)
     assert b.push_and_get_batch(100, _board(100)) is None
     assert b.push_and_get_batch(101, _board(101)) is None
@@ -159,8 +167,9 @@ def test_push_and_get_batch_triggers_at_max_batch_size(api):
     assert b.pending() == (0, 1)
 
 
-def test_batcher_conserves_every_event_under_threads(api):
+def test_batcher_conserves_every_event_under_threads(api_full):
     """Many game threads push, several workers drain: every tag comes out exactly once, no batch exceeds the maximum."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Batcher(None, max_batch_size=16, max_batches=3)
     produced = 8 * 250
     seen, lock, done = [], threading.Lock(), threading.Event()
@@ -283,10 +292,11 @@ def test_idle_pool_workers_sleep(api):
     pool.close()
 
 
-def test_adaptive_batches_alive_follow_the_unique_positions_per_second(api):
+def test_adaptive_batches_alive_follow_the_unique_positions_per_second(api_full):
     """Round 4: between 2 and 3 batches alive per lane, chosen by the pool from what it measures.  Here over the
     CPU stand-in of a device: the rule can only be switched on for a pool of board records that was created with enough batches and
     workers; it counts repeated positions (same stones, same colour to move, ANY symmetry) and never leaves [lo, hi]."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     pool = api.LeafPool.over_dry_device(base_us=50.0, per_board_us=0.5, max_batch_size=64, batches_per_lane=3, workers_per_lane=3)
     import pytest
     with pytest.raises(api.Error):
@@ -316,11 +326,12 @@ def test_adaptive_batches_alive_follow_the_unique_positions_per_second(api):
     features_pool.close()
 
 
-def test_requests_for_a_position_in_flight_follow_it(api):
+def test_requests_for_a_position_in_flight_follow_it(api_full):
     """Round 4: dgnn_pool_set_coalescing.  A slow stand-in device; one thread asks for a position in symmetry 0, seven more ask for the
     SAME position in the other symmetries while it is out: ONE board reaches the device, and every follower receives the leader's
     answer re-oriented to its own symmetry -- value as is, policy = with_transform(with_transform(p, inverse(leader)), own): what
     NnPredictor::fetch returns for a table hit (predictors/nn.rs:72-81).  A different position is evaluated on its own."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import threading
     import time
     board = api.Board(7.5)
@@ -368,8 +379,9 @@ def test_requests_for_a_position_in_flight_follow_it(api):
     features_pool.close()
 
 
-def test_a_third_batch_only_while_enough_boards_wait(api):
+def test_a_third_batch_only_while_enough_boards_wait(api_full):
     """dgnn_pool_set_extra_batch_queue: two batches alive per lane, a third only while at least `min_queued` boards are waiting."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import pytest
     pool = api.LeafPool.over_dry_device(base_us=0.0, per_board_us=0.0, max_batch_size=64, batches_per_lane=3, workers_per_lane=3)
     with pytest.raises(api.Error):
@@ -387,11 +399,12 @@ def test_a_third_batch_only_while_enough_boards_wait(api):
     pool.close()
 
 
-def test_the_table_behaves_like_a_textbook_lru_under_random_traffic(api):
+def test_the_table_behaves_like_a_textbook_lru_under_random_traffic(api_full):
     """The arena / open-addressing form of the table (batcher.cpp CacheShard) against an OrderedDict that restates
     lru_cache.rs:95-147 -- get moves an entry to the front, an insert of a present key changes nothing, an insert into a full
     table drops the least recently used entry -- over 60 000 random operations on few enough keys that buckets collide, entries
     are evicted and re-inserted, and deletions shift probe chains; then a clear, and the same again on the re-used arena."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     from collections import OrderedDict
     rng = np.random.default_rng(11)
     for capacity, keys in ((7, 40), (64, 400), (500, 1200)):
@@ -479,11 +492,12 @@ def test_back_to_back_holds_partial_batches_until_the_device_is_about_to_be_free
     lanes.close()
 
 
-def test_a_leader_that_could_not_be_queued_leaves_no_position_behind(api):
+def test_a_leader_that_could_not_be_queued_leaves_no_position_behind(api_full):
     """with coalescing a slot registers as the LEADER of its position before it is pushed into the queue.  A push that
     fails (an allocation) used to leave the entry: every later request for the position followed a leader nobody would ever answer
     and blocked for ever.  The hook makes one push fail like a failed allocation: the call reports it, the boards of the request
     that WERE queued are still evaluated, and the position can be asked for again."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import threading
     board = api.Board(7.5)
     for i, (x, y) in enumerate([(3, 3), (15, 15), (3, 15), (16, 3)]):

@@ -1,4 +1,4 @@
-"""CPU-side tests of the C-ABI library: it loads, exports every symbol include/dgnn.h declares, ingests the
+"""CPU-side tests of the C-ABI library: it loads, exports exactly the symbols its product headers declare, ingests the
 reference's weights format identically to the oracle's restatement of loader.rs, and fails with status codes
 (never a crash, never a silent fallback) when there is no GPU.  No compute is launched here."""
 import ctypes
@@ -11,20 +11,41 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "dgnn.h")).read()
+def _declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dgnn_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol(api):
-    declared = _declared_symbols()
-    assert len(declared) >= 25
-    raw = ctypes.CDLL(api.LIB_PATH)
-    missing = [name for name in declared if not hasattr(raw, name)]
-    assert not missing, missing
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("dgnn_")})
+
+
+def test_the_shipped_library_exports_the_two_product_headers_and_nothing_else(api):
+    """include/dgnn.h is the drop-in boundary, include/dgnn_host.h the C++ host rows (8f); what the
+    tests need beyond them is in include/dgnn_test.h and is exported by the TEST build only.  The shipped .so exports exactly the
+    product surface: at most 110 entry points (round 4: 170 from one 749-line header)."""
+    boundary, host, test = _declared_symbols("dgnn.h"), _declared_symbols("dgnn_host.h"), _declared_symbols("dgnn_test.h")
+    assert len(boundary) >= 40 and not set(boundary) & set(host) and not (set(boundary) | set(host)) & set(test)
+    exported = _exported(api.LIB_PATH)
+    assert exported == sorted(set(boundary) | set(host)), set(exported) ^ (set(boundary) | set(host))
+    assert len(exported) <= 110
+    assert set(test) == set(api.TEST_ONLY)
     bound = {name for name, _, _ in api.SYMBOLS}
-    assert set(declared) == bound, set(declared) ^ bound
+    assert bound == set(boundary) | set(host) | set(test), bound ^ (set(boundary) | set(host) | set(test))
+    # a test-only entry point is not reachable through the shipped library: it fails loudly at the call
+    with pytest.raises(AttributeError):
+        api.lib.dgnn_layer_conv3x3
+
+
+def test_the_test_library_exports_all_three_headers(api_full):
+    assert api_full.LIB_PATH != __import__("dream_go_amd").api.LIB_PATH or os.environ.get("DGNN_LIBRARY")
+    exported = set(_exported(api_full.LIB_PATH))
+    for header in ("dgnn.h", "dgnn_host.h", "dgnn_test.h"):
+        missing = [name for name in _declared_symbols(header) if name not in exported]
+        assert not missing, (header, missing)
 
 
 def test_status_strings(api):
@@ -146,9 +167,10 @@ def test_weight_image_layout_and_prescaling(api, synth, oracle):
     assert _find(net.weight_image_host().view(np.uint16), bl1) >= 0
 
 
-def test_image_carries_only_the_layouts_its_kernels_read(api, synth, monkeypatch):
+def test_image_carries_only_the_layouts_its_kernels_read(api_full, synth, monkeypatch):
     """the image held every filter three ways (148.5 MB for 20 x 256).  By default only the board layout is
     packed where the board kernel covers the network; the NHWC layouts are packed when DGNN_CONV selects those kernels."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     blocks, c = 2, 256
     text = synth.to_json(synth.make_tensors(blocks, c, seed=8))
     filters = (2 * blocks * 9 * c * c + 9 * 32 * c) * 2                      # residual + up-layer filter bytes
@@ -210,7 +232,8 @@ def test_checksum_is_deterministic(api, synth):
     assert api.Network.from_json(t1).weight_checksum() != api.Network.from_json(t2).weight_checksum()
 
 
-def test_no_gpu_is_an_error_not_a_fallback(api, synth):
+def test_no_gpu_is_an_error_not_a_fallback(api_full, synth):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     try:
         count = api.Device.len()
     except api.Error as e:

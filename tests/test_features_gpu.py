@@ -10,7 +10,8 @@ from test_features_host import describe_mismatch, expected_and_records, game_pos
 pytestmark = pytest.mark.gpu
 
 
-def test_device_planes_equal_features_v1_on_every_position_of_the_reference_games(api):
+def test_device_planes_equal_features_v1_on_every_position_of_the_reference_games(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     expected, records, n = expected_and_records(api, list(b.clone() for b in game_positions(api)))
     assert n == 648 * 16
     got = api.board_records_to_packed(records, n, device=0).reshape(n, api.PACKED_WORDS)
@@ -23,7 +24,8 @@ def test_device_planes_equal_features_v1_on_every_position_of_the_reference_game
 
 
 @pytest.mark.parametrize("komi", [0.5, -20.0])
-def test_device_planes_equal_features_v1_on_dense_random_positions(api, komi):
+def test_device_planes_equal_features_v1_on_dense_random_positions(api_full, komi):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     boards = [b.clone() for b in random_positions(api, seed=11 + int(abs(komi)), games=3, stones=340, komi=komi) if b.count() % 2 == 0]
     expected, records, n = expected_and_records(api, boards)
     got = api.board_records_to_packed(records, n, device=0).reshape(n, api.PACKED_WORDS)

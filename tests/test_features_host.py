@@ -66,8 +66,9 @@ def test_record_planes_equal_features_v1_on_the_reference_games(api):
 
 
 @pytest.mark.parametrize("komi", [0.5, 7.5, -7.5, -20.0])
-def test_record_planes_equal_features_v1_on_dense_random_positions(api, komi):
+def test_record_planes_equal_features_v1_on_dense_random_positions(api_full, komi):
     """komi -7.5 and below clamp the colour plane's constant to 0 (features.rs:236-239): plane 0 / 1 is then all zero."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     total, with_ko, with_ladder = 0, 0, 0
     for board in random_positions(api, seed=int(komi * 10) + 300, games=2, stones=330, komi=komi):
         if board.count() % 3:
@@ -105,11 +106,12 @@ def test_record_layout_and_argument_checks(api):
         api.board_records_to_packed(bad, 1)
 
 
-def test_selfplay_through_a_pool_of_board_records_plays_the_same_games(api):
+def test_selfplay_through_a_pool_of_board_records_plays_the_same_games(api_full):
     """The search worker hands the pool 896-byte records instead of 23 KB of planes (search.cpp: Predictor::encode); a pool whose
     lanes are callbacks expands them with the host statement of the device kernel.  One search thread and a transposition table per
     game make a game a function of (seed, network outputs): the records pool must reproduce the games of the planes pool, move
     for move and record for record."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     kw = dict(num_games=4, num_moves=14, num_rollouts=60, threads_per_search=1, leaves_per_thread=4, seed=77, cache_per_game=4096,
               return_moves=True, return_sgf=True)
     out = {}
@@ -125,7 +127,8 @@ def test_selfplay_through_a_pool_of_board_records_plays_the_same_games(api):
     assert [strip(g) for g in out[False]["sgf"]] == [strip(g) for g in out[True]["sgf"]]
 
 
-def test_pools_refuse_the_other_input_form(api):
+def test_pools_refuse_the_other_input_form(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     planes = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=8)
     records = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=8, boards=True)
     board = api.Board(7.5)
@@ -144,10 +147,11 @@ def test_pools_refuse_the_other_input_form(api):
     records.close()
 
 
-def test_games_as_fibers_play_the_games_of_one_thread_per_game(api):
+def test_games_as_fibers_play_the_games_of_one_thread_per_game(api_full):
     """csrc/fiber.h: with host_threads > 0 the games in flight are fibers on that many OS threads, switched in user space where a
     game waits for the leaf pool.  A game is a function of its seed and the network's outputs, so the records are those of the
     thread-per-game run -- with one, two and three scheduler threads, more games than fit in flight, and both pool forms."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     kw = dict(num_games=10, num_moves=10, num_rollouts=48, threads_per_search=1, leaves_per_thread=4, seed=91, cache_per_game=2048,
               num_parallel=6, return_moves=True, return_sgf=True)
     strip = lambda sgf: re.sub(r"DT\[[^\]]*\]", "", sgf)

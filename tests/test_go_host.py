@@ -10,7 +10,8 @@ import numpy as np
 B, W = 0, 1
 
 
-def test_capture(api):
+def test_capture(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(B, 9, 9)
     for x, y in ((8, 9), (10, 9), (9, 8), (9, 10)):
@@ -18,7 +19,8 @@ def test_capture(api):
     assert b.at(9, 9) is None
 
 
-def test_capture_group(api):
+def test_capture_group(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     for x, y in ((0, 1), (1, 0), (0, 0), (1, 1)):
         b.place(B, x, y)
@@ -27,14 +29,16 @@ def test_capture_group(api):
     assert all(b.at(x, y) is None for x, y in ((0, 0), (0, 1), (1, 0), (1, 1)))
 
 
-def test_suicide_corner(api):
+def test_suicide_corner(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(W, 0, 0); b.place(B, 1, 0); b.place(B, 0, 1)
     assert b.at(0, 0) is None
     assert not b.is_valid(W, 0, 0) and b.is_valid(B, 0, 0)
 
 
-def test_suicide_middle(api):
+def test_suicide_middle(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(B, 9, 9)
     for x, y in ((8, 9), (10, 9), (9, 8), (9, 10)):
@@ -48,7 +52,8 @@ def test_ko(api):
     assert not b.is_valid(B, 0, 0)
 
 
-def test_double_liberty_subtraction(api):
+def test_double_liberty_subtraction(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     for x, y in ((1, 1), (1, 2), (2, 1), (0, 2), (2, 0)):
         b.place(B, x, y)
@@ -60,7 +65,8 @@ def test_double_liberty_subtraction(api):
     assert all(b.at(x, y) == B for x, y in ((1, 1), (1, 2), (2, 1), (0, 2), (2, 0)))
 
 
-def test_turns(api):
+def test_turns(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(0.5)
     assert b.to_move() == B
     b.place(B, 0, 0); assert b.to_move() == W
@@ -68,7 +74,8 @@ def test_turns(api):
     b.place(W, 2, 2); assert b.to_move() == B            # "if black pass, it should not mess everything up"
 
 
-def test_check_get_n_liberty_if(api):
+def test_check_get_n_liberty_if(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(B, 0, 1); b.place(B, 1, 0); b.place(W, 1, 1); b.place(W, 2, 0)
     assert b.get_n_liberty_if(W, 0, 0) == 1
@@ -86,7 +93,8 @@ def test_check_get_n_liberty_if(api):
     assert c.get_n_liberty_if(W, 0, 0) == 3
 
 
-def test_ladder_corner_capture(api):
+def test_ladder_corner_capture(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     for x, y in ((0, 0), (0, 18), (18, 0), (18, 18)):
         b.place(B, x, y)
@@ -97,7 +105,8 @@ def test_ladder_corner_capture(api):
                 assert b.is_ladder_capture(W, x, y) == ((x, y) in ladders), (x, y)
 
 
-def test_ladder_capture(api):
+def test_ladder_capture(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(W, 3, 3); b.place(B, 2, 3); b.place(B, 3, 2); b.place(B, 4, 2)
     for y in range(19):
@@ -106,7 +115,8 @@ def test_ladder_capture(api):
                 assert b.is_ladder_capture(B, x, y) == ((x, y) == (3, 4)), (x, y)
 
 
-def test_ladder_escape(api):
+def test_ladder_escape(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(W, 3, 3); b.place(W, 15, 15)                 # ladder breaker on the diagonal
     for x, y in ((2, 3), (3, 2), (4, 2), (3, 4)):
@@ -130,15 +140,17 @@ NOT_LADDER_GAME = [
 ]
 
 
-def test_not_ladder(api):
+def test_not_ladder(api_full):
     """ladder.rs:282-317: a real game that once sent the reference's reader into an infinite loop."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     for color, x, y in NOT_LADDER_GAME:
         b.place(color, x, y)
     assert b.is_ladder_escape(W, 4, 13) is True
 
 
-def test_not_ladder_due_to_self_atari(api):
+def test_not_ladder_due_to_self_atari(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     for first in ((1, 2), (3, 4)):                       # ladder.rs:319-350, both variants
         b = api.Board(7.5)
         for color, x, y in ((B,) + first, (W, 2, 4), (B, 2, 3), (W, 1, 5), (B, 1, 4)):
@@ -181,7 +193,8 @@ def test_features_history_liberties_ko_and_ladder_planes(api):
     assert g[0, 0, 29] == 1 and np.all(g[:, :, 2] == 1)            # "is super-ko" at the point, "any move is super-ko" everywhere
 
 
-def test_features_follow_the_symmetry(api):
+def test_features_follow_the_symmetry(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(B, 3, 2); b.place(W, 15, 16); b.place(B, 4, 4)
     base = b.get_features(W).reshape(361, 32)
@@ -193,7 +206,8 @@ def test_features_follow_the_symmetry(api):
     assert all(api.Board(7.5).is_symmetric(t) for t in api.Transform.ALL)
 
 
-def test_search_and_selfplay_on_the_real_board(api):
+def test_search_and_selfplay_on_the_real_board(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(B, 3, 3)
     prior = np.full(362, 1.0 / 361, dtype=np.float32); prior[3 * 19 + 3] = -np.inf; prior[361] = -np.inf
@@ -218,10 +232,11 @@ def test_search_and_selfplay_on_the_real_board(api):
             replay.place(m % 2, index % 19, index // 19)
 
 
-def test_full_forward_of_the_empty_board(api):
+def test_full_forward_of_the_empty_board(api_full):
     """full_forward (src/libdg_mcts/lib.rs:83-130): every symmetry is evaluated, the candidates are what the initial policy
     leaves (symmetric duplicates removed: on the empty board one eighth of the points, incl. the diagonals and the centre,
     = 55, plus pass), the result sums to one, and a second call is served from the transposition cache."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     value, prior, n = api.full_forward(b, B)
     assert n == 8 and 0.0 <= value <= 1.0
@@ -239,7 +254,8 @@ def test_full_forward_of_the_empty_board(api):
     assert n == 8 and np.isfinite(prior).sum() == 361 and prior[4 * 19 + 3] == -np.inf
 
 
-def test_cached_search_reports_hits_and_same_tree(api):
+def test_cached_search_reports_hits_and_same_tree(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5)
     b.place(B, 3, 3)
     prior = np.full(362, 1.0 / 361, dtype=np.float32); prior[3 * 19 + 3] = -np.inf; prior[361] = -np.inf
@@ -270,11 +286,12 @@ def test_selfplay_records_games_in_the_reference_format(api):
             assert ";%s[%s%s]" % ("BW"[m % 2], letters[x], letters[y]) in game
 
 
-def test_real_games_reach_the_reference_positions(api):
+def test_real_games_reach_the_reference_positions(api_full):
     """src/dg_tests/tests/real_games.rs:27-117 replays three professional games (one with a triple ko) and pins the final
     zobrist hash.  The build keeps its own zobrist constants, so the pin is on the final POSITION: tests/golden/real_games.json
     holds the positions that reproduced the reference's expected hashes under the reference's table when the fixture was
     made (tests/golden/make_real_games.py); when the reference checkout is present the hash is recomputed here as well."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import importlib.util
     import json
     import os
@@ -325,7 +342,8 @@ def test_benson_restatement_reproduces_the_reference_example():
     assert {p for p, s in status.items() if s != restated.NONE} == invalid
 
 
-def test_benson_matches_the_restatement_on_random_positions(api):
+def test_benson_matches_the_restatement_on_random_positions(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     from oracle import benson as restated
     rng = np.random.default_rng(11)
     interesting = 0
@@ -350,8 +368,9 @@ def test_benson_matches_the_restatement_on_random_positions(api):
     assert interesting >= 10                                       # the comparison was not all-zero boards
 
 
-def test_benson_eyes_and_empty(api):
+def test_benson_eyes_and_empty(api_full):
     """benson.rs:601-609 (empty_is_all_valid) and :655-676 (eyes)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     assert not api.Board(0.5).benson(B).any()
     b = api.Board(0.5)
     for x, y in ((0, 1), (1, 1), (2, 0), (2, 1), (3, 1), (4, 0), (4, 1)):
@@ -366,8 +385,9 @@ def test_benson_eyes_and_empty(api):
                 assert status[y, x] == 2
 
 
-def test_scores(api):
+def test_scores(api_full):
     """score.rs:289-353: score_black, score_white, score_black_white, checker_board_black / white."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(7.5); b.place(B, 0, 0)
     assert not b.is_scorable() and b.get_score() == (361, 0)
     b = api.Board(7.5); b.place(W, 0, 0)
@@ -387,8 +407,9 @@ def test_scores(api):
     assert api.Board(7.5).get_score() == (0, 0)                    # score.rs:131-135: nothing played
 
 
-def test_eyes_should_be_territory(api):
+def test_eyes_should_be_territory(api_full):
     """score.rs:355-405, and the RE[] / TB / TW text GameResult::Ended makes of it (game_result.rs:46-93)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(0.5)
     for x, y in ((0, 1), (1, 1), (2, 0), (2, 1), (3, 1), (4, 0), (4, 1)):
         b.place(W, x, y)
@@ -409,9 +430,10 @@ def test_eyes_should_be_territory(api):
     assert territory.startswith("TB[jj]TW[aa][ba]") and territory.count("[") == 361
 
 
-def test_scoring_search_candidates(api):
+def test_scoring_search_candidates(api_full):
     """ScoringPolicyChecker (options.rs:110-139): no pass, no Benson eye of either colour, no own simple eye (is_eye :192-213,
     tests :221-258 corner / side / middle)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     b = api.Board(0.5)
     for x, y in ((0, 1), (1, 1), (2, 0), (2, 1), (3, 1), (4, 0), (4, 1)):
         b.place(W, x, y)
@@ -433,8 +455,9 @@ def test_scoring_search_candidates(api):
         assert np.isfinite(prior[eye[1] * 19 + eye[0]]) == b.is_valid(W, *eye)
 
 
-def test_choose_on_a_policy(api):
+def test_choose_on_a_policy(api_full):
     """choose.rs:54-88 on real weights: -inf entries are ignored by the total and never chosen."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     p = np.array([0.1, -np.inf, 0.6, 0.3, -np.inf])
     assert api.choose_f64(p, 0.5, 1.0, 0.0)[0] == 2
     picks = {api.choose_f64(p, 0.05, 1.0, at)[0] for at in np.linspace(0.0, 1.0, 21)}
@@ -442,9 +465,10 @@ def test_choose_on_a_policy(api):
     assert api.choose_f64(p, 0.5, 1.0, 1.0)[0] == 2               # the lower half of the mass (0.1, 0.3) is cut off
 
 
-def test_selfplay_plays_games_to_the_end(api):
+def test_selfplay_plays_games_to_the_end(api_full):
     """self_play_one (self_play.rs:423-459) with the deterministic hash predictor: tiny budgets, but whole games: every record
     is a GameResult::Ended record, every stone was legal, and a game that ended did so on a scorable board after two passes."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     out = api.selfplay_go(num_games=2, num_moves=0, num_rollouts=12, threads_per_search=1, seed=5, cache=api.LruCache(20000),
                           return_moves=True, return_sgf=True)
     assert out["games"] == 2 and len(out["sgf"]) == 2
@@ -468,10 +492,11 @@ def test_selfplay_plays_games_to_the_end(api):
     assert out["games_ended"] == sum(int((r >= 0).sum()) < 722 for r in out["record"])
 
 
-def test_incremental_bookkeeping_equals_a_flood_fill(api):
+def test_incremental_bookkeeping_equals_a_flood_fill(api_full):
     """place() keeps blocks and liberties incrementally (merges, captures of several blocks at once, snap-backs); after every
     stone of dense random games -- legal moves and, now and then, an illegal one (place() does not check) -- the state must
     equal a from-scratch flood fill, and the liberty counts must equal a brute-force count."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(5)
     for game in range(6):
         b = api.Board(0.5)
@@ -565,11 +590,12 @@ def _check_fast_forms(api, board):
     return int((status[0] == 1).any() or (status[1] == 1).any())
 
 
-def test_bitboard_benson_and_candidates_equal_the_flood_fill_forms(api):
+def test_bitboard_benson_and_candidates_equal_the_flood_fill_forms(api_full):
     """go.cpp: benson_sets / valid_moves / go_candidates_scoring (bit boards, what every rollout calls) against benson_flood (the
     reference's steps, utils/benson.rs:62-190) and the per-point definitions (options.rs:44-214, board.rs:140-142): every 7th position
     of the three reference games, and random games played to the end with the ScoringSearch rule (no own eyes filled), which leave
     boards full of small eyes, unconditionally alive groups, captures and kos."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import json as _json, re as _re
     checked = alive = 0
     for game in _json.load(open(os.path.join(os.path.dirname(__file__), "golden", "real_games.json")))["games"]:

@@ -17,6 +17,7 @@ graft.package()
 from dream_go_amd import api
 out = api.selfplay_go(3, 40, 48, threads_per_search=1, seed=31, pool=None, cache=None, cache_per_game=2000, leaves_per_thread=4,
                       return_moves=True, return_sgf=True)
+api = api.load_full()          # full_forward and the candidate lists on their own are test-build entry points (include/dgnn_test.h)
 board = api.Board(7.5)
 for i, (x, y) in enumerate([(3, 3), (15, 15), (3, 15), (15, 3), (9, 9), (9, 10), (10, 9)]):
     board.place(i %% 2, x, y)

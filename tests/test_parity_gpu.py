@@ -29,8 +29,9 @@ def _close_fp16(got_bits, ref_bits, ulps=2.0, atol=2e-3):
 
 # --------------------------------------------------------------------------------------------- layer level
 
-def test_conv2d_pick_middle_and_sum_through_hip(api):
+def test_conv2d_pick_middle_and_sum_through_hip(api_full):
     """The reference's own layer test (conv2d.rs:252-291) through the HIP kernel; cin padded 1 -> 32 with zeros."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     k = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))["conv2d_pick_middle_and_sum"]
     x = np.zeros((9, 32), dtype=np.float16); x[:, 0] = k["input"]
     w = np.zeros((2, 9, 32), dtype=np.float16); w[:, :, 0] = np.asarray(k["filter_kcrs_as_listed"], dtype=np.float16).reshape(2, 9)
@@ -38,8 +39,9 @@ def test_conv2d_pick_middle_and_sum_through_hip(api):
     assert f16_to_f32(y).tolist() == [float(v) for v in k["expected_nhwc"]]
 
 
-def test_conv_asymmetric_taps_and_channels(api, oracle):
+def test_conv_asymmetric_taps_and_channels(api_full, oracle):
     """A transpose-detecting case: every (tap, cin, cout) weight distinct, single hot input pixels."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     cin, cout = 32, 16
     w = (np.arange(cout * 9 * cin, dtype=np.float32).reshape(cout, 9, cin) % 251) / 64.0
     x = np.zeros((1, 19, 19, cin), dtype=np.float32)
@@ -63,7 +65,8 @@ def test_conv_asymmetric_taps_and_channels(api, oracle):
     (2, 128, 2, None, True),       # value-head conv (value_head.rs:47), scalar epilogue
     (5, 64, 2, None, True),
 ])
-def test_conv_layer_against_oracle(api, oracle, batch, cin, cout, alpha, relu):
+def test_conv_layer_against_oracle(api_full, oracle, batch, cin, cout, alpha, relu):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng([batch, cin, cout])
     x = np.maximum(rng.normal(0, 1, (batch, 19, 19, cin)), 0).astype(np.float16)     # post-ReLU like activations
     w = rng.normal(0, np.sqrt(2.0 / (9 * cin)), (cout, 3, 3, cin)).astype(np.float16)
@@ -93,9 +96,10 @@ def _need_tile_kernels(api):
     (2, 128, 512, 0.25),     # two output-channel blocks (grid.y = 2)
     (8, 256, 256, 0.5),      # several tiles
 ])
-def test_tile_kernel_against_oracle_and_generic_kernel(api, oracle, monkeypatch, variant, fm, batch, cin, cout, alpha):
+def test_tile_kernel_against_oracle_and_generic_kernel(api_full, oracle, monkeypatch, variant, fm, batch, cin, cout, alpha):
     """The tuned tile kernels (conv_tile.hip; lock-step and staggered pipeline, every position-tile height) against
     the oracle and against the generic kernel on the same inputs."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     _need_tile_kernels(api)
     rng = np.random.default_rng([fm, batch, cin, cout])
     x = np.maximum(rng.normal(0, 1, (batch, 19, 19, cin)), 0).astype(np.float16)
@@ -117,9 +121,10 @@ def test_tile_kernel_against_oracle_and_generic_kernel(api, oracle, monkeypatch,
         assert np.count_nonzero(got != ref) <= 0.02 * got.size
 
 
-def test_tile_kernel_exact_on_integers(api, monkeypatch):
+def test_tile_kernel_exact_on_integers(api_full, monkeypatch):
     """All products and sums exactly representable: the tile kernel must equal the generic kernel bit for bit
     (catches any wrong row / slot / tap in the swizzled LDS image, which a tolerance could hide)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     _need_tile_kernels(api)
     rng = np.random.default_rng(11)
     batch, cin, cout = 5, 128, 256
@@ -138,10 +143,11 @@ def test_tile_kernel_exact_on_integers(api, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["tile1", "tile2", "tile3"])
-def test_tile_kernel_exact_under_full_load(api, monkeypatch, variant):
+def test_tile_kernel_exact_under_full_load(api_full, monkeypatch, variant):
     """BASELINE.json configs[2] layer shape at full size (256 boards, 256 -> 256 channels, every CU busy, two rounds
     of workgroups): integer-valued data make the generic kernel a bit-exact reference; three runs must be identical
     (a pipeline race would show up as run-to-run differences under load)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     _need_tile_kernels(api)
     rng = np.random.default_rng(23)
     batch, cin, cout = 256, 256, 256
@@ -160,9 +166,10 @@ def test_tile_kernel_exact_under_full_load(api, monkeypatch, variant):
 
 # ---- board kernel (conv_board.hip): padded slot-major layout, one board per workgroup
 
-def test_board_kernel_asymmetric_taps(api, oracle, monkeypatch):
+def test_board_kernel_asymmetric_taps(api_full, oracle, monkeypatch):
     """Transpose- and shift-detecting: distinct weight per (tap, cin, cout), hot pixels in corners, on edges and in
     the interior; every output is one exact product (+ bias), so the board path must be bit-exact."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     cin, cout = 32, 256
     w = ((np.arange(cout * 9 * cin, dtype=np.float32).reshape(cout, 9, cin) * 7) % 251) / 64.0
     x = np.zeros((2, 19, 19, cin), dtype=np.float32)
@@ -188,7 +195,8 @@ def test_board_kernel_asymmetric_taps(api, oracle, monkeypatch):
 ])
 @pytest.mark.parametrize("skip_mode", ["0", "1"])     # skip folded into the K loop (default) / added in the epilogue
 @pytest.mark.parametrize("ns", ["16", "4", "2", "1"])  # 32-channel slices per workgroup (ignored when it does not divide C_out / 32); 16 = eight on four waves, 1 = twelve waves
-def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode, ns):
+def test_board_kernel_against_oracle(api_full, oracle, monkeypatch, batch, cin, cout, alpha, relu, skip_mode, ns):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     monkeypatch.setenv("DGNN_BOARD_SKIP", skip_mode)
     monkeypatch.setenv("DGNN_BOARD_NS", ns)
     rng = np.random.default_rng([7, batch, cin, cout])
@@ -207,10 +215,11 @@ def test_board_kernel_against_oracle(api, oracle, monkeypatch, batch, cin, cout,
 
 
 @pytest.mark.parametrize("ns", ["16", "4", "2", "1"])
-def test_board_kernel_exact_under_full_load(api, monkeypatch, ns):
+def test_board_kernel_exact_under_full_load(api_full, monkeypatch, ns):
     """configs[2] layer shape at full size (256 boards = 256 workgroups, every CU busy): integer-valued data make the
     generic kernel a bit-exact reference; three runs must be identical (a DMA / ring race shows up as run-to-run
     differences under load)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(29)
     batch, cin, cout = 256, 256, 256
     x = rng.integers(0, 4, (batch, 19, 19, cin)).astype(np.float16)
@@ -241,8 +250,9 @@ def test_board_path_whole_network(api, oracle, synth, monkeypatch):
     assert np.abs(p1.astype(np.float32) - p2.astype(np.float32)).max() <= POLICY_TOL
 
 
-def test_conv_does_not_read_skip_when_alpha2_is_zero(api, oracle):
+def test_conv_does_not_read_skip_when_alpha2_is_zero(api_full, oracle):
     """Conv2d::forward aliases z to the uninitialised output with alpha2 = 0 (conv2d.rs:188-190): z must be ignored."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(5)
     x = rng.normal(0, 1, (1, 19, 19, 32)).astype(np.float16)
     w = rng.normal(0, 0.1, (32, 3, 3, 32)).astype(np.float16)
@@ -253,8 +263,9 @@ def test_conv_does_not_read_skip_when_alpha2_is_zero(api, oracle):
     assert np.array_equal(a, c) and not np.isnan(f16_to_f32(a)).any()
 
 
-def test_conv_linearity(api):
+def test_conv_linearity(api_full):
     """Size-independent property: conv(x1 + x2) == conv(x1) + conv(x2) for exactly representable small integers."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(8)
     cin, cout, batch = 64, 64, 4
     x1 = rng.integers(0, 3, (batch, 19, 19, cin)).astype(np.float16)
@@ -465,9 +476,10 @@ def test_partial_batches_from_one_workspace(api, synth):
     net.destroy()
 
 
-def test_batcher_forward_matches_direct_forward(api, synth):
+def test_batcher_forward_matches_direct_forward(api_full, synth):
     """Batch::forward (batch.rs:35-40): boards evaluated through the batcher, in batches of whatever size the queue
     had, give bit-identical results to evaluating each board alone."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(synth.make_tensors(2, 64, seed=43))
     net = api.Network.from_json(text)
     feats = synth.make_features(23, seed=430).reshape(23, 11552)
@@ -492,9 +504,10 @@ def test_batcher_forward_matches_direct_forward(api, synth):
     assert b.stats() == {"boards": 23, "batches": 3} and b.pending() == (0, 0)
 
 
-def test_leaf_pool_coalesces_callers(api, synth):
+def test_leaf_pool_coalesces_callers(api_full, synth):
     """Many threads call predict() with <= 8 boards each (the shape of full_forward, lib.rs:83-130): everyone gets the
     result of evaluating its boards alone, and the device saw fewer, larger batches than there were calls."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import threading
     text = synth.to_json(synth.make_tensors(2, 64, seed=47))
     net = api.Network.from_json(text)
@@ -531,10 +544,11 @@ def test_leaf_pool_coalesces_callers(api, synth):
 
 # --------------------------------------------------------------------------------------------- search (f-2) on the GPU
 
-def test_search_visit_counts_hip_vs_oracle(api, oracle, synth):
+def test_search_visit_counts_hip_vs_oracle(api_full, oracle, synth):
     """north_star: MCTS visit counts under a fixed seed, HIP predictor against the CPU oracle as the predictor.  Single
     search thread, same seed, same synthetic game: the searches see the same positions as long as they choose the same
     children, so identical network outputs give identical counts; the outputs agree to fp16 rounding (<= 1e-3)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(synth.make_tensors(2, 64, seed=71))
     net = api.Network.from_json(text)
     tensors, _ = oracle.load_weights(text)
@@ -558,7 +572,8 @@ def test_search_visit_counts_hip_vs_oracle(api, oracle, synth):
     assert moved == 0                                      # north_star: bit-identical visit counts (more seeds: tests/test_round2_gpu.py)
 
 
-def test_synthetic_selfplay_through_the_pool(api, synth):
+def test_synthetic_selfplay_through_the_pool(api_full, synth):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(synth.make_tensors(2, 64, seed=73))
     net = api.Network.from_json(text)
     batcher = api.Batcher(net, max_batch_size=64, max_batches=2)
@@ -592,9 +607,10 @@ def test_real_board_features_through_the_engine(api, oracle, synth):
     _compare(api, oracle, text, features, len(planes), "real-board feature planes (8 positions, 8 symmetries)")
 
 
-def test_go_selfplay_through_the_pool(api, synth):
+def test_go_selfplay_through_the_pool(api_full, synth):
     """Board + ladders + feature planes + search + transposition cache + pool + HIP engine in one piece: every stone legal,
     every evaluation accounted for by the batcher."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(synth.make_tensors(2, 64, seed=83))
     net = api.Network.from_json(text)
     batcher = api.Batcher(net, max_batch_size=64, max_batches=2)
@@ -613,11 +629,12 @@ def test_go_selfplay_through_the_pool(api, synth):
     print(f"go self-play: {out['evals']} evals in {pooled['batches']} device batches, {out['cache_hits']} cache hits")
 
 
-def test_selfplay_on_the_engine_is_a_function_of_the_seed(api, synth):
+def test_selfplay_on_the_engine_is_a_function_of_the_seed(api_full, synth):
     """north_star: visit counts bit-identical under a fixed seed -- here for whole self-play games on the HIP engine: one search
     thread per game with 8 leaves in flight, games coalesced by the pool into device batches whose composition depends on timing
     and on how many games run at a time.  The engine's result for a board does not depend on what else is in the batch (a board is
     one workgroup, the contraction order is fixed), so the records must not depend on it either."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(synth.make_tensors(3, 64, seed=85))
     net = api.Network.from_json(text)
     records = []

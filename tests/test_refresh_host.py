@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 
-def test_cache_clear_drops_every_entry(api):
+def test_cache_clear_drops_every_entry(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     cache = api.LruCache(100, num_shards=4)
     policy = np.linspace(0, 1, 362).astype(np.float16)
     for h in range(40):
@@ -22,10 +23,11 @@ def test_cache_clear_drops_every_entry(api):
 
 
 @pytest.mark.parametrize("boards", [False, True])
-def test_pause_refresh_resume_under_pool_traffic(api, boards):
+def test_pause_refresh_resume_under_pool_traffic(api_full, boards):
     """Eight caller threads hammer the pool; the main thread pauses it, checks that nothing is being evaluated, swaps the "weights",
     resumes.  No caller may see an old-version answer that was REQUESTED after resume returned, no evaluation may overlap the
     swap, and callers that were waiting during the pause are answered by the new version."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     state = {"version": 1, "inside": 0, "overlap": False, "swapping": False}
     lock = threading.Lock()
 
@@ -76,9 +78,10 @@ def test_pause_refresh_resume_under_pool_traffic(api, boards):
     assert len(seen) > 50
 
 
-def test_an_answer_requested_before_a_clear_is_not_stored_after_it(api):
+def test_an_answer_requested_before_a_clear_is_not_stored_after_it(api_full):
     """a request in flight across pause -> set weights -> clear -> resume used to put the OLD network's output back
     into the emptied table.  The table carries a generation: the miss is seen at one, the insert names it."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     cache = api.LruCache(100, num_shards=4)
     policy = np.linspace(0, 1, 362).astype(np.float16)
     seen = cache.generation()
@@ -92,10 +95,11 @@ def test_an_answer_requested_before_a_clear_is_not_stored_after_it(api):
     assert len(cache) == 2
 
 
-def test_the_search_does_not_cache_what_it_requested_before_a_refresh(api):
+def test_the_search_does_not_cache_what_it_requested_before_a_refresh(api_full):
     """The search driver with a shared table: the predictor itself plays the refresh in the middle of call 3 (clears the table, bumps its
     "weights") and answers THAT call with the old version -- what a pool does to a request that was on the device during the pause.  No
     position may be left in the table with the old version's value once the search is over."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     board = api.Board(7.5)
     board.place(0, 3, 3)
     cache = api.LruCache(10_000, num_shards=2)

@@ -55,9 +55,10 @@ def test_full_size_network_every_board(api, oracle, synth):
 # --------------------------------------------------------------------------------------------- search: visit counts
 
 @pytest.mark.parametrize("seed", [3, 11, 29])
-def test_search_visit_counts_are_identical_hip_vs_oracle(api, oracle, synth, seed):
+def test_search_visit_counts_are_identical_hip_vs_oracle(api_full, oracle, synth, seed):
     """north_star: "MCTS visit counts must be bit-identical under a fixed RNG seed".  One search thread, the same seed and game;
     the HIP engine behind the pool vs the CPU oracle as the predictor.  Equality, not a tolerance."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(synth.make_tensors(2, 64, seed=71))
     net = api.Network.from_json(text)
     tensors, _ = oracle.load_weights(text)
@@ -79,8 +80,9 @@ def test_search_visit_counts_are_identical_hip_vs_oracle(api, oracle, synth, see
 
 # --------------------------------------------------------------------------------------------- dense / heads, layer level
 
-def test_dense_kats_through_the_policy_gemm(api):
+def test_dense_kats_through_the_policy_gemm(api_full):
     """The reference's own Dense tests (src/libdg_nn/layers/dense.rs:243-299) through policy_gemm_kernel."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     kats = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))
     eye = np.eye(8, dtype=np.float16)
     x = np.arange(1, 9, dtype=np.float16)
@@ -99,9 +101,10 @@ def test_dense_kats_through_the_policy_gemm(api):
     (3, 64, 40, 0.5, True),             # ReLU Dense (dense.rs:108-116), ragged output tile
     (70, 722, 1, 1.0, False),           # the value head's Dense as a GEMM
 ])
-def test_dense_layer_against_oracle_arithmetic(api, batch, k_in, n_out, alpha, relu):
+def test_dense_layer_against_oracle_arithmetic(api_full, batch, k_in, n_out, alpha, relu):
     """y = act(fp16(alpha * (x . w) + b)) with fp32 accumulation: against float64 numpy rounded once to fp16 (the summation
     order differs, so a few outputs may flip one fp16 rounding)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng([batch, k_in, n_out])
     x = np.maximum(rng.normal(0, 1, (batch, k_in)), 0).astype(np.float16)
     w = rng.normal(0, np.sqrt(1.0 / k_in), (k_in, n_out)).astype(np.float16)
@@ -116,8 +119,9 @@ def test_dense_layer_against_oracle_arithmetic(api, batch, k_in, n_out, alpha, r
     assert np.count_nonzero(got.view(np.uint16) != ref16.view(np.uint16)) <= 0.02 * got.size
 
 
-def test_softmax_and_value_tail_against_oracle_arithmetic(api):
+def test_softmax_and_value_tail_against_oracle_arithmetic(api_full):
     """cudnnSoftmaxForward ACCURATE over 362 logits and tanh(fp16(w . v + b)) (softmax.rs:58-79, value_head.rs:80-81)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(41)
     batch = 9
     logits = rng.normal(-6.5, 2.0, (batch, 362)).astype(np.float16)

@@ -237,10 +237,11 @@ def test_search_records_of_engine_played_games_decode_to_the_oracles(api, oracle
     assert worst_p <= 1e-3 and worst_v <= 1e-3
 
 
-def test_policy_play_records_hold_the_oracles_value_of_the_position(api, oracle, synth):
+def test_policy_play_records_hold_the_oracles_value_of_the_position(api_full, oracle, synth):
     """Policy play (--num-rollout 1, self_play.rs:369-405): a move's record is `V[..]` of the eight-symmetry ensemble
     (lib.rs:83-130).  The stones are replayed on a fresh board and the ensemble is evaluated with the ORACLE as the predictor:
     every V[] the engine wrote must be the oracle's value of that position within 1e-3 (%.4f text included)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(synth.make_sharp_tensors(2, 64, seed=78, policy_gain=8.0, value_gain=4.0))
     net = api.Network.from_json(text)
     tensors, _ = oracle.load_weights(text)

@@ -54,7 +54,8 @@ WORKLOADS = [
 
 
 @pytest.mark.parametrize("kind,blocks,channels,batch,gains,kernel,conditioning", WORKLOADS)
-def test_logits_and_pre_tanh_in_ulps_and_against_exact_arithmetic(api, oracle, synth, kind, blocks, channels, batch, gains, kernel, conditioning):
+def test_logits_and_pre_tanh_in_ulps_and_against_exact_arithmetic(api_full, oracle, synth, kind, blocks, channels, batch, gains, kernel, conditioning):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     text = synth.to_json(build(synth, kind, blocks, channels, gains))
     features = real_game_features(api, batch)
     net = api.Network.from_json(text)
@@ -179,12 +180,13 @@ def test_pair_split_tower_equals_one_launch_per_layer(api, synth, blocks, batch,
     net.destroy()
 
 
-def test_coalescing_on_the_device_answers_with_the_evaluation_of_some_symmetry(api, synth):
+def test_coalescing_on_the_device_answers_with_the_evaluation_of_some_symmetry(api_full, synth):
     """dgnn_pool_set_coalescing on the real engine: sixteen threads ask for six positions in random symmetries at once.  Whatever the
     timing made of it -- evaluated on its own, or answered by following a request for the same position that was in flight -- every
     answer, brought back to the canonical orientation, must be bit for bit the canonical form of the DIRECT evaluation of that position
     under one of its eight symmetries (with that evaluation's value): exactly what a transposition-table hit may return
     (predictors/nn.rs:72-81), nothing else."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import threading
     net = api.Network.from_json(synth.to_json(synth.make_sharp_tensors(2, 64, seed=930, policy_gain=8.0, value_gain=4.0)))
     board = api.Board(7.5)

@@ -18,8 +18,9 @@ def _prior_distribution(rng):
     return prior / prior.sum()
 
 
-def test_visit_order(api):
+def test_visit_order(api_full):
     """tree.rs:1773-1823."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(1)
     root = api.Node(api.BLACK, 0.5, _prior_distribution(rng))
     vloss = api.config.VLOSS_CNT
@@ -44,8 +45,9 @@ def test_visit_order(api):
     assert 300 < len(choices) <= 362 and trace == api.PROBE_CONFLICT
 
 
-def test_virtual_loss(api):
+def test_virtual_loss(api_full):
     """tree.rs:1825-1860."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(2)
     root = api.Node(api.BLACK, 0.5, _prior_distribution(rng))
     vloss = api.config.VLOSS_CNT
@@ -57,8 +59,9 @@ def test_virtual_loss(api):
     assert root.with_(i).count() == 1 and root.total_count == 1
 
 
-def test_value_update(api):
+def test_value_update(api_full):
     """tree.rs:1862-1925: two parallel probes below a pre-expanded child; incremental mean 0.9 -> 0.85 -> 0.8."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     vloss = api.config.VLOSS_CNT
     root = api.Node(api.BLACK, 0.5, [1.0 if i == 60 else 0.0 for i in range(362)])
     other_prior = [0.5 if i in (61, 62) else 0.0 for i in range(362)]
@@ -87,16 +90,18 @@ def test_value_update(api):
     assert root.with_(60).vcount() == 0 and root.vtotal_count == 0
 
 
-def test_undo_trace(api):
+def test_undo_trace(api_full):
     """tree.rs:1927-1945: the second probe hits the child the first one is still expanding and is undone."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     root = api.Node(api.BLACK, 0.5, [1.0 if i == 60 else 0.0 for i in range(362)])
     assert isinstance(api.probe(root), api.Trace)
     assert api.probe(root) == api.PROBE_CONFLICT
     assert root.vtotal_count == api.config.VLOSS_CNT
 
 
-def test_undo_restores_the_expanding_flag(api):
+def test_undo_restores_the_expanding_flag(api_full):
     """undo(trace, true) (tree.rs:1397-1409, used when a worker gives a probe up): the child can be chosen again."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     root = api.Node(api.BLACK, 0.5, [1.0 if i == 60 else 0.0 for i in range(362)])
     trace = api.probe(root)
     api.undo(trace, True)
@@ -110,8 +115,9 @@ def test_no_result_when_every_prior_is_minus_infinity(api):
     assert api.probe(root) == api.PROBE_NO_RESULT
 
 
-def test_intp(api):
+def test_intp(api_full):
     """config.rs:352-375."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     pts = [(0, 0.0), (100, 1.0)]
     g = api.config.get_intp_value
     assert g(pts, -100) == 0.0 and g(pts, 200) == 1.0 and g(pts, 0) == 0.0 and g(pts, 100) == 1.0
@@ -123,14 +129,16 @@ def test_intp(api):
     assert api.config.VLOSS_CNT == 32
 
 
-def test_choose(api):
+def test_choose(api_full):
     """choose.rs:108-140."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     assert api.choose([2, 1, 4, 3], 0.5, 1.0, 0.0) == (2, 4.0 / 7.0)
     assert api.choose([4, 3, 2, 1], 0.5, 1.0, 1.0) == (1, 1.0)
 
 
-def test_argmax(api):
+def test_argmax(api_full):
     """asm/argmax.rs: first maximal element of the last 8-group that holds one; None when nothing is finite."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     v = np.full(368, -np.inf, dtype=np.float32)
     assert api.argmax_f32(v) is None
     v[5] = 1.0; v[100] = 3.0; v[200] = 2.0
@@ -152,8 +160,9 @@ def test_argmax(api):
         assert api.argmax_f32(v) == (index if np.isfinite(v[index]) else None)
 
 
-def test_best_and_softmax_follow_the_visit_counts(api):
+def test_best_and_softmax_follow_the_visit_counts(api_full):
     """Node::softmax (tree.rs:1293-1307) and the greedy Node::best (tree.rs:1263-1268, compare_children :1524-1560)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     prior = np.zeros(362, dtype=np.float32); prior[10] = 0.6; prior[20] = 0.4
     root = api.Node(api.BLACK, 0.5, prior)
     child_prior = np.full(362, 1.0 / 362, dtype=np.float32)
@@ -182,9 +191,10 @@ def _fresh_root(api):
     return api.Node(api.BLACK, 0.5, prior)
 
 
-def test_seeded_single_thread_search_is_reproducible(api):
+def test_seeded_single_thread_search_is_reproducible(api_full):
     """The determinism the reference does not have (it draws from thread_rng everywhere): with one
     search thread the visit counts are a pure function of the seed and the predictor's outputs."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     runs = []
     for seed in (7, 7, 8):
         root = _fresh_root(api)
@@ -198,9 +208,10 @@ def test_seeded_single_thread_search_is_reproducible(api):
     assert not np.array_equal(runs[0], runs[2])           # another seed draws other symmetries
 
 
-def test_multi_threaded_search_keeps_the_tree_consistent(api):
+def test_multi_threaded_search_keeps_the_tree_consistent(api_full):
     """Several threads in one tree (virtual loss + the expanding flag): every virtual loss is returned, every rollout
     is counted once, the search stops within threads - 1 rollouts of the limit (worker_thread.rs:144-146)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     root = _fresh_root(api)
     evals, conflicts = api.search_run(root, api.SyntheticBoard(5), num_rollouts=400, num_threads=8, seed=1)
     assert root.total_count <= 400 + 7 and root.total_count == evals and root.is_done(400)
@@ -210,14 +221,16 @@ def test_multi_threaded_search_keeps_the_tree_consistent(api):
     assert np.isclose(root.softmax().sum(), 1.0)
 
 
-def test_synthetic_selfplay_counts_every_evaluation(api):
+def test_synthetic_selfplay_counts_every_evaluation(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     stats = api.selfplay_synthetic(num_games=3, num_moves=4, num_rollouts=20, threads_per_search=2, seed=11)
     assert stats["games"] == 3 and stats["moves"] == 12
     assert 12 * 2 <= stats["evals"] <= 12 * (21 + 1)       # at most 20 rollouts (+ up to threads - 1) + the root evaluation
 
 
-def test_forward_keeps_the_sub_tree(api):
+def test_forward_keeps_the_sub_tree(api_full):
     """Node::forward (src/libdg_mcts/tree.rs:1225-1250): the child's statistics become the new root."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     root = _fresh_root(api)
     api.search_run(root, api.SyntheticBoard(9), num_rollouts=300, num_threads=1, seed=2)
     counts = _visit_counts(root)
@@ -230,7 +243,8 @@ def test_forward_keeps_the_sub_tree(api):
     assert api.Node(api.BLACK, 0.5, np.full(362, 1.0 / 362, dtype=np.float32)).forward(17) is None    # nothing below: no tree
 
 
-def test_set_prior_replaces_the_prior_only(api):
+def test_set_prior_replaces_the_prior_only(api_full):
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     root = _fresh_root(api)
     api.search_run(root, api.SyntheticBoard(9), num_rollouts=50, num_threads=1, seed=2)
     before = _visit_counts(root)
@@ -240,9 +254,10 @@ def test_set_prior_replaces_the_prior_only(api):
     assert np.allclose(root.prior, prior)
 
 
-def test_dirichlet_noise(api):
+def test_dirichlet_noise(api_full):
     """dirichlet::add_ex (src/libdg_mcts/dirichlet.rs:40-70, tests 80-101): mixes beta of a Dirichlet(shape) sample into the
     finite entries, keeps -inf entries, preserves the sum."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     x = np.full(362, 1.0 / 300, dtype=np.float32); x[300:] = -np.inf
     y = api.dirichlet_add(x, 0.03, 0.25, seed=5)
     assert np.all(np.isneginf(y[300:])) and np.all(np.isfinite(y[:300])) and np.all(y[:300] >= 0.75 / 300 - 1e-7)
@@ -251,9 +266,10 @@ def test_dirichlet_noise(api):
     assert np.array_equal(api.dirichlet_add(x, 0.03, 0.0, seed=5), x)
 
 
-def test_early_termination_rule(api):
+def test_early_termination_rule(api_full):
     """time_control::is_done (time_control/mod.rs:86-101) with min_promote_rollouts (:48-73): not done before the first
     visit; done at the limit; done early exactly when the lead of the most visited child exceeds the rollouts left."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     root = _fresh_root(api)
     assert not root.is_done(10) and root.min_promote_rollouts() == 0
     uniform = np.full(362, 1.0 / 362, dtype=np.float32)
@@ -275,10 +291,11 @@ def test_early_termination_rule(api):
         assert not root.is_done(total + lead)                   # lead == remaining: it still can
 
 
-def test_many_leaves_per_thread_stay_deterministic(api):
+def test_many_leaves_per_thread_stay_deterministic(api_full):
     """dgnn_search_run_batched: one worker with K leaves in flight probes them one after the other (virtual loss steers each
     probe away from the previous ones), evaluates them in ONE predictor call and inserts them -- still a pure function of the
     seed, unlike K threads; every virtual loss is returned; K = 1 is the plain search."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     calls = []
 
     def predictor(features, n):
@@ -323,9 +340,10 @@ def test_selfplay_with_batched_leaves_is_a_function_of_the_seed(api):
             replay.place(m % 2, int(index % 19), int(index // 19))
 
 
-def test_to_pretty_summarises_a_search_like_the_reference(api):
+def test_to_pretty_summarises_a_search_like_the_reference(api_full):
     """tree::to_pretty (src/libdg_mcts/tree.rs:1683-1731): "Nodes: N, Win: W%, PV: path" and a line per child, best first, with the
     child's visits, value, lower confidence bound, prior and its own greedy path; vertices in GTP style (no i column)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     prior = np.full(362, 1e-3, dtype=np.float32)
     prior[3 * 19 + 3], prior[15 * 19 + 8], prior[361] = 0.5, 0.3, 0.01
     root = api.Node(api.BLACK, 0.5, prior / prior.sum())
@@ -343,12 +361,13 @@ def test_to_pretty_summarises_a_search_like_the_reference(api):
     assert "i" not in "".join(l.split("PV:")[1] for l in lines).replace("pass", "")
 
 
-def test_sparse_children_answer_like_a_dense_node(api):
+def test_sparse_children_answer_like_a_dense_node(api_full):
     """tree.cpp keeps a slot per child that was ever selected (eight in the node, chunks of 16 .. 256 beyond, an index map from
     the sixteenth on); a child without a slot must read as Child::with_value (tree.rs:276-285).  A root is driven across every
     one of those boundaries -- probes that each pick a new child (the "expanding" flag keeps them apart), inserts in a shuffled
     order, undos -- and after every step all 362 children, the totals, softmax, best and the early-termination lead are compared
     with a dense restatement kept in numpy."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     rng = np.random.default_rng(5)
     vloss = api.config.VLOSS_CNT
     prior = _prior_distribution(rng)
@@ -400,12 +419,13 @@ def test_sparse_children_answer_like_a_dense_node(api):
     assert not root.with_(untouched).has_node() and root.with_(untouched).value() == np.float32(0.5)
 
 
-def test_many_threads_in_one_root_cross_the_slot_map_boundary_safely(api):
+def test_many_threads_in_one_root_cross_the_slot_map_boundary_safely(api_full):
     """a node keeps its first 15 child slots in the node and in one 16-slot chunk, and an index -> slot map from the
     sixteenth on.  A reader that saw "no map yet" and THEN a slot count past 23 (other threads adding slots in between) scanned
     past the chunk.  Now the map is published before the count that needs it and the reader switches to it.  Sixteen search
     threads probing fresh roots with a flat prior (every probe's virtual loss sends the next one to a new child) cross that
     boundary in every attempt; the tree must come out consistent every time (ASan / TSan run the same stress in tools/sanitize_host.sh)."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import threading
     prior = np.full(362, 1.0 / 362, dtype=np.float32)
     for attempt in range(20):
@@ -432,10 +452,11 @@ def test_many_threads_in_one_root_cross_the_slot_map_boundary_safely(api):
         assert counts.sum() == root.total_count and int((counts > 0).sum()) > 24        # well past the first chunk: the map is in use
 
 
-def test_nodes_freed_on_another_thread_than_the_one_that_made_them(api):
+def test_nodes_freed_on_another_thread_than_the_one_that_made_them(api_full):
     """tree nodes and leaf boards come from per-thread free lists (dgnn_internal.h BlockPool); the sanitizer builds bypass
     them.  The shipped path: trees built on one thread and freed on another (what pool workers and migrating fibers do), more nodes
     than a list keeps, and a thread that ends with blocks in its list."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import threading
     trees = []
 

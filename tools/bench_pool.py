@@ -22,6 +22,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 graft.package()
 from dream_go_amd import api, synth  # noqa: E402
+api = api.load_full()          # this tool uses entry points of include/dgnn_test.h (raw batcher / single layers): the test build of the library
 
 
 def main():

@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "dgnn.h"
+#include "dgnn_test.h"
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 

@@ -15,7 +15,7 @@
 #include <sys/time.h>
 #include <ucontext.h>
 #include <vector>
-#include "dgnn.h"
+#include "dgnn_test.h"
 static uint64_t* g_pcs; static volatile size_t g_n; static const size_t kMax = 1 << 20;
 static void on_prof(int, siginfo_t*, void* ctx) { if (g_n < kMax) g_pcs[g_n++] = ((ucontext_t*)ctx)->uc_mcontext.gregs[REG_RIP]; }
 int main(int argc, char** argv) {

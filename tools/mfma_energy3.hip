@@ -9,12 +9,16 @@
 //   3  + the activation chunk's LDS-DMA: one 1 KB global_load_lds piece per wave every third iteration (25.6 KB per 9 k-steps and
 //        workgroup), from a buffer that lives in the L2 / Infinity Cache
 //   4  1 + 2 + 3 together: the shipped K loop's memory instructions without its epilogue and skip fold
-//   5  4 + the epilogue's share of VALU work: 16 v_pk_fma_f32-class instructions per iteration on accumulator-sized data
+//   5  4 + the epilogue's share of VALU work: 16 v_fma_f32 per iteration
+//   6  no MFMA at all: sleeping waves on the same CUs (what the clocked chip draws without the matrix pipe)
+// Each mode runs with 256, 128 and 64 workgroups (one per CU).
 // The script (tools/mfma_energy.sh <seconds> mfma_energy3) samples the socket's clock and power twice a second beside it.
 // hipcc --offload-arch=gfx950 -O3 tools/mfma_energy3.hip -o /tmp/mfma_energy3 && /tmp/mfma_energy3 [seconds per mode]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
+#include <initializer_list>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -62,33 +66,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i) { side[i][0] = (float)id * 1e-9f + i; side[i][1] = 1.0f; }
     const half8* fsrc = filter + (size_t)(blockIdx.x & 7) * 8192 + wave * 256 + lane;     // a slice per wave, 8 slices chip-wide hot in the L2
     const half8* xsrc = acts + (size_t)blockIdx.x * 4096 + wave * 64 + lane;
-    // (the MFMAs are inline asm with the accumulator tied to the destination and pinned to AGPRs, as in the tower kernels: as a builtin
-    // the instruction is untied to hipcc, which then shuffles accumulators through v_accvgpr moves and measures those instead)
-    // (two iterations per trip so that the double buffers are indexed by constants: a run-time index would put them in scratch)
+    // The MFMAs are inline asm with the accumulator tied to the destination and pinned to AGPRs, as in the tower kernels (as a builtin
+    // the instruction is untied to hipcc, which then shuffles accumulators through v_accvgpr moves and measures those instead); the
+    // loads are inline asm too, placed BEHIND the MFMAs of a row tile like the shipped loop places them (hipcc would issue them in
+    // one clump in front of the MFMAs), and waited for once per iteration: they were requested a whole iteration earlier.
+    // Two iterations per trip so that the double buffers are indexed by constants (a run-time index would put them in scratch).
+    if (MODE == 6) {                                           // the clock and the rest of the chip without the matrix pipe: idle waves
+        for (int i = 0; i < iters * 4; ++i) asm volatile("s_sleep 8");
+        out[id] = 0.0f;
+        return;
+    }
 #define DGNN_STEP(cur, nxt, i)                                                                                                        \
     {                                                                                                                                 \
-        if (kLdsB) {                                           /* next iteration's B fragments: another 12 KB window */                \
-            const char* w = lds + (((i) + 1) & 3) * kWindow + lane * 16;                                                              \
-            _Pragma("unroll") for (int t = 0; t < 12; ++t) b[nxt][t] = *reinterpret_cast<const half8*>(w + t * 1024);                 \
-        }                                                                                                                             \
-        if (kGlobalA) {                                        /* next iteration's A fragments: 4 KB further into the wave's slice */  \
-            const half8* g = fsrc + (size_t)(((i) * 4) & 127) * 64;                                                                   \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) a[nxt][c] = g[c * 64];                                                      \
+        const unsigned lds_at = (unsigned)(size_t)(lds + (((i) + 1) & 3) * kWindow + lane * 16);                                      \
+        const half8* g = fsrc + (size_t)(((i) * 4) & 127) * 64;                                                                       \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");                                                                                \
+        _Pragma("unroll") for (int t = 0; t < 12; ++t) {                                                                              \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                             \
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[c][t]) : "v"(a[kGlobalA ? cur : 0][c]), "v"(b[kLdsB ? cur : 0][t])); \
+            if (kLdsB) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[nxt][t]) : "v"(lds_at), "n"(t * 1024));                 \
+            if (kGlobalA && t % 3 == 0) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(a[nxt][t / 3]) : "v"(g), "n"((t / 3) * 1024)); \
+            if (kValu && t < 8) { side[t][0] = side[t][0] * 1.0001f + side[(t + 1) & 7][1]; side[t][1] = side[t][1] * 0.9999f + side[t][0]; } \
         }                                                                                                                             \
         if (kDma && (i) % 3 == 0) {                                                                                                   \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (size_t)(((i) / 3) & 31) * 256),  \
                                              (__attribute__((address_space(3))) void*)(lds + 4 * kWindow + wave * 1024), 16, 0, 0);   \
-        }                                                                                                                             \
-        _Pragma("unroll") for (int t = 0; t < 12; ++t) {                                                                              \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                             \
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[c][t]) : "v"(a[kGlobalA ? cur : 0][c]), "v"(b[kLdsB ? cur : 0][t])); \
-            if (kValu && t < 8) { side[t][0] = side[t][0] * 1.0001f + side[(t + 1) & 7][1]; side[t][1] = side[t][1] * 0.9999f + side[t][0]; } \
         }                                                                                                                             \
     }
     for (int i = 0; i < iters; i += 2) {
         DGNN_STEP(0, 1, i)
         DGNN_STEP(1, 0, i + 1)
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");
 #undef DGNN_STEP
     float s = 0.0f;
     for (int c = 0; c < 4; ++c) for (int t = 0; t < 12; ++t) for (int r = 0; r < 4; ++r) s += acc[c][t][r];
@@ -97,10 +106,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     out[id] = s;
 }
 
-template <int MODE>
-static void run(float* out, const half8* filter, const half8* acts, double seconds)
+__global__ void fill_random(_Float16* p, size_t n, int half_zero)
 {
-    const int blocks = 256, iters = 4000, threads = 256;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned h = hash32((unsigned)i * 2654435761u + 12345u);
+        float x = ((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f);
+        if (half_zero && (h >> 16 & 1)) x = 0.0f;
+        p[i] = (_Float16)x;
+    }
+}
+
+template <int MODE>
+static void run(float* out, const half8* filter, const half8* acts, double seconds, int blocks)
+{
+    const int iters = 4000, threads = 256;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipFuncSetAttribute((const void*)mfma_loop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     const double flops_per_launch = (double)blocks * (threads / 64) * iters * 48 * 16384.0;
@@ -113,7 +132,9 @@ static void run(float* out, const half8* filter, const half8* acts, double secon
         done += ms * 1e-3;
         last = 50.0 * flops_per_launch / (ms * 1e-3) / 1e12;
     }
-    std::printf("t=%.2f mode %d final: %.1f TFLOP/s (%.1f %% of the nominal 2500)\n", (double)time(nullptr), MODE, last, last / 25.0);
+    if (MODE == 6) last = 0.0;
+    std::printf("t=%.2f workgroups %d mode %d final: %.1f TFLOP/s (%.1f %% of the nominal 2500 x %d / 256)\n", (double)time(nullptr), blocks, MODE, last,
+                last / 25.0 * 256.0 / blocks, blocks);
     std::fflush(stdout);
 }
 
@@ -125,11 +146,18 @@ int main(int argc, char** argv)
     (void)hipMalloc(&out, 256 * 256 * sizeof(float));
     (void)hipMalloc(&filter, 8 * 8192 * 16 * 2 + 65536);      // 8 slices of 128 KB (+ slack)
     (void)hipMalloc(&acts, 256 * 4096 * 16 + 65536);          // 64 KB per workgroup
-    (void)hipMemset(filter, 0x3c, 8 * 8192 * 16 * 2 + 65536);
-    (void)hipMemset(acts, 0x2e, 256 * 4096 * 16 + 65536);
-    for (int rep = 0; rep < 2; ++rep) {
-        run<0>(out, filter, acts, seconds); run<1>(out, filter, acts, seconds); run<2>(out, filter, acts, seconds);
-        run<3>(out, filter, acts, seconds); run<4>(out, filter, acts, seconds); run<5>(out, filter, acts, seconds);
+    // the operands a probe loads must look like the operands it keeps in registers: random filter values, half-zero activations
+    // (a first version memset both buffers: with a CONSTANT filter operand the part ran mode 2 at its maximum clock and 1 180 W --
+    // what the multiplier array draws depends on how much its inputs toggle, profiles/r05/mfma_energy3_first.txt)
+    hipLaunchKernelGGL(fill_random, dim3(1024), dim3(256), 0, 0, (_Float16*)filter, (size_t)(8 * 8192 * 16 * 2 + 65536) / 2, 0);
+    hipLaunchKernelGGL(fill_random, dim3(1024), dim3(256), 0, 0, (_Float16*)acts, (size_t)(256 * 4096 * 16 + 65536) / 2, 1);
+    (void)hipDeviceSynchronize();
+    // every CU busy: the package sits at its power cap and the clock is the answer; half / a quarter of the CUs: nothing is capped,
+    // every mode runs at the same clock and the socket's watts per TFLOP/s separate the ingredients
+    for (int blocks : {256, 128, 64}) {
+        run<6>(out, filter, acts, seconds, blocks);
+        run<0>(out, filter, acts, seconds, blocks); run<1>(out, filter, acts, seconds, blocks); run<2>(out, filter, acts, seconds, blocks);
+        run<3>(out, filter, acts, seconds, blocks); run<4>(out, filter, acts, seconds, blocks); run<5>(out, filter, acts, seconds, blocks);
     }
     return 0;
 }

@@ -7,7 +7,7 @@
 #include <cstdlib>
 #include <thread>
 #include <vector>
-#include "dgnn.h"
+#include "dgnn_test.h"
 int main() {
     for (int mode = 0; mode < 3; ++mode) {
         dgnn_selfplay_params p{};

@@ -14,7 +14,7 @@ mkdir -p "$TMP"
 cat > "$TMP/stubs.cpp" <<'STUBS'
 // A stand-in engine behind the batcher: "evaluates" a batch with the CPU stand-in predictor, so that the leaf pool, its worker
 // threads and the batcher run for real under the sanitizers.
-#include "dgnn.h"
+#include "dgnn_test.h"
 extern "C" {
 int dgnn_network_get_workspace(dgnn_network*, int, int, dgnn_workspace** out) { *out = reinterpret_cast<dgnn_workspace*>(0x10); return DGNN_OK; }
 int dgnn_forward_n(dgnn_workspace*, const uint16_t* features, int n, uint16_t* value, uint16_t* policy)

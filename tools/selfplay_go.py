@@ -50,7 +50,31 @@ def main():
     ap.add_argument("--planes", choices=["device", "host"], default="device",
                     help="where the feature planes are built: on the device from 896-byte board records (dgnn_forward_boards), or on the host")
     ap.add_argument("--host-threads", type=int, default=4, help="the games in flight run as fibers on this many host threads (0 = one OS thread per game)")
+    ap.add_argument("--steady", default="", metavar="RAMP,SECONDS",
+                    help="the STEADY STATE of whole games instead of a fixed set: --games in flight per GPU with replacement, game i started i / games of the "
+                         "way into a game played out by policy play, RAMP untimed seconds, then a window of SECONDS (bench.py's whole_games leg: "
+                         "dgnn_selfplay_window); prints that leg's JSON")
     args = ap.parse_args()
+    lost_rules = args.extra_batch_queue > 0 or args.min_fill > 0 or args.max_batches == 0 or bool(args.snap)
+    if lost_rules and not hasattr(api.lib, "dgnn_pool_set_min_fill"):
+        raise SystemExit("--extra-batch-queue / --min-fill / --max-batches 0 / --snap are batching rules that were measured and lost (DESIGN.md 13.5, 13.10): "
+                         "their entry points are exported by the test build only -- DGNN_LIBRARY=dream-go_amd/lib/libdgnn_hip_test.so")
+    if args.steady:
+        # the same leg bench.py runs, with this tool's own settings, on one GPU
+        sys.path.insert(0, ROOT)
+        import bench
+        ramp, seconds = [float(v) for v in args.steady.split(",")]
+        bargs = bench.parse_args(["--blocks", str(args.blocks), "--channels", str(args.channels), "--batch", str(args.max_batch), "--whole-games", str(args.games),
+                                  "--whole-games-ramp", str(ramp), "--whole-games-seconds", str(seconds), "--selfplay-rollouts", str(args.rollouts),
+                                  "--selfplay-leaves", str(args.leaves), "--selfplay-batches", str(args.max_batches), "--selfplay-workers", str(args.workers),
+                                  "--selfplay-coalesce", str(args.coalesce), "--selfplay-back-to-back", str(args.back_to_back),
+                                  "--selfplay-host-threads", str(args.host_threads), "--selfplay-planes", args.planes])
+        job = bench.Job(bargs)
+        job.start(False)
+        net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
+        print(json.dumps(bench.whole_games_leg(job, api, replicas, net, bargs)), flush=True)
+        net.destroy()
+        return
 
     # one process per GPU (python -m torch.distributed.run --nproc-per-node N tools/selfplay_go.py ...): every rank owns an
     # engine, a batcher, a pool and a cache; rank 0's weights are broadcast once over RCCL; nothing else is exchanged
@@ -67,9 +91,15 @@ def main():
     net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1 if rank == 0 else 100 + rank)))
     broadcast = None
     if dist is not None:
-        sys.path.insert(0, ROOT)
-        import bench
-        broadcast = bench.broadcast_weights(net, device, torch, dist, replicas)
+        # ONE broadcast of rank 0's weight image by the library's own RCCL (dgnn_broadcast_weights), the unique id through torch.distributed
+        ident = torch.zeros(api.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8, device=f"cuda:{device}")
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(api.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(ident, src=0)
+        comm = api.Comm.create(device, world, rank, bytes(ident.cpu().numpy().tobytes()))
+        net.broadcast_weights(comm, root=0)
+        comm.destroy()
+        broadcast = ("rccl (dgnn_broadcast_weights)", net.weight_image(device)[1])
     import time
     capacity = 3 if (args.max_batches == 0 or args.extra_batch_queue > 0) else args.max_batches
     pool = api.LeafPool.over_devices(net, [device], max_batch_size=args.max_batch, batches_per_device=capacity,
