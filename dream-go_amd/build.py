@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libdgnn_hip.so")
 TEST_LIB_PATH = LIB_PATH if ABLATIONS else os.path.join(LIB_DIR, "libdgnn_hip_test.so")
 
 HOST_SOURCES = ["loader.cpp", "network.cpp", "engine.cpp", "rccl.cpp", "batcher.cpp", "formats.cpp", "tree.cpp", "search.cpp", "go.cpp", "fiber.cpp"]
-KERNEL_SOURCES = ["kernels.hip", "conv_board.hip", "conv_board_tower.hip", "heads.hip", "features.hip"]
+KERNEL_SOURCES = ["conv_board.hip", "conv_board_b.hip", "conv_board_tower.hip", "kernels.hip", "heads.hip", "features.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 if ABLATIONS:
     FLAGS.append("-DDGNN_ABLATIONS")

@@ -1,26 +1,9 @@
 // conv3x3_board_kernel: one launch per layer of the board kernel (conv_board_body.h), the launcher's rules, and the layout
 // conversions at the two ends of the tower.  The tower kernels are in conv_board_tower.hip.
-#include "conv_board_body.h"
+#include "conv_board_launch.h"
 
 namespace dgnn {
 namespace {
-
-template <int NS, int SKIP, bool RELU, int ABL>
-__global__ __launch_bounds__(Split<NS>::Threads)
-void conv3x3_board_kernel(ConvBoardLaunch a)
-{
-    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
-    half8 af[2][Split<NS>::CT][2];
-    conv_board_body<NS, SKIP, RELU, ABL>(a, lds, blockIdx.x, blockIdx.y, af);
-}
-
-// The whole residual tower of one board in one workgroup.  A board's convolutions depend on that board only, and with
-// NS = C_out / 32 a workgroup writes every channel of its board, so the layers need no grid-wide synchronisation: between
-// two layers the workgroup waits for its own stores and meets at a barrier (workgroup-scope release / acquire: the CU's
-// vector L1 is write-through and shared by the workgroup's waves).  Workgroups drift apart, so prologues, HBM write bursts
-// and epilogues of different boards no longer fall on the same instants, and there are no launch gaps.
-// `layers` = 2 * blocks descriptors in HBM (conv_1 / conv_2 of every block: alpha2 == 0 / != 0), all with relu and
-// cin = cout = 32 * NS.
 
 __global__ __launch_bounds__(256)
 void nhwc_to_board_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int batch, int c)
@@ -103,45 +86,9 @@ bool conv_board_supported(int cin, int cout)
     return cin >= 32 && cin % 32 == 0 && cout >= 64 && cout % 64 == 0;
 }
 
-template <int NS>
-static void launch_board_variant(const ConvBoardLaunch& args, int skip, bool relu, int ablate, hipStream_t stream)
-{
-    const dim3 grid(args.batch, args.cout / (32 * Split<NS>::SL));
-#define DGNN_BOARD(S, R, A) hipLaunchKernelGGL((conv3x3_board_kernel<NS, S, R, A>), grid, dim3(Split<NS>::Threads), 0, stream, args)
-    // The ablated kernels (tools/ablate.sh, tools/ablate2.sh: timing only, garbage results) are 34 more instantiations of the
-    // body -- half the compile time of this file.  They are built only with -DDGNN_ABLATIONS (DGNN_ABLATIONS=1 python
-    // dream-go_amd/build.py); a library without them ignores DGNN_CONV_ABLATE.
-#ifdef DGNN_ABLATIONS
-    if constexpr (NS == 1) {
-        if (ablate == 1 && relu && skip != 1) {      // timing only: the chunked kernel without its MFMAs
-            if (skip == 2) DGNN_BOARD(2, true, 1); else DGNN_BOARD(0, true, 1);
-            return;
-        }
-    }
-    if constexpr (NS == 4) {
-        // measurement only (tools/ablate.sh, tools/ablate2.sh; garbage results), residual shapes of the four-slice split:
-        // 1 = no MFMAs, 3 = neither MFMAs nor in-loop memory instructions (filter loads, activation pieces), 16 = no barrier at the
-        // chunk boundaries.  (Round 2's 2 / 8 / 24 / 32 / 64 priced the wave-private filter ring, which this split no longer has.)
-        if ((ablate == 1 || ablate == 3 || ablate == 16) && relu && skip != 1) {
-            if (skip == 2) {
-                switch (ablate) { case 1: DGNN_BOARD(2, true, 1); break; case 3: DGNN_BOARD(2, true, 3); break; default: DGNN_BOARD(2, true, 16); break; }
-            } else {
-                switch (ablate) { case 1: DGNN_BOARD(0, true, 1); break; case 3: DGNN_BOARD(0, true, 3); break; default: DGNN_BOARD(0, true, 16); break; }
-            }
-            return;
-        }
-    }
-#else
-    (void)ablate;
-#endif
-    if (skip == 2 && relu) DGNN_BOARD(2, true, 0);
-    else if (skip == 2) DGNN_BOARD(2, false, 0);
-    else if (skip == 1 && relu) DGNN_BOARD(1, true, 0);
-    else if (skip == 1) DGNN_BOARD(1, false, 0);
-    else if (relu) DGNN_BOARD(0, true, 0);
-    else DGNN_BOARD(0, false, 0);
-#undef DGNN_BOARD
-}
+// (launch_board_variant<NS>: conv_board_launch.h; the splits <4> and <2> are instantiated in conv_board_b.hip)
+extern template void launch_board_variant<4>(const ConvBoardLaunch&, int, bool, int, hipStream_t);
+extern template void launch_board_variant<2>(const ConvBoardLaunch&, int, bool, int, hipStream_t);
 
 // Slices per workgroup: the largest that divides C_out / 32, unless a smaller one is needed to put a workgroup on most
 // of the 256 CUs (a launch has batch * C_out / (32 * NS) workgroups).  DGNN_BOARD_NS=1|2|4|8 overrides.
