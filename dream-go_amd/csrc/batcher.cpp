@@ -112,6 +112,7 @@ struct CacheShard {
     struct Bucket { uint32_t id, hash; };
 
     std::mutex mutex;
+    MutexLife mutex_life{&mutex};
     size_t capacity = 0, size = 0;
     std::vector<Bucket> buckets;
     uint32_t mask = 0;
@@ -201,6 +202,7 @@ struct Batcher {
     size_t item = DGNN_FEATURE_SIZE;
 
     std::mutex mutex;               // batch.rs:60-73: the list lock
+    MutexLife mutex_life{&mutex};
     std::vector<uint16_t> features;
     std::vector<uint64_t> tags;
     std::vector<std::vector<uint16_t>> spare_features;   // buffers of retired batches, so that the queue does not grow from zero
@@ -317,6 +319,7 @@ struct LeafRequest {
     int status;
     Fiber* fiber = nullptr;     // the caller is a fiber (fiber.h): made ready by whoever completes the request, instead of `done`
     std::mutex mutex;
+    MutexLife mutex_life{&mutex};
     std::condition_variable done;
 };
 
@@ -354,6 +357,7 @@ struct LeafPool {
 
     std::vector<std::thread> workers;
     std::mutex mutex;
+    MutexLife mutex_life{&mutex};
     std::condition_variable work;
     bool stopping = false;
     bool paused = false;            // dgnn_pool_pause: workers take no new batch (callers keep queueing and wait)
@@ -368,6 +372,7 @@ struct LeafPool {
     // (predictors/nn.rs:72-81) -- instead of being evaluated again.
     std::atomic<bool> coalesce{false};
     std::mutex inflight_mutex;
+    MutexLife inflight_mutex_life{&inflight_mutex};
     struct InFlight { const LeafRequest* owner; std::vector<LeafSlot*> followers; };
     std::unordered_map<uint64_t, InFlight> inflight;                    // position -> who leads it, and the slots that follow
     std::atomic<uint64_t> coalesced{0};
@@ -433,8 +438,7 @@ struct LeafPool {
                 // (with a minimum fill the predicate also turns true by the clock: short naps while boards are waiting for company)
                 const bool holding = (min_fill.load(std::memory_order_relaxed) > 0 || lead_us.load(std::memory_order_relaxed) > 0) &&
                                      batcher->queued.load(std::memory_order_acquire) > 0;
-                work.wait_for(lock, holding ? std::chrono::microseconds(100) : std::chrono::microseconds(20000),
-                              [&] { return stopping || (!paused && ready()); });
+                wait_for_us(work, lock, holding ? 100 : 20000, [&] { return stopping || (!paused && ready()); });
                 if (stopping) return;
                 if (paused || !ready()) continue;
                 ++evaluating;       // from here to done(): a pause waits for us

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "tsan_mutex.h"
 #include "../../include/dgnn_test.h"   // dgnn.h + dgnn_host.h + the test-only entry points (exported by the test build only)
 
 namespace dgnn {
@@ -100,6 +101,7 @@ struct Network {
     bool destroy_pending = false;  // dgnn_network_destroy came while workspaces were checked out: the last release deletes the network
 
     std::mutex mutex;
+    MutexLife mutex_life{&mutex};
     std::map<int, std::unique_ptr<DeviceState>> devices;
 
     ~Network();
@@ -181,6 +183,7 @@ bool host_simd(bool need_f16c = false);
 
 // thread-local HIP error detail
 void set_last_hip_error(int code);
+
 
 // Test hook (include/dgnn_test.h: dgnn_test_fail_push_after): >= 0 counts down with every board pushed into a batcher's queue; the
 // push that finds it at 0 fails with DGNN_OUT_OF_MEMORY, as an allocation that failed would.  -1 (always, outside the tests): off.

@@ -1,5 +1,6 @@
 // User-level fibers (fiber.h).  Host code only.
 #include "fiber.h"
+#include "tsan_mutex.h"
 
 #include <sys/mman.h>
 
@@ -85,6 +86,7 @@ namespace {
 
 struct Scheduler {
     std::mutex mutex;
+    dgnn::MutexLife mutex_life{&mutex};
     std::condition_variable cv;
     std::vector<Fiber*> ready;                 // pushed by any thread
     bool sleeping = false;

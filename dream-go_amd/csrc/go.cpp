@@ -1542,6 +1542,7 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
     dgnn_selfplay_window* window = params->window;
     std::thread watcher;
     std::mutex watch_mutex;
+    MutexLife watch_mutex_life{&watch_mutex};
     std::condition_variable watch_cv;
     bool job_over = false;
     if (window && window->seconds > 0.0) {
@@ -1550,7 +1551,8 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
             auto snapshot = [&] { return Snapshot{moves.load(), evals.load(), hits.load(), conflicts.load(), started.load(), completed.load(), ended.load(), stones_completed.load(), std::chrono::steady_clock::now()}; };
             auto sleep_until = [&](double seconds_after_start) {              // false: the job ended before that
                 std::unique_lock<std::mutex> lock(watch_mutex);
-                return !watch_cv.wait_until(lock, t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds_after_start)), [&] { return job_over; });
+                const long long left_us = (long long)(1e6 * (seconds_after_start - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()));
+                return !wait_for_us(watch_cv, lock, left_us > 0 ? left_us : 0, [&] { return job_over; });
             };
             sleep_until(std::max(0.0, window->ramp_seconds));
             if (window->on_edge) window->on_edge(window->ctx, 0);

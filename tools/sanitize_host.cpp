@@ -130,6 +130,30 @@ int main() {
         dgnn_pool_destroy(pool);
         dgnn_cache_destroy(cache);
     }
+    {   // twelve threads probing ONE root while its child slots grow past the inline eight, the first chunk and the point
+        // where the index -> slot map appears (tree.cpp: TreeNode::find / find_or_create) -- every probe's virtual loss sends the
+        // next one to a new child of a flat prior
+        std::vector<float> prior(362, 1.0f / 362.0f);
+        for (int attempt = 0; attempt < 40; ++attempt) {
+            dgnn_tree_node* root = dgnn_tree_node_new(0, 0.5f, prior.data());
+            std::vector<std::thread> threads;
+            for (int t = 0; t < 12; ++t)
+                threads.emplace_back([&] {
+                    for (int i = 0; i < 6; ++i) {
+                        dgnn_trace* trace = nullptr;
+                        if (dgnn_tree_probe(root, nullptr, nullptr, &trace) != DGNN_PROBE_FOUND) continue;
+                        dgnn_tree_insert(trace, 1, 0.5f, prior.data());
+                        dgnn_trace_free(trace);
+                    }
+                });
+            for (std::thread& t : threads) t.join();
+            int total = 0, vtotal = 0;
+            dgnn_tree_node_info(root, nullptr, &total, &vtotal, nullptr, nullptr);
+            if (vtotal != 0 || total <= 0) std::printf("one root, twelve threads: total %d vtotal %d\n", total, vtotal);
+            dgnn_tree_node_free(root);
+        }
+        std::printf("one root probed by twelve threads across the slot-map boundary: 40 roots\n");
+    }
     // synthetic self-play with many threads
     dgnn_selfplay_stats st;
     int rc = dgnn_selfplay_synthetic(dgnn_hash_predictor(), nullptr, 4, 4, 60, 8, 3, &st);

@@ -2,10 +2,11 @@
 # Sanitizer runs of the host rows (board, search, tree, cache, formats) on the CPU -- GPU sanitizers are not available on the
 # pool.  The engine entry points the batcher links against are replaced by a CPU stand-in, so the leaf pool runs for real.
 #   tools/sanitize_host.sh            AddressSanitizer + UBSan, then ThreadSanitizer
-# Expected: ASan / UBSan silent.  TSan reports only the search tree's documented plain reads: the PUCT loop reads the children's
-# counters and values without locks while other threads update them (tree.cpp puct_*; the reference does the same, tree.rs:63-115),
-# and a "mutex is already destroyed" pair on the leaf pool: a std::mutex (constexpr constructor, invisible to TSan) living at a
-# heap address where an earlier object's mutex was destroyed -- the accesses it flags are under that very mutex.
+# Expected: ASan / UBSan silent; TSan silent BY CONSTRUCTION (round 5): halt_on_error=1, no suppression file.  The search tree's
+# counters and the children's running values are relaxed atomics (tree.cpp: the same loads and stores on x86; the reference reads
+# them plainly, tree.rs:63-115).  What rounds 3-4 triaged as "a std::mutex at a reused address" was this toolchain's TSan runtime
+# not intercepting pthread_cond_clockwait (libstdc++'s steady-clock wait_for): it missed the unlock / relock inside the wait.  Under
+# TSan the timed waits go through pthread_cond_timedwait, and mutex lifetimes are announced (csrc/tsan_mutex.h).
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 SRC="$ROOT/dream-go_amd/csrc"
@@ -65,6 +66,6 @@ FILES="$SRC/go.cpp $SRC/batcher.cpp $SRC/formats.cpp $SRC/tree.cpp $SRC/search.c
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/asan" -lpthread
 echo "== AddressSanitizer + UBSan"; ASAN_OPTIONS="detect_stack_use_after_return=1" "$TMP/asan"
 g++ -O1 -g -std=c++17 -fsanitize=thread -fno-omit-frame-pointer -I"$ROOT/include" -I"$SRC" $FILES -o "$TMP/tsan" -lpthread
-echo "== ThreadSanitizer"; TSAN_OPTIONS="halt_on_error=0" "$TMP/tsan" > "$TMP/tsan.out" 2>&1 || true
-grep -A6 "WARNING: ThreadSanitizer" "$TMP/tsan.out" | grep -E "#0" | sed 's/0x[0-9a-f]* //' | awk '{print $2, $3}' | sort | uniq -c | sort -rn
-tail -4 "$TMP/tsan.out"
+echo "== ThreadSanitizer (halt_on_error=1, no suppressions)"
+TSAN_OPTIONS="halt_on_error=1" "$TMP/tsan" > "$TMP/tsan.out" 2>&1 && echo "TSan: clean" || { echo "TSan: FAILED"; grep -A12 "WARNING: ThreadSanitizer" "$TMP/tsan.out" | head -60; }
+tail -6 "$TMP/tsan.out"
