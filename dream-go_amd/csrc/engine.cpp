@@ -908,9 +908,11 @@ int dgnn_last_hip_error(void) { return g_last_hip_error; }
 const char* dgnn_version(void)
 {
 #ifdef DGNN_ABLATIONS
-    return "dgnn-hip 0.3 (gfx950; board kernel mfma_f32_16x16x32_f16; +ablations: tile kernels, ablated board kernels)";
+    return "dgnn-hip 0.5 (gfx950; board kernel mfma_f32_16x16x32_f16; +ablations: tile kernels, pair split, ablated board kernels, measurement hooks; +test entries)";
+#elif defined(DGNN_TEST_ENTRIES)
+    return "dgnn-hip 0.5 (gfx950; board kernel mfma_f32_16x16x32_f16; +test entries of include/dgnn_test.h)";
 #else
-    return "dgnn-hip 0.3 (gfx950; board kernel mfma_f32_16x16x32_f16)";
+    return "dgnn-hip 0.5 (gfx950; board kernel mfma_f32_16x16x32_f16)";
 #endif
 }
 

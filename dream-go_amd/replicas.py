@@ -183,11 +183,22 @@ def gpu_numa_node(local_rank=0, sysfs_root="/sys"):
     return node if node >= 0 else None
 
 
-def numa_node_cpus(node, sysfs_root="/sys"):
+def numa_node_cpus(node, sysfs_root="/sys", primary_threads=0):
+    """The CPUs of a NUMA node.  primary_threads > 0: when the node lists its CPUs as several ranges ("0-63,128-191": the cores' first
+    hardware threads, then their SMT siblings) and the first range alone holds that many CPUs, only the first range -- a rank's slice
+    is then one thread on each of `quota` neighbouring cores, not a handful of cores and their siblings (whose other halves may
+    belong to somebody else's busy threads: /proc/stat calls such a sibling idle)."""
     import os
     try:
-        return _parse_cpulist(open(os.path.join(sysfs_root, "devices", "system", "node", f"node{int(node)}", "cpulist")).read())
+        text = open(os.path.join(sysfs_root, "devices", "system", "node", f"node{int(node)}", "cpulist")).read()
     except (OSError, ValueError):
+        return []
+    ranges = [r for r in text.strip().split(",") if r]
+    try:
+        if primary_threads > 0 and len(ranges) > 1 and len(_parse_cpulist(ranges[0])) >= primary_threads:
+            return _parse_cpulist(ranges[0])
+        return _parse_cpulist(text)
+    except ValueError:
         return []
 
 
@@ -210,8 +221,18 @@ def pin_to_compact_cpus(local_rank=0, quota=None, sysfs_root="/sys"):
         return None
     allowed = sorted(os.sched_getaffinity(0))
     node = gpu_numa_node(local_rank, sysfs_root)
+    if node is not None and quota is None:
+        quota_hint = 16
+        try:
+            q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota_hint = max(1, int(int(q) / int(period)))
+        except (OSError, ValueError):
+            pass
+    else:
+        quota_hint = quota or 16
     if node is not None:
-        local = [c for c in numa_node_cpus(node, sysfs_root) if c in set(allowed)]
+        local = [c for c in numa_node_cpus(node, sysfs_root, primary_threads=quota_hint) if c in set(allowed)]
         if local:
             # my turn among the node's ranks: the lower local ranks whose GPU sits on the same node
             world_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))

@@ -53,11 +53,12 @@ def test_forward_boards_gives_the_bits_of_forward_on_the_same_planes(api, synth,
     assert np.array_equal(a[1].view(np.uint16)[: half * 362], c[1].view(np.uint16))
 
 
-def test_device_planes_equal_the_committed_oracle_fixture(api):
+def test_device_planes_equal_the_committed_oracle_fixture(api_full):
     """The device kernel against an oracle that is NOT product code: tests/golden/planes_real_games.npz holds the
     planes oracle/features.py computes -- flood fills, simulated moves, whole-position super-ko; made by tests/golden/make_planes.py
     -- for every 5th position of the three reference games x both colours x eight symmetries.  board_records_kernel builds the same
     words from 896-byte records."""
+    api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     import json
     import os
     from conftest import GOLDEN

@@ -189,6 +189,13 @@ def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(monkeypatch, tmp_path):
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
     assert replicas.visible_gpu_index(1) == 6 and replicas.gpu_numa_node(1, root) == 1
     assert replicas.visible_gpu_index(2) is None and replicas.gpu_numa_node(2, root) is None      # not a visible device
+    # a node that lists SMT siblings as a second range ("0-63,128-191"): a rank's slice is one thread on each of 16 neighbouring cores
+    open(os.path.join(root, "devices", "system", "node", "node0", "cpulist"), "w").write("0-63,128-191\n")
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    assert replicas.numa_node_cpus(0, root) == list(range(64)) + list(range(128, 192))
+    assert replicas.numa_node_cpus(0, root, primary_threads=16) == list(range(64))
+    assert replicas.pin_to_compact_cpus(2, quota=16, sysfs_root=root) == list(range(32, 48))
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))
     # no topology (this container): the numeric slices, as before
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
