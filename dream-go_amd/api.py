@@ -268,7 +268,7 @@ SYMBOLS = [
 
 # include/dgnn_test.h: exported by the test build (and the ablations build) only; calling one of them through a binding of the shipped
 # library raises AttributeError -- loudly, at the call
-TEST_ONLY = frozenset('dgnn_pool_create_callbacks_boards dgnn_go_count dgnn_argmax_f32 dgnn_batch_destroy dgnn_batch_features dgnn_batch_forward dgnn_batch_forward_on dgnn_batch_records dgnn_batch_size dgnn_batch_tags dgnn_batcher_create dgnn_batcher_create_boards dgnn_batcher_destroy dgnn_batcher_get_batch dgnn_batcher_pending dgnn_batcher_push dgnn_batcher_push_and_get_batch dgnn_batcher_push_board dgnn_batcher_stats dgnn_board_records_to_packed_device dgnn_cache_fetch dgnn_cache_generation dgnn_cache_insert dgnn_cache_insert_at dgnn_choose dgnn_choose_f64 dgnn_config_fpu_reduce dgnn_config_lcb_critical_value dgnn_config_uct_exp dgnn_config_vloss_cnt dgnn_dirichlet_add dgnn_forward_pipelined_timed dgnn_full_forward dgnn_full_forward_boards dgnn_go_at dgnn_go_benson dgnn_go_benson_flood dgnn_go_candidates dgnn_go_check dgnn_go_hash dgnn_go_is_ladder_capture dgnn_go_is_ladder_escape dgnn_go_is_scorable dgnn_go_is_symmetric dgnn_go_n_liberty dgnn_go_n_liberty_if dgnn_go_result_sgf dgnn_go_score dgnn_go_stone_status dgnn_go_to_move dgnn_intp_value dgnn_layer_conv3x3 dgnn_layer_dense dgnn_layer_heads dgnn_policy_with_transform dgnn_pool_adaptive_stats dgnn_pool_create dgnn_pool_set_adaptive_batches dgnn_pool_set_extra_batch_queue dgnn_pool_set_min_fill dgnn_rollout_limit_is_done dgnn_search_run dgnn_search_run_cached dgnn_selfplay_synthetic dgnn_symmetry_apply dgnn_symmetry_inverse dgnn_synthetic_board_free dgnn_synthetic_board_new dgnn_synthetic_game_ops dgnn_test_fail_push_after dgnn_trace_get dgnn_trace_len dgnn_tree_node_child dgnn_tree_node_disqualify dgnn_tree_node_min_promote dgnn_tree_node_prior dgnn_tree_undo dgnn_workspace_download_pre'.split())
+TEST_ONLY = frozenset('dgnn_forward_stage_times dgnn_workspace_device_buffers dgnn_pool_create_callbacks_boards dgnn_go_count dgnn_argmax_f32 dgnn_batch_destroy dgnn_batch_features dgnn_batch_forward dgnn_batch_forward_on dgnn_batch_records dgnn_batch_size dgnn_batch_tags dgnn_batcher_create dgnn_batcher_create_boards dgnn_batcher_destroy dgnn_batcher_get_batch dgnn_batcher_pending dgnn_batcher_push dgnn_batcher_push_and_get_batch dgnn_batcher_push_board dgnn_batcher_stats dgnn_board_records_to_packed_device dgnn_cache_generation dgnn_cache_insert_at dgnn_choose dgnn_choose_f64 dgnn_config_fpu_reduce dgnn_config_lcb_critical_value dgnn_config_uct_exp dgnn_config_vloss_cnt dgnn_dirichlet_add dgnn_forward_pipelined_timed dgnn_full_forward dgnn_full_forward_boards dgnn_go_at dgnn_go_benson dgnn_go_benson_flood dgnn_go_candidates dgnn_go_check dgnn_go_hash dgnn_go_is_ladder_capture dgnn_go_is_ladder_escape dgnn_go_is_scorable dgnn_go_is_symmetric dgnn_go_n_liberty dgnn_go_n_liberty_if dgnn_go_result_sgf dgnn_go_score dgnn_go_stone_status dgnn_go_to_move dgnn_intp_value dgnn_layer_conv3x3 dgnn_layer_dense dgnn_layer_heads dgnn_policy_with_transform dgnn_pool_adaptive_stats dgnn_pool_create dgnn_pool_set_adaptive_batches dgnn_pool_set_extra_batch_queue dgnn_pool_set_min_fill dgnn_rollout_limit_is_done dgnn_search_run dgnn_search_run_cached dgnn_selfplay_synthetic dgnn_symmetry_apply dgnn_symmetry_inverse dgnn_synthetic_board_free dgnn_synthetic_board_new dgnn_synthetic_game_ops dgnn_test_fail_push_after dgnn_trace_get dgnn_trace_len dgnn_tree_node_child dgnn_tree_node_disqualify dgnn_tree_node_min_promote dgnn_tree_node_prior dgnn_tree_undo dgnn_workspace_download_pre'.split())
 
 
 def load_full():

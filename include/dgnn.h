@@ -182,10 +182,6 @@ int dgnn_board_records_to_packed(const uint8_t* records, int count, uint32_t* pa
 
 int dgnn_workspace_batch_size(const dgnn_workspace* ws, int* batch_size, int* device);
 
-/* The workspace's own HBM buffers: features [batch*11552] fp16, value [batch] fp16,
- * policy [batch*362] fp16.  Valid until the workspace is destroyed. */
-int dgnn_workspace_device_buffers(dgnn_workspace* ws, void** d_features, void** d_value, void** d_policy);
-
 /* The workspace's pinned host staging buffers (same shapes).  A batcher may assemble features directly in
  * h_features and pass that pointer to dgnn_forward / dgnn_forward_submit: the staging memcpy is then skipped
  * (likewise for value_out == h_value, policy_out == h_policy). */
@@ -224,14 +220,6 @@ int dgnn_forward_timed(dgnn_workspace* ws, int steps, float* total_ms, float* to
  * *seconds = wall time of the `steps` evaluations. */
 int dgnn_forward_pipelined_timed_n(dgnn_workspace* const* workspaces, int in_flight, int form, const void* input, int count, int steps,
                                    double* seconds);
-
-/* Where the wall time of one device batch goes: `steps` submissions of `count` board records with HIP events between the stages of a
- * submission on the workspace's stream, `in_flight` (1..8) distinct workspaces kept busy the way a leaf pool keeps batches alive.
- * stage_us[7]: mean microseconds per stage -- H2D of the records, planes kernel, tower, head convolution, policy GEMM, soft-max +
- * value, D2H of the outputs (a stage that waits for compute units held by another submission's tower shows as long);  host_us[4]:
- * the submit call, submit -> answers with the caller, the device's span first -> last stamp, and the difference of the last two. */
-int dgnn_forward_stage_times(dgnn_workspace* const* workspaces, int in_flight, const uint8_t* records, int count, int steps,
-                             float* stage_us /* 7 */, double* host_us /* 4 */);
 
 /* ---- multi-GPU: weight image for an RCCL broadcast ------------------------------------------ */
 

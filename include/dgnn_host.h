@@ -44,7 +44,10 @@ extern "C" {
 typedef struct dgnn_cache dgnn_cache;
 int dgnn_cache_create(size_t capacity, int num_shards, dgnn_cache** out);        /* reference: 200 000 + 1, nn.rs:29,57 */
 void dgnn_cache_destroy(dgnn_cache* cache);
-/* (fetch / insert of single entries, which the search driver does inside the library: dgnn_test.h.) */
+/* NnPredictor::{fetch, cache} (nn.rs:60-82).  fetch: 1 on a hit (value_out / policy_out[362] filled, remapped by `symmetry`), 0 on a
+ * miss, < 0 on error.  insert: stores the prediction remapped by symmetry.inverse(); a key that is already present is left untouched. */
+int dgnn_cache_fetch(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t* value_out, uint16_t* policy_out);
+int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy);
 int dgnn_cache_stats(dgnn_cache* cache, uint64_t* entries, uint64_t* hits, uint64_t* misses);
 int dgnn_cache_clear(dgnn_cache* cache);     /* drops every entry: the table holds the outputs of the weights that are being replaced */
 /* A clear also starts a new GENERATION of the table: the search driver reads the generation before a fetch and stores the answer of a

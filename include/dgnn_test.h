@@ -50,6 +50,16 @@ DGNN_TEST_API int dgnn_layer_heads(int device, const uint16_t* logits, const uin
 DGNN_TEST_API int dgnn_workspace_download_pre(dgnn_workspace* ws, uint16_t* logits_out, uint16_t* value_pre_out);
 /* The planes the DEVICE builds from `count` board records (features.hip), downloaded in packed form (allocates, runs, frees). */
 DGNN_TEST_API int dgnn_board_records_to_packed_device(int device, const uint8_t* records, int count, uint32_t* packed);
+/* Where the wall time of one device batch goes: `steps` submissions of `count` board records with HIP events between the stages of a
+ * submission on the workspace's stream, `in_flight` (1..8) distinct workspaces kept busy the way a leaf pool keeps batches alive.
+ * stage_us[7]: mean microseconds per stage -- H2D of the records, planes kernel, tower, head convolution, policy GEMM, soft-max +
+ * value, D2H of the outputs (a stage that waits for compute units held by another submission's tower shows as long);  host_us[4]:
+ * the submit call, submit -> answers with the caller, the device's span first -> last stamp, and the difference of the last two. */
+DGNN_TEST_API int dgnn_forward_stage_times(dgnn_workspace* const* workspaces, int in_flight, const uint8_t* records, int count, int steps,
+                             float* stage_us /* 7 */, double* host_us /* 4 */);
+/* The workspace's own HBM buffers: features [batch*11552] fp16, value [batch] fp16,
+ * policy [batch*362] fp16.  Valid until the workspace is destroyed. */
+DGNN_TEST_API int dgnn_workspace_device_buffers(dgnn_workspace* ws, void** d_features, void** d_value, void** d_policy);
 /* dgnn_forward_pipelined_timed_n with two workspaces (rounds 2-4 called this form). */
 DGNN_TEST_API int dgnn_forward_pipelined_timed(dgnn_workspace* a, dgnn_workspace* b, int form, const void* input, int count, int steps, double* seconds);
 
@@ -60,11 +70,8 @@ DGNN_TEST_API int dgnn_forward_pipelined_timed(dgnn_workspace* a, dgnn_workspace
 DGNN_TEST_API int dgnn_symmetry_inverse(int transform);
 DGNN_TEST_API int dgnn_symmetry_apply(int transform, int packed_index);
 DGNN_TEST_API int dgnn_policy_with_transform(const uint16_t* policy, int transform, uint16_t* out);
-/* NnPredictor::{fetch, cache} (src/libdg_mcts/predictors/nn.rs:60-82): fetch returns 1 on a hit (value / policy[362] remapped by
- * `symmetry`), 0 on a miss; insert stores the prediction remapped by symmetry.inverse(), a key that is present is left untouched;
- * insert_at drops an answer whose miss predates a dgnn_cache_clear (generation = dgnn_cache_generation read before the fetch). */
-DGNN_TEST_API int dgnn_cache_fetch(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t* value_out, uint16_t* policy_out);
-DGNN_TEST_API int dgnn_cache_insert(dgnn_cache* cache, uint64_t board_hash, int to_move, int symmetry, uint16_t value, const uint16_t* policy);
+/* The table's generation (dgnn_cache_clear starts a new one) and an insert that drops an answer whose miss predates a clear
+ * (generation = dgnn_cache_generation read before the fetch): what the library's search driver does inside. */
 DGNN_TEST_API uint64_t dgnn_cache_generation(const dgnn_cache* cache);
 DGNN_TEST_API int dgnn_cache_insert_at(dgnn_cache* cache, uint64_t generation, uint64_t board_hash, int to_move, int symmetry, uint16_t value,
                          const uint16_t* policy);

@@ -27,6 +27,7 @@ def main():
     import __graft_entry__ as graft
     graft.package()
     from dream_go_amd import api, synth
+    api = api.load_full()          # dgnn_forward_stage_times is a measurement entry of include/dgnn_test.h: the test build of the library
     import bench
     net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
     positions = bench.real_game_positions(api)
