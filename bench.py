@@ -151,6 +151,29 @@ def cpu_baseline(text, features, batch, sample):
     }, (value, policy)
 
 
+def cpu_second_opinion(text, features, batch, sample, threads):
+    """a second CPU figure beside the OpenMP port -- the same network stated from the trainer's graph in torch-CPU fp32
+    (F.conv2d; oracle/torch_statement.py, the statement tests/test_third_statement.py holds against the oracle), on as many threads."""
+    import torch
+    from oracle import oracle
+    from oracle.torch_statement import trainer_graph_forward
+    tensors, _ = oracle.load_weights(text)
+    sample = min(sample, batch)
+    f = np.ascontiguousarray(features.reshape(batch, 11552)[:sample].reshape(-1))
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(1, int(threads)))
+    try:
+        with torch.no_grad():
+            trainer_graph_forward(tensors, f[:11552], 1, round_layers=True)          # warm
+            t0 = time.perf_counter()
+            value, policy = trainer_graph_forward(tensors, f, sample, round_layers=True)
+            dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(before)
+    return {"value": sample / dt, "unit": "evals/s", "cores": int(threads), "kind": "port",
+            "sample": f"{sample} boards, torch-CPU fp32 F.conv2d with fp16 rounding per layer (oracle/torch_statement.py), {dt:.1f} s"}, (value, policy)
+
+
 def real_game_positions(api):
     """Every position of the three committed reference games (tests/golden/real_games.json; the SGF fixtures of
     src/dg_tests/tests/real_games.rs) as (board, colour to move)."""
@@ -845,6 +868,12 @@ def main():
                 if pinned is not None:
                     os.sched_setaffinity(0, pinned)
                 out["cpu_baseline"] = baseline
+                # the second opinion SURVEY.md 8d names: torch-CPU F.conv2d on a quarter of the sample, and how far its outputs are from the port's
+                second, (tv, tp) = cpu_second_opinion(text, features, args.batch, max(8, args.cpu_sample // 4), baseline["cores"])
+                k = min(len(tv), n)
+                second["max_abs_diff_vs_port"] = [float(np.abs(tv[:k] - np.asarray(ref_value).view(np.float16).astype(np.float32)[:k]).max()),
+                                                  float(np.abs(tp[:k] - np.asarray(ref_policy).view(np.float16).astype(np.float32)[:k * 362].reshape(k, 362)).max())]
+                out["cpu_baseline_second_opinion"] = second
                 flat_what = "the network and batch of `value` (He-init, Bernoulli(0.2) planes): HIP resident path vs oracle/dgnn_oracle.c"
             parity = {"flat": parity_entry(leg_ws, features, n, ref_value, ref_policy, flat_what)}
             if not job.dry and not args.lean and positions is not None:
