@@ -63,13 +63,15 @@ def parse_args(argv=None):
     ap.add_argument("--selfplay-leaves", type=int, default=16,
                     help="leaves a search thread keeps on the device (dgnn_search_run_batched): one thread x 16 leaves = the reference's default of 16 "
                          "parallel probes per search tree (--num-threads, libdg_utils/config.rs:143-149; rounds 1-3 ran 8)")
-    ap.add_argument("--selfplay-batches", type=int, default=2,
-                    help="device batches the leaf pool keeps alive per GPU.  The reference keeps 2 (nn.rs:64-67); a third raises the engine's "
-                         "rate on partial batches and puts more leaves in flight (more positions evaluated twice before the first answer "
-                         "reaches the transposition table; measured in DESIGN.md 11.7, 13.5)")
+    ap.add_argument("--selfplay-batches", type=int, default=3,
+                    help="device batches the leaf pool keeps alive per GPU.  The reference keeps 2 (nn.rs:64-67: the reference-rule leg runs "
+                         "that).  A third keeps the device supplied across the host's turn-around between batches and on partial batches; it "
+                         "puts more leaves in flight, but with coalescing a position evaluated twice in flight is a follower, not a second "
+                         "evaluation (DESIGN.md 11.7, 13.5; round 5, same box: steady-state whole games 0.97 -> 1.00 of `value`, 14.2)")
     ap.add_argument("--selfplay-workers", type=int, default=0,
-                    help="pool worker threads per GPU; 0 (default) = as many as batches alive.  One more lets a free worker take the next batch while "
-                         "another is still handing 256 answers to their games (about a millisecond per cycle, DESIGN.md 13.10 / 13.11: not measured yet)")
+                    help="pool worker threads per GPU; 0 (default) = one more than batches alive: a free worker takes the next batch while another "
+                         "is still handing 256 answers to their games (round 5, same box, two runs each: mid-game leg 0.95 -> 0.985 of `value`, "
+                         "steady-state whole games 0.97 -> 0.99 with two alive; DESIGN.md 14.2)")
     ap.add_argument("--selfplay-coalesce", type=int, default=1,
                     help="1 (default): a request for a position that is already queued or on the device follows it instead of being evaluated "
                          "again (dgnn_pool_set_coalescing: what the shared transposition table does, one evaluation earlier); 0: the reference's behaviour")
@@ -298,31 +300,31 @@ def broadcast_weights(job, api, net):
             "distinct_images_before": len(set(before)), "seconds_incl_comm_setup": seconds}
 
 
-def selfplay_pool(job, api, net, args, coalesce=None, back_to_back=None):
+def selfplay_pool(job, api, net, args, coalesce=None, back_to_back=None, batches=None):
     """The leaf pool of every self-play leg: one device (or its stand-in), `--selfplay-batches` batches alive, coalescing and
-    back-to-back batching as the arguments say (coalesce / back_to_back override them: the reference-rule leg)."""
+    back-to-back batching as the arguments say (coalesce / back_to_back / batches override them: the reference-rule leg)."""
     boards = args.selfplay_planes == "device"
+    alive = args.selfplay_batches if batches is None else batches
+    workers = max(args.selfplay_workers, alive) if (args.selfplay_workers > 0 or batches is not None) else alive + 1
     if job.dry and boards:
         # no GPU: the CPU stand-in behind a stand-in for the device (a batch of n boards takes 500 + 10.8 n us, one at a time: the
         # 20x256 engine's 3.3 ms at 256 boards) -- what is measured is the HOST side alone, rollouts per second and core
-        pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=args.selfplay_batches,
-                                           workers_per_lane=max(args.selfplay_workers, args.selfplay_batches))
+        pool = api.LeafPool.over_dry_device(base_us=500.0, per_board_us=10.8, max_batch_size=args.batch, batches_per_lane=alive, workers_per_lane=workers)
     elif job.dry:
         pool = api.LeafPool.over_callbacks(api.lib.dgnn_hash_predictor(), None, num_lanes=1, max_batch_size=args.batch)
     else:
-        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=args.selfplay_batches,
-                                        workers_per_device=max(args.selfplay_workers, args.selfplay_batches), boards=boards)
+        pool = api.LeafPool.over_devices(net, [job.device], max_batch_size=args.batch, batches_per_device=alive, workers_per_device=workers, boards=boards)
     coalesce = (bool(args.selfplay_coalesce) if coalesce is None else coalesce) and pool.takes_boards   # (the games of a leg share one transposition table)
     if coalesce:
         pool.set_coalescing(True)
     lead = args.selfplay_back_to_back if back_to_back is None else back_to_back
     if lead > 0:
         pool.set_back_to_back(lead)
-    return pool, {"coalesce": coalesce, "back_to_back": lead, "boards": boards}
+    return pool, {"coalesce": coalesce, "back_to_back": lead, "boards": boards, "alive": alive, "workers": workers}
 
 
 def pool_rule_text(args, rule):
-    return (f"{args.selfplay_batches} device batches alive" +
+    return (f"{rule['alive']} device batches alive, {rule['workers']} pool workers" +
             (f", partial batches back to back (lead {rule['back_to_back']} us)" if rule["back_to_back"] > 0 else ", a free slot takes what is queued (the reference's rule)") +
             (", positions in flight coalesced" if rule["coalesce"] else ", no coalescing (the reference: every miss is evaluated)"))
 
@@ -442,7 +444,8 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0, reference_rule=F
     reference's own behaviour."""
     games = args.selfplay_games * job.world
     cache = api.LruCache(200_001, num_shards=8)                                    # predictors/nn.rs:29,57
-    pool, rule = selfplay_pool(job, api, net, args, coalesce=False if reference_rule else None, back_to_back=0 if reference_rule else None)
+    pool, rule = selfplay_pool(job, api, net, args, coalesce=False if reference_rule else None, back_to_back=0 if reference_rule else None,
+                               batches=2 if reference_rule else None)        # (nn.rs:64-67: 2 batches alive per device, a worker each)
     coalesce, boards = rule["coalesce"], rule["boards"]
     opening = None
     if fast_forward > 0:
@@ -508,7 +511,7 @@ def selfplay_leg(job, api, replicas, net, args, fast_forward=0, reference_rule=F
         # what one rollout (probe, board, record, cache, prior, insert, queueing) costs this rank's host: CPU seconds / rollouts
         "host_us_per_rollout": 1e6 * cpu_seconds / max(rank_rollouts, 1),
         "host_us_per_eval": 1e6 * cpu_seconds / max(out["evals"], 1),
-        "batching_rule": "reference (no coalescing, a free slot takes what is queued)" if reference_rule else "tuned (see `what`)",
+        "batching_rule": "reference (2 batches alive, no coalescing, a free slot takes what is queued)" if reference_rule else "tuned (see `what`)",
     }
     leg["coalescing"] = coalesce
     leg["coalesced_boards_rank0"] = coalesced      # boards that followed a position in flight instead of being evaluated (whole pool lifetime)

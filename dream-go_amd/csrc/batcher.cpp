@@ -471,26 +471,37 @@ struct LeafPool {
             dgnn_batch_destroy(batch);
             wake();                                 // a batch slot is free again
             auto deliver = [&](LeafSlot* slot, uint16_t v, const uint16_t* p) { complete_slot(slot, status, v, p); };
-            std::vector<LeafSlot*> followers;
+            // followers of the batch's leaders: ONE pass under the table's lock for the whole batch (a lock per slot was 256 lock / unlock
+            // pairs per batch against the game threads that register their own positions), before the first answer is handed out --
+            // after it a leader's request may return and take its slots with it
+            std::vector<std::pair<int, std::vector<LeafSlot*>>> followed;      // (index in the batch, the slots that followed it)
+            std::vector<uint8_t> leader_symmetry;
+            if (coalesce.load(std::memory_order_relaxed)) {
+                leader_symmetry.assign((size_t)n, 0);
+                std::lock_guard<std::mutex> lock(inflight_mutex);
+                for (int i = 0; i < n; ++i) {
+                    LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
+                    if (!slot->leads) continue;
+                    leader_symmetry[(size_t)i] = slot->symmetry;
+                    auto it = inflight.find(slot->position);
+                    if (it == inflight.end()) continue;
+                    if (!it->second.followers.empty()) { followed.emplace_back(i, std::vector<LeafSlot*>()); followed.back().second.swap(it->second.followers); }
+                    inflight.erase(it);
+                }
+            }
+            size_t next_followed = 0;
             for (int i = 0; i < n; ++i) {
                 LeafSlot* slot = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i]);
                 const uint16_t* p = policy.data() + (size_t)i * DGNN_NUM_MOVES;
-                followers.clear();
-                int leader_symmetry = 0;
-                if (slot->leads) {                         // (read before the leader's request can return and take its slots with it)
-                    leader_symmetry = slot->symmetry;
-                    std::lock_guard<std::mutex> lock(inflight_mutex);
-                    auto it = inflight.find(slot->position);
-                    if (it != inflight.end()) { followers.swap(it->second.followers); inflight.erase(it); }
-                }
                 deliver(slot, value[i], p);
-                if (!followers.empty()) {
+                if (next_followed < followed.size() && followed[next_followed].first == i) {
                     uint16_t canonical[DGNN_NUM_MOVES], oriented[DGNN_NUM_MOVES];
-                    if (status == DGNN_OK) with_transform(p, kInverse[leader_symmetry], canonical);        // nn.rs:78-81
-                    for (LeafSlot* f : followers) {
-                        if (status == DGNN_OK) with_transform(canonical, f->symmetry, oriented);           // nn.rs:72-74
+                    if (status == DGNN_OK) with_transform(p, kInverse[leader_symmetry[(size_t)i]], canonical);        // nn.rs:78-81
+                    for (LeafSlot* f : followed[next_followed].second) {
+                        if (status == DGNN_OK) with_transform(canonical, f->symmetry, oriented);                       // nn.rs:72-74
                         deliver(f, value[i], oriented);
                     }
+                    ++next_followed;
                 }
             }
             done();     // after the answers are with their requests: a pause returns with no old-weights answer still on its way

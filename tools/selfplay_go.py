@@ -40,8 +40,8 @@ def main():
     ap.add_argument("--back-to-back", type=int, default=300, metavar="LEAD_US", help="> 0 (default 300): a partial batch waits until this long before the batch on the device is expected to finish (dgnn_pool_set_back_to_back)")
     ap.add_argument("--snap", default="", metavar="LO,HI", help="with --back-to-back: a batch of LO < n < HI boards is cut to its LO oldest, e.g. 128,208")
     ap.add_argument("--coalesce", type=int, default=1, help="1: requests for a position in flight follow it (dgnn_pool_set_coalescing; only with a shared table); 0: off")
-    ap.add_argument("--max-batches", type=int, default=2, help="device batches the pool keeps alive: 2 (the reference's rule, default), 3, or 0 = adaptive, 2 or 3 by the unique positions per second the pool measures (dgnn_pool_set_adaptive_batches, DESIGN.md 13)")
-    ap.add_argument("--workers", type=int, default=0, help="pool worker threads per device; 0 (default) = as many as batches alive.  One more than that lets a free worker take the next batch while another is still handing its answers to the games (DESIGN.md 13.11: not measured yet)")
+    ap.add_argument("--max-batches", type=int, default=3, help="device batches the pool keeps alive: 3 (default since round 5, DESIGN.md 14.2), 2 (the reference's rule), or 0 = adaptive (a rule that lost; test build)")
+    ap.add_argument("--workers", type=int, default=0, help="pool worker threads per device; 0 (default) = one more than batches alive: a free worker takes the next batch while another is still handing its answers to the games (DESIGN.md 14.2: +2.5 %)")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
@@ -103,7 +103,7 @@ def main():
     import time
     capacity = 3 if (args.max_batches == 0 or args.extra_batch_queue > 0) else args.max_batches
     pool = api.LeafPool.over_devices(net, [device], max_batch_size=args.max_batch, batches_per_device=capacity,
-                                    workers_per_device=max(args.workers, capacity) if args.workers > 0 else capacity, boards=args.planes == "device")
+                                    workers_per_device=max(args.workers, capacity) if args.workers > 0 else capacity + 1, boards=args.planes == "device")
     if args.extra_batch_queue > 0:
         pool.set_extra_batch_queue(2, 3, args.extra_batch_queue)
     if args.min_fill > 0:
@@ -150,7 +150,7 @@ def main():
             "rollouts_per_move": args.rollouts, "ex_it_rollouts": args.ex_it or None, "ex_it_searches": job["ex_it_searches"], "search_threads_per_game": args.threads, "leaves_per_thread": args.leaves, "mean_device_batch": boards / max(batches, 1), "device_batch_us_by_size": {str(k): v for k, v in batch_times.items()},
             "probe_conflicts": job["conflicts"], "cache_hits": job["cache_hits"], "cache_entries": args.cache,
             "seconds": job["seconds"], "net": f"{args.blocks}x{args.channels}",
-            "pool_workers": max(args.workers, capacity) if args.workers > 0 else capacity, "batches_alive": adaptive_stats if adaptive else (f"2, a third while >= {args.extra_batch_queue} boards wait" if args.extra_batch_queue > 0 else args.max_batches), "coalescing": coalesce, "min_fill": [args.min_fill, args.min_fill_wait_us] if args.min_fill > 0 else None, "back_to_back": [args.back_to_back] + snap if (args.back_to_back > 0 or snap[0] > 0) else None, "coalesced_boards_rank0": coalesced,
+            "pool_workers": max(args.workers, capacity) if args.workers > 0 else capacity + 1, "batches_alive": adaptive_stats if adaptive else (f"2, a third while >= {args.extra_batch_queue} boards wait" if args.extra_batch_queue > 0 else args.max_batches), "coalescing": coalesce, "min_fill": [args.min_fill, args.min_fill_wait_us] if args.min_fill > 0 else None, "back_to_back": [args.back_to_back] + snap if (args.back_to_back > 0 or snap[0] > 0) else None, "coalesced_boards_rank0": coalesced,
             "feature_planes": args.planes, "host_threads": args.host_threads, "host_cpus_busy_rank0": host_cpus_busy,
             "weight_broadcast": {"mode": broadcast[0], "bytes": broadcast[1], "backend": "rccl"} if broadcast else None,
             "sharding": "game_id mod world, one engine + batcher + pool + cache per rank, no data-path collective",
