@@ -51,7 +51,7 @@ PACKED_WORDS = 368
 BOARD_RECORD_BYTES = 896
 RCCL_UNIQUE_ID_BYTES = 128
 
-# every symbol include/dgnn.h declares: (name, restype, argtypes)
+# every symbol the three headers declare (include/dgnn.h, dgnn_host.h, dgnn_test.h): (name, restype, argtypes)
 _u16p = ctypes.POINTER(ctypes.c_uint16)
 _vp = ctypes.c_void_p
 _vpp = ctypes.POINTER(ctypes.c_void_p)

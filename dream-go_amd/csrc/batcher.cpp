@@ -1,5 +1,5 @@
 // Host side of the boundary, row f-1 of the scope table: the many-game leaf batcher, the transposition cache and the
-// policy symmetry remap of dream-go's libdg_mcts, as a C++ library behind the C ABI (include/dgnn.h).
+// policy symmetry remap of dream-go's libdg_mcts, as a C++ library behind the C ABI (include/dgnn_host.h; single steps: dgnn_test.h).
 //
 //   symmetry   src/libdg_go/utils/symmetry.rs:19-128 (the 8 board symmetries and their inverses),
 //              Prediction::with_transform, src/libdg_mcts/predictor.rs:30-44

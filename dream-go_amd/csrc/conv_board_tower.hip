@@ -1,15 +1,20 @@
 // The residual tower as ONE launch: tower_board_kernel (a workgroup per board walks all layers) and tower_split_kernel (a board
 // split over several workgroups that hand channel blocks -- and, row split, row halves -- to each other).  Body: conv_board_body.h.
 #include "conv_board_body.h"
+#include "head_conv_body.h"
 
 namespace dgnn {
 namespace {
 
-template <int NS>
+// HEAD (round 5, the wide split only): the workgroup stays on its CU after the last layer and runs both head convolutions of the board it
+// has just finished (head_conv_body.h: the body of head_conv_board_kernel, the same arithmetic) -- one launch less per batch, and no
+// waiting for a free CU behind another batch's tower.
+template <int NS, bool HEAD>
 __global__ __launch_bounds__(Split<NS>::Threads)
-void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
+void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count, HeadConvLaunch head)
 {
-    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
+    constexpr int kHeadLds = HEAD ? headc::head_conv_lds_bytes<1, 6>() : 0;
+    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes > kHeadLds ? Split<NS>::LdsBytes : kHeadLds];
     int carry = 0;
     half8 af[2][Split<NS>::CT][2];                    // the filter fragments in registers, handed from layer to layer (DirectA)
     for (int i = 0; i < count; ++i) {
@@ -21,6 +26,13 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
         if (a.alpha2 != 0.0f) carry = conv_board_body<NS, 2, true, 0>(a, lds, blockIdx.x, 0, af, none, carry);
         else carry = conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0, af, none, carry);
         carry |= kChained;
+    }
+    if constexpr (HEAD) {
+        static_assert(Split<NS>::Threads == headc::kHeadThreads, "the head body runs on the tower's four waves");
+        // the last layer's stores are waited for by their waves (a layer ends that way); the barrier makes them the workgroup's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        headc::head_conv_board_body<1, 6>(head, lds, blockIdx.x, 0);
     }
 }
 
@@ -98,16 +110,25 @@ bool tower_board_supported(int batch, int channels)
     return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || ((slices == 4 || slices == 8) && batch >= tower_min_batch()));
 }
 
-hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream)
+// The head convolution can ride in the tower launch where the tower is the wide split (256 channels: the head body's 256 threads)
+// and the head is the one-tile, whole-board form (S + 2 <= 16 output channels).
+bool tower_board_takes_head(int channels, int samples) { return channels == 256 && samples + 2 <= 16; }
+
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, const HeadConvLaunch* head)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     if (!tower_board_supported(batch, channels)) return hipErrorInvalidValue;
+    if (head && !tower_board_takes_head(channels, head->samples)) return hipErrorInvalidValue;
     const dim3 grid(batch, 1);
+    const HeadConvLaunch none{};
     // A 256-channel tower walks with the wide work split (Split<16>: four waves, two 32-channel tiles each)
     switch (channels / 32) {
-        case 8: hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count); break;
-        case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
-        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count); break;
+        case 8:
+            if (head) hipLaunchKernelGGL((tower_board_kernel<16, true>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, *head);
+            else hipLaunchKernelGGL((tower_board_kernel<16, false>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, none);
+            break;
+        case 4: hipLaunchKernelGGL((tower_board_kernel<4, false>), grid, dim3(kThreads), 0, stream, d_layers, count, none); break;
+        default: hipLaunchKernelGGL((tower_board_kernel<2, false>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, none); break;
     }
     return hipGetLastError();
 }

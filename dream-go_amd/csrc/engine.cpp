@@ -371,6 +371,9 @@ int tower_mode(const Workspace* ws)
 
 bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
 
+// The head convolution inside the whole-board tower launch (round 5); DGNN_HEAD_IN_TOWER=0 (test / ablations build): a launch of its own (A/B).
+const bool kHeadInTower = [] { const char* e = test_env("DGNN_HEAD_IN_TOWER"); return !(e && std::atoi(e) == 0); }();
+
 // Enqueues graph.rs:134-152 on the workspace's stream.  `tower_pair` (may be -1) selects the event pair that
 // brackets the residual convolutions.
 enum InputForm { kInputFeatures = 0, kInputPacked = 1, kInputRecords = 2 };   // d_features / d_packed / d_records hold the batch
@@ -438,6 +441,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     };
 
     int cur = 0;
+    bool head_in_tower = false;
     const uint16_t* tower = nullptr;   // NHWC tower output for the heads
     auto stamp = [&](int stage) -> hipError_t { return ws->stage_on ? hipEventRecord(ws->stage_ev[stage], ws->stream) : hipSuccess; };
     // compact board records: the planes are built on the device (features.hip), straight into the up-layer's input on the board path
@@ -511,7 +515,23 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 DGNN_HIP(hipEventRecord(chain->done, ws->stream));
                 chain->recorded = true;
             } else {
-                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
+                // the head convolution rides in the tower launch where it can (the wide split, a one-tile head): its workgroup goes on with the
+                // board it has just finished
+                head_in_tower = kHeadInTower && t.head_w_board_offset != 0 && tower_board_takes_head(t.num_channels, t.num_samples) && !ws->d_tower_timing;
+                HeadConvLaunch hc;
+                if (head_in_tower) {
+                    int last = cur;
+                    for (int i = 0; i < t.num_blocks; ++i) last = (last + 2) % 3;
+                    hc.x = ws->d_act[last];
+                    hc.w = (const uint16_t*)(image + t.head_w_board_offset);
+                    hc.bias = (const uint16_t*)(image + t.head_b_offset);
+                    hc.policy_features = ws->d_policy_features;
+                    hc.value_features = ws->d_value_features;
+                    hc.batch = ws->active;
+                    hc.cin = t.num_channels;
+                    hc.samples = t.num_samples;
+                }
+                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream, head_in_tower ? &hc : nullptr));
                 if (ws->d_tower_timing) {
                     DGNN_HIP(hipStreamSynchronize(ws->stream));
                     const size_t words = (size_t)ws->tower_timing_layers * ws->batch * 8 * 4;
@@ -536,7 +556,9 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
         }
         if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
         DGNN_HIP(stamp(3));
-        if (t.head_w_board_offset != 0) {
+        if (head_in_tower) {
+            // (done by the tower launch)
+        } else if (t.head_w_board_offset != 0) {
             HeadConvLaunch hc;                                                      // value_head.rs:76 + policy_head.rs:92
             hc.x = ws->d_act[cur];
             hc.w = (const uint16_t*)(image + t.head_w_board_offset);
@@ -1383,7 +1405,7 @@ int dgnn_workspace_download(dgnn_workspace* handle, uint16_t* value_out, uint16_
     return DGNN_OK;
 }
 
-// Test-only (include/dgnn.h): the two fp16 tensors in front of the output activations, as the LAST pass on this workspace left them.
+// Test-only (include/dgnn_test.h): the two fp16 tensors in front of the output activations, as the LAST pass on this workspace left them.
 int dgnn_workspace_download_pre(dgnn_workspace* handle, uint16_t* logits_out, uint16_t* value_pre_out)
 {
     if (!handle || !logits_out || !value_pre_out) return DGNN_BAD_ARGUMENT;
