@@ -409,16 +409,31 @@ def whole_games_leg(job, api, replicas, net, args):
                    f"(not timed), so games at every stage are in flight from the start and END inside the window; {args.whole_games_ramp:.0f} s ramp, then the timed window; "
                    "random-init weights (such a net plays 600-700 stones per game: games_per_hour_at_250_stones is the same moves per second at a trained net's game length)")
     leg["games_per_hour_at_250_stones"] = leg["moves_per_sec"] * 3600.0 / 250.0
-    cross = os.path.join(ROOT, "profiles", "r04_final", "selfplay_full_games_96g_l16_h4_sparse_b2b300.json")
-    if os.path.exists(cross) and not job.dry:
-        try:
-            c = json.load(open(cross))
-            leg["cross_check_committed"] = {"games_per_hour_measured": c["games_per_hour_measured"], "moves_per_sec": c["moves_per_sec"],
-                                            "mean_stones_per_game": c["mean_stones_per_game"],
-                                            "source": "profiles/r04_final/selfplay_full_games_96g_l16_h4_sparse_b2b300.json: 96 games from the empty board to their end, no "
-                                                      "replacement (tools/selfplay_go.py --games 96 --moves 0), a builder-run file -- a label beside the measurement, not the measurement"}
-        except Exception:   # noqa: BLE001
-            pass
+    # Labelled cross-checks, builder-run files: (1) the same steady state measured over TEN minutes with tools/selfplay_go.py --steady 20,600
+    # -- the figure this leg's moves per second are to be compared with, and the game length a window of 90 s cannot see: the games that
+    # end inside it were seeded by policy play and are ~100 stones shorter than games searched from the empty board; (2) round 4's file:
+    # 96 games STARTED TOGETHER, whose searches share 40 % of their leaves -- not comparable, kept to say so.
+    if not job.dry:
+        for key, name, note in (
+                ("steady_state_profile", os.path.join("r05_final", "selfplay_steady_96g_600s.json"),
+                 "the same leg over a 600 s window (tools/selfplay_go.py --games 96 --steady 20,600); a builder-run file beside the measurement, not the measurement"),
+                ("started_together_r04", os.path.join("r04_final", "selfplay_full_games_96g_l16_h4_sparse_b2b300.json"),
+                 "96 games started together from the empty board and played to their end, no replacement (round 4): correlated games, 40 % of their "
+                 "leaves followed a position in flight -- a different quantity")):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                continue
+            try:
+                c = json.load(open(path))
+                stones = c.get("mean_stones_per_completed_game") or c.get("mean_stones_per_game")
+                leg.setdefault("cross_check_committed", {})[key] = {
+                    "games_per_hour_measured": c["games_per_hour_measured"], "moves_per_sec": c["moves_per_sec"], "mean_stones_per_game": stones,
+                    "source": "profiles/" + name.replace(os.sep, "/") + ": " + note}
+                if key == "steady_state_profile" and stones:
+                    # this run's moves per second at the game length the ten-minute window measured
+                    leg["games_per_hour_at_profile_length"] = leg["moves_per_sec"] * 3600.0 / stones
+            except Exception:   # noqa: BLE001
+                pass
     return leg
 
 

@@ -6,9 +6,13 @@
 namespace dgnn {
 namespace {
 
-// HEAD (round 5, the wide split only): the workgroup stays on its CU after the last layer and runs both head convolutions of the board it
-// has just finished (head_conv_body.h: the body of head_conv_board_kernel, the same arithmetic) -- one launch less per batch, and no
-// waiting for a free CU behind another batch's tower.
+// HEAD (round 5, the wide split only; instantiated in the DGNN_ABLATIONS build): the workgroup stays on its CU after the last layer and
+// runs both head convolutions of the board it has just finished (head_conv_body.h: the body of head_conv_board_kernel, the same
+// arithmetic, bit-identical outputs) -- one launch less per batch, and no waiting for a free CU behind another batch's tower.
+// Measured on one box (profiles/r05_final/ab_head_in_tower.txt): resident passes 3.068-3.081 -> 3.065-3.070 ms (+0.1-0.4 %), 256
+// boards PCIe-inclusive one / two alive +1.0 / +1.1 %, nothing at 192 boards and nothing with three batches alive (the heads of one
+// batch already run under the towers of the others) -- while the tower launch that `roofline` times grows by the head's 20 us.
+// Not worth a second instantiation of the dominant kernel in the shipped library.
 template <int NS, bool HEAD>
 __global__ __launch_bounds__(Split<NS>::Threads)
 void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count, HeadConvLaunch head)
@@ -112,7 +116,15 @@ bool tower_board_supported(int batch, int channels)
 
 // The head convolution can ride in the tower launch where the tower is the wide split (256 channels: the head body's 256 threads)
 // and the head is the one-tile, whole-board form (S + 2 <= 16 output channels).
-bool tower_board_takes_head(int channels, int samples) { return channels == 256 && samples + 2 <= 16; }
+bool tower_board_takes_head(int channels, int samples)
+{
+#ifdef DGNN_ABLATIONS
+    return channels == 256 && samples + 2 <= 16;
+#else
+    (void)channels; (void)samples;
+    return false;
+#endif
+}
 
 hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, const HeadConvLaunch* head)
 {
@@ -124,8 +136,10 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
     // A 256-channel tower walks with the wide work split (Split<16>: four waves, two 32-channel tiles each)
     switch (channels / 32) {
         case 8:
-            if (head) hipLaunchKernelGGL((tower_board_kernel<16, true>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, *head);
-            else hipLaunchKernelGGL((tower_board_kernel<16, false>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, none);
+#ifdef DGNN_ABLATIONS
+            if (head) { hipLaunchKernelGGL((tower_board_kernel<16, true>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, *head); break; }
+#endif
+            hipLaunchKernelGGL((tower_board_kernel<16, false>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, none);
             break;
         case 4: hipLaunchKernelGGL((tower_board_kernel<4, false>), grid, dim3(kThreads), 0, stream, d_layers, count, none); break;
         default: hipLaunchKernelGGL((tower_board_kernel<2, false>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, none); break;

@@ -371,8 +371,9 @@ int tower_mode(const Workspace* ws)
 
 bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
 
-// The head convolution inside the whole-board tower launch (round 5); DGNN_HEAD_IN_TOWER=0 (test / ablations build): a launch of its own (A/B).
-const bool kHeadInTower = [] { const char* e = test_env("DGNN_HEAD_IN_TOWER"); return !(e && std::atoi(e) == 0); }();
+// The head convolution inside the whole-board tower launch (round 5: built, bit-identical, +0.1-0.4 % -- conv_board_tower.hip says why it is
+// not shipped): DGNN_HEAD_IN_TOWER=1 in the ablations build.
+const bool kHeadInTower = [] { const char* e = ablation_env("DGNN_HEAD_IN_TOWER"); return e && std::atoi(e) != 0; }();
 
 // Enqueues graph.rs:134-152 on the workspace's stream.  `tower_pair` (may be -1) selects the event pair that
 // brackets the residual convolutions.
