@@ -554,6 +554,7 @@ static int batcher_get_batch(Batcher* b, int min_batch_size, int cap, dgnn_batch
 }  // namespace dgnn
 
 const uint16_t* dgnn::symmetry_map(int transform) { return tables().map[transform & 7]; }
+bool dgnn::pool_coalesces(const dgnn_pool* handle) { return handle && reinterpret_cast<const LeafPool*>(handle)->coalesce.load(std::memory_order_relaxed); }
 
 using namespace dgnn;
 

@@ -158,9 +158,13 @@ struct Predictor {
     }
     // completed weight refreshes of the pool behind this predictor (dgnn_pool_generation); 0 for any other predictor (search.cpp)
     uint64_t generation() const;
+    // the pool behind this predictor lets requests FOLLOW a position in flight: which evaluation a search sees is then a matter of timing
+    // across games, like a shared table -- games with a table of their own (reproducible games) must not run on it
+    bool coalesces() const;
     bool usable_with(const dgnn_game_ops* ops) const { return takes_records() ? ops->record != nullptr : (features != nullptr && ops->features != nullptr); }
 };
 
+bool pool_coalesces(const dgnn_pool* pool);      // batcher.cpp
 int search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, const Predictor& predictor, dgnn_cache* cache, int num_rollouts,
                int num_threads, int leaves_per_thread, uint64_t seed, uint64_t* evals_out, uint64_t* conflicts_out, uint64_t* cache_hits_out);
 int full_forward(const dgnn_game_ops* ops, void* board, int to_move, const Predictor& predictor, dgnn_cache* cache, float* value_out, float* policy_out);

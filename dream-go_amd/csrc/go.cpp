@@ -1351,6 +1351,9 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
     if (num_games <= 0 || first_game < 0 || max_moves < 0 || num_rollouts <= 0 || leaves_per_thread > 64) return DGNN_BAD_ARGUMENT;
     if (num_parallel <= 0 || num_parallel > num_games) num_parallel = num_games;
     if (max_moves == 0 || max_moves > 722) max_moves = 722;
+    // a table per game promises games that are a function of their seed; a pool that coalesces positions in flight hands one game the
+    // evaluation another game asked for (other last moves, other ko state behind the same stones): refused, not silently mixed
+    if (private_cache > 0 && predictor.coalesces()) return DGNN_BAD_ARGUMENT;
     std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0}, ex_it_searches{0}, started{0}, completed{0}, stones_completed{0};
     std::atomic<int> status{DGNN_OK};
     std::atomic<bool> stop{false};                                              // set at the end of a measurement window (params->window)

@@ -423,6 +423,13 @@ uint64_t dgnn::Predictor::generation() const
     return pool ? dgnn_pool_generation(static_cast<const dgnn_pool*>(ctx)) : 0;
 }
 
+// 1 when the predictor is a leaf pool that coalesces positions in flight (dgnn_pool_set_coalescing)
+bool dgnn::Predictor::coalesces() const
+{
+    const bool pool = takes_records() ? boards == pool_predict_boards : features == pool_predict;
+    return pool && pool_coalesces(static_cast<const dgnn_pool*>(ctx));
+}
+
 dgnn_predict_boards_fn dgnn_pool_boards_predictor(void) { return pool_predict_boards; }
 
 int dgnn_search_run(dgnn_tree_node* root, const dgnn_game_ops* ops, void* board, dgnn_predict_fn predict, void* predict_ctx,

@@ -108,7 +108,8 @@ int dgnn_pool_takes_boards(const dgnn_pool* pool);               /* 1 for a pool
  * coalescing a request for a position (same stones, same colour to move) that the pool already has queued or on a device FOLLOWS it
  * and receives that answer re-oriented from the leader's symmetry to its own: what a table hit would have returned
  * (nn.rs:72-81), one evaluation earlier.  Like the shared table it makes WHICH evaluation a search sees a matter of timing: games that
- * must be a function of their seed (cache_entries_per_game > 0) keep it off.  DGNN_BUSY while requests are in flight. */
+ * must be a function of their seed (cache_entries_per_game > 0) keep it off -- dgnn_selfplay_go refuses that combination with
+ * DGNN_BAD_ARGUMENT.  DGNN_BUSY while requests are in flight. */
 int dgnn_pool_set_coalescing(dgnn_pool* pool, int enabled);
 /* Back to back (pools of ONE lane; off by default): while a batch occupies the device, a PARTIAL batch is held back until
  * `lead_us` before that batch is expected to finish (the pool keeps a moving average of how long a batch of each size took) and

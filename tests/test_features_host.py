@@ -180,3 +180,16 @@ def test_fibers_over_the_dry_device_and_a_shared_table(api):
     assert out["moves"] == 512 and (out["record"][:, :2] >= 0).all()
     assert stats["boards"] == out["evals"] and out["cache_hits"] > 0
     print(f"256 fibers / 2 threads: {out['evals']} evals in {stats['batches']} batches (mean {stats['boards'] / stats['batches']:.0f}), {out['cache_hits']} table hits")
+
+
+def test_private_tables_on_a_coalescing_pool_are_refused(api):
+    """a table per game promises games that are a function of their seed; a pool that lets requests follow positions in
+    flight hands one game an evaluation another game asked for.  The C API refuses the combination instead of mixing silently."""
+    pool = api.LeafPool.over_dry_device(base_us=0.0, per_board_us=0.0, max_batch_size=32, batches_per_lane=2, workers_per_lane=2)
+    pool.set_coalescing(True)
+    with pytest.raises(api.Error) as refused:
+        api.selfplay_go(2, 4, 16, 1, seed=3, pool=pool, cache_per_game=2000)
+    assert refused.value.status == api.BAD_ARGUMENT
+    pool.set_coalescing(False)
+    assert api.selfplay_go(2, 4, 16, 1, seed=3, pool=pool, cache_per_game=2000)["moves"] == 8
+    pool.close()
