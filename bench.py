@@ -865,6 +865,10 @@ def main():
                     "steps": reps,
                 }
                 out["value_pcie_inclusive"]["records_vs_resident"] = out["value_pcie_inclusive"]["board_records"] / value
+                # ... and with THREE in flight, the pool's round-5 default
+                ws3 = net.get_workspace(args.batch, device=device)
+                out["value_pcie_inclusive"]["board_records_three_in_flight"] = api.forward_pipelined_timed_n([ws, ws2, ws3], "records", records, args.batch, max(reps, 30))
+                ws3.release()
                 ws2.release()
             # (b) the reference's own harness; a dry run walks every 16th position (the order of the legs is what it is for)
             out["reference_style"] = reference_style_leg(fw, api, leg_ws, positions[::16] if job.dry else positions, args.batch)
