@@ -2,6 +2,8 @@
 # Same box: the self-play legs and whole games with two pool workers for two batches alive (as shipped) and with three
 # (a free worker takes the next batch while another hands 256 answers to their games).  Not run yet: the
 # round's GPU budget was spent when the per-size batch times (dgnn_pool_batch_times) pointed at it.
+# ROUND 5: run in the form of tools/r05_measure_f.sh (the three settings interleaved twice on one box): profiles/r05_final/ab_batches_workers.txt --
+# a third worker + 2.5-3.5 %, a third batch alive + 1-2 % more; both are the tools' defaults now.
 #   gpurun --timeout 900 -- 'bash tools/ab_workers.sh gpurun_out/ab_workers'
 out=${1:-gpurun_out/ab_workers}
 mkdir -p $out
