@@ -353,13 +353,29 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
     and whole games END inside the window at the rate they would in hour six."""
     pool, rule = selfplay_pool(job, api, net, args)
     cache = api.LruCache(200_001, num_shards=8)
-    opening, prep_seconds = None, 0.0
+    opening, prep_seconds, seeded_by = None, 0.0, None
     if staggered:
         t0 = time.perf_counter()
-        ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=in_flight * job.world, num_moves=0, num_rollouts=1, threads_per_search=1,
-                                          seed=seed, pool=pool, cache=api.LruCache(50_001, num_shards=8), device=job.tensor_device,
-                                          host_threads=args.selfplay_host_threads, return_moves=True)
-        opening = np.array(ahead["record"], copy=True)
+        # the games to start inside: whole games SEARCHED by this very network (tools/make_searched_games.py; positions to start from,
+        # nothing else), so that the games in flight are a sample of the steady state from the first second.  Without the file (another
+        # network, a dry run): games played out by policy play -- ~100 stones shorter, and none of them near its end when the window opens
+        seeds = os.path.join(ROOT, "profiles", "searched_games_20x256.npz")
+        record = None
+        if os.path.exists(seeds) and not job.dry:
+            try:
+                z = np.load(seeds)
+                if (int(z["blocks"]), int(z["channels"]), int(z["rollouts"])) == (args.blocks, args.channels, rollouts) and z["record"].shape[0] >= in_flight:
+                    record = np.asarray(z["record"][:in_flight], dtype=np.int32)
+                    seeded_by = "whole games searched by this network (profiles/searched_games_20x256.npz, tools/make_searched_games.py)"
+            except Exception:   # noqa: BLE001
+                record = None
+        if record is None:
+            ahead = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=in_flight * job.world, num_moves=0, num_rollouts=1, threads_per_search=1,
+                                              seed=seed, pool=pool, cache=api.LruCache(50_001, num_shards=8), device=job.tensor_device,
+                                              host_threads=args.selfplay_host_threads, return_moves=True)
+            record = ahead["record"]
+            seeded_by = "games played out by policy play (--num-rollout 1, not timed)"
+        opening = np.array(record, copy=True)
         for i in range(opening.shape[0]):
             stones = int((opening[i] >= 0).sum())
             opening[i, stones * i // opening.shape[0]:] = -1
@@ -378,7 +394,7 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
     cores = job.gather_float(probe.delta("cpu") / max(probe.delta("wall"), 1e-9))
     stones = w["stones_completed"] / max(w["games_completed"], 1)
     leg = {
-        "seconds": sec, "ramp_seconds": ramp, "preparation_seconds": prep_seconds, "games_in_flight_per_gpu": in_flight,
+        "seconds": sec, "ramp_seconds": ramp, "preparation_seconds": prep_seconds, "games_in_flight_per_gpu": in_flight, "seeded_by": seeded_by,
         "moves": w["moves"], "moves_per_sec": w["moves"] / sec,
         "games_completed": w["games_completed"], "games_ended_by_passes": w["games_ended"], "games_started": w["games_started"],
         "mean_stones_per_completed_game": stones if w["games_completed"] else None,
@@ -405,8 +421,8 @@ def whole_games_leg(job, api, replicas, net, args):
                            staggered=True, seed=20261001)
     leg["what"] = (f"steady state of WHOLE games: {args.whole_games} games in flight per GPU with replacement, --num-rollout {args.selfplay_rollouts}, 1 search thread x "
                    f"{args.selfplay_leaves} leaves per game, games as fibers on {args.selfplay_host_threads} host threads, shared transposition table 200001 x 8, "
-                   f"{pool_rule_text(args, rule)}; game i of the first {args.whole_games} starts i / {args.whole_games} of the way into a game played to its end by policy play "
-                   f"(not timed), so games at every stage are in flight from the start and END inside the window; {args.whole_games_ramp:.0f} s ramp, then the timed window; "
+                   f"{pool_rule_text(args, rule)}; game i of the first {args.whole_games} starts i / {args.whole_games} of the way into a finished game -- {leg['seeded_by']} -- "
+                   f"so games at every stage are in flight from the start and END inside the window; {args.whole_games_ramp:.0f} s ramp, then the timed window; "
                    "random-init weights (such a net plays 600-700 stones per game: games_per_hour_at_250_stones is the same moves per second at a trained net's game length)")
     leg["games_per_hour_at_250_stones"] = leg["moves_per_sec"] * 3600.0 / 250.0
     # Labelled cross-checks, builder-run files: (1) the same steady state measured over TEN minutes with tools/selfplay_go.py --steady 20,600
