@@ -104,9 +104,13 @@ static int tower_min_batch()
     return v;
 }
 
-bool tower_board_supported(int batch, int channels)
+bool tower_board_supported(int batch, int channels, bool crowded)
 {
     const int slices = channels / 32;
+    // `crowded`: other submissions share the device (engine.cpp: boards in flight).  A workgroup per board is then the better form at ANY
+    // batch size: it is the form that spends the fewest bytes and joules per board, and the CUs a small batch leaves idle are not
+    // idle -- the other submissions' workgroups have them (round 5)
+    if (crowded) return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || slices == 4 || slices == 8) && batch >= 1;
     // a workgroup per board: at 64 channels always (the layers are short, launches would dominate), at 128 / 256 channels
     // from 129 boards on: a board split over two workgroups would need more workgroups than there are CUs (two rounds per
     // layer), and a chip that is only half full clocks higher (power cap) -- measured 20x256, batch 144 / 160 / 176: 56.4 k /
@@ -129,7 +133,7 @@ bool tower_board_takes_head(int channels, int samples)
 hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, const HeadConvLaunch* head)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
-    if (!tower_board_supported(batch, channels)) return hipErrorInvalidValue;
+    if (!tower_board_supported(batch, channels, true)) return hipErrorInvalidValue;
     if (head && !tower_board_takes_head(channels, head->samples)) return hipErrorInvalidValue;
     const dim3 grid(batch, 1);
     const HeadConvLaunch none{};

@@ -75,6 +75,9 @@ struct Workspace {
     uint16_t* h_value = nullptr;
     uint16_t* h_policy = nullptr;
 
+    bool crowded = false;                   // the submission being enqueued shares the device with enough boards of other submissions
+                                            // that a workgroup per board is the better tower at any size (tower_mode, kCrowdedBoards)
+    int counted_in_flight = 0;              // boards of this workspace's submission counted in DeviceState::boards_in_flight
     bool host_io = false;                   // the submission being enqueued reads its records from / writes its outputs to the PINNED HOST buffers
                                             // themselves (zero copy: no H2D / D2H blit kernels around the compute, see kZeroCopy)
     int active = 0;                         // boards of the submission in flight / being enqueued (<= batch, the capacity)
@@ -118,6 +121,7 @@ struct DeviceState {
     uint8_t* d_image = nullptr;
     bool image_valid = false;               // d_image holds net->image (false between a reserve and the copy that fills it)
     struct SplitChain* chain = nullptr;     // the device's chain of split-tower launches (process-global, see split_chain)
+    std::atomic<int> boards_in_flight{0};   // boards of submissions between their submit and their wait, all workspaces of this device
     std::map<int, std::vector<Workspace*>> idle;   // batch size -> pooled workspaces
     std::vector<Workspace*> all;                   // ownership
 
@@ -360,7 +364,7 @@ int tower_mode(const Workspace* ws)
 {
     if (!(ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero)) return 0;
     const int channels = ws->net->topo.num_channels;
-    const bool whole = tower_board_supported(ws->active, channels);
+    const bool whole = tower_board_supported(ws->active, channels, ws->crowded);
     if (whole && ws->use_pair && !ws->split_failed && tower_pair_supported(ws->active, channels, ws->dev->num_cus)) return 24;
     if (ws->split_pref != 0 && !ws->split_failed && (!whole || ws->split_pref == 2)) {
         const int ns = tower_split_ns(ws->active, channels, ws->dev->num_cus);
@@ -370,6 +374,9 @@ int tower_mode(const Workspace* ws)
 }
 
 bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
+
+// Whole-board towers for small batches on a crowded device (round 5); DGNN_CROWDED=0 (test / ablations build): the size alone decides (A/B).
+const bool kCrowdedTowers = [] { const char* e = test_env("DGNN_CROWDED"); return !(e && std::atoi(e) == 0); }();
 
 // The head convolution inside the whole-board tower launch (round 5: built, bit-identical, +0.1-0.4 % -- conv_board_tower.hip says why it is
 // not shipped): DGNN_HEAD_IN_TOWER=1 in the ablations build.
@@ -655,6 +662,27 @@ void nap_ns(long long ns)
     if (ns <= 0) return;
     struct timespec ts = {(time_t)(ns / 1000000000ll), (long)(ns % 1000000000ll)};
     nanosleep(&ts, nullptr);
+}
+
+// A small batch alone on the device is best split over many workgroups (latency); the same batch beside other submissions is best run
+// with a workgroup per board: the CUs it leaves are taken by the others' workgroups, and a whole-board workgroup moves the fewest bytes
+// per board.  kCrowdedBoards: from this many boards in flight on the device (this submission included) on, a workgroup per board.
+constexpr int kCrowdedBoards = 176;
+void note_submission_begins(Workspace* ws)       // in front of enqueue_forward: which tower this submission gets
+{
+    const int others = ws->dev->boards_in_flight.load(std::memory_order_relaxed);
+    ws->crowded = kCrowdedTowers && others > 0 && others + ws->active >= kCrowdedBoards;
+}
+void note_submission_in_flight(Workspace* ws)    // with `pending = true`
+{
+    ws->counted_in_flight = ws->active;
+    ws->dev->boards_in_flight.fetch_add(ws->active, std::memory_order_relaxed);
+}
+void note_submission_ends(Workspace* ws)
+{
+    if (ws->counted_in_flight > 0) ws->dev->boards_in_flight.fetch_sub(ws->counted_in_flight, std::memory_order_relaxed);
+    ws->counted_in_flight = 0;
+    ws->crowded = false;
 }
 
 int mark_submission(Workspace* ws)      // behind the last copy of a submission
@@ -1077,6 +1105,7 @@ void dgnn_workspace_release(dgnn_workspace* handle)
         (void)hipSetDevice(ws->device);
         (void)hipStreamSynchronize(ws->stream);
         ws->pending = false;
+        note_submission_ends(ws);
     }
     Network* net = ws->net;
     bool last = false;
@@ -1131,6 +1160,7 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
     if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
     if (ws->pending) return DGNN_BAD_ARGUMENT;
     ws->active = count;
+    note_submission_begins(ws);
     const size_t num_features = (size_t)count * DGNN_FEATURE_SIZE;
 
     DGNN_HIP(hipSetDevice(ws->device));
@@ -1147,6 +1177,7 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
     DGNN_HIP(enqueue_outputs(ws));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
     ws->pending = true;
+    note_submission_in_flight(ws);
     return DGNN_OK;
 }
 
@@ -1158,6 +1189,7 @@ int dgnn_forward_wait(dgnn_workspace* handle, uint16_t* value_out, uint16_t* pol
 
     DGNN_HIP(hipSetDevice(ws->device));
     ws->pending = false;
+    struct Ends { Workspace* w; ~Ends() { note_submission_ends(w); } } ends{ws};         // (on every way out: the device's count of boards in flight)
     { const int waited = wait_submission(ws); if (waited != DGNN_OK) return waited; }   // graph.rs:155-156 (to_vec + synchronize)
     const int split_status = resolve_split_failure(ws);
     if (split_status != DGNN_OK) { ws->active = ws->batch; return split_status; }
@@ -1194,6 +1226,7 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
     if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
     if (ws->pending) return DGNN_BAD_ARGUMENT;
     ws->active = count;
+    note_submission_begins(ws);
     const size_t in_bytes = (size_t)count * DGNN_PACKED_WORDS * sizeof(uint32_t);
 
     DGNN_HIP(hipSetDevice(ws->device));
@@ -1209,6 +1242,7 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
     DGNN_HIP(enqueue_outputs(ws));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
     ws->pending = true;
+    note_submission_in_flight(ws);
     return DGNN_OK;
 }
 
@@ -1228,6 +1262,7 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
     if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
     if (ws->pending) return DGNN_BAD_ARGUMENT;
     ws->active = count;
+    note_submission_begins(ws);
     const size_t in_bytes = (size_t)count * DGNN_BOARD_RECORD_BYTES;
 
     DGNN_HIP(hipSetDevice(ws->device));
@@ -1246,6 +1281,7 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[7], ws->stream));
     { const int marked = mark_submission(ws); if (marked != DGNN_OK) return marked; }
     ws->pending = true;
+    note_submission_in_flight(ws);
     return DGNN_OK;
 }
 

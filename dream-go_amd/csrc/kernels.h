@@ -125,7 +125,7 @@ int conv_board_pick_ns(int batch, int cout, int forced_ns = 0);   // 32-channel 
 hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches& env, hipStream_t stream);
 // The residual tower as ONE launch, a workgroup per board walking all `count` layers (descriptors in HBM; conv_1 / conv_2 of
 // every block, relu, C -> C).  Only where a workgroup owns all channels of its board: conv_board_pick_ns(batch, C) == C / 32.
-bool tower_board_supported(int batch, int channels);
+bool tower_board_supported(int batch, int channels, bool crowded = false);
 struct HeadConvLaunch;
 bool tower_board_takes_head(int channels, int samples);
 hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, const HeadConvLaunch* head = nullptr);
