@@ -236,3 +236,30 @@ def test_coalescing_on_the_device_answers_with_the_evaluation_of_some_symmetry(a
     print(f"960 requests: {boards} boards evaluated, {followed} followed a position in flight")
     assert not problems, problems[:5]
     assert followed > 0 and boards + followed == 960
+
+
+def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_bits(api, synth):
+    """Round 5: a submission that finds other submissions on the device and brings the boards in flight to 176 or more runs the tower
+    with a workgroup per board whatever its size (alone it would be split over several workgroups per board).  Every work split sums
+    in the same order, so the answers are those of the same batches evaluated one at a time -- bit for bit."""
+    import ctypes
+    batch = 96
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(6, 256, seed=71)))
+    feats = [np.ascontiguousarray(synth.make_features(batch, seed=700 + k)).view(np.uint16).reshape(-1) for k in range(3)]
+    spaces = [net.get_workspace(batch) for _ in range(3)]
+    alone = []
+    for ws, f in zip(spaces, feats):
+        assert ws.conv_kernel() == "tower_split_kernel"                       # 96 boards alone: two workgroups per board
+        v, p = api.forward(ws, f).unwrap()
+        alone.append((v.view(np.uint16).copy(), p.view(np.uint16).copy()))
+    u16p = ctypes.POINTER(ctypes.c_uint16)
+    for rounds in range(4):                                                    # three submissions alive: 288 boards in flight
+        for ws, f in zip(spaces, feats):
+            assert api.lib.dgnn_forward_submit_n(ws.handle, f.ctypes.data_as(u16p), batch) == 0
+        for k, ws in enumerate(spaces):
+            v, p = np.empty(batch, dtype=np.uint16), np.empty(batch * 362, dtype=np.uint16)
+            assert api.lib.dgnn_forward_wait(ws.handle, v.ctypes.data_as(u16p), p.ctypes.data_as(u16p)) == 0
+            assert np.array_equal(v, alone[k][0]) and np.array_equal(p, alone[k][1]), (rounds, k)
+    for ws in spaces:
+        ws.release()
+    net.destroy()
