@@ -666,12 +666,12 @@ void nap_ns(long long ns)
 
 // A small batch alone on the device is best split over many workgroups (latency); the same batch beside other submissions is best run
 // with a workgroup per board: the CUs it leaves are taken by the others' workgroups, and a whole-board workgroup moves the fewest bytes
-// per board.  kCrowdedBoards: from this many boards in flight on the device (this submission included) on, a workgroup per board.
-constexpr int kCrowdedBoards = 176;
+// per board.  From 11 / 16 of the CU count in boards in flight on the device (this submission included; 176 on an MI355X) on, a workgroup per
+// board: below that the split's extra workgroups find free CUs of their own (2 x 64 boards run better split, 3 x 64 the same either way).
 void note_submission_begins(Workspace* ws)       // in front of enqueue_forward: which tower this submission gets
 {
     const int others = ws->dev->boards_in_flight.load(std::memory_order_relaxed);
-    ws->crowded = kCrowdedTowers && others > 0 && others + ws->active >= kCrowdedBoards;
+    ws->crowded = kCrowdedTowers && others > 0 && others + ws->active >= ws->dev->num_cus * 11 / 16;
 }
 void note_submission_in_flight(Workspace* ws)    // with `pending = true`
 {
