@@ -678,6 +678,11 @@ void note_submission_in_flight(Workspace* ws)    // with `pending = true`
     ws->counted_in_flight = ws->active;
     ws->dev->boards_in_flight.fetch_add(ws->active, std::memory_order_relaxed);
 }
+struct SubmissionBegins {                        // a submit that fails half way leaves no tower choice behind for the resident entry points
+    Workspace* ws;
+    explicit SubmissionBegins(Workspace* w) : ws(w) { note_submission_begins(w); }
+    ~SubmissionBegins() { if (!ws->pending) ws->crowded = false; }
+};
 void note_submission_ends(Workspace* ws)
 {
     if (ws->counted_in_flight > 0) ws->dev->boards_in_flight.fetch_sub(ws->counted_in_flight, std::memory_order_relaxed);
@@ -1160,7 +1165,7 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
     if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
     if (ws->pending) return DGNN_BAD_ARGUMENT;
     ws->active = count;
-    note_submission_begins(ws);
+    SubmissionBegins begins(ws);
     const size_t num_features = (size_t)count * DGNN_FEATURE_SIZE;
 
     DGNN_HIP(hipSetDevice(ws->device));
@@ -1226,7 +1231,7 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
     if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
     if (ws->pending) return DGNN_BAD_ARGUMENT;
     ws->active = count;
-    note_submission_begins(ws);
+    SubmissionBegins begins(ws);
     const size_t in_bytes = (size_t)count * DGNN_PACKED_WORDS * sizeof(uint32_t);
 
     DGNN_HIP(hipSetDevice(ws->device));
@@ -1262,7 +1267,7 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
     if (count <= 0 || count > ws->batch) return DGNN_BAD_ARGUMENT;
     if (ws->pending) return DGNN_BAD_ARGUMENT;
     ws->active = count;
-    note_submission_begins(ws);
+    SubmissionBegins begins(ws);
     const size_t in_bytes = (size_t)count * DGNN_BOARD_RECORD_BYTES;
 
     DGNN_HIP(hipSetDevice(ws->device));
