@@ -76,7 +76,7 @@ struct Workspace {
     uint16_t* h_policy = nullptr;
 
     bool crowded = false;                   // the submission being enqueued shares the device with enough boards of other submissions
-                                            // that a workgroup per board is the better tower at any size (tower_mode, kCrowdedBoards)
+                                            // that a workgroup per board is the better tower at any size (tower_mode, note_submission_begins)
     int counted_in_flight = 0;              // boards of this workspace's submission counted in DeviceState::boards_in_flight
     bool host_io = false;                   // the submission being enqueued reads its records from / writes its outputs to the PINNED HOST buffers
                                             // themselves (zero copy: no H2D / D2H blit kernels around the compute, see kZeroCopy)
