@@ -401,6 +401,8 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
         # whole games that ENDED inside the window, per hour of window -- and the same figure from the window's moves (less noisy: a
         # window sees a few dozen endings): moves per second x 3600 / the mean stones of the games that ended
         "games_per_hour_measured": w["games_completed"] * 3600.0 / sec,
+        # (a count of a dozen or two: its own one-sigma counting noise, so that a reader does not take 12 against 18 endings for a change)
+        "games_per_hour_measured_sigma": max(w["games_completed"], 1) ** 0.5 * 3600.0 / sec,
         "games_per_hour_from_moves": (w["moves"] / sec) * 3600.0 / stones if w["games_completed"] else None,
         "answers_per_sec": w["evals"] / sec,                          # what the searches were answered (table misses; followers of positions in flight included)
         "rollouts_per_sec": (w["evals"] + w["cache_hits"]) / sec,
