@@ -87,6 +87,7 @@ def parse_args(argv=None):
                     help="games in flight PER GPU, with replacement, in the steady-state WHOLE-GAME leg (the setting of tools/selfplay_go.py; 0 = skip the leg)")
     ap.add_argument("--whole-games-seconds", type=float, default=90.0, help="the timed window of the whole-game leg")
     ap.add_argument("--whole-games-ramp", type=float, default=20.0, help="untimed seconds in front of that window")
+    ap.add_argument("--whole-games-records", default="", help="write the move lists of the whole-game leg's games to this .npz (diagnosis: which seeded games ended, and when)")
     ap.add_argument("--policy-play-games", type=int, default=1024,
                     help="games in flight PER GPU in the policy-play leg (BASELINE.json configs[4]: --num-rollout 1; 0 = skip the leg)")
     ap.add_argument("--policy-play-seconds", type=float, default=10.0, help="the timed window of the policy-play leg (after 2 untimed seconds)")
@@ -383,7 +384,11 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
     probe = EdgeProbe(pool)
     out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=4096 * job.world, num_moves=0, num_rollouts=rollouts, threads_per_search=1,
                                     seed=seed + 1, pool=pool, cache=cache, device=job.tensor_device, leaves_per_thread=args.selfplay_leaves,
-                                    host_threads=args.selfplay_host_threads, opening=opening, num_parallel=in_flight, window=(ramp, seconds, probe))
+                                    host_threads=args.selfplay_host_threads, opening=opening, num_parallel=in_flight, window=(ramp, seconds, probe),
+                                    return_moves=bool(staggered and args.whole_games_records))
+    if staggered and args.whole_games_records and job.rank == 0 and "record" in out:
+        np.savez_compressed(args.whole_games_records, record=np.asarray(out["record"][:4 * in_flight], dtype=np.int16), opening=np.asarray(opening, dtype=np.int16),
+                            ramp=ramp, seconds=seconds)
     batch_times = pool.batch_times()
     pool.close()
     w = out["job"]["window"]
