@@ -13,6 +13,7 @@ Both depend only on the HIP runtime (libamdhip64); neither links torch.
 """
 import os
 import subprocess
+import time
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -107,16 +108,31 @@ def build(force=False, verbose=False):
             tobj = os.path.join(LIB_DIR, "test", src.rsplit(".", 1)[0] + ".o")
             test_objects.append(tobj)
             jobs.append((src, tobj, ["-DDGNN_TEST_ENTRIES"], _headers()))
+    # The translation units are independent: compile them side by side, as many at a time as there are CPUs, the kernel units (the
+    # long ones: the critical path of a clean build) first, so that they never share a core with the twenty short host units.
+    pending = []
     for src, obj, extra, headers in jobs:
         if not force and not _stale(os.path.join(CSRC, src), obj, headers):
             continue
-        cmd = [hipcc(), *FLAGS, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        running.append((cmd, subprocess.Popen(cmd)))      # the translation units are independent: compile them side by side
-    for cmd, proc in running:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        pending.append([hipcc(), *FLAGS, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj])
+    slots = max(2, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2))
+    while pending or running:
+        while pending and len(running) < slots:
+            cmd = pending.pop(0)
+            if verbose:
+                print(" ".join(cmd))
+            running.append((cmd, subprocess.Popen(cmd)))
+        for entry in running:
+            if entry[1].poll() is not None:
+                if entry[1].returncode != 0:
+                    for _, other in running:
+                        if other.poll() is None:
+                            other.kill()
+                    raise subprocess.CalledProcessError(entry[1].returncode, entry[0])
+                running.remove(entry)
+                break
+        else:
+            time.sleep(0.05)
     links = [(LIB_PATH, host_objects + kernel_objects)]
     if not ABLATIONS:
         links.append((TEST_LIB_PATH, test_objects + kernel_objects))
