@@ -382,10 +382,17 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
             opening[i, stones * i // opening.shape[0]:] = -1
         prep_seconds = time.perf_counter() - t0
     probe = EdgeProbe(pool)
+    # the games' records leave the way the reference's do (self_play.rs:471-497: a channel whose reader prints them): counted and let go of
+    taken = {"records": 0, "whole": 0, "bytes": 0}
+
+    def take_record(_game, text, whole):
+        taken["records"] += 1
+        taken["whole"] += int(whole)
+        taken["bytes"] += len(text)
     out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=4096 * job.world, num_moves=0, num_rollouts=rollouts, threads_per_search=1,
                                     seed=seed + 1, pool=pool, cache=cache, device=job.tensor_device, leaves_per_thread=args.selfplay_leaves,
                                     host_threads=args.selfplay_host_threads, opening=opening, num_parallel=in_flight, window=(ramp, seconds, probe),
-                                    return_moves=bool(staggered and args.whole_games_records))
+                                    return_moves=bool(staggered and args.whole_games_records), on_game=take_record)
     if staggered and args.whole_games_records and job.rank == 0 and "record" in out:
         np.savez_compressed(args.whole_games_records, record=np.asarray(out["record"][:4 * in_flight], dtype=np.int16), opening=np.asarray(opening, dtype=np.int16),
                             ramp=ramp, seconds=seconds)
@@ -418,6 +425,8 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
         "device_batch_us_by_size": {str(k): v for k, v in batch_times.items()},
         "host_cpus_busy": cores[0], "per_rank_host_cpus_busy": cores, "host_cpus": effective_cpus(), "host_threads": args.selfplay_host_threads,
         "probe_conflicts": w["conflicts"],
+        # (rank 0's, ramp and the games the window's end cut short included: that the records ARE produced and handed over, not a rate)
+        "records_streamed": {"records": taken["records"], "of_whole_games": taken["whole"], "megabytes": taken["bytes"] / 1e6},
     }
     return leg, rule
 

@@ -1314,10 +1314,11 @@ class SelfplayParams(ctypes.Structure):
                 ("max_moves", ctypes.c_int), ("num_rollouts", ctypes.c_int), ("num_ex_it_rollouts", ctypes.c_int),
                 ("threads_per_search", ctypes.c_int), ("leaves_per_thread", ctypes.c_int), ("cache_entries_per_game", ctypes.c_int),
                 ("seed", ctypes.c_uint64), ("host_threads", ctypes.c_int), ("opening_len", ctypes.c_int), ("opening", ctypes.c_void_p),
-                ("opening_games", ctypes.c_int), ("window", ctypes.c_void_p)]
+                ("opening_games", ctypes.c_int), ("window", ctypes.c_void_p), ("on_game", ctypes.c_void_p), ("on_game_ctx", ctypes.c_void_p)]
 
 
 WINDOW_EDGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
+GAME_RECORD_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
 
 
 class SelfplayWindow(ctypes.Structure):
@@ -1558,13 +1559,15 @@ def choose_f64(items, cutoff_percentile, temperature, at):
 
 def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0, pool=None, cache=None, return_moves=False,
                 return_sgf=False, first_game=0, game_stride=1, num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1, cache_per_game=0,
-                host_threads=0, opening=None, window=None):
+                host_threads=0, opening=None, window=None, on_game=None):
     """self_play (src/libdg_mcts/self_play.rs:423-505) for num_games games in parallel; num_moves caps the stones per game
     (0 = the reference's 722).  The games are the global ids first_game, first_game + game_stride, ... (sharding across ranks);
     num_parallel of them run at a time (0 = all); host_threads > 0 runs them as fibers on that many OS threads (csrc/fiber.h).
     opening: [rows][len] packed indices, -1 ends a row; fewer rows than games: the later games start from the empty board.
     window = (ramp_seconds, seconds[, on_edge(edge)]): the job runs num_parallel games WITH REPLACEMENT (num_games bounds how many may
-    be started) and is stopped at the end of a timed window; out["window"] holds what happened inside it (dgnn_selfplay_window)."""
+    be started) and is stopped at the end of a timed window; out["window"] holds what happened inside it (dgnn_selfplay_window).
+    on_game(game_id, record_bytes, whole): the reference's channel (self_play.rs:471-497) -- called as each game leaves, one call at a
+    time; how a long job takes its records (return_sgf holds them all until the call returns)."""
     fn, ctx = _predictor(pool)
     stats = SelfplayStats()
     if num_moves <= 0 or num_moves > 722:
@@ -1573,7 +1576,11 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     sgf = ctypes.create_string_buffer(num_games * (num_moves * 2600 + 4 * 722 * 6 + 2048)) if return_sgf else None
     params = SelfplayParams(int(num_games), int(num_parallel), int(first_game), int(game_stride), int(num_moves), int(num_rollouts),
                             int(ex_it_rollouts), int(threads_per_search), int(leaves_per_thread), int(cache_per_game), int(seed),
-                            int(host_threads), 0, None, 0, None)
+                            int(host_threads), 0, None, 0, None, None, None)
+    game_thunk = None
+    if on_game is not None:
+        game_thunk = GAME_RECORD_FN(lambda _ctx, game_id, text, size, whole: on_game(int(game_id), ctypes.string_at(text, size), bool(whole)))
+        params.on_game = ctypes.cast(game_thunk, ctypes.c_void_p)
     if opening is not None:                                    # [rows][opening_len] packed indices: game g < rows starts from the position of row g
         opening = np.ascontiguousarray(opening, dtype=np.int32)
         opening = opening.reshape(opening.shape[0] if opening.ndim == 2 else num_games, -1)

@@ -1357,7 +1357,8 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
     std::atomic<uint64_t> evals{0}, conflicts{0}, moves{0}, hits{0}, ended{0}, ex_it_searches{0}, started{0}, completed{0}, stones_completed{0};
     std::atomic<int> status{DGNN_OK};
     std::atomic<bool> stop{false};                                              // set at the end of a measurement window (params->window)
-    std::vector<std::string> records((size_t)num_games);
+    std::vector<std::string> records(sgf_out ? (size_t)num_games : 0);          // kept only for a caller who asked for them all at the end
+    std::mutex on_game_mutex;                                                   // (params->on_game: one call at a time)
     const int opening_games = params->opening_games > 0 ? std::min(params->opening_games, num_games) : num_games;
     const auto t0 = std::chrono::steady_clock::now();
 
@@ -1518,7 +1519,8 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
             if (roots[1 - me]) roots[1 - me] = dgnn_tree_node_forward(roots[1 - me], played);   // players[1].forward, self_play.rs:453
         }
         if (finished) ended.fetch_add(1);
-        if ((finished || board.count >= max_moves) && status.load() == DGNN_OK) {   // a whole game: two passes on a scorable board, or the stone cap
+        const bool whole = (finished || board.count >= max_moves) && status.load() == DGNN_OK;   // a whole game: two passes on a scorable board, or the stone cap
+        if (whole) {
             stones_completed.fetch_add((uint64_t)board.count);                  // (before `completed`: a window edge between the two counts a game without its stones at worst)
             completed.fetch_add(1);
         }
@@ -1534,7 +1536,14 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
         gmtime_r(&now, &utc);
         std::strftime(date, sizeof(date), "%Y-%m-%dT%H:%M:%S+0000", &utc);
         std::snprintf(header, sizeof(header), "(;GM[1]FF[4]DT[%s]SZ[19]RU[Chinese]KM[%.1f]RE[%s]", date, (double)komi, winner_sgf(board, point_status).c_str());
-        records[(size_t)g] = header + sgf + territory_sgf(point_status) + ")";
+        // the record goes where the reference's goes -- over the channel to whoever prints it (self_play.rs:488-492) -- and is let go of:
+        // a job that replaces its games for hours must not hold a megabyte and a half for each that ever ended
+        std::string record = header + sgf + territory_sgf(point_status) + ")";
+        if (params->on_game) {
+            std::lock_guard<std::mutex> lock(on_game_mutex);
+            params->on_game(params->on_game_ctx, first_game + g * game_stride, record.data(), record.size(), whole ? 1 : 0);
+        }
+        if (sgf_out) records[(size_t)g] = std::move(record);
     };
     std::atomic<int> next_game{0};
     auto play = [&](int) { for (int g; !stop.load(std::memory_order_relaxed) && (g = next_game.fetch_add(1)) < num_games && status.load() == DGNN_OK;) game(g); };

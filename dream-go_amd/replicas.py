@@ -80,7 +80,7 @@ def games_of_rank(num_games, world, rank):
 
 def selfplay_sharded(api, dist, torch, num_games, num_moves, num_rollouts, threads_per_search, seed, pool=None, cache=None,
                      return_moves=False, return_sgf=False, device="cpu", num_parallel=0, ex_it_rollouts=0, leaves_per_thread=1, cache_per_game=0,
-                     host_threads=0, opening=None, window=None):
+                     host_threads=0, opening=None, window=None, on_game=None):
     """One self-play job over all ranks (BASELINE.json configs[3]): every rank plays its games against its own engine, pool and
     transposition cache, nothing is exchanged while the games run, the counters are summed and the clock is the slowest
     rank's.  `dist` may be None (one rank).  Returns this rank's result with the job totals under "job"."""
@@ -93,7 +93,7 @@ def selfplay_sharded(api, dist, torch, num_games, num_moves, num_rollouts, threa
         out = api.selfplay_go(count, num_moves, num_rollouts, threads_per_search, seed=seed, pool=pool, cache=cache,
                               return_moves=return_moves, return_sgf=return_sgf, first_game=first, game_stride=stride,
                               num_parallel=num_parallel, ex_it_rollouts=ex_it_rollouts, leaves_per_thread=leaves_per_thread, cache_per_game=cache_per_game,
-                              host_threads=host_threads, opening=opening, window=window)
+                              host_threads=host_threads, opening=opening, window=window, on_game=on_game)
     else:
         out = {"seconds": 0.0, "games": 0, "moves": 0, "evals": 0, "conflicts": 0, "cache_hits": 0, "games_ended": 0, "ex_it_searches": 0}
     out["game_ids"] = [first + i * stride for i in range(count)]

@@ -320,6 +320,14 @@ typedef struct dgnn_selfplay_params {     /* zero the whole struct first: fields
     const int* opening;       /* [num_games][opening_len] packed indices, e.g. the moves_out of an earlier call; NULL = empty boards */
     int opening_games;        /* > 0: `opening` holds rows for the first opening_games games only, later games start from the empty board */
     struct dgnn_selfplay_window* window;   /* non-NULL with seconds > 0: a timed window over a steady state of num_parallel games, see below */
+    void (*on_game)(void* ctx, int game_id, const char* record, size_t bytes, int whole);
+                              /* non-NULL: the reference's channel (self_play.rs:471-497: every game thread sends its GameResult, the caller
+                                 prints it and lets go of it).  Called when a game leaves, with its global id, its record (GameResult::Ended,
+                                 game_result.rs:35-41; not NUL-terminated, valid during the call) and whether it was a WHOLE game (two passes on
+                                 a scorable board, or the stone cap) rather than one a window's end or an error cut short.  Calls are
+                                 serialised by the library (one at a time, from the games' threads).  A job that runs for hours takes its
+                                 records this way: sgf_out holds every record until the call returns (~1.5 MB per searched game). */
+    void* on_game_ctx;
 } dgnn_selfplay_params;
 /* A measurement window over a running self-play job: games per hour on somebody's clock needs whole games, and a whole game is
  * minutes.  The job starts num_parallel games (each from its row of `opening`, so that the games in flight can be at EVERY stage of

@@ -558,6 +558,31 @@ def test_policy_play_and_expert_iteration(api):
         assert np.array_equal(a[:max(first - 1, 0)], b[:max(first - 1, 0)])
 
 
+def test_records_leave_over_the_channel_as_their_games_end(api):
+    """self_play.rs:471-497: every game thread SENDS its GameResult and the caller prints it and lets go of it.  `on_game` is that
+    channel: one call per game as it leaves, the record the same bytes `sgf_out` would hold at the end, the calls serialised, the
+    global game id with each -- and nothing is kept for a caller who did not ask for all records at the end (a job that replaces its
+    games for hours, dgnn_selfplay_window, would otherwise hold every record it ever produced)."""
+    import threading
+    kw = dict(num_games=6, num_moves=30, num_rollouts=1, threads_per_search=1, seed=23, first_game=2, game_stride=3, num_parallel=3)
+    kept = api.selfplay_go(return_sgf=True, **kw)
+    streamed, inside = {}, []
+    busy = threading.Lock()
+
+    def on_game(game_id, record, whole):
+        inside.append(busy.acquire(blocking=False))
+        streamed[game_id] = (record.decode("ascii"), whole)
+        busy.release()
+    both = api.selfplay_go(return_sgf=True, on_game=on_game, **kw)
+    only = {}
+    api.selfplay_go(on_game=lambda g, r, w: only.__setitem__(g, r.decode("ascii")), **kw)
+    strip = lambda text: __import__("re").sub(r"DT\[[^\]]*\]", "", text)               # (the header carries the time of day)
+    assert sorted(streamed) == [2 + 3 * i for i in range(6)] == sorted(only) and all(inside)
+    assert [strip(streamed[2 + 3 * i][0]) for i in range(6)] == [strip(g) for g in both["sgf"]] == [strip(g) for g in kept["sgf"]]
+    assert [strip(only[2 + 3 * i]) for i in range(6)] == [strip(g) for g in kept["sgf"]]
+    assert all(whole for _, whole in streamed.values())                                 # 30 stones is this call's cap: whole games
+
+
 # ---- round 3: the bit-board forms the search calls (Benson, candidate moves) against the flood-fill forms they replaced
 
 def _simple_eye(board, color, x, y):
