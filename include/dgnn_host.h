@@ -317,7 +317,10 @@ typedef struct dgnn_selfplay_params {     /* zero the whole struct first: fields
                                  ignored (= 0) where fibers are not available. */
     int opening_len;          /* > 0: every game starts from a given position: the first opening_len entries of its row of `opening` are
                                  placed, black first, before the first move is searched (a -1 ends a row early) */
-    const int* opening;       /* [num_games][opening_len] packed indices, e.g. the moves_out of an earlier call; NULL = empty boards */
+    const int* opening;       /* [num_games][opening_len] packed indices, e.g. the moves_out of an earlier call; NULL = empty boards.
+                                 (A row holds stones only and is placed with strictly alternating colours, ending at the first entry
+                                 that is not a legal move then: the moves_out of a game with a pass in it gives a position to start
+                                 from, not that game's position.) */
     int opening_games;        /* > 0: `opening` holds rows for the first opening_games games only, later games start from the empty board */
     struct dgnn_selfplay_window* window;   /* non-NULL with seconds > 0: a timed window over a steady state of num_parallel games, see below */
     void (*on_game)(void* ctx, int game_id, const char* record, size_t bytes, int whole);
