@@ -334,6 +334,16 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_packed = (uint32_t*)p; p += sz_packed;
     ws->d_split_sync = (unsigned*)p; p += sz_split;
     ws->d_split_arrive = ws->d_split_sync + (size_t)batch * kSplitWordsPerBoard;
+    // (tests) the running counters of the split towers started where a job finds them after hours: "flags,arrivals" -- the flag base a
+    // few launches below its refill at 0xf0000000 (two days of launches), the 32-bit arrival count a few launches below its wrap (eight hours)
+    if (const char* start = test_env("DGNN_SPLIT_COUNTERS_START")) {
+        unsigned flags_at = 0, arrivals_at = 0;
+        if (std::sscanf(start, "%u,%u", &flags_at, &arrivals_at) == 2) {
+            ws->split_base = flags_at;
+            ws->split_arrive_base = arrivals_at;
+            DGNN_HIP(hipMemcpy(ws->d_split_arrive, &arrivals_at, sizeof(unsigned), hipMemcpyHostToDevice));
+        }
+    }
     ws->d_records = p; p += sz_records;
     ws->d_value_pre = (uint16_t*)p; p += sz_vpre;
     if (ws->use_board) {

@@ -233,6 +233,34 @@ def test_a_launch_that_is_not_fully_resident_gives_up_within_milliseconds(api_fu
     net.destroy()
 
 
+def test_split_towers_run_through_the_wrap_of_their_running_counters(api_full, synth, monkeypatch, capfd):
+    """The split towers' flags and their arrival count are RUNNING counters, never reset between launches: the flag base is refilled
+    when it passes 0xf0000000 (two days of back-to-back launches), the 32-bit arrival count simply wraps (eight hours at 20x256, batch
+    128) and is compared by signed difference.  Nobody waits eight hours in a test: DGNN_SPLIT_COUNTERS_START (test build) starts a
+    workspace's counters a few launches below both, and the passes across them are the bits of the per-layer path, without a give-up."""
+    api = api_full
+    blocks, channels, batch = 2, 256, 16
+    text = synth.to_json(synth.make_tensors(blocks, channels, seed=660))
+    features = synth.make_features(batch, seed=661)
+    monkeypatch.setenv("DGNN_TOWER", "0")
+    net = api.Network.from_json(text)
+    with net.get_workspace(batch) as ws:
+        want = _bits(api.forward(ws, features).unwrap())
+    net.destroy()
+    monkeypatch.setenv("DGNN_TOWER", "1")
+    monkeypatch.setenv("DGNN_SPLIT_COUNTERS_START", f"{0xf0000000 - 10},{2 ** 32 - 600}")     # 6 flag epochs and 256 arrivals per launch
+    net = api.Network.from_json(text)
+    ws = net.get_workspace(batch)
+    assert ws.conv_kernel() == "tower_split_kernel"
+    for _ in range(8):
+        got = _bits(api.forward(ws, features).unwrap())
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        assert ws.conv_kernel() == "tower_split_kernel"
+    assert "gave up" not in capfd.readouterr().err
+    ws.release()
+    net.destroy()
+
+
 TWO_RANKS_ONE_GPU = r"""
 import json, os, sys, time
 sys.path.insert(0, %(root)r)
