@@ -121,18 +121,20 @@ def main():
     cache = api.LruCache(args.cache, 8) if args.cache > 0 else None
     before = pool.stats()
     cpu0, wall0 = time.process_time(), time.perf_counter()
+    # the records are written as their games end (params.on_game: the reference's channel, self_play.rs:471-497), not held until the last one has
+    sgf_file = open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") if args.sgf else None
+    write_record = (lambda _game, record, _whole: (sgf_file.write(record.decode("ascii") + "\n"), sgf_file.flush())) if sgf_file else None
     stats = replicas.selfplay_sharded(api, dist, torch, args.games, args.moves, args.rollouts, args.threads, seed=2, pool=pool, cache=cache,
-                                      return_sgf=args.sgf is not None, device=f"cuda:{device}" if dist is not None else "cpu",
+                                      device=f"cuda:{device}" if dist is not None else "cpu", on_game=write_record,
                                       num_parallel=args.parallel, ex_it_rollouts=args.ex_it, leaves_per_thread=args.leaves, cache_per_game=args.cache_per_game,
                                       host_threads=args.host_threads)
+    if sgf_file:
+        sgf_file.close()
     host_cpus_busy = (time.process_time() - cpu0) / max(time.perf_counter() - wall0, 1e-9)
     after = pool.stats()
     adaptive_stats = pool.adaptive_stats() if adaptive else None
     coalesced = pool.coalesced()
     batch_times = pool.batch_times()
-    if args.sgf:
-        with open(args.sgf if world == 1 else f"{args.sgf}.rank{rank}", "w") as f:
-            f.write("\n".join(stats.get("sgf", [])) + "\n")
     pool.close()
     boards, batches = after["boards"] - before["boards"], after["batches"] - before["batches"]
     if dist is not None:
