@@ -54,6 +54,10 @@ int main() {
         dgnn_selfplay_params p{};
         p.num_games = 16; p.num_parallel = 16; p.game_stride = 1; p.max_moves = 30; p.num_rollouts = 48; p.threads_per_search = 2;
         p.leaves_per_thread = 4; p.seed = 78; p.host_threads = 0;
+        // the records leave over the channel (params.on_game): sixteen game threads, one call at a time, into plain unguarded state
+        struct Taken { int records = 0; size_t bytes = 0; } taken;
+        p.on_game = [](void* ctx, int, const char* record, size_t bytes, int) { Taken* t = static_cast<Taken*>(ctx); ++t->records; t->bytes += bytes + (size_t)(record[0] == '('); };
+        p.on_game_ctx = &taken;
         dgnn_selfplay_stats st;
         std::thread refresher([&] {
             for (int i = 0; i < 5; ++i) {
@@ -65,8 +69,8 @@ int main() {
         });
         int rc = dgnn_selfplay_go_boards(dgnn_pool_boards_predictor(), pool, cache, &p, &st, nullptr, nullptr, 0);
         refresher.join();
-        std::printf("records pool rc %d moves %llu evals %llu hits %llu\n", rc, (unsigned long long)st.moves, (unsigned long long)st.evals,
-                    (unsigned long long)st.cache_hits);
+        std::printf("records pool rc %d moves %llu evals %llu hits %llu; %d records over the channel, %zu bytes\n", rc, (unsigned long long)st.moves,
+                    (unsigned long long)st.evals, (unsigned long long)st.cache_hits, taken.records, taken.bytes);
         // ... and every record of a game against the host statement of the device kernel
         dgnn_go_board* board = dgnn_go_board_new(6.5f);
         std::vector<uint8_t> record(DGNN_BOARD_RECORD_BYTES);
