@@ -263,3 +263,24 @@ def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_b
     for ws in spaces:
         ws.release()
     net.destroy()
+
+
+@pytest.mark.parametrize("blocks,channels,batch", [(2, 256, 600), (9, 128, 1000), (2, 64, 1537), (2, 96, 300)])
+def test_batches_far_above_256_boards_are_the_same_boards(api, synth, blocks, channels, batch):
+    """graph.rs:123-158 takes any batch; 256 is only what the reference's pool sends.  A workspace of 300-1 537 boards (more workgroups
+    than compute units, not a multiple of eight, a channel count the board kernel does not cover) gives every board the bits it gets in
+    a batch of at most 256 -- the sizes the oracle tests pin."""
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(blocks, channels, seed=7000 + batch)))
+    features = synth.make_features(batch, seed=7001 + batch).reshape(batch, -1)
+    with net.get_workspace(batch) as ws:
+        value, policy = api.forward(ws, features.reshape(-1)).unwrap()
+        kernel = ws.conv_kernel()
+    value, policy = value.view(np.uint16).reshape(batch), policy.view(np.uint16).reshape(batch, 362)
+    step = 200
+    with net.get_workspace(step) as ws:
+        for lo in range(0, batch, step):
+            n = min(step, batch - lo)
+            v, p = api.forward_n(ws, features[lo:lo + n].reshape(-1), n).unwrap()
+            assert np.array_equal(v.view(np.uint16).reshape(-1)[:n], value[lo:lo + n]), (kernel, lo)
+            assert np.array_equal(p.view(np.uint16).reshape(-1, 362)[:n], policy[lo:lo + n]), (kernel, lo)
+    net.destroy()
