@@ -284,3 +284,22 @@ def test_batches_far_above_256_boards_are_the_same_boards(api, synth, blocks, ch
             assert np.array_equal(v.view(np.uint16).reshape(-1)[:n], value[lo:lo + n]), (kernel, lo)
             assert np.array_equal(p.view(np.uint16).reshape(-1, 362)[:n], policy[lo:lo + n]), (kernel, lo)
     net.destroy()
+
+
+def test_a_batch_past_two_to_the_31_activation_elements_is_the_same_boards(api, synth):
+    """288 GB invite large batches: at 256 channels 24 000 boards are 2.46 G fp16 elements per activation tensor -- past what a 32-bit
+    index holds.  Every block of 256 boards of such a batch is the bits a batch of 256 gives (the same 256 positions repeated)."""
+    blocks, channels, batch = 2, 256, 24000
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(blocks, channels, seed=7100)))
+    small = synth.make_features(256, seed=7101).reshape(256, -1)
+    with net.get_workspace(256) as ws:
+        v, p = api.forward(ws, small.reshape(-1)).unwrap()
+    v, p = v.view(np.uint16).reshape(256).copy(), p.view(np.uint16).reshape(256, 362).copy()
+    features = np.tile(small, ((batch + 255) // 256, 1))[:batch]
+    with net.get_workspace(batch) as ws:
+        value, policy = api.forward(ws, features.reshape(-1)).unwrap()
+    value, policy = value.view(np.uint16).reshape(batch), policy.view(np.uint16).reshape(batch, 362)
+    for lo in range(0, batch, 256):
+        n = min(256, batch - lo)
+        assert np.array_equal(value[lo:lo + n], v[:n]) and np.array_equal(policy[lo:lo + n], p[:n]), lo
+    net.destroy()
