@@ -4,12 +4,21 @@
  *   ./selfplay                          (no weights: the deterministic CPU stand-in predictor, no GPU needed)
  *   ./selfplay dream_go.json 64 800     (weights file, games, rollouts: HIP engine behind the leaf pool)
  *
- * Prints one GameResult::Ended record per game (src/libdg_mcts/game_result.rs:35-41), the format dream-go's trainer reads. */
+ * Prints one GameResult::Ended record per game (src/libdg_mcts/game_result.rs:35-41), the format dream-go's trainer reads, as each
+ * game ends -- the reference's reader of self_play()'s channel (src/libdg_mcts/self_play.rs:471-497) -- and keeps none of them. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "dgnn_host.h"
+
+static void print_record(void* ctx, int game_id, const char* record, size_t bytes, int whole)
+{
+    (void)game_id;
+    (void)whole;
+    fwrite(record, 1, bytes, (FILE*)ctx);       /* (one call at a time: the library serialises them) */
+    fputc('\n', (FILE*)ctx);
+}
 
 int main(int argc, char** argv)
 {
@@ -20,8 +29,6 @@ int main(int argc, char** argv)
     dgnn_pool* pool = NULL;
     dgnn_predict_fn predict = dgnn_hash_predictor();
     void* predict_ctx = NULL;
-    size_t capacity;
-    char* sgf;
     int status;
 
     memset(&params, 0, sizeof params);          /* fields added later (host_threads, opening) default to "off" */
@@ -36,6 +43,8 @@ int main(int argc, char** argv)
     params.leaves_per_thread = 8;
     params.cache_entries_per_game = 20001;     /* a table per game, not a shared one: see dgnn_selfplay_go in dgnn_host.h */
     params.seed = 2024;
+    params.on_game = print_record;             /* a job of any length holds no record longer than it takes to print it */
+    params.on_game_ctx = stdout;
 
     if (path) {
         if ((status = dgnn_network_load(path, &net)) != DGNN_OK) { fprintf(stderr, "%s: %s\n", path, dgnn_status_string(status)); return 1; }
@@ -46,16 +55,11 @@ int main(int argc, char** argv)
         predict = dgnn_pool_predictor();
         predict_ctx = pool;
     }
-    capacity = (size_t)params.num_games * ((size_t)(params.max_moves ? params.max_moves : 722) * 2600 + 4 * 722 * 6 + 2048);
-    sgf = (char*)malloc(capacity);
-    if (!sgf) return 1;
-    status = dgnn_selfplay_go(predict, predict_ctx, NULL, &params, &stats, NULL, sgf, capacity);
+    status = dgnn_selfplay_go(predict, predict_ctx, NULL, &params, &stats, NULL, NULL, 0);
     if (status != DGNN_OK) { fprintf(stderr, "self-play: %s\n", dgnn_status_string(status)); return 1; }
-    fputs(sgf, stdout);
     fprintf(stderr, "%llu games, %llu stones, %llu evaluations (%llu from the cache) in %.2f s\n", (unsigned long long)stats.games,
             (unsigned long long)stats.moves, (unsigned long long)stats.evals, (unsigned long long)stats.cache_hits, stats.seconds);
 
-    free(sgf);
     if (pool) dgnn_pool_destroy(pool);
     if (net) dgnn_network_destroy(net);
     return 0;
