@@ -2,10 +2,11 @@
 # A ten-minute soak of the steady state at the shipped settings (the whole-game leg of bench.py over 600 s), with the process's resident
 # memory and the device's used VRAM sampled every 10 s: what a long self-play job holds after its first minute it must still hold at
 # its tenth.    tools/soak.sh [seconds, default 600] [out dir, default gpurun_out/soak]
+#   SOAK_ARGS="--games 1024 --rollouts 1 --threads 1 --leaves 16 --host-threads 4" tools/soak.sh ...   policy play: sixteen games end and start every second
 SECS=${1:-600}
 OUT=${2:-gpurun_out/soak}
 mkdir -p "$OUT"
-python tools/selfplay_go.py --games 96 --rollouts 800 --threads 1 --leaves 16 --host-threads 4 --steady 20,$SECS > "$OUT/steady.json" 2> "$OUT/steady.err" &
+python tools/selfplay_go.py ${SOAK_ARGS:---games 96 --rollouts 800 --threads 1 --leaves 16 --host-threads 4} --steady 20,$SECS > "$OUT/steady.json" 2> "$OUT/steady.err" &
 PID=$!
 : > "$OUT/memory.log"
 while kill -0 $PID 2>/dev/null; do
