@@ -678,10 +678,15 @@ void nap_ns(long long ns)
 // with a workgroup per board: the CUs it leaves are taken by the others' workgroups, and a whole-board workgroup moves the fewest bytes
 // per board.  From 11 / 16 of the CU count in boards in flight on the device (this submission included; 176 on an MI355X) on, a workgroup per
 // board: below that the split's extra workgroups find free CUs of their own (2 x 64 boards run better split, 3 x 64 the same either way).
+// Up to 128 channels only: there a CU holds two boards' workgroups, whole-board launches of different submissions overlap, and the
+// POOL gains what the sweep promised (9x128, 16 / 32 games in flight: + 11 / + 9 % moves per second).  At 256 channels a CU holds one;
+// a small batch behind a full one gets the chip sooner as a split launch -- the CUs of the batch in front come free together -- and the
+// pool LOSES 2.4 % at 48 games in flight although three equal submissions at once (the sweep) gain 14 %
+// (profiles/r05_final/crowded_in_the_pool_*.txt).
 void note_submission_begins(Workspace* ws)       // in front of enqueue_forward: which tower this submission gets
 {
     const int others = ws->dev->boards_in_flight.load(std::memory_order_relaxed);
-    ws->crowded = kCrowdedTowers && others > 0 && others + ws->active >= ws->dev->num_cus * 11 / 16;
+    ws->crowded = kCrowdedTowers && ws->net->topo.num_channels <= 128 && others > 0 && others + ws->active >= ws->dev->num_cus * 11 / 16;
 }
 void note_submission_in_flight(Workspace* ws)    // with `pending = true`
 {

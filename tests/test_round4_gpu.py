@@ -238,13 +238,16 @@ def test_coalescing_on_the_device_answers_with_the_evaluation_of_some_symmetry(a
     assert followed > 0 and boards + followed == 960
 
 
-def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_bits(api, synth):
+@pytest.mark.parametrize("channels", [128, 256])
+def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_bits(api, synth, channels):
     """Round 5: a submission that finds other submissions on the device and brings the boards in flight to 176 or more runs the tower
-    with a workgroup per board whatever its size (alone it would be split over several workgroups per board).  Every work split sums
-    in the same order, so the answers are those of the same batches evaluated one at a time -- bit for bit."""
+    with a workgroup per board whatever its size (alone it would be split over several workgroups per board) -- at up to 128 channels,
+    where a compute unit holds two boards' workgroups (at 256 the pool is better off with the split launch: engine.cpp,
+    note_submission_begins).  Every work split sums in the same order, so the answers are those of the same batches evaluated one at
+    a time -- bit for bit, whichever tower each submission got."""
     import ctypes
     batch = 96
-    net = api.Network.from_json(synth.to_json(synth.make_tensors(6, 256, seed=71)))
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(6, channels, seed=71)))
     feats = [np.ascontiguousarray(synth.make_features(batch, seed=700 + k)).view(np.uint16).reshape(-1) for k in range(3)]
     spaces = [net.get_workspace(batch) for _ in range(3)]
     alone = []
