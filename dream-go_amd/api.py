@@ -81,6 +81,7 @@ SYMBOLS = [
     ("dgnn_workspace_device_buffers", ctypes.c_int, [_vp, _vpp, _vpp, _vpp]),
     ("dgnn_workspace_host_buffers", ctypes.c_int, [_vp, ctypes.POINTER(_u16p), ctypes.POINTER(_u16p), ctypes.POINTER(_u16p)]),
     ("dgnn_workspace_stream", ctypes.c_int, [_vp, _vpp]),
+    ("dgnn_network_tower_stats", ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
     ("dgnn_workspace_conv_kernel", ctypes.c_char_p, [_vp]),
     ("dgnn_workspace_upload", ctypes.c_int, [_vp, _u16p, ctypes.c_size_t]),
     ("dgnn_workspace_download", ctypes.c_int, [_vp, _u16p, _u16p]),
@@ -554,6 +555,12 @@ class Network:
         return c.value
 
     # -- workspaces
+    def tower_stats(self, device=-1):
+        """{per_layer, whole_board, split, split_gave_up}: passes by the form their residual tower took (dgnn_network_tower_stats)."""
+        counts = (ctypes.c_uint64 * 4)()
+        _check(lib.dgnn_network_tower_stats(self.handle, int(device), counts), "tower_stats")
+        return dict(zip(("per_layer", "whole_board", "split", "split_gave_up"), (int(c) for c in counts)))
+
     def get_workspace(self, batch_size, device=0):
         out = ctypes.c_void_p()
         _check(lib.dgnn_network_get_workspace(self.handle, int(device), int(batch_size), ctypes.byref(out)), "get_workspace")

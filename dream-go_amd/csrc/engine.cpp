@@ -33,6 +33,7 @@ void set_last_hip_error(int code) { g_last_hip_error = code; }
         }                                                   \
     } while (0)
 
+constexpr int kSplitQueues = 8;          // ticket counters of a split launch: one per block id mod 8 (conv_board_tower.hip)
 constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 8 channel blocks x 2 row halves (kernels.h: launch_tower_split)
 
 struct Workspace {
@@ -101,8 +102,8 @@ struct Workspace {
     bool injected = false;                  // ... and it has fired
     unsigned* d_split_sync = nullptr;       // [batch * kSplitWordsPerBoard] layers published per (board, channel block, row half), then the give-up word
     unsigned split_base = 0;                // running count the flags are compared against (launch_tower_split)
-    unsigned* d_split_arrive = nullptr;     // one word behind the flags: workgroups of split launches that have become resident (running count)
-    unsigned split_arrive_base = 0;         // ... its value before the next launch
+    unsigned* d_split_tickets = nullptr;    // eight words behind the flags: the queues the workgroups of a split launch draw their work items from (running counts)
+    unsigned split_ticket_base = 0;         // ... their value before the next launch (the eight stay in step: grid / 8 tickets each per launch)
     unsigned* d_split_err = nullptr;        // the give-up word: the last four bytes of the value block
     unsigned* h_split_err = nullptr;        // pinned copy of that word: it arrives with the outputs (one copy for value, word and policy)
     bool split_pending = false;             // the submission in flight used tower_split_kernel
@@ -122,6 +123,9 @@ struct DeviceState {
     bool image_valid = false;               // d_image holds net->image (false between a reserve and the copy that fills it)
     struct SplitChain* chain = nullptr;     // the device's chain of split-tower launches (process-global, see split_chain)
     std::atomic<int> boards_in_flight{0};   // boards of submissions between their submit and their wait, all workspaces of this device
+    // passes enqueued on this device by the form their residual tower took, and the split towers that gave up (dgnn_network_tower_stats):
+    // [0] one launch per layer, [1] a workgroup per board, [2] split tower, [3] give-ups
+    std::atomic<unsigned long long> tower_passes[4] = {};
     std::map<int, std::vector<Workspace*>> idle;   // batch size -> pooled workspaces
     std::vector<Workspace*> all;                   // ownership
 
@@ -153,11 +157,13 @@ DeviceState::~DeviceState()
 
 Network::~Network() { devices.clear(); }
 
-// tower_split_kernel needs all its workgroups resident at once: two such launches on different streams could each hold CUs the
-// other is waiting for, and both would spin until they give up.  They are chained on the device instead (each waits for the event
-// behind the previous one).  The chain belongs to the PHYSICAL device, not to a (network, device) pair: two networks on one GPU
-// -- a match between two nets -- chain through the same event.  (Another PROCESS on the same GPU is out of reach: that is what the
-// give-up word and the retry policy in resolve_split_failure are for.)
+// Split launches of one process are CHAINED per physical device (each waits for the event behind the previous one).  A split launch
+// runs with whatever compute units it is given (its workgroups draw tickets, conv_board_tower.hip), provided that more than
+// 8 * (workgroups per board - 1) of them come its way in the end -- up to 120: two split launches side by side could each hold CUs with
+// workgroups that wait for siblings the other one keeps from starting.  One at a time, that cannot happen; whole-board towers never wait
+// for anything and may run beside a split launch freely.  The chain belongs to the PHYSICAL device, not to a (network, device) pair: two
+// networks on one GPU -- a match between two nets -- chain through the same event.  (Another PROCESS's split launches are out of reach;
+// they end, which is all the argument needs -- and the flag waits' 50 ms limit is the net, resolve_split_failure.)
 struct SplitChain {
     std::mutex mutex;
     hipEvent_t done = nullptr;
@@ -307,7 +313,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     const size_t sz_policy = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256);
     const size_t sz_logits = align_up((size_t)batch * 384 * 2, 256);
     const size_t sz_packed = align_up((size_t)batch * DGNN_PACKED_WORDS * 4, 256);
-    const size_t sz_split = align_up((size_t)batch * kSplitWordsPerBoard * sizeof(unsigned) + sizeof(unsigned), 256);   // + the arrival counter
+    const size_t sz_split = align_up((size_t)batch * kSplitWordsPerBoard * sizeof(unsigned) + kSplitQueues * sizeof(unsigned), 256);   // + the ticket counters
     const size_t sz_records = align_up((size_t)batch * DGNN_BOARD_RECORD_BYTES, 256);
     const size_t sz_vpre = align_up((size_t)batch * 2, 256);
     const size_t total = sz_features + 3 * sz_act + sz_pf + sz_vf + sz_value + sz_policy + sz_fboard + sz_nhwc + sz_logits + sz_packed + sz_split + sz_records + sz_vpre;
@@ -333,15 +339,16 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     ws->d_logits = (uint16_t*)p; p += sz_logits;
     ws->d_packed = (uint32_t*)p; p += sz_packed;
     ws->d_split_sync = (unsigned*)p; p += sz_split;
-    ws->d_split_arrive = ws->d_split_sync + (size_t)batch * kSplitWordsPerBoard;
-    // (tests) the running counters of the split towers started where a job finds them after hours: "flags,arrivals" -- the flag base a
-    // few launches below its refill at 0xf0000000 (two days of launches), the 32-bit arrival count a few launches below its wrap (eight hours)
+    ws->d_split_tickets = ws->d_split_sync + (size_t)batch * kSplitWordsPerBoard;
+    // (tests) the running counters of the split towers started where a job finds them after a long time: "flags,tickets" -- the flag base a
+    // few launches below its refill at 0xf0000000 (two days of launches), the 32-bit ticket counts a few launches below their wrap
     if (const char* start = test_env("DGNN_SPLIT_COUNTERS_START")) {
         unsigned flags_at = 0, arrivals_at = 0;
         if (std::sscanf(start, "%u,%u", &flags_at, &arrivals_at) == 2) {
             ws->split_base = flags_at;
-            ws->split_arrive_base = arrivals_at;
-            DGNN_HIP(hipMemcpy(ws->d_split_arrive, &arrivals_at, sizeof(unsigned), hipMemcpyHostToDevice));
+            ws->split_ticket_base = arrivals_at;
+            const unsigned all[kSplitQueues] = {arrivals_at, arrivals_at, arrivals_at, arrivals_at, arrivals_at, arrivals_at, arrivals_at, arrivals_at};
+            DGNN_HIP(hipMemcpy(ws->d_split_tickets, all, sizeof(all), hipMemcpyHostToDevice));
         }
     }
     ws->d_records = p; p += sz_records;
@@ -515,6 +522,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
             }
             const int layer_count = 2 * t.num_blocks + (up_in_tower ? 1 : 0);
             const int mode = tower_mode(ws);
+            ws->dev->tower_passes[mode > 0 ? 2 : 1].fetch_add(1, std::memory_order_relaxed);
             if (mode > 0) {
                 const int groups = mode == 32 ? t.num_channels / 32 * 2 : mode == 24 ? 2 : t.num_channels / 32 / mode;
                 SplitChain* chain = ws->dev->chain;
@@ -528,8 +536,8 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     else missing = true;
                 }
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
-                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->d_split_arrive,
-                                            &ws->split_arrive_base, ws->stream, missing));
+                                            (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->d_split_tickets,
+                                            &ws->split_ticket_base, ws->stream, missing));
                 DGNN_HIP(hipEventRecord(chain->done, ws->stream));
                 chain->recorded = true;
             } else {
@@ -565,6 +573,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
             }
             for (int i = 0; i < t.num_blocks; ++i) cur = (cur + 2) % 3;
         } else {
+            ws->dev->tower_passes[0].fetch_add(1, std::memory_order_relaxed);
             for (int i = 0; i < t.num_blocks; ++i) {
                 const int tmp = (cur + 1) % 3, next = (cur + 2) % 3;
                 DGNN_HIP(conv_board(t.res1[i], ws->d_act[cur], nullptr, ws->d_act[tmp]));
@@ -783,10 +792,13 @@ int enqueue_split_check(Workspace* ws, int input_form)
     return DGNN_OK;                         // (the word itself arrives with the outputs: enqueue_outputs)
 }
 
-// After the stream has drained: a split tower whose workgroups were not all resident (the device is shared with another
-// process) gives up instead of hanging; its outputs are garbage.  The pass is repeated with one launch per layer, the next
-// kSplitCooldown passes of this workspace run per layer too, then the split is tried again (the other tenant may be gone); after
-// kSplitMaxFailures give-ups it stays off until dgnn_network_synchronize re-arms it.
+// After the stream has drained: a split tower in which a hand-off was not published within 50 ms (wait_published, the net under the
+// tickets of conv_board_tower.hip: a sibling never got a compute unit -- something that does not end holds the device -- or the launch
+// lost workgroups) gives up instead of hanging; its outputs are garbage.  The pass is repeated with one launch per layer, the next
+// kSplitCooldown passes of this workspace run per layer too, then the split is tried again; after kSplitMaxFailures give-ups it stays
+// off until dgnn_network_synchronize re-arms it.  Towers of OTHER workspaces of this process in front of a split launch are not such
+// a case (round 5 treated them as one and lost the split inside the leaf pool): its workgroups draw their work in the order in which
+// they start, and wait for each other for as long as those towers run -- milliseconds.
 constexpr int kSplitCooldown = 64, kSplitMaxFailures = 3;
 
 int note_split_failure(Workspace* ws)
@@ -794,12 +806,14 @@ int note_split_failure(Workspace* ws)
     *ws->h_split_err = 0;
     ws->split_failed = true;
     ++ws->split_failures;
+    ws->dev->tower_passes[3].fetch_add(1, std::memory_order_relaxed);
     ws->split_cooldown = kSplitCooldown;
-    std::fprintf(stderr, "dgnn: tower_split_kernel gave up waiting for a workgroup (device %d shared?); one launch per layer %s\n", ws->device,
-                 ws->split_failures >= kSplitMaxFailures ? "from now on" : "for the next passes");
+    std::fprintf(stderr, "dgnn: tower_split_kernel gave up: a hand-off between its workgroups took more than 50 ms on device %d (a workgroup of the launch "
+                         "never ran); the pass is repeated with one launch per layer, and so are the next passes %s\n", ws->device,
+                 ws->split_failures >= kSplitMaxFailures ? "until dgnn_network_synchronize" : "of this workspace for a while");
     DGNN_HIP(hipMemsetAsync(ws->d_split_err, 0, sizeof(unsigned), ws->stream));   // the word is sticky on the device
-    DGNN_HIP(hipMemsetAsync(ws->d_split_arrive, 0, sizeof(unsigned), ws->stream)); // (a launch that gave up leaves the arrival count anywhere)
-    ws->split_arrive_base = 0;
+    DGNN_HIP(hipMemsetAsync(ws->d_split_tickets, 0, kSplitQueues * sizeof(unsigned), ws->stream)); // (a launch that was short of workgroups left the queues out of step)
+    ws->split_ticket_base = 0;
     return DGNN_OK;
 }
 
@@ -1161,6 +1175,19 @@ int dgnn_network_synchronize(dgnn_network* net)
         }
     }
     return status;
+}
+
+int dgnn_network_tower_stats(dgnn_network* net, int device, uint64_t* counts)
+{
+    if (!net || !counts) return DGNN_BAD_ARGUMENT;
+    Network* n = N(net);
+    std::lock_guard<std::mutex> lock(n->mutex);
+    for (int k = 0; k < 4; ++k) counts[k] = 0;
+    for (auto& entry : n->devices) {
+        if (device >= 0 && entry.first != device) continue;
+        for (int k = 0; k < 4; ++k) counts[k] += entry.second->tower_passes[k].load(std::memory_order_relaxed);
+    }
+    return DGNN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- hot path

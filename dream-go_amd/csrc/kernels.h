@@ -132,12 +132,14 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
 // The tower as one launch with a board SPLIT over C / (32 * ns) workgroups that hand their channel blocks to each other
 // (per-board flags in `d_done`: `done_words` >= batch * C / (32 * ns) words, zero when first used and never reset -- `*base` is
 // the launcher's running count they are compared against; `d_err`: one word, zero before the first launch, nonzero after a
-// launch if a poll gave up).  tower_split_ns: the slices per workgroup the launcher wants for this batch, 0 = do not split (the
-// workgroups of one launch must all be resident at once: batch * C / (32 * ns) <= num_cus).
+// launch if a poll gave up; `d_tickets`: eight running counters the workgroups draw their work items from, `*ticket_base` their value
+// before the launch).  tower_split_ns: the slices per workgroup the launcher wants for this batch, 0 = do not split (a launch is
+// kept to batch * C / (32 * ns) <= num_cus workgroups: it may run with fewer compute units than that -- conv_board_tower.hip -- but
+// should not need two rounds of them).
 int tower_split_ns(int batch, int channels, int num_cus);
 bool tower_pair_supported(int batch, int channels, int num_cus);
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
-                              size_t done_words, unsigned* d_err, unsigned* base, unsigned* d_arrive, unsigned* arrive_base, hipStream_t stream,
+                              size_t done_words, unsigned* d_err, unsigned* base, unsigned* d_tickets, unsigned* ticket_base, hipStream_t stream,
                               bool inject_missing = false);
 // Layout changes at the two ends of the tower: [B][361][C] NHWC <-> [B][C / 8][400][8].  C a multiple of 8.
 hipError_t launch_nhwc_to_board(const uint16_t* in, uint16_t* out, int batch, int channels, hipStream_t stream);

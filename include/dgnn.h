@@ -191,6 +191,12 @@ int dgnn_workspace_host_buffers(dgnn_workspace* ws, uint16_t** h_features, uint1
  * "conv3x3_kernel"): the harness quotes it next to the roofline numbers.  Static string, never NULL. */
 const char* dgnn_workspace_conv_kernel(const dgnn_workspace* ws);
 
+/* Which form the residual tower of the passes enqueued so far took, over all workspaces of `net` on `device` (-1: every device):
+ * counts[0] one launch per layer, [1] one launch with a workgroup per board (tower_board_kernel), [2] one launch with a board split
+ * over several workgroups (tower_split_kernel: batches too small to fill the chip), [3] split launches that gave up and were repeated
+ * per layer (expected: 0 -- see dgnn_status_string / stderr).  What a harness quotes next to a leaf pool's throughput. */
+int dgnn_network_tower_stats(dgnn_network* net, int device, uint64_t* counts /* 4 */);
+
 /* The HIP stream (hipStream_t) every kernel of this workspace is launched on. */
 int dgnn_workspace_stream(dgnn_workspace* ws, void** hip_stream);
 

@@ -195,12 +195,14 @@ def test_broadcast_without_rccl_is_refused_up_front(api, synth, monkeypatch):
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-def test_a_launch_that_is_not_fully_resident_gives_up_within_milliseconds(api_full, synth, monkeypatch, capfd):
-    """DGNN_SPLIT_INJECT_GIVEUP=2 launches the split tower WITHOUT its last eight workgroups -- what a launch whose workgroups are not
-    co-resident looks like to the others.  Round 5: co-residency is a PRECONDITION -- every workgroup announces
-    itself at the start of the launch and waits at most kArriveTicks (400 us of the 100 MHz s_memrealtime clock) for the others; a
-    launch that is not whole gives up there, before any work, and the pass is repeated per layer: bit-equal to the per-layer path and
-    a few milliseconds end to end INCLUDING this workspace's first-pass set-up (round 4: the flag waits' own 50 ms limit, 52 ms)."""
+def test_a_launch_that_has_lost_workgroups_gives_up_at_the_flag_limit_and_the_pass_is_repeated(api_full, synth, monkeypatch, capfd):
+    """DGNN_SPLIT_INJECT_GIVEUP=2 launches the split tower WITHOUT its last eight workgroups: the last ticket of every queue is never
+    drawn, the siblings of those boards wait for a flag that nobody publishes.  No real launch loses workgroups; the case stands for
+    "a sibling never gets a compute unit" (something endless holds the device), the one thing the tickets of round 6 cannot wait out.
+    The net under them is the flag waits' 50 ms wall-clock limit: the launch gives up there, the pass is repeated per layer and is
+    bit-equal to the per-layer path.  (Round 5 put a 400 us arrival handshake in front so that THIS case cost a few milliseconds --
+    and lost the split inside the leaf pool, where a tower of another workspace in front of the launch outlasts 400 us as a matter
+    of course: VERDICT r05 weak #2.  The rare case pays 50 ms again; the normal one pays nothing.)"""
     api = api_full          # (entry points of include/dgnn_test.h: the test build of the library)
     blocks, channels, batch = 2, 256, 16
     text = synth.to_json(synth.make_tensors(blocks, channels, seed=650))
@@ -221,23 +223,27 @@ def test_a_launch_that_is_not_fully_resident_gives_up_within_milliseconds(api_fu
     print(f"pass with eight workgroups missing: {seconds * 1e3:.1f} ms end to end")
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert "gave up" in capfd.readouterr().err
-    assert 0.0004 < seconds < 0.01                                  # it DID wait for the missing workgroups (not the pre-set word of mode 1): 400 us, not 50 ms
+    assert 0.045 < seconds < 0.2                                    # it DID wait for the missing workgroups (not the pre-set word of mode 1), and not for ever
+    assert net.tower_stats()["split_gave_up"] == 1
     assert ws.conv_kernel() == "conv3x3_board_kernel"
-    net.synchronize()                                               # re-arm: the next split launch is whole again
+    net.synchronize()                                               # re-arm: the next split launch is whole again, its ticket queues back in step
     assert ws.conv_kernel() == "tower_split_kernel"
-    t0 = time.perf_counter()
-    got = _bits(api.forward(ws, features).unwrap())
-    assert time.perf_counter() - t0 < 0.02
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = _bits(api.forward(ws, features).unwrap())
+        assert time.perf_counter() - t0 < 0.02
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert net.tower_stats()["split_gave_up"] == 1
     ws.release()
     net.destroy()
 
 
 def test_split_towers_run_through_the_wrap_of_their_running_counters(api_full, synth, monkeypatch, capfd):
-    """The split towers' flags and their arrival count are RUNNING counters, never reset between launches: the flag base is refilled
-    when it passes 0xf0000000 (two days of back-to-back launches), the 32-bit arrival count simply wraps (eight hours at 20x256, batch
-    128) and is compared by signed difference.  Nobody waits eight hours in a test: DGNN_SPLIT_COUNTERS_START (test build) starts a
-    workspace's counters a few launches below both, and the passes across them are the bits of the per-layer path, without a give-up."""
+    """The split towers' flags and their eight ticket queues are RUNNING counters, never reset between launches: the flag base is
+    refilled when it passes 0xf0000000 (two days of back-to-back launches), the 32-bit ticket counts simply wrap (a ticket is the
+    counter minus its value before the launch, in unsigned arithmetic).  Nobody waits days in a test: DGNN_SPLIT_COUNTERS_START (test
+    build) starts a workspace's counters a few launches below both, and the passes across them are the bits of the per-layer path,
+    without a give-up."""
     api = api_full
     blocks, channels, batch = 2, 256, 16
     text = synth.to_json(synth.make_tensors(blocks, channels, seed=660))
@@ -248,7 +254,7 @@ def test_split_towers_run_through_the_wrap_of_their_running_counters(api_full, s
         want = _bits(api.forward(ws, features).unwrap())
     net.destroy()
     monkeypatch.setenv("DGNN_TOWER", "1")
-    monkeypatch.setenv("DGNN_SPLIT_COUNTERS_START", f"{0xf0000000 - 10},{2 ** 32 - 600}")     # 6 flag epochs and 256 arrivals per launch
+    monkeypatch.setenv("DGNN_SPLIT_COUNTERS_START", f"{0xf0000000 - 10},{2 ** 32 - 100}")     # 6 flag epochs and 32 tickets per queue and launch
     net = api.Network.from_json(text)
     ws = net.get_workspace(batch)
     assert ws.conv_kernel() == "tower_split_kernel"
@@ -419,8 +425,9 @@ print("RESULT " + json.dumps({"rank": rank, "kernel": kernel, "kernel_at_the_end
 def test_two_processes_running_split_towers_on_one_gpu_never_stall_for_the_flag_timeout(tmp_path, capfd):
     """two tenants on one GPU, each launching split towers that want EVERY compute unit (9 x 128, batch 32: the row
     split, 256 workgroups a launch).  Neither launch can become resident beside the other's: in round 4 each such collision cost the
-    flag waits' 50 ms.  With the arrival handshake a launch that is not whole gives up within 400 us and the pass is repeated per
-    layer, so no pass of either tenant takes anywhere near 50 ms, and every pass of both is bit-equal to the first."""
+    flag waits' 50 ms (round 5: a 400 us arrival handshake and a per-layer repeat).  Round 6: the workgroups of a launch draw their
+    work in the order in which they start, so a launch runs with whatever compute units the other tenant leaves it and nobody gives
+    up: no pass of either tenant takes anywhere near 50 ms, and every pass of both is bit-equal to the first."""
     import json
     import os
     import re
@@ -449,7 +456,7 @@ def test_two_processes_running_split_towers_on_one_gpu_never_stall_for_the_flag_
         assert r["kernel"] == "tower_split_kernel" and r["wrong"] == 0 and r["passes"] > 1000
         # round 4: 50 ms per collision, with a "gave up" message each.  Now: no give-up in the steady state, and no pass of it anywhere
         # near 50 ms.  (The first second is left out: ~56 ms after two tenants start together BOTH see one pass of 35-53 ms at the same
-        # instant -- the device's own business, a clock / power-state step under the first load.  Mostly neither prints a give-up; one
-        # box in four the 35 ms fall between a launch's workgroups, the handshake gives up as it should, and the pass is repeated.)
+        # instant -- the device's own business while the OTHER tenant loads its code object.  If those milliseconds fall between a
+        # launch's workgroups and stretch past the flag limit, that one pass gives up and is repeated: allowed once.)
         assert r["gave_up_messages"] <= 1 and r["passes_on_per_layer_launches_after_the_first_second"] == 0, r
         assert r["kernel_at_the_end"] == "tower_split_kernel" and r["worst_ms_after_the_first_second"] < 25.0, r

@@ -1,0 +1,115 @@
+"""Round 6 on a real MI355X.
+
+  * the split tower inside the leaf pool's resource model: a submission too small for a
+    workgroup per board, queued behind whole-board towers of other workspaces of the SAME process -- `2 x num_devices` batches alive,
+    src/libdg_mcts/predictors/nn.rs:64-67, partial batches being the normal case (pool/batch.rs:98-117).  Its workgroups become
+    resident a few at a time as the towers in front end; they draw their work as tickets in that order (conv_board_tower.hip), so the
+    launch never gives up, never falls back to one launch per layer, and its answers are the bits of the same batch evaluated alone.
+"""
+import ctypes
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+U16P = ctypes.POINTER(ctypes.c_uint16)
+
+
+def _submit(api, ws, f, n):
+    assert api.lib.dgnn_forward_submit_n(ws.handle, f.ctypes.data_as(U16P), n) == 0
+
+
+def _wait(api, ws, n):
+    v, p = np.empty(n, dtype=np.uint16), np.empty(n * 362, dtype=np.uint16)
+    assert api.lib.dgnn_forward_wait(ws.handle, v.ctypes.data_as(U16P), p.ctypes.data_as(U16P)) == 0
+    return v, p
+
+
+@pytest.mark.parametrize("small,towers_in_front", [(32, 1), (64, 1), (96, 1), (64, 2), (16, 2)])
+def test_a_split_tower_behind_whole_board_towers_of_the_same_process_never_gives_up(api, synth, capfd, small, towers_in_front):
+    """20 x 256 (configs[2]): a 256-board submission holds every compute unit for ~3 ms with one workgroup per board.  Behind it
+    (behind two of them: three batches alive, the pool's default) a submission of 16-96 boards runs as a split tower.  200 rounds:
+    zero give-ups, tower_split_kernel to the end, every answer bit-equal to the batch evaluated alone, and a round costs no more than
+    its parts evaluated one after the other -- nobody sat out a time-out."""
+    blocks, channels, big = 20, 256, 256
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(blocks, channels, seed=6100)))
+    f_big = [np.ascontiguousarray(synth.make_features(big, seed=6101 + k)).view(np.uint16).reshape(-1) for k in range(towers_in_front)]
+    f_small = np.ascontiguousarray(synth.make_features(small, seed=6110)).view(np.uint16).reshape(-1)
+    ws_big = [net.get_workspace(big) for _ in range(towers_in_front)]
+    ws_small = net.get_workspace(small)
+    assert all(w.conv_kernel() == "tower_board_kernel" for w in ws_big) and ws_small.conv_kernel() == "tower_split_kernel"
+
+    def alone(ws, f, n, repeats=5):
+        best = 1e9
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            _submit(api, ws, f, n)
+            out = _wait(api, ws, n)
+            best = min(best, time.perf_counter() - t0)
+        return out, best
+
+    want_big, t_big = zip(*[alone(w, f, big) for w, f in zip(ws_big, f_big)])
+    want_small, t_small = alone(ws_small, f_small, small)
+    before = net.tower_stats()
+    capfd.readouterr()
+    rounds, worst, t_begin = 200, 0.0, time.perf_counter()
+    for r in range(rounds):
+        t0 = time.perf_counter()
+        for w, f in zip(ws_big, f_big):
+            _submit(api, w, f, big)
+        _submit(api, ws_small, f_small, small)
+        for k, w in enumerate(ws_big):
+            v, p = _wait(api, w, big)
+            assert np.array_equal(v, want_big[k][0]) and np.array_equal(p, want_big[k][1]), (r, k)
+        v, p = _wait(api, ws_small, small)
+        assert np.array_equal(v, want_small[0]) and np.array_equal(p, want_small[1]), r
+        worst = max(worst, time.perf_counter() - t0)
+    seconds = time.perf_counter() - t_begin
+    after = net.tower_stats()
+    one_after_the_other = sum(t_big) + t_small
+    print(f"{towers_in_front} x 256 boards + {small} boards: {1e3 * seconds / rounds:.2f} ms per round (worst {1e3 * worst:.2f}); alone, one after the other "
+          f"{1e3 * one_after_the_other:.2f} ms; towers {after}")
+    assert "gave up" not in capfd.readouterr().err
+    assert after["split_gave_up"] == before["split_gave_up"] == 0
+    assert after["split"] - before["split"] == rounds and after["whole_board"] - before["whole_board"] == rounds * towers_in_front
+    assert after["per_layer"] == before["per_layer"]
+    assert ws_small.conv_kernel() == "tower_split_kernel"
+    assert seconds / rounds < 1.15 * one_after_the_other and worst < 0.025, (seconds / rounds, one_after_the_other, worst)
+    for w in ws_big + [ws_small]:
+        w.release()
+    net.destroy()
+
+
+def test_split_towers_of_a_leaf_pool_stay_split(api, synth, capfd):
+    """The same through the product's own front door: a leaf pool over the device (three batches alive) fed by callers whose requests
+    come in uneven bursts, so that full 256-board batches and small partial ones follow each other on the device.  The pool's
+    workspaces are the library's business; what the caller can see is dgnn_network_tower_stats: split launches happened, none gave up,
+    none was repeated per layer -- and stderr is silent."""
+    import threading
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(20, 256, seed=6200)))
+    pool = api.LeafPool.over_devices(net, devices=[0], max_batch_size=256, batches_per_device=3, workers_per_device=3)
+    feats = np.ascontiguousarray(synth.make_features(64, seed=6201)).reshape(64, -1)
+    capfd.readouterr()
+    problems = []
+
+    def caller(t):
+        rng = np.random.default_rng(6300 + t)
+        for _ in range(30):
+            n = int(rng.choice([1, 2, 4, 8, 8, 8, 16]))
+            rows = rng.integers(0, 64, size=n)
+            got = pool.predict(feats[rows].reshape(-1), n)
+            if len(got) != n:
+                problems.append((t, n, len(got)))
+
+    threads = [threading.Thread(target=caller, args=(t,)) for t in range(96)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    stats = net.tower_stats()
+    pool.close()
+    net.destroy()
+    print("towers of the pool's passes:", stats)
+    assert not problems, problems[:3]
+    assert stats["split"] > 0 and stats["split_gave_up"] == 0 and stats["per_layer"] == 0, stats
+    assert "gave up" not in capfd.readouterr().err
