@@ -334,13 +334,15 @@ class EdgeProbe:
     """What the library does not count, read at the two edges of a dgnn_selfplay_window (from the watcher thread): the pool's device
     boards / batches / followers, the process's CPU time, the wall clock."""
 
-    def __init__(self, pool):
-        self.pool, self.edges = pool, {}
+    def __init__(self, pool, net=None):
+        self.pool, self.net, self.edges = pool, net, {}
 
     def __call__(self, edge):
         st = self.pool.stats()
         self.edges[edge] = {"boards": st["boards"], "batches": st["batches"], "coalesced": self.pool.coalesced(),
                             "cpu": time.process_time(), "wall": time.perf_counter()}
+        if self.net is not None:
+            self.edges[edge].update(self.net.tower_stats())    # device passes by the form their residual tower took (dgnn_network_tower_stats)
 
     def delta(self, key):
         return self.edges[1][key] - self.edges[0][key] if 0 in self.edges and 1 in self.edges else 0
@@ -381,7 +383,7 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
             stones = int((opening[i] >= 0).sum())
             opening[i, stones * i // opening.shape[0]:] = -1
         prep_seconds = time.perf_counter() - t0
-    probe = EdgeProbe(pool)
+    probe = EdgeProbe(pool, None if job.dry else net)
     # the games' records leave the way the reference's do (self_play.rs:471-497: a channel whose reader prints them): counted and let go of
     taken = {"records": 0, "whole": 0, "bytes": 0}
 
@@ -423,6 +425,10 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
         "device_boards_per_sec": boards / sec, "mean_device_batch": boards / max(batches, 1),
         "followers_per_sec": followers / sec,                         # boards that followed a position in flight instead of being evaluated
         "device_batch_us_by_size": {str(k): v for k, v in batch_times.items()},
+        # rank 0's device passes inside the window by the form their residual tower took: one launch with a workgroup per board, one launch
+        # with a board split over several workgroups (batches too small to fill the chip), one launch per layer (the fallback of a split
+        # launch that gave up: expected 0, as is split_gave_up -- round 5's line had nine such give-ups on stderr)
+        "tower_passes": None if job.dry else {k: probe.delta(k) for k in ("whole_board", "split", "per_layer", "split_gave_up")},
         "host_cpus_busy": cores[0], "per_rank_host_cpus_busy": cores, "host_cpus": effective_cpus(), "host_threads": args.selfplay_host_threads,
         "probe_conflicts": w["conflicts"],
         # (rank 0's, ramp and the games the window's end cut short included: that the records ARE produced and handed over, not a rate)

@@ -9,6 +9,8 @@
 // was handed (hipSetDevice is per-thread).
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +38,28 @@ void set_last_hip_error(int code) { g_last_hip_error = code; }
 constexpr int kSplitQueues = 8;          // ticket counters of a split launch: one per block id mod 8 (conv_board_tower.hip)
 constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 8 channel blocks x 2 row halves (kernels.h: launch_tower_split)
 
+// The ORDER of tower launches on a physical device, where it matters (process-global per device; two networks on one GPU -- a match
+// between two nets -- go through the same chain):
+//   * split launches are chained (each waits for the event behind the previous one).  A split launch runs with whatever compute units
+//     it is given (its workgroups draw tickets, conv_board_tower.hip), provided that more than 8 * (workgroups per board - 1) of them
+//     come its way in the end -- up to 120: two split launches side by side could each hold CUs with workgroups that wait for
+//     siblings the other one keeps from starting.  One at a time, that cannot happen.
+//   * a split launch waits for the whole-board towers enqueued before it, and a whole-board tower for the split launch enqueued
+//     before it (round 6).  Not for safety -- whole-board workgroups never wait for anything -- but for the rounds: 256 whole-board
+//     workgroups are ONE round of the chip's 256 CUs; a split launch that takes half of the CUs the tower in front has just
+//     released turns the next tower's one round of 3 ms into two (measured, 20x256: two 256-board towers and a 64-board split
+//     launch 9.5 ms side by side against 8.1 ms one after the other -- tests/test_round6_gpu.py).  Whole-board towers behind
+//     whole-board towers are not ordered: their workgroups end together and the next tower's start as they do, and below 256 boards
+//     the CUs one tower leaves idle are what the next one runs on.
+// (Another PROCESS's launches are out of reach; they end, which is all the ticket argument needs -- and the flag waits' 50 ms limit is
+// the net, resolve_split_failure.)
+struct SplitChain {
+    std::mutex mutex;
+    hipEvent_t done = nullptr;              // behind the most recent split launch
+    bool recorded = false;
+    std::vector<hipEvent_t> whole;          // behind the whole-board towers enqueued since then (Workspace::ev_tower, one per workspace)
+};
+
 struct Workspace {
     Network* net = nullptr;
     DeviceState* dev = nullptr;
@@ -45,6 +69,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_done = nullptr;           // event behind the outputs' copies: what dgnn_forward_wait waits for
+    hipEvent_t ev_tower = nullptr;          // event behind this workspace's most recent whole-board tower launch (SplitChain::whole)
     long long submit_ns = 0;                // when it was recorded
     double wait_ns = 0.0;                   // how long submissions of `wait_boards` boards took lately (submit -> outputs on the host)
     double wait_last = 0.0;                 // ... the most recent one (wait_submission)
@@ -141,6 +166,14 @@ Workspace::~Workspace()
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (ev_done) (void)hipEventDestroy(ev_done);
+    if (ev_tower) {
+        if (dev && dev->chain) {            // the device's chain may still name it
+            std::lock_guard<std::mutex> chained(dev->chain->mutex);
+            auto& whole = dev->chain->whole;
+            whole.erase(std::remove(whole.begin(), whole.end(), ev_tower), whole.end());
+        }
+        (void)hipEventDestroy(ev_tower);
+    }
     if (arena) (void)hipFree(arena);
     if (d_tower_layers) (void)hipFree(d_tower_layers);
     if (d_tower_timing) (void)hipFree(d_tower_timing);
@@ -157,18 +190,6 @@ DeviceState::~DeviceState()
 
 Network::~Network() { devices.clear(); }
 
-// Split launches of one process are CHAINED per physical device (each waits for the event behind the previous one).  A split launch
-// runs with whatever compute units it is given (its workgroups draw tickets, conv_board_tower.hip), provided that more than
-// 8 * (workgroups per board - 1) of them come its way in the end -- up to 120: two split launches side by side could each hold CUs with
-// workgroups that wait for siblings the other one keeps from starting.  One at a time, that cannot happen; whole-board towers never wait
-// for anything and may run beside a split launch freely.  The chain belongs to the PHYSICAL device, not to a (network, device) pair: two
-// networks on one GPU -- a match between two nets -- chain through the same event.  (Another PROCESS's split launches are out of reach;
-// they end, which is all the argument needs -- and the flag waits' 50 ms limit is the net, resolve_split_failure.)
-struct SplitChain {
-    std::mutex mutex;
-    hipEvent_t done = nullptr;
-    bool recorded = false;
-};
 SplitChain* split_chain(int device)
 {
     static std::mutex table_mutex;
@@ -297,6 +318,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
     DGNN_HIP(hipEventCreate(&ws->ev_begin));
     DGNN_HIP(hipEventCreate(&ws->ev_end));
     DGNN_HIP(hipEventCreateWithFlags(&ws->ev_done, hipEventBlockingSync | hipEventDisableTiming));
+    DGNN_HIP(hipEventCreateWithFlags(&ws->ev_tower, hipEventDisableTiming));
 
     const size_t num_pos = (size_t)batch * DGNN_NUM_POINTS;
     const size_t sz_features = align_up(num_pos * DGNN_NUM_FEATURES * 2, 256);
@@ -391,6 +413,10 @@ int tower_mode(const Workspace* ws)
 }
 
 bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
+
+// Split launches behind the whole-board towers enqueued before them and in front of those enqueued after them (round 6, SplitChain);
+// DGNN_TOWER_ORDER=0 (test / ablations build): only split launches among themselves, as in rounds 2-5 (A/B).
+const bool kOrderedTowers = [] { const char* e = test_env("DGNN_TOWER_ORDER"); return !(e && std::atoi(e) == 0); }();
 
 // Whole-board towers for small batches on a crowded device (round 5); DGNN_CROWDED=0 (test / ablations build): the size alone decides (A/B).
 const bool kCrowdedTowers = [] { const char* e = test_env("DGNN_CROWDED"); return !(e && std::atoi(e) == 0); }();
@@ -528,6 +554,8 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 SplitChain* chain = ws->dev->chain;
                 std::lock_guard<std::mutex> chained(chain->mutex);
                 if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
+                if (kOrderedTowers) for (hipEvent_t e : chain->whole) DGNN_HIP(hipStreamWaitEvent(ws->stream, e, 0));
+                chain->whole.clear();
                 (void)groups;
                 bool missing = false;
                 if (ws->inject_giveup != 0 && !ws->injected) {  // fault injection (tests)
@@ -557,7 +585,17 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     hc.cin = t.num_channels;
                     hc.samples = t.num_samples;
                 }
-                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream, head_in_tower ? &hc : nullptr));
+                {
+                    SplitChain* chain = ws->dev->chain;
+                    std::lock_guard<std::mutex> chained(chain->mutex);
+                    if (kOrderedTowers && chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
+                    DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream, head_in_tower ? &hc : nullptr));
+                    if (kOrderedTowers) {
+                        DGNN_HIP(hipEventRecord(ws->ev_tower, ws->stream));
+                        auto& whole = chain->whole;
+                        if (std::find(whole.begin(), whole.end(), ws->ev_tower) == whole.end()) whole.push_back(ws->ev_tower);
+                    }
+                }
                 if (ws->d_tower_timing) {
                     DGNN_HIP(hipStreamSynchronize(ws->stream));
                     const size_t words = (size_t)ws->tower_timing_layers * ws->batch * 8 * 4;

@@ -76,7 +76,7 @@ def test_a_split_tower_behind_whole_board_towers_of_the_same_process_never_gives
     assert after["split"] - before["split"] == rounds and after["whole_board"] - before["whole_board"] == rounds * towers_in_front
     assert after["per_layer"] == before["per_layer"]
     assert ws_small.conv_kernel() == "tower_split_kernel"
-    assert seconds / rounds < 1.15 * one_after_the_other and worst < 0.025, (seconds / rounds, one_after_the_other, worst)
+    assert seconds / rounds < 1.10 * one_after_the_other and worst < 0.025, (seconds / rounds, one_after_the_other, worst)
     for w in ws_big + [ws_small]:
         w.release()
     net.destroy()

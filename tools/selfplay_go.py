@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--snap", default="", metavar="LO,HI", help="with --back-to-back: a batch of LO < n < HI boards is cut to its LO oldest, e.g. 128,208")
     ap.add_argument("--coalesce", type=int, default=1, help="1: requests for a position in flight follow it (dgnn_pool_set_coalescing; only with a shared table); 0: off")
     ap.add_argument("--max-batches", type=int, default=3, help="device batches the pool keeps alive: 3 (default since round 5, DESIGN.md 14.2), 2 (the reference's rule), or 0 = adaptive (a rule that lost; test build)")
-    ap.add_argument("--workers", type=int, default=0, help="pool worker threads per device; 0 (default) = one more than batches alive: a free worker takes the next batch while another is still handing its answers to the games (DESIGN.md 14.2: +2.5 %)")
+    ap.add_argument("--workers", type=int, default=0, help="pool worker threads per device; 0 (default) = one more than batches alive: a free worker takes the next batch while another is still handing its answers to the games (DESIGN.md 14.2: +2.5 %%)")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--cache", type=int, default=200_001, help="transposition table entries (0 = none); nn.rs:48 uses 200_001 per shard")
