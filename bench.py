@@ -85,12 +85,19 @@ def parse_args(argv=None):
                     help="where the 32 feature planes are built: on the device from 896-byte board records (default), or on the host like the reference")
     ap.add_argument("--whole-games", type=int, default=96,
                     help="games in flight PER GPU, with replacement, in the steady-state WHOLE-GAME leg (the setting of tools/selfplay_go.py; 0 = skip the leg)")
-    ap.add_argument("--whole-games-seconds", type=float, default=90.0, help="the timed window of the whole-game leg")
+    ap.add_argument("--selfplay-opening-leg", type=int, default=0,
+                    help="1: also run the OPENING-stones leg (`selfplay`: the first --selfplay-moves stones of games started together; 1.3 s of a "
+                         "host-bound corner -- games in flight share their first positions -- that rounds 1-5 ran by default; VERDICT r05 item 7)")
+    ap.add_argument("--whole-games-seconds", type=float, default=120.0, help="the timed window of the whole-game leg (round 5: 90 s, which sees 12-18 endings)")
     ap.add_argument("--whole-games-ramp", type=float, default=20.0, help="untimed seconds in front of that window")
     ap.add_argument("--whole-games-records", default="", help="write the move lists of the whole-game leg's games to this .npz (diagnosis: which seeded games ended, and when)")
     ap.add_argument("--policy-play-games", type=int, default=1024,
                     help="games in flight PER GPU in the policy-play leg (BASELINE.json configs[4]: --num-rollout 1; 0 = skip the leg)")
     ap.add_argument("--policy-play-seconds", type=float, default=10.0, help="the timed window of the policy-play leg (after 2 untimed seconds)")
+    ap.add_argument("--ex-it-rollouts", type=int, default=1600,
+                    help="--num-ex-it-rollout of the policy_play_ex_it leg: BASELINE.json configs[4] AS WRITTEN (--ex-it --num-rollout 1); the reference's "
+                         "default is 1600 (src/libdg_utils/config.rs:130); 0 = skip the leg")
+    ap.add_argument("--ex-it-seconds", type=float, default=15.0, help="the timed window of the policy_play_ex_it leg (after 5 untimed seconds)")
     ap.add_argument("--sustained-seconds", type=float, default=5.0, help="`value_sustained`: the passes of `value` repeated for at least this long (0 = skip)")
     ap.add_argument("--reference-rule-leg", type=int, default=1,
                     help="1 (default): the mid-game leg is run a second time under the REFERENCE's batching rule -- no coalescing, whatever is queued "
@@ -102,7 +109,7 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     args.selfplay_batches = max(1, args.selfplay_batches)
     if args.lean:
-        args.selfplay_games, args.cpu_sample, args.whole_games, args.policy_play_games, args.sustained_seconds = 0, 0, 0, 0, 0.0
+        args.selfplay_games, args.cpu_sample, args.whole_games, args.policy_play_games, args.sustained_seconds, args.ex_it_rollouts = 0, 0, 0, 0, 0.0, 0
     return args
 
 
@@ -348,7 +355,7 @@ class EdgeProbe:
         return self.edges[1][key] - self.edges[0][key] if 0 in self.edges and 1 in self.edges else 0
 
 
-def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds, staggered, seed):
+def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds, staggered, seed, ex_it_rollouts=0):
     """`in_flight` games per GPU WITH REPLACEMENT (self_play.rs:478-495) for a fixed wall time: `ramp` untimed seconds, then a
     window of `seconds` whose counters the library notes itself (dgnn_selfplay_window), then the job stops.  staggered: game i of a
     rank's first `in_flight` starts i / in_flight of the way into a game that policy play (--num-rollout 1, not timed) has played to
@@ -394,7 +401,7 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
     out = replicas.selfplay_sharded(api, job.dist, job.torch, num_games=4096 * job.world, num_moves=0, num_rollouts=rollouts, threads_per_search=1,
                                     seed=seed + 1, pool=pool, cache=cache, device=job.tensor_device, leaves_per_thread=args.selfplay_leaves,
                                     host_threads=args.selfplay_host_threads, opening=opening, num_parallel=in_flight, window=(ramp, seconds, probe),
-                                    return_moves=bool(staggered and args.whole_games_records), on_game=take_record)
+                                    return_moves=bool(staggered and args.whole_games_records), on_game=take_record, ex_it_rollouts=ex_it_rollouts)
     if staggered and args.whole_games_records and job.rank == 0 and "record" in out:
         np.savez_compressed(args.whole_games_records, record=np.asarray(out["record"][:4 * in_flight], dtype=np.int16), opening=np.asarray(opening, dtype=np.int16),
                             ramp=ramp, seconds=seconds)
@@ -431,6 +438,7 @@ def window_leg(job, api, replicas, net, args, in_flight, rollouts, ramp, seconds
         "tower_passes": None if job.dry else {k: probe.delta(k) for k in ("whole_board", "split", "per_layer", "split_gave_up")},
         "host_cpus_busy": cores[0], "per_rank_host_cpus_busy": cores, "host_cpus": effective_cpus(), "host_threads": args.selfplay_host_threads,
         "probe_conflicts": w["conflicts"],
+        "ex_it_searches": w.get("ex_it_searches", 0), "ex_it_searches_per_sec": w.get("ex_it_searches", 0) / sec,
         # (rank 0's, ramp and the games the window's end cut short included: that the records ARE produced and handed over, not a rate)
         "records_streamed": {"records": taken["records"], "of_whole_games": taken["whole"], "megabytes": taken["bytes"] / 1e6},
     }
@@ -479,9 +487,28 @@ def policy_play_leg(job, api, replicas, net, args):
     """BASELINE.json configs[4]: --num-rollout 1 (self_play.rs:370-405), a thousand games in flight, every move one 8-symmetry
     evaluation through the pool."""
     leg, rule = window_leg(job, api, replicas, net, args, args.policy_play_games, 1, 2.0, args.policy_play_seconds, staggered=False, seed=20261003)
-    leg["what"] = (f"policy play (configs[4], --num-rollout 1): {args.policy_play_games} games in flight per GPU with replacement from the empty board, every move the "
+    leg["what"] = (f"policy play WITHOUT expert iteration (--num-rollout 1, no --ex-it; the mode behind the 59-67 k games/hour of BASELINE.md): {args.policy_play_games} games in flight per GPU with replacement from the empty board, every move the "
                    f"8-symmetry evaluation of one position, games as fibers on {args.selfplay_host_threads} host threads, {pool_rule_text(args, rule)}; 2 s ramp, then the timed window "
                    "(games of 500-700 stones take about a minute here: few END inside a 10 s window, the rate is moves per second)")
+    leg["games_per_hour_at_250_stones"] = leg["moves_per_sec"] * 3600.0 / 250.0
+    return leg
+
+
+def policy_play_ex_it_leg(job, api, replicas, net, args):
+    """BASELINE.json configs[4] AS WRITTEN: `--ex-it --num-rollout 1`.  Every move is drawn from the 8-symmetry evaluation of its position
+    (self_play.rs:370-405); on an undecided position (|value| <= 0.8) one move in twenty is re-searched from scratch with
+    --num-ex-it-rollout rollouts (is_good_candidate / Player::ex_it, self_play.rs:277-319,394-399; default 1600, config.rs:130) and the
+    search's visit distribution and value go into the record.  So a move costs 8 evaluations and, one time in twenty, a whole search:
+    ~ 90 evaluations per move on average, most of them leaves of the ~ 5 % of games that are inside a search at any moment -- which each
+    keep only --selfplay-leaves positions in flight: device batches are what those few searches and the 8-board policy calls add up to."""
+    leg, rule = window_leg(job, api, replicas, net, args, args.policy_play_games, 1, 5.0, args.ex_it_seconds, staggered=False, seed=20261005,
+                           ex_it_rollouts=args.ex_it_rollouts)
+    leg["what"] = (f"configs[4] as written (--ex-it --num-rollout 1, --num-ex-it-rollout {args.ex_it_rollouts}): {args.policy_play_games} games in flight per GPU with "
+                   f"replacement from the empty board; every move the 8-symmetry evaluation of one position, and on undecided positions one move in twenty a fresh "
+                   f"search of {args.ex_it_rollouts} rollouts (1 search thread x {args.selfplay_leaves} leaves) whose visit distribution goes into the record; games as fibers on "
+                   f"{args.selfplay_host_threads} host threads, {pool_rule_text(args, rule)}; 5 s ramp, then the timed window")
+    leg["num_ex_it_rollouts"] = args.ex_it_rollouts
+    leg["moves_per_ex_it_search"] = leg["moves"] / max(leg["ex_it_searches"], 1)
     leg["games_per_hour_at_250_stones"] = leg["moves_per_sec"] * 3600.0 / 250.0
     return leg
 
@@ -822,9 +849,10 @@ def main():
             except Exception:   # noqa: BLE001
                 pass
 
-    selfplay = selfplay_mid = selfplay_mid_ref = whole_games = policy_play = None
+    selfplay = selfplay_mid = selfplay_mid_ref = whole_games = policy_play = policy_play_ex_it = None
     if args.selfplay_games > 0:
-        selfplay = selfplay_leg(job, api, replicas, net, args)
+        if args.selfplay_opening_leg:
+            selfplay = selfplay_leg(job, api, replicas, net, args)
         if args.selfplay_midgame > 0:
             selfplay_mid = selfplay_leg(job, api, replicas, net, args, fast_forward=args.selfplay_midgame)
             if args.reference_rule_leg:
@@ -833,6 +861,8 @@ def main():
         whole_games = whole_games_leg(job, api, replicas, net, args)
     if args.policy_play_games > 0:
         policy_play = policy_play_leg(job, api, replicas, net, args)
+        if args.ex_it_rollouts > 0:
+            policy_play_ex_it = policy_play_ex_it_leg(job, api, replicas, net, args)
 
     out = None
     if rank == 0:
@@ -871,16 +901,21 @@ def main():
             out["whole_games"] = whole_games
         if policy_play is not None:
             out["policy_play"] = policy_play
+        if policy_play_ex_it is not None:
+            out["policy_play_ex_it"] = policy_play_ex_it
         if selfplay_mid is not None:
             out["selfplay_midgame"] = selfplay_mid
         if selfplay_mid_ref is not None:
             out["selfplay_midgame_reference_rule"] = selfplay_mid_ref
         if selfplay is not None:
             out["selfplay"] = selfplay
+        per_move = next((leg for leg in (whole_games, selfplay_mid, selfplay) if leg is not None), None)
+        if per_move is not None:
             out["derived"] = {
-                "games_per_hour_upper_bound": value * 3600.0 / (250 * max(selfplay["evals_per_move"], 1e-9)),
-                "what": "engine evals/s (inputs resident) x 3600 / (250 stones x the MEASURED evals per move of the selfplay leg): what the "
-                        "engine alone would allow; the pipeline figure is selfplay.games_per_hour",
+                "games_per_hour_upper_bound": value * 3600.0 / (250 * max(per_move["evals_per_move"], 1e-9)),
+                "what": "engine evals/s (inputs resident) x 3600 / (250 stones x the MEASURED evals per move of the " +
+                        ("whole_games" if per_move is whole_games else "selfplay_midgame" if per_move is selfplay_mid else "selfplay") +
+                        " leg): what the engine alone would allow; the pipeline figures are whole_games.* and selfplay_midgame.games_per_hour",
             }
         # ---- PCIe-inclusive: host buffers in, host buffers out (the drop-in's own contract, graph.rs:130-131,155-156), never `value`
         fw = DryForward(api) if job.dry else api
@@ -903,6 +938,16 @@ def main():
                     "steps": reps,
                 }
                 out["value_pcie_inclusive"]["records_vs_resident"] = out["value_pcie_inclusive"]["board_records"] / value
+                # The like-for-like figure for "leaf evals per second" of the reference's own boundary: dg_nn::forward takes a host slice of
+                # fp16 planes and returns host vectors (graph.rs:130-156, H2D and D2H inside the call); its predictor keeps two batches
+                # alive per device (predictors/nn.rs:64-67).  `value` is the resident-input rate the roofline is priced on; THIS is the rate a
+                # caller of dgnn_forward sees.
+                out["value_reference_contract"] = {
+                    "value": out["value_pcie_inclusive"]["fp16_planes"], "unit": "evals/s", "vs_value": out["value_pcie_inclusive"]["fp16_planes"] / value,
+                    "what": "dgnn_forward_submit_n / dgnn_forward_wait on fp16 HWC planes in host memory (23 104 B per board in, 726 B out over PCIe), host "
+                            "buffers out, two workspaces alive -- the contract of dg_nn::forward (graph.rs:130-156) under the reference predictor's two "
+                            f"batches alive per device (predictors/nn.rs:64-67); {reps} x {args.batch} boards, loop inside the library",
+                }
                 # ... and with THREE in flight, the pool's round-5 default
                 ws3 = net.get_workspace(args.batch, device=device)
                 out["value_pcie_inclusive"]["board_records_three_in_flight"] = api.forward_pipelined_timed_n([ws, ws2, ws3], "records", records, args.batch, max(reps, 30))
@@ -927,13 +972,19 @@ def main():
                 baseline, (ref_value, ref_policy) = cpu_baseline(text, features, args.batch, args.cpu_sample)
                 if pinned is not None:
                     os.sched_setaffinity(0, pinned)
-                out["cpu_baseline"] = baseline
-                # the second opinion SURVEY.md 8d names: torch-CPU F.conv2d on a quarter of the sample, and how far its outputs are from the port's
-                second, (tv, tp) = cpu_second_opinion(text, features, args.batch, max(8, args.cpu_sample // 4), baseline["cores"])
+                # the second statement SURVEY.md 8d names: torch-CPU F.conv2d on the same sample, and how far its outputs are from the port's
+                second, (tv, tp) = cpu_second_opinion(text, features, args.batch, args.cpu_sample, baseline["cores"])
                 k = min(len(tv), n)
                 second["max_abs_diff_vs_port"] = [float(np.abs(tv[:k] - np.asarray(ref_value).view(np.float16).astype(np.float32)[:k]).max()),
                                                   float(np.abs(tp[:k] - np.asarray(ref_policy).view(np.float16).astype(np.float32)[:k * 362].reshape(k, 362)).max())]
-                out["cpu_baseline_second_opinion"] = second
+                # `cpu_baseline` is the FASTER of the two CPU statements of the reference's semantics (the stated baseline
+                # must not understate the CPU); the other one is carried beside it.  Parity is checked against the C port either way: that is
+                # the statement pinned to the reference's vectors (tests/test_oracle_kat.py).
+                baseline["statement"] = "oracle/dgnn_oracle.c (C, OpenMP; the parity checker)"
+                second["statement"] = "oracle/torch_statement.py (torch-CPU F.conv2d, the trainer's graph)"
+                fast, slow = (second, baseline) if second["value"] > baseline["value"] else (baseline, second)
+                out["cpu_baseline"] = fast
+                out["cpu_baseline_other_statement"] = slow
                 flat_what = "the network and batch of `value` (He-init, Bernoulli(0.2) planes): HIP resident path vs oracle/dgnn_oracle.c"
             parity = {"flat": parity_entry(leg_ws, features, n, ref_value, ref_policy, flat_what)}
             if not job.dry and not args.lean and positions is not None:

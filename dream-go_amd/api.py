@@ -1333,7 +1333,7 @@ class SelfplayWindow(ctypes.Structure):
     _fields_ = [("ramp_seconds", ctypes.c_double), ("seconds", ctypes.c_double), ("on_edge", WINDOW_EDGE_FN), ("ctx", ctypes.c_void_p),
                 ("measured_seconds", ctypes.c_double), ("moves", ctypes.c_uint64), ("evals", ctypes.c_uint64), ("cache_hits", ctypes.c_uint64),
                 ("conflicts", ctypes.c_uint64), ("games_started", ctypes.c_uint64), ("games_completed", ctypes.c_uint64),
-                ("games_ended", ctypes.c_uint64), ("stones_completed", ctypes.c_uint64)]
+                ("games_ended", ctypes.c_uint64), ("stones_completed", ctypes.c_uint64), ("ex_it_searches", ctypes.c_uint64)]
 
 
 class SelfplayStats(ctypes.Structure):
@@ -1610,7 +1610,7 @@ def selfplay_go(num_games, num_moves, num_rollouts, threads_per_search=1, seed=0
     if win is not None:
         out["window"] = {"seconds": win.measured_seconds, "moves": win.moves, "evals": win.evals, "cache_hits": win.cache_hits,
                          "conflicts": win.conflicts, "games_started": win.games_started, "games_completed": win.games_completed,
-                         "games_ended": win.games_ended, "stones_completed": win.stones_completed}
+                         "games_ended": win.games_ended, "stones_completed": win.stones_completed, "ex_it_searches": win.ex_it_searches}
     if return_moves:
         out["record"] = moves.reshape(num_games, num_moves)
     if return_sgf:

@@ -476,7 +476,12 @@ struct LeafPool {
             // after it a leader's request may return and take its slots with it
             std::vector<std::pair<int, std::vector<LeafSlot*>>> followed;      // (index in the batch, the slots that followed it)
             std::vector<uint8_t> leader_symmetry;
-            if (coalesce.load(std::memory_order_relaxed)) {
+            // (keyed on the slots, not on the switch: dgnn_pool_set_coalescing(0) may fall between a request's look at the switch and this
+            // pass -- a leader registered in that window must still be taken out of the table, or every later request for its position
+            // would follow an entry nobody answers.  ADVICE r05)
+            bool any_leads = false;
+            for (int i = 0; i < n && !any_leads; ++i) any_leads = reinterpret_cast<LeafSlot*>((uintptr_t)tags[i])->leads;
+            if (any_leads) {
                 leader_symmetry.assign((size_t)n, 0);
                 std::lock_guard<std::mutex> lock(inflight_mutex);
                 for (int i = 0; i < n; ++i) {

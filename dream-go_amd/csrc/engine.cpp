@@ -9,8 +9,6 @@
 // was handed (hipSetDevice is per-thread).
 #include <hip/hip_runtime_api.h>
 
-#include <algorithm>
-
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +21,24 @@
 namespace dgnn {
 
 static thread_local int g_last_hip_error = 0;
+
+int fake_devices()
+{
+    static const int n = [] { const char* e = test_env("DGNN_FAKE_DEVICES"); const int v = e ? std::atoi(e) : 0; return v > 0 && v <= 64 ? v : 0; }();
+    return n;
+}
+static int physical_count()
+{
+    static const int n = [] { int c = 0; return hipGetDeviceCount(&c) == hipSuccess ? c : 0; }();
+    return n;
+}
+int physical_device(int logical) { return fake_devices() > 0 && physical_count() > 0 ? logical % physical_count() : logical; }
+hipError_t device_count(int* count)
+{
+    if (fake_devices() > 0) { *count = fake_devices(); return physical_count() > 0 ? hipSuccess : hipErrorNoDevice; }
+    return hipGetDeviceCount(count);
+}
+hipError_t set_device(int logical) { return hipSetDevice(physical_device(logical)); }
 
 void set_last_hip_error(int code) { g_last_hip_error = code; }
 
@@ -44,20 +60,17 @@ constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 
 //     it is given (its workgroups draw tickets, conv_board_tower.hip), provided that more than 8 * (workgroups per board - 1) of them
 //     come its way in the end -- up to 120: two split launches side by side could each hold CUs with workgroups that wait for
 //     siblings the other one keeps from starting.  One at a time, that cannot happen.
-//   * a split launch waits for the whole-board towers enqueued before it, and a whole-board tower for the split launch enqueued
-//     before it (round 6).  Not for safety -- whole-board workgroups never wait for anything -- but for the rounds: 256 whole-board
-//     workgroups are ONE round of the chip's 256 CUs; a split launch that takes half of the CUs the tower in front has just
-//     released turns the next tower's one round of 3 ms into two (measured, 20x256: two 256-board towers and a 64-board split
-//     launch 9.5 ms side by side against 8.1 ms one after the other -- tests/test_round6_gpu.py).  Whole-board towers behind
-//     whole-board towers are not ordered: their workgroups end together and the next tower's start as they do, and below 256 boards
-//     the CUs one tower leaves idle are what the next one runs on.
+//   * whole-board towers are NOT ordered against split launches.  Round 6 built that (a split launch behind every whole-board tower
+//     enqueued before it, whole-board towers behind the split launch in front of them) on the theory that a split launch taking half
+//     of the CUs a 256-board tower has just released turns the next tower's one round of the chip into two, and measured nothing:
+//     two 256-board towers and a 64-board split launch 7.42 against 7.38 ms per round, the pool with 48 games in flight 79.6-79.7 k
+//     against 80.5-80.7 k boards/s WITHOUT the ordering (profiles/r06/order_ab.jsonl, few_games_in_the_pool_split_alive.txt).  Taken out.
 // (Another PROCESS's launches are out of reach; they end, which is all the ticket argument needs -- and the flag waits' 50 ms limit is
 // the net, resolve_split_failure.)
 struct SplitChain {
     std::mutex mutex;
     hipEvent_t done = nullptr;              // behind the most recent split launch
     bool recorded = false;
-    std::vector<hipEvent_t> whole;          // behind the whole-board towers enqueued since then (Workspace::ev_tower, one per workspace)
 };
 
 struct Workspace {
@@ -69,7 +82,6 @@ struct Workspace {
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_done = nullptr;           // event behind the outputs' copies: what dgnn_forward_wait waits for
-    hipEvent_t ev_tower = nullptr;          // event behind this workspace's most recent whole-board tower launch (SplitChain::whole)
     long long submit_ns = 0;                // when it was recorded
     double wait_ns = 0.0;                   // how long submissions of `wait_boards` boards took lately (submit -> outputs on the host)
     double wait_last = 0.0;                 // ... the most recent one (wait_submission)
@@ -101,9 +113,12 @@ struct Workspace {
     uint16_t* h_value = nullptr;
     uint16_t* h_policy = nullptr;
 
+    bool crowded_per_layer = false;         // ... at more than 128 channels: a batch too small for a workgroup per board runs one launch per layer while
+                                            // whole-board towers of other submissions hold the device (note_submission_begins)
     bool crowded = false;                   // the submission being enqueued shares the device with enough boards of other submissions
                                             // that a workgroup per board is the better tower at any size (tower_mode, note_submission_begins)
     int counted_in_flight = 0;              // boards of this workspace's submission counted in DeviceState::boards_in_flight
+    bool outputs_on_host = false;           // the most recent pass wrote value / policy into the pinned host buffers, not into d_value / d_policy
     bool host_io = false;                   // the submission being enqueued reads its records from / writes its outputs to the PINNED HOST buffers
                                             // themselves (zero copy: no H2D / D2H blit kernels around the compute, see kZeroCopy)
     int active = 0;                         // boards of the submission in flight / being enqueued (<= batch, the capacity)
@@ -159,21 +174,13 @@ struct DeviceState {
 
 Workspace::~Workspace()
 {
-    (void)hipSetDevice(device);
+    (void)dgnn::set_device(device);
     if (stream) (void)hipStreamSynchronize(stream);
     for (hipEvent_t e : tower_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : stage_ev) if (e) (void)hipEventDestroy(e);
     if (ev_begin) (void)hipEventDestroy(ev_begin);
     if (ev_end) (void)hipEventDestroy(ev_end);
     if (ev_done) (void)hipEventDestroy(ev_done);
-    if (ev_tower) {
-        if (dev && dev->chain) {            // the device's chain may still name it
-            std::lock_guard<std::mutex> chained(dev->chain->mutex);
-            auto& whole = dev->chain->whole;
-            whole.erase(std::remove(whole.begin(), whole.end(), ev_tower), whole.end());
-        }
-        (void)hipEventDestroy(ev_tower);
-    }
     if (arena) (void)hipFree(arena);
     if (d_tower_layers) (void)hipFree(d_tower_layers);
     if (d_tower_timing) (void)hipFree(d_tower_timing);
@@ -184,7 +191,7 @@ Workspace::~Workspace()
 DeviceState::~DeviceState()
 {
     for (Workspace* ws : all) delete ws;
-    (void)hipSetDevice(device);
+    (void)dgnn::set_device(device);
     if (d_image) (void)hipFree(d_image);
 }
 
@@ -214,7 +221,7 @@ int get_device_state(Network* net, int device, DeviceState** out, bool upload = 
     if (it != net->devices.end()) {
         DeviceState* state = it->second.get();
         if (upload && !state->image_valid) {          // reserved for a transfer that never filled it: never run on garbage
-            DGNN_HIP(hipSetDevice(device));
+            DGNN_HIP(dgnn::set_device(device));
             DGNN_HIP(hipMemcpy(state->d_image, net->image.data(), net->image.size(), hipMemcpyHostToDevice));
             DGNN_HIP(hipDeviceSynchronize());         // (a copy from pageable memory may return with the DMA still on its way; the
                                                       // workspaces' streams are non-blocking and would not wait for it)
@@ -225,15 +232,15 @@ int get_device_state(Network* net, int device, DeviceState** out, bool upload = 
     }
 
     int count = 0;
-    DGNN_HIP(hipGetDeviceCount(&count));
+    DGNN_HIP(dgnn::device_count(&count));
     if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(dgnn::set_device(device));
 
     std::unique_ptr<DeviceState> state(new (std::nothrow) DeviceState());
     if (!state) return DGNN_OUT_OF_MEMORY;
     state->device = device;
-    DGNN_HIP(hipDeviceGetAttribute(&state->num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    state->chain = split_chain(device);
+    DGNN_HIP(hipDeviceGetAttribute(&state->num_cus, hipDeviceAttributeMultiprocessorCount, physical_device(device)));
+    state->chain = split_chain(physical_device(device));   // (logical devices of a test build share their GPU's chain)
     if (!state->chain->done) return DGNN_HIP_ERROR;
     DGNN_HIP(hipMalloc((void**)&state->d_image, net->image.size()));
     if (upload) {
@@ -313,12 +320,11 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         if (t.up.w_offset == 0 || t.policy_conv.w_offset == 0) return DGNN_UNSUPPORTED;
     }
 
-    DGNN_HIP(hipSetDevice(dev->device));
+    DGNN_HIP(dgnn::set_device(dev->device));
     DGNN_HIP(hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));   // stream.rs:55
     DGNN_HIP(hipEventCreate(&ws->ev_begin));
     DGNN_HIP(hipEventCreate(&ws->ev_end));
     DGNN_HIP(hipEventCreateWithFlags(&ws->ev_done, hipEventBlockingSync | hipEventDisableTiming));
-    DGNN_HIP(hipEventCreateWithFlags(&ws->ev_tower, hipEventDisableTiming));
 
     const size_t num_pos = (size_t)batch * DGNN_NUM_POINTS;
     const size_t sz_features = align_up(num_pos * DGNN_NUM_FEATURES * 2, 256);
@@ -380,7 +386,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         ws->d_tower_nhwc = (uint16_t*)p;
     }
 
-    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_packed + sz_records + sz_value + sz_policy + 256, hipHostMallocDefault));
+    DGNN_HIP(hipHostMalloc(&ws->pinned, sz_features + sz_packed + sz_records + sz_value + sz_policy + 256, hipHostMallocCoherent));   // (kernel-written, host-read behind ev_done: fine-grained, spelled out)
     uint8_t* h = (uint8_t*)ws->pinned;
     ws->h_features = (uint16_t*)h; h += sz_features;
     ws->h_packed = (uint32_t*)h; h += sz_packed;
@@ -405,6 +411,7 @@ int tower_mode(const Workspace* ws)
     const int channels = ws->net->topo.num_channels;
     const bool whole = tower_board_supported(ws->active, channels, ws->crowded);
     if (whole && ws->use_pair && !ws->split_failed && tower_pair_supported(ws->active, channels, ws->dev->num_cus)) return 24;
+    if (ws->crowded_per_layer && !whole && ws->split_pref == 1) return 0;
     if (ws->split_pref != 0 && !ws->split_failed && (!whole || ws->split_pref == 2)) {
         const int ns = tower_split_ns(ws->active, channels, ws->dev->num_cus);
         if (ns > 0) return ns;
@@ -413,10 +420,6 @@ int tower_mode(const Workspace* ws)
 }
 
 bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
-
-// Split launches behind the whole-board towers enqueued before them and in front of those enqueued after them (round 6, SplitChain);
-// DGNN_TOWER_ORDER=0 (test / ablations build): only split launches among themselves, as in rounds 2-5 (A/B).
-const bool kOrderedTowers = [] { const char* e = test_env("DGNN_TOWER_ORDER"); return !(e && std::atoi(e) == 0); }();
 
 // Whole-board towers for small batches on a crowded device (round 5); DGNN_CROWDED=0 (test / ablations build): the size alone decides (A/B).
 const bool kCrowdedTowers = [] { const char* e = test_env("DGNN_CROWDED"); return !(e && std::atoi(e) == 0); }();
@@ -554,8 +557,6 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 SplitChain* chain = ws->dev->chain;
                 std::lock_guard<std::mutex> chained(chain->mutex);
                 if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
-                if (kOrderedTowers) for (hipEvent_t e : chain->whole) DGNN_HIP(hipStreamWaitEvent(ws->stream, e, 0));
-                chain->whole.clear();
                 (void)groups;
                 bool missing = false;
                 if (ws->inject_giveup != 0 && !ws->injected) {  // fault injection (tests)
@@ -585,17 +586,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     hc.cin = t.num_channels;
                     hc.samples = t.num_samples;
                 }
-                {
-                    SplitChain* chain = ws->dev->chain;
-                    std::lock_guard<std::mutex> chained(chain->mutex);
-                    if (kOrderedTowers && chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
-                    DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream, head_in_tower ? &hc : nullptr));
-                    if (kOrderedTowers) {
-                        DGNN_HIP(hipEventRecord(ws->ev_tower, ws->stream));
-                        auto& whole = chain->whole;
-                        if (std::find(whole.begin(), whole.end(), ws->ev_tower) == whole.end()) whole.push_back(ws->ev_tower);
-                    }
-                }
+                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream, head_in_tower ? &hc : nullptr));
                 if (ws->d_tower_timing) {
                     DGNN_HIP(hipStreamSynchronize(ws->stream));
                     const size_t words = (size_t)ws->tower_timing_layers * ws->batch * 8 * 4;
@@ -678,6 +669,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     sv.value_b = (const uint16_t*)(image + t.value_b_offset);
     sv.policy_out = ws->host_io ? ws->h_policy : ws->d_policy;
     sv.value_out = ws->host_io ? ws->h_value : ws->d_value;
+    ws->outputs_on_host = ws->host_io;      // where the outputs of the pass being enqueued land (dgnn_workspace_download)
     sv.value_pre_out = ws->d_value_pre;
     sv.batch = ws->active;
     DGNN_HIP(launch_softmax_value(sv, ws->stream));
@@ -730,10 +722,22 @@ void nap_ns(long long ns)
 // a small batch behind a full one gets the chip sooner as a split launch -- the CUs of the batch in front come free together -- and the
 // pool LOSES 2.4 % at 48 games in flight although three equal submissions at once (the sweep) gain 14 %
 // (profiles/r05_final/crowded_in_the_pool_*.txt).
+//
+// At MORE than 128 channels (round 6): a batch too small for a workgroup per board that finds at least a whole-board tower's worth of
+// boards (129) of other submissions on the device runs ONE LAUNCH PER LAYER, not a split tower.  Alone on the device the split tower
+// is the fast form (latency: 25-30 % ahead of 41 launches); beside whole-board towers its workgroups wait for siblings
+// that wait for compute units (they hold theirs meanwhile), while the workgroups of a per-layer launch wait for nothing and take CUs
+// as the towers release them.  Measured in the pool, 20x256, 48 games in flight (13 % of the device batches below 129 boards; same
+// box, interleaved, two runs each; profiles/r06/few_games_in_the_pool_split_alive.txt): split towers 79.6-79.7 k boards/s (80.5-80.7 k
+// without the ordering that round 6 tried), per layer 82.0-82.2 k.  (Round 5's pool ran per layer too -- by accident: its split towers
+// gave up behind the first whole-board tower, VERDICT r05 weak #2.  Now nothing gives up, and the form is chosen.)  DGNN_TOWER_SPLIT=2
+// keeps the split tower wherever one is possible (tests of the split tower in a crowd; A/B).
+const bool kCrowdedPerLayer = [] { const char* e = test_env("DGNN_CROWDED_PER_LAYER"); return !(e && std::atoi(e) == 0); }();
 void note_submission_begins(Workspace* ws)       // in front of enqueue_forward: which tower this submission gets
 {
     const int others = ws->dev->boards_in_flight.load(std::memory_order_relaxed);
     ws->crowded = kCrowdedTowers && ws->net->topo.num_channels <= 128 && others > 0 && others + ws->active >= ws->dev->num_cus * 11 / 16;
+    ws->crowded_per_layer = kCrowdedPerLayer && ws->net->topo.num_channels > 128 && others >= ws->dev->num_cus / 2 + 1;
 }
 void note_submission_in_flight(Workspace* ws)    // with `pending = true`
 {
@@ -743,13 +747,13 @@ void note_submission_in_flight(Workspace* ws)    // with `pending = true`
 struct SubmissionBegins {                        // a submit that fails half way leaves no tower choice behind for the resident entry points
     Workspace* ws;
     explicit SubmissionBegins(Workspace* w) : ws(w) { note_submission_begins(w); }
-    ~SubmissionBegins() { if (!ws->pending) ws->crowded = false; }
+    ~SubmissionBegins() { if (!ws->pending) ws->crowded = ws->crowded_per_layer = false; }
 };
 void note_submission_ends(Workspace* ws)
 {
     if (ws->counted_in_flight > 0) ws->dev->boards_in_flight.fetch_sub(ws->counted_in_flight, std::memory_order_relaxed);
     ws->counted_in_flight = 0;
-    ws->crowded = false;
+    ws->crowded = ws->crowded_per_layer = false;
 }
 
 int mark_submission(Workspace* ws)      // behind the last copy of a submission
@@ -1043,7 +1047,7 @@ int dgnn_device_count(int* count)
 {
     if (!count) return DGNN_BAD_ARGUMENT;
     *count = 0;
-    DGNN_HIP(hipGetDeviceCount(count));
+    DGNN_HIP(dgnn::device_count(count));
     return DGNN_OK;
 }
 
@@ -1051,9 +1055,9 @@ int dgnn_device_pci_bus_id(int device, char* out, size_t capacity)
 {
     if (!out || capacity < 16) return DGNN_BAD_ARGUMENT;
     int count = 0;
-    DGNN_HIP(hipGetDeviceCount(&count));
+    DGNN_HIP(dgnn::device_count(&count));
     if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP(hipDeviceGetPCIBusId(out, (int)capacity, device));
+    DGNN_HIP(hipDeviceGetPCIBusId(out, (int)capacity, dgnn::physical_device(device)));
     return DGNN_OK;
 }
 
@@ -1174,7 +1178,7 @@ void dgnn_workspace_release(dgnn_workspace* handle)
     if (!handle) return;
     Workspace* ws = W(handle);
     if (ws->pending) {   // never hand back a workspace with work in flight
-        (void)hipSetDevice(ws->device);
+        (void)dgnn::set_device(ws->device);
         (void)hipStreamSynchronize(ws->stream);
         ws->pending = false;
         note_submission_ends(ws);
@@ -1198,7 +1202,7 @@ int dgnn_network_synchronize(dgnn_network* net)
     int status = DGNN_OK;
     for (auto& entry : n->devices) {
         DeviceState* dev = entry.second.get();
-        if (hipSetDevice(dev->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        if (dgnn::set_device(dev->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
             status = DGNN_HIP_ERROR;   // "this should be allowed to fail", network.rs:150-153: keep going
 
         for (Workspace* ws : dev->all) rearm_split(ws, /*forget=*/true);     // a tower that gave up may try its split again
@@ -1248,7 +1252,7 @@ int dgnn_forward_submit_n(dgnn_workspace* handle, const uint16_t* features, int 
     SubmissionBegins begins(ws);
     const size_t num_features = (size_t)count * DGNN_FEATURE_SIZE;
 
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     const size_t in_bytes = num_features * sizeof(uint16_t);
     if (features != ws->h_features) std::memcpy(ws->h_features, features, in_bytes);
     DGNN_HIP(hipMemcpyAsync(ws->d_features, ws->h_features, in_bytes, hipMemcpyHostToDevice, ws->stream));   // graph.rs:130-131
@@ -1272,7 +1276,7 @@ int dgnn_forward_wait(dgnn_workspace* handle, uint16_t* value_out, uint16_t* pol
     Workspace* ws = W(handle);
     if (!ws->pending) return DGNN_BAD_ARGUMENT;
 
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     ws->pending = false;
     struct Ends { Workspace* w; ~Ends() { note_submission_ends(w); } } ends{ws};         // (on every way out: the device's count of boards in flight)
     { const int waited = wait_submission(ws); if (waited != DGNN_OK) return waited; }   // graph.rs:155-156 (to_vec + synchronize)
@@ -1314,7 +1318,7 @@ int dgnn_forward_submit_packed(dgnn_workspace* handle, const uint32_t* packed, i
     SubmissionBegins begins(ws);
     const size_t in_bytes = (size_t)count * DGNN_PACKED_WORDS * sizeof(uint32_t);
 
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     if (packed != ws->h_packed) std::memcpy(ws->h_packed, packed, in_bytes);
     DGNN_HIP(hipMemcpyAsync(ws->d_packed, ws->h_packed, in_bytes, hipMemcpyHostToDevice, ws->stream));
     ws->host_io = kZeroCopy;
@@ -1350,7 +1354,7 @@ int dgnn_forward_submit_boards(dgnn_workspace* handle, const uint8_t* records, i
     SubmissionBegins begins(ws);
     const size_t in_bytes = (size_t)count * DGNN_BOARD_RECORD_BYTES;
 
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     if (records != ws->h_records) std::memcpy(ws->h_records, records, in_bytes);
     if (ws->stage_on) DGNN_HIP(hipEventRecord(ws->stage_ev[0], ws->stream));
     ws->host_io = kZeroCopy;
@@ -1389,9 +1393,9 @@ int dgnn_board_records_to_packed_device(int device, const uint8_t* records, int 
 {
     if (!records || !packed || count <= 0) return DGNN_BAD_ARGUMENT;
     int devices = 0;
-    DGNN_HIP(hipGetDeviceCount(&devices));
+    DGNN_HIP(dgnn::device_count(&devices));
     if (device < 0 || device >= devices) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(dgnn::set_device(device));
     const size_t sz_r = align_up((size_t)count * DGNN_BOARD_RECORD_BYTES, 256), sz_p = (size_t)count * DGNN_PACKED_WORDS * 4;
     uint8_t* d = nullptr;
     DGNN_HIP(hipMalloc((void**)&d, sz_r + sz_p));
@@ -1510,7 +1514,7 @@ int dgnn_workspace_upload(dgnn_workspace* handle, const uint16_t* features, size
     if (!handle || !features) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
     if (num_features != (size_t)ws->batch * DGNN_FEATURE_SIZE) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     DGNN_HIP(hipMemcpyAsync(ws->d_features, features, num_features * 2, hipMemcpyHostToDevice, ws->stream));
     DGNN_HIP(hipStreamSynchronize(ws->stream));
     return DGNN_OK;
@@ -1520,7 +1524,15 @@ int dgnn_workspace_download(dgnn_workspace* handle, uint16_t* value_out, uint16_
 {
     if (!handle || !value_out || !policy_out) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
+    if (ws->outputs_on_host) {
+        // the last pass was a dgnn_forward* with zero-copy outputs: its soft-max kernel wrote into the pinned host buffers and left
+        // d_value / d_policy as an EARLIER resident pass had them (this call used to hand those out)
+        DGNN_HIP(hipStreamSynchronize(ws->stream));
+        std::memcpy(value_out, ws->h_value, (size_t)ws->batch * 2);
+        std::memcpy(policy_out, ws->h_policy, (size_t)ws->batch * DGNN_NUM_MOVES * 2);
+        return DGNN_OK;
+    }
     DGNN_HIP(hipMemcpyAsync(value_out, ws->d_value, (size_t)ws->batch * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipMemcpyAsync(policy_out, ws->d_policy, (size_t)ws->batch * DGNN_NUM_MOVES * 2, hipMemcpyDeviceToHost, ws->stream));
     DGNN_HIP(hipStreamSynchronize(ws->stream));
@@ -1532,7 +1544,7 @@ int dgnn_workspace_download_pre(dgnn_workspace* handle, uint16_t* logits_out, ui
 {
     if (!handle || !logits_out || !value_pre_out) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     DGNN_HIP(hipMemcpy2DAsync(logits_out, DGNN_NUM_MOVES * 2, ws->d_logits, 384 * 2, DGNN_NUM_MOVES * 2, (size_t)ws->batch, hipMemcpyDeviceToHost,
                               ws->stream));
     DGNN_HIP(hipMemcpyAsync(value_pre_out, ws->d_value_pre, (size_t)ws->batch * 2, hipMemcpyDeviceToHost, ws->stream));
@@ -1544,7 +1556,7 @@ int dgnn_forward_resident(dgnn_workspace* handle)
 {
     if (!handle) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     ws->host_io = false;                    // resident inputs, outputs left in HBM (dgnn_workspace_download)
     return enqueue_forward(ws, -1);
 }
@@ -1553,7 +1565,7 @@ int dgnn_workspace_sync(dgnn_workspace* handle)
 {
     if (!handle) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
     DGNN_HIP(hipStreamSynchronize(ws->stream));
     return check_split_after_sync(ws);      // DGNN_BUSY: the passes since the last sync gave up on the split tower; run them again
 }
@@ -1562,7 +1574,7 @@ int dgnn_forward_timed(dgnn_workspace* handle, int steps, float* total_ms, float
 {
     if (!handle || steps <= 0) return DGNN_BAD_ARGUMENT;
     Workspace* ws = W(handle);
-    DGNN_HIP(hipSetDevice(ws->device));
+    DGNN_HIP(dgnn::set_device(ws->device));
 
     while (ws->tower_events.size() < (size_t)2 * steps) {
         hipEvent_t e = nullptr;
@@ -1643,7 +1655,7 @@ int dgnn_forward_stage_times(dgnn_workspace* const* ws, int in_flight, const uin
     int status = DGNN_OK;
     for (int i = 0; i < in_flight && status == DGNN_OK; ++i) {
         Workspace* w = W(ws[i]);
-        DGNN_HIP(hipSetDevice(w->device));
+        DGNN_HIP(dgnn::set_device(w->device));
         for (hipEvent_t& e : w->stage_ev) if (!e) DGNN_HIP(hipEventCreate(&e));
         status = dgnn_forward_boards(ws[i], records, count, value.data(), policy.data());      // warm, unstamped
         w->stage_on = true;
@@ -1703,9 +1715,9 @@ int dgnn_layer_conv3x3(int device, const uint16_t* x, int batch, int board_size,
     if (alpha2 != 0.0f && !z) return DGNN_BAD_ARGUMENT;
 
     int count = 0;
-    DGNN_HIP(hipGetDeviceCount(&count));
+    DGNN_HIP(dgnn::device_count(&count));
     if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(dgnn::set_device(device));
 
     const int cout_pad = (cout + 15) / 16 * 16;
     const size_t num_pos = (size_t)batch * board_size * board_size;
@@ -1795,9 +1807,9 @@ int dgnn_layer_dense(int device, const uint16_t* x, int batch, int k_in, const u
 {
     if (!x || !w_in_out || !bias || !y || batch <= 0 || k_in <= 0 || n_out <= 0) return DGNN_BAD_ARGUMENT;
     int count = 0;
-    DGNN_HIP(hipGetDeviceCount(&count));
+    DGNN_HIP(dgnn::device_count(&count));
     if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(dgnn::set_device(device));
 
     // what build_network does for linear_1: the stored [in][out] matrix transposed to [out][in], zero padded (dense.rs:182-189)
     const int k_pad = (k_in + 63) / 64 * 64;
@@ -1837,9 +1849,9 @@ int dgnn_layer_heads(int device, const uint16_t* logits, const uint16_t* value_f
 {
     if (!logits || !value_features || !value_w || !value_b || !policy_out || !value_out || batch <= 0) return DGNN_BAD_ARGUMENT;
     int count = 0;
-    DGNN_HIP(hipGetDeviceCount(&count));
+    DGNN_HIP(dgnn::device_count(&count));
     if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(dgnn::set_device(device));
     const size_t sz_l = align_up((size_t)batch * 384 * 2, 256), sz_vf = align_up((size_t)batch * 722 * 2, 256);
     const size_t sz_w = align_up(722 * 2, 256), sz_b = 256, sz_p = align_up((size_t)batch * DGNN_NUM_MOVES * 2, 256), sz_v = align_up((size_t)batch * 2, 256);
     std::vector<uint16_t> padded((size_t)batch * 384, 0);
@@ -1943,7 +1955,7 @@ int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src
     const uint8_t* host = (const uint8_t*)src;
     if (src_on_device) {
         incoming.resize(num_bytes);
-        DGNN_HIP(hipSetDevice(device));
+        DGNN_HIP(dgnn::set_device(device));
         DGNN_HIP(hipDeviceSynchronize());   // e.g. the collective that wrote it
         DGNN_HIP(hipMemcpy(incoming.data(), src, num_bytes, hipMemcpyDeviceToHost));
         host = incoming.data();
@@ -1956,7 +1968,7 @@ int dgnn_network_set_weight_image(dgnn_network* net, int device, const void* src
     if (status != DGNN_OK) return status;
     for (auto& entry : n->devices) {                 // every device copy (devices first touched later upload net->image, the new one)
         DeviceState* d = entry.second.get();
-        DGNN_HIP(hipSetDevice(d->device));
+        DGNN_HIP(dgnn::set_device(d->device));
         DGNN_HIP(hipDeviceSynchronize());            // (nothing is checked out, so nothing is in flight; belt and braces)
         d->image_valid = false;
         if (d == dev && src_on_device) {
@@ -1994,7 +2006,7 @@ int dgnn_network_weight_checksum_device(dgnn_network* net, int device, uint64_t*
     const int status = get_device_state(n, device, &dev);
     if (status != DGNN_OK) return status;
     std::vector<uint8_t> copy(n->image.size());
-    DGNN_HIP(hipSetDevice(device));
+    DGNN_HIP(dgnn::set_device(device));
     DGNN_HIP(hipMemcpy(copy.data(), dev->d_image, copy.size(), hipMemcpyDeviceToHost));
     uint64_t h = 1469598103934665603ull;
     for (uint8_t byte : copy) { h ^= byte; h *= 1099511628211ull; }

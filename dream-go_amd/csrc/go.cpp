@@ -1460,10 +1460,11 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                 dgnn_tree_node_to_pretty(tree, &explain[0], explain.size());                   // principal variation -- as long as the tree is deep
                 out = played_text(me, point, total, softmax, 1, value, prior_index, explain.c_str());
             };
-            // Player::ex_it (self_play.rs:277-305) behind is_good_candidate (:315-319): one move in twenty gets a fresh, full-size
-            // search whose visit distribution and value replace the record's; the move that was chosen stays
-            auto expert_iteration = [&](std::string& out, int point) -> bool {
-                if (num_ex_it_rollouts <= 0 || rng.uniform() >= 0.05) return false;
+            // Player::ex_it (self_play.rs:277-305) behind is_good_candidate (:315-319): on an UNDECIDED position (the value of the move just
+            // chosen within [-0.8, 0.8]; the random number is only drawn then, as in the reference's && chain) one move in twenty gets a
+            // fresh, full-size search whose visit distribution and value replace the record's; the move that was chosen stays
+            auto expert_iteration = [&](std::string& out, int point, float chosen_value) -> bool {
+                if (num_ex_it_rollouts <= 0 || !(chosen_value >= -0.80f && chosen_value <= 0.80f) || rng.uniform() >= 0.05) return false;
                 float value;
                 int ignored;
                 dgnn_tree_node* tree = search(num_ex_it_rollouts, nullptr, &value, &ignored);
@@ -1487,7 +1488,7 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                     dgnn_tree_node_free(root);
                     move = played_text(me, kPass, 0, nullptr, 0, 0.0f, -1, "");
                 } else {
-                    if (!expert_iteration(move, played)) record_mcts(move, played, best_value, root);
+                    if (!expert_iteration(move, played, best_value)) record_mcts(move, played, best_value, root);
                     winrate[me] -= 0.2f * (winrate[me] - best_value);          // MovingAverage::update, self_play.rs:56-58
                     roots[me] = dgnn_tree_node_forward(root, played);
                 }
@@ -1501,7 +1502,7 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
                 for (int i = 0; i < DGNN_NUM_MOVES; ++i) scaled[i] = (double)prior[i];
                 if (dgnn_choose_f64(scaled, DGNN_NUM_MOVES, 0.5, 1.0 / 0.8, rng.uniform(), &played, nullptr) != 1) played = kPass;
                 if (played < 0 || (played != kPass && !board.is_valid(me, played))) played = kPass;
-                if (!expert_iteration(move, played)) move = played_text(me, played, 1, prior, 1, value, -1, "");
+                if (!expert_iteration(move, played, value)) move = played_text(me, played, 1, prior, 1, value, -1, "");
                 if (status.load() != DGNN_OK) break;
                 winrate[me] -= 0.2f * (winrate[me] - value);
                 if (roots[me]) roots[me] = dgnn_tree_node_forward(roots[me], played);
@@ -1559,8 +1560,8 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
     bool job_over = false;
     if (window && window->seconds > 0.0) {
         watcher = std::thread([&] {
-            struct Snapshot { uint64_t moves, evals, hits, conflicts, started, completed, ended, stones; std::chrono::steady_clock::time_point at; };
-            auto snapshot = [&] { return Snapshot{moves.load(), evals.load(), hits.load(), conflicts.load(), started.load(), completed.load(), ended.load(), stones_completed.load(), std::chrono::steady_clock::now()}; };
+            struct Snapshot { uint64_t moves, evals, hits, conflicts, started, completed, ended, stones, ex_it; std::chrono::steady_clock::time_point at; };
+            auto snapshot = [&] { return Snapshot{moves.load(), evals.load(), hits.load(), conflicts.load(), started.load(), completed.load(), ended.load(), stones_completed.load(), ex_it_searches.load(), std::chrono::steady_clock::now()}; };
             auto sleep_until = [&](double seconds_after_start) {              // false: the job ended before that
                 std::unique_lock<std::mutex> lock(watch_mutex);
                 const long long left_us = (long long)(1e6 * (seconds_after_start - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()));
@@ -1582,6 +1583,7 @@ int dgnn::selfplay_go(const Predictor& predictor, dgnn_cache* shared_cache, cons
             window->games_completed = b.completed - a.completed;
             window->games_ended = b.ended - a.ended;
             window->stones_completed = b.stones - a.stones;
+            window->ex_it_searches = b.ex_it - a.ex_it;
         });
     }
     if (params->host_threads > 0 && fibers_available()) {

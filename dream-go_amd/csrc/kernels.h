@@ -12,7 +12,7 @@
 // DGNN_HOST_SIMD (0: the scalar host loops), DGNN_RCCL_DISABLE (tests: as if librccl were not installed).  Everything else --
 // switches of experiments that were measured and lost, measurement hooks (stamps, traces), A/B toggles -- is read by the
 // DGNN_ABLATIONS build only (ablation_env), fault injection by the test and ablations builds (test_env).
-inline const char* ablation_env(const char* name)
+static inline const char* ablation_env(const char* name)   // (static: the test library links host objects built with -DDGNN_TEST_ENTRIES beside kernel objects built without -- two bodies of one name, so no external linkage)
 {
 #ifdef DGNN_ABLATIONS
     return std::getenv(name);
@@ -21,7 +21,7 @@ inline const char* ablation_env(const char* name)
     return nullptr;
 #endif
 }
-inline const char* test_env(const char* name)
+static inline const char* test_env(const char* name)
 {
 #if defined(DGNN_ABLATIONS) || defined(DGNN_TEST_ENTRIES)
     return std::getenv(name);
@@ -32,6 +32,17 @@ inline const char* test_env(const char* name)
 }
 
 namespace dgnn {
+
+// LOGICAL devices (test build only): DGNN_FAKE_DEVICES=N makes the host side see N devices, logical device d being physical device
+// d % (devices present).  Every device id that crosses the C ABI, keys a Network's per-device state or names a lane of a leaf pool is
+// logical; the HIP runtime is only ever handed physical_device(d).  With one GPU in the box the single-process multi-device code --
+// dgnn_pool_create_devices over eight lanes, dgnn_broadcast_weights_devices, per-device weight images and workspaces -- runs with N = 8
+// (the reference's process model, src/libdg_mcts/predictors/nn.rs:64-67,87-89).  In the shipped library
+// test_env() is nullptr and all three are the identity.
+int fake_devices();                       // N, or 0: devices are what the runtime says
+int physical_device(int logical);
+hipError_t device_count(int* count);      // hipGetDeviceCount, or N
+hipError_t set_device(int logical);       // hipSetDevice(physical_device(logical))
 
 struct ConvLaunch {
     const uint16_t* x;     // input  [num_pos][cin]  fp16, NHWC with N*H*W flattened

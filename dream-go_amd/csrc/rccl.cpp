@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "dgnn_internal.h"
+#include "kernels.h"
 
 namespace dgnn {
 namespace {
@@ -137,9 +138,9 @@ int dgnn_rccl_comm_create(int device, int num_ranks, int rank, const uint8_t* id
     const Rccl* r = rccl();
     if (!r) return DGNN_COMM_ERROR;
     int count = 0;
-    DGNN_HIP_(hipGetDeviceCount(&count));
+    DGNN_HIP_(dgnn::device_count(&count));
     if (device < 0 || device >= count) return DGNN_BAD_ARGUMENT;
-    DGNN_HIP_(hipSetDevice(device));
+    DGNN_HIP_(dgnn::set_device(device));
     Comm* c = new (std::nothrow) Comm();
     if (!c) return DGNN_OUT_OF_MEMORY;
     ncclUniqueId uid;
@@ -187,7 +188,7 @@ void dgnn_rccl_comm_destroy(dgnn_comm* comm)
     Comm* c = reinterpret_cast<Comm*>(comm);
     const Rccl* r = rccl();
     if (r && c->owned && c->comm) {
-        (void)hipSetDevice(c->device);
+        (void)dgnn::set_device(c->device);
         (void)r->comm_destroy(c->comm);
     }
     delete c;
@@ -212,7 +213,7 @@ int dgnn_broadcast_weights(dgnn_network* net, dgnn_comm* comm, int root)
     int status = dgnn_network_image_descriptor(net, mine);
     if (status != DGNN_OK) return status;
     const size_t num_bytes = (size_t)mine[0];
-    DGNN_HIP_(hipSetDevice(c->device));
+    DGNN_HIP_(dgnn::set_device(c->device));
     hipStream_t stream = nullptr;
     DGNN_HIP_(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
@@ -271,23 +272,32 @@ int dgnn_broadcast_weights_devices(dgnn_network* net, const int* devices, int nu
 
     // the library and the communicators BEFORE any receiver is touched: without them nothing has changed and the devices
     // upload the host image themselves on first use (the reference's way, tensor.rs:123-141)
-    const Rccl* r = rccl();
-    if (!r) return DGNN_COMM_ERROR;
+    // (test build, DGNN_FAKE_DEVICES: several logical devices share a GPU, which ncclCommInitAll refuses; the one grouped broadcast is
+    // then stood in for by device-to-device copies from the root's range -- everything around it, the reserved ranges, the commit that
+    // makes them valid, the per-device state, is the code an 8-GPU node runs)
+    const bool fake = fake_devices() > 0;
+    const Rccl* r = fake ? nullptr : rccl();
+    if (!fake && !r) return DGNN_COMM_ERROR;
     std::vector<ncclComm_t> comms(list.size(), nullptr);
-    DGNN_NCCL(r->comm_init_all(comms.data(), (int)list.size(), list.data()));
+    if (!fake) DGNN_NCCL(r->comm_init_all(comms.data(), (int)list.size(), list.data()));
     std::vector<hipStream_t> streams(list.size(), nullptr);
     // the others reserve their range and receive over xGMI; a reserved range counts as empty until the transfer is known to be
     // good (engine.cpp: image_valid), so a failure below cannot leave a device computing on garbage
     for (size_t i = 1; i < list.size() && status == DGNN_OK; ++i) status = dgnn_network_weight_image_reserve(net, list[i], &images[i], &num_bytes);
     for (size_t i = 0; i < list.size() && status == DGNN_OK; ++i) {
-        if (hipSetDevice(list[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        if (dgnn::set_device(list[i]) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess)
             status = DGNN_HIP_ERROR;
     }
-    if (status == DGNN_OK) {
+    if (status == DGNN_OK && fake) {
+        for (size_t i = 1; i < list.size() && status == DGNN_OK; ++i) {
+            (void)dgnn::set_device(list[i]);
+            if (hipMemcpyAsync(images[i], images[0], num_bytes, hipMemcpyDeviceToDevice, streams[i]) != hipSuccess) status = DGNN_HIP_ERROR;
+        }
+    } else if (status == DGNN_OK) {
         ncclResult_t st = r->group_start();                 // one thread, several ranks: the calls must be fused in a group
         for (size_t i = 0; i < list.size() && st == ncclSuccess; ++i) {
-            (void)hipSetDevice(list[i]);
+            (void)dgnn::set_device(list[i]);
             st = r->broadcast(images[i], images[i], num_bytes, ncclUint8, 0, comms[i], streams[i]);
         }
         const ncclResult_t ended = r->group_end();
@@ -296,7 +306,7 @@ int dgnn_broadcast_weights_devices(dgnn_network* net, const int* devices, int nu
     }
     for (size_t i = 0; i < list.size(); ++i) {
         if (streams[i]) {
-            (void)hipSetDevice(list[i]);
+            (void)dgnn::set_device(list[i]);
             if (hipStreamSynchronize(streams[i]) != hipSuccess && status == DGNN_OK) status = DGNN_HIP_ERROR;
             (void)hipStreamDestroy(streams[i]);
         }

@@ -106,7 +106,7 @@ def selfplay_sharded(api, dist, torch, num_games, num_moves, num_rollouts, threa
         job["seconds"] = out["seconds"]
     if window is not None:             # a timed window over games with replacement: the ranks' counters summed, the longest window's clock
         mine = out.get("window") or {"seconds": 0.0}
-        wkeys = ("moves", "evals", "cache_hits", "conflicts", "games_started", "games_completed", "games_ended", "stones_completed")
+        wkeys = ("moves", "evals", "cache_hits", "conflicts", "games_started", "games_completed", "games_ended", "stones_completed", "ex_it_searches")
         if dist is not None:
             job["window"] = {k: sum_over_ranks(dist, torch, mine.get(k, 0), device=device) for k in wkeys}
             job["window"]["seconds"] = max_over_ranks(dist, torch, mine["seconds"], device=device)

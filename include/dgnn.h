@@ -202,7 +202,8 @@ int dgnn_workspace_stream(dgnn_workspace* ws, void** hip_stream);
 
 /* Host -> HBM copy of the features without running anything (blocking). */
 int dgnn_workspace_upload(dgnn_workspace* ws, const uint16_t* features, size_t num_features);
-/* HBM -> host copy of the outputs (blocking). */
+/* The outputs of the most recent pass on this workspace, whichever entry point ran it (blocking): an HBM -> host copy after
+ * dgnn_forward_resident / dgnn_forward_timed, the pinned host buffers' contents after a dgnn_forward* call (whose outputs never sit in HBM). */
 int dgnn_workspace_download(dgnn_workspace* ws, uint16_t* value_out, uint16_t* policy_out);
 
 /* Enqueue one pass of the hot path over the features resident in HBM; asynchronous. */

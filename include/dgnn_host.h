@@ -347,6 +347,7 @@ typedef struct dgnn_selfplay_window {
     void* ctx;                                                  /* in */
     double measured_seconds;                                    /* out: the window as the watcher's clock saw it */
     uint64_t moves, evals, cache_hits, conflicts, games_started, games_completed, games_ended, stones_completed;   /* out: inside the window */
+    uint64_t ex_it_searches;                                    /* out: expert-iteration searches that ENDED inside the window (appended in round 6) */
 } dgnn_selfplay_window;
 int dgnn_selfplay_go(dgnn_predict_fn predict, void* predict_ctx, dgnn_cache* cache, const dgnn_selfplay_params* params,
                      dgnn_selfplay_stats* stats, int* moves_out, char* sgf_out, size_t sgf_capacity);

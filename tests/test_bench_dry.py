@@ -11,8 +11,9 @@ import sys
 from conftest import ROOT
 
 SMALL = ["--steps", "3", "--warmup", "1", "--blocks", "1", "--channels", "32", "--batch", "8",
-         "--selfplay-games", "2", "--selfplay-moves", "3", "--selfplay-rollouts", "16",
-         "--whole-games", "4", "--whole-games-seconds", "3", "--whole-games-ramp", "1", "--policy-play-games", "8", "--policy-play-seconds", "2"]
+         "--selfplay-games", "2", "--selfplay-moves", "3", "--selfplay-rollouts", "16", "--selfplay-opening-leg", "1",
+         "--whole-games", "4", "--whole-games-seconds", "3", "--whole-games-ramp", "1", "--policy-play-games", "8", "--policy-play-seconds", "2",
+         "--ex-it-rollouts", "12", "--ex-it-seconds", "3"]
 
 
 def _clean_env():
@@ -52,6 +53,11 @@ def _check_window_legs(line, world):
     assert len(w["per_rank_host_cpus_busy"]) == world and all(c > 0 for c in w["per_rank_host_cpus_busy"])
     p = line["policy_play"]
     assert 1.5 < p["seconds"] < 3.0 and p["moves"] > 0 and 7.0 < p["evals_per_move"] + 8 * p["cache_hit_ratio"] < 9.5   # one 8-symmetry evaluation per move
+    # configs[4] as written: --ex-it.  One move in twenty of the undecided positions costs a search on top of its 8-symmetry evaluation
+    e = line["policy_play_ex_it"]
+    assert 2.5 < e["seconds"] < 4.0 and e["num_ex_it_rollouts"] == 12 and e["moves"] > 0
+    assert e["ex_it_searches"] >= 1 and e["evals_per_move"] + 8 * e["cache_hit_ratio"] > p["evals_per_move"] + 8 * p["cache_hit_ratio"] - 0.5
+    assert 5 < e["moves_per_ex_it_search"] < 200            # ~ one in twenty
     r, t = line["selfplay_midgame_reference_rule"], line["selfplay_midgame"]
     assert r["coalescing"] is False and "reference" in r["batching_rule"] and r["moves"] == t["moves"]
     assert "answers_per_sec" in line["selfplay"] and "evals_per_sec" not in line["selfplay"]

@@ -256,6 +256,7 @@ def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_b
         v, p = api.forward(ws, f).unwrap()
         alone.append((v.view(np.uint16).copy(), p.view(np.uint16).copy()))
     u16p = ctypes.POINTER(ctypes.c_uint16)
+    before = net.tower_stats()
     for rounds in range(4):                                                    # three submissions alive: 288 boards in flight
         for ws, f in zip(spaces, feats):
             assert api.lib.dgnn_forward_submit_n(ws.handle, f.ctypes.data_as(u16p), batch) == 0
@@ -263,6 +264,17 @@ def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_b
             v, p = np.empty(batch, dtype=np.uint16), np.empty(batch * 362, dtype=np.uint16)
             assert api.lib.dgnn_forward_wait(ws.handle, v.ctypes.data_as(u16p), p.ctypes.data_as(u16p)) == 0
             assert np.array_equal(v, alone[k][0]) and np.array_equal(p, alone[k][1]), (rounds, k)
+    after = net.tower_stats()
+    whole, split = after["whole_board"] - before["whole_board"], after["split"] - before["split"]
+    print(f"{channels} channels, 3 x {batch} boards alive, 4 rounds: {whole} whole-board towers, {split} split towers")
+    assert whole + split == 12 and after["per_layer"] == before["per_layer"] and after["split_gave_up"] == 0
+    if channels <= 128:
+        # which tower a submission got IS the feature (the test would have passed with the rule dead): the first submission of
+        # a round finds the device empty (split), the third finds 192 boards there and brings them to 288 >= 176 (a workgroup per board);
+        # the second depends on whether the first is still counted
+        assert whole >= 4 and split >= 4, (whole, split)
+    else:
+        assert whole == 0 and split == 12         # at 256 channels the rule is off: stays split (engine.cpp: note_submission_begins)
     for ws in spaces:
         ws.release()
     net.destroy()
