@@ -6,8 +6,10 @@
     lib/libdgnn_hip_test.so   the SAME kernel objects + the host sources compiled with -DDGNN_TEST_ENTRIES: additionally exports the
                               test-only entry points of include/dgnn_test.h (layer-level calls, accessors the reference's unit tests
                               look at, fault injection).  The tests that need them load this one (tests/conftest.py: api_full).
-    DGNN_ABLATIONS=1          one library (lib/ablations/libdgnn_hip.so) with the experiments that were measured and lost -- the NHWC
-                              tile kernels, the pair split, the staged filter, the timing-only ablated kernels -- and every test entry
+    DGNN_ABLATIONS=1          one library (lib/ablations/libdgnn_hip.so) with what measurements need and the shipped library does not carry:
+                              the NHWC tile kernels of round 1 (csrc/ablations/conv_tile.hip, an A/B baseline), the timing-only ablated
+                              board kernels, the stamp / trace hooks -- and every test entry.  Its tests: tests/ablations/ (collected only
+                              when that library is the one loaded, DGNN_LIBRARY=dream-go_amd/lib/ablations/libdgnn_hip.so)
 
 Both depend only on the HIP runtime (libamdhip64); neither links torch.
 """
@@ -28,7 +30,7 @@ KERNEL_SOURCES = ["conv_board.hip", "conv_board_b.hip", "conv_board_tower.hip", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 if ABLATIONS:
     FLAGS.append("-DDGNN_ABLATIONS")
-    KERNEL_SOURCES.append("conv_tile.hip")
+    KERNEL_SOURCES.append(os.path.join("ablations", "conv_tile.hip"))
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic-functions"]    # calls inside the library bind inside it: the shipped
                                                                                            # and the test library may live in one process
 
@@ -97,7 +99,7 @@ def build(force=False, verbose=False):
     jobs, running = [], []
     kernel_objects, host_objects, test_objects = [], [], []
     for src in KERNEL_SOURCES:
-        obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(LIB_DIR, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         kernel_objects.append(obj)
         jobs.append((src, obj, [], _kernel_headers()))
     for src in HOST_SOURCES:

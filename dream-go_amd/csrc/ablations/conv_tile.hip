@@ -20,7 +20,7 @@
 //                   k-step (~1500 cycles) to land.
 //   MFMA            v_mfma_f32_16x16x32_f16, A operand = filter rows (output channels), B operand = positions: a lane
 //                   ends up with 4 consecutive output channels of one position -> 8-byte NHWC epilogue accesses.
-#include "kernels.h"
+#include "../kernels.h"
 
 #include <hip/hip_runtime.h>
 

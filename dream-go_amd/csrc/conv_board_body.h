@@ -225,11 +225,6 @@ __device__ __forceinline__ void mfma_fence(floatx4& c0, floatx4& c1, floatx4& c2
 //            small batches (twice the workgroups per board).  [Four waves x 3 row tiles, one per SIMD, is slower: round 1 and
 //            again round 3 -- 0.25 against 0.224 ms per pass at 9x128.]
 //   NS = 32  the one slice of NS = 1 on HALF a board: six waves x one row tile, two workgroups per channel block (row split)
-//   NS = 24  ("pair", round 4; 256 channels, inside the split tower only) 4 slices = 128 output channels of a board on FOUR waves x
-//            one 32-channel tile x all 384 rows: 192 accumulator registers per wave, 256 registers in all -- TWO such workgroups,
-//            the two halves of a board's channels, fit a CU side by side (two waves per SIMD).  The half that owns channels
-//            128..255 needs the other's output for its first input chunk and so runs an epilogue behind it: each half's epilogue
-//            (VALU and stores, 8 % of a layer with the matrix pipe idle in the one-workgroup form) falls into the other's K loop.
 // Smaller splits = more, smaller workgroups per board: narrow networks, and filling the chip at small batch sizes.
 // Filter packing (host, pack_filter_board): [k-step][C_out / 16 tiles][64 lanes][8 halfs], k-step = chunk * 9 + tap,
 // lane l holds w[co = tile * 16 + (l & 15)][tap][ci = chunk * 32 + (l >> 4) * 8 .. + 8].
@@ -246,7 +241,7 @@ struct Split {
     // their own two activation fragments per k-step: 48 KB against 128 B per clock); taking the parallelism from the rows instead
     // of more waves halves that per CU and fills 256 CUs with 16 boards of 256 channels or 32 boards of 128.
     static constexpr int RS = NS == 32 ? 2 : 1;        // row halves a board is split into (workgroups per channel block)
-    static constexpr int SL = NS == 16 ? 8 : NS == 32 ? 1 : NS == 24 ? 4 : NS;       // 32-channel slices per workgroup
+    static constexpr int SL = NS == 16 ? 8 : NS == 32 ? 1 : NS;       // 32-channel slices per workgroup
     static constexpr int CT = NS == 16 ? 2 : 1;        // 32-channel MFMA tiles per wave
     static constexpr int CW = SL / CT;                 // waves along the channels
     static constexpr bool Chunked = NS <= 2 || NS == 32;
@@ -255,16 +250,15 @@ struct Split {
     // and spills them (343 spilled registers in the K loop of the eight-wave skip variant).
     static constexpr bool AsmMfma = true;
     // the wide variant needs both register files: 32-row tiles 0..7 of both channel tiles in AGPRs (exactly 256), 8..11 in VGPRs
-    // (pair split: 128 of its 192 accumulators in AGPRs, so that the 256 registers a wave may have with two waves per SIMD split 128 / 128)
-    static constexpr bool acc_in_agpr(int rt32) { return (NS == 16 || NS == 24) && rt32 < 8; }
+    static constexpr bool acc_in_agpr(int rt32) { return NS == 16 && rt32 < 8; }
     // DirectA (round 3, the wide variant): the A (filter) fragments go from memory straight into the registers of the NEXT k-step
     // (global_load_dwordx4, one k-step = 1536 MFMA-cycles ahead: more than a trip to HBM) instead of through a wave-private LDS
     // ring.  With one wave per 64 channels no two waves ever want the same filter bytes, so the ring bought nothing but prefetch
     // depth -- at the price of 16 KiB of LDS writes, four LDS-DMA instructions (the dearest instruction to issue beside MFMAs) and
     // four ds_read_b128 per k-step and wave.
-    static constexpr bool DirectA = NS == 16 || NS == 4 || NS == 24;
-    static constexpr int WAVES = NS == 1 ? 12 : (NS == 16 || NS == 24) ? 4 : NS == 32 ? 6 : 8;
-    static constexpr int MinWavesPerSimd = NS == 24 ? 2 : 1;          // __launch_bounds__: the pair split must leave room for its sibling
+    static constexpr bool DirectA = NS == 16 || NS == 4;
+    static constexpr int WAVES = NS == 1 ? 12 : NS == 16 ? 4 : NS == 32 ? 6 : 8;
+    static constexpr int MinWavesPerSimd = 1;
     static constexpr int Threads = WAVES * 64;
     static constexpr int XP = (4 * (NS == 32 ? 4 : NS <= 2 ? 6 : kPieces) + WAVES - 1) / WAVES;   // activation pieces per wave and chunk: 4 (one repeated), 7, 3 (row split), 2 / 3 (twelve / eight waves)
     static constexpr int RG = WAVES / CW;              // row groups of the workgroup
@@ -314,17 +308,16 @@ struct Split {
     static constexpr int CT2 = 2 * CT;                 // 16-channel MFMA tiles per wave
     static constexpr int RT2 = 2 * RT;                 // 16-row MFMA tiles per wave
     static constexpr int NP = RT2;                     // "pairs" per k-step: one B fragment (16 rows x the chunk's 32 channels), CT2 MFMAs each
-    static constexpr int BD = (NS == 16 || NS == 24) ? 3 : NS == 8 ? 4 : NS == 4 ? 4 : NS == 2 ? 5 : 2;   // B-fragment registers in rotation = pairs of read-ahead (<= NP)
+    static constexpr int BD = NS == 16 ? 3 : NS == 4 ? 4 : NS == 2 ? 5 : 2;   // B-fragment registers in rotation = pairs of read-ahead (<= NP)
     // byte offset of the B fragment of pair i = 16-row tile i relative to the lane's base row
     static constexpr int b_offset(int i) { return i * 256; }
     // pair index behind which the j-th filter piece / the activation piece of the step is issued
-    static constexpr int w_pair(int j) { return NS == 16 ? 2 + 4 * j : NS == 24 ? 2 + 8 * j : NS == 8 ? 3 + 7 * j : NS == 4 ? 1 + 3 * j : j; }
-    static constexpr int x_pair() { return (NS == 16 || NS == 24) ? 17 : NS == 8 ? 14 : NS == 4 ? 6 : 2; }
+    static constexpr int w_pair(int j) { return NS == 16 ? 2 + 4 * j : NS == 4 ? 1 + 3 * j : j; }
+    static constexpr int x_pair() { return NS == 16 ? 17 : NS == 4 ? 6 : 2; }
     // pair at which the NEXT step's A fragments are requested (behind this step's DMA instructions)
-    static constexpr int a_pair() { return (NS == 16 || NS == 24) ? 19 : NS == 8 ? 17 : NS == 4 ? 8 : NS == 2 ? 3 : 0; }
+    static constexpr int a_pair() { return NS == 16 ? 19 : NS == 4 ? 8 : NS == 2 ? 3 : 0; }
 };
 static_assert(Split<4>::LdsBytes <= 160 * 1024 && Split<2>::LdsBytes <= 160 * 1024 && Split<16>::LdsBytes <= 160 * 1024, "LDS budget");
-static_assert(2 * (Split<24>::LdsBytes + 16) <= 160 * 1024 && Split<24>::RT == 12 && Split<24>::NP == 24 && Split<24>::XP == 7, "pair split: two workgroups per CU");
 static_assert(Split<1>::BD <= Split<1>::NP && Split<2>::BD <= Split<2>::NP && Split<32>::BD <= Split<32>::NP, "the B rotation reaches one step ahead at most");
 static_assert(Split<32>::PPW <= 9 && Split<32>::RT == 1 && Split<32>::NP == 2, "row split: a piece per tap");
 

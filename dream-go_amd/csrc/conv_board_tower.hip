@@ -1,24 +1,15 @@
 // The residual tower as ONE launch: tower_board_kernel (a workgroup per board walks all layers) and tower_split_kernel (a board
 // split over several workgroups that hand channel blocks -- and, row split, row halves -- to each other).  Body: conv_board_body.h.
 #include "conv_board_body.h"
-#include "head_conv_body.h"
 
 namespace dgnn {
 namespace {
 
-// HEAD (round 5, the wide split only; instantiated in the DGNN_ABLATIONS build): the workgroup stays on its CU after the last layer and
-// runs both head convolutions of the board it has just finished (head_conv_body.h: the body of head_conv_board_kernel, the same
-// arithmetic, bit-identical outputs) -- one launch less per batch, and no waiting for a free CU behind another batch's tower.
-// Measured on one box (profiles/r05_final/ab_head_in_tower.txt): resident passes 3.068-3.081 -> 3.065-3.070 ms (+0.1-0.4 %), 256
-// boards PCIe-inclusive one / two alive +1.0 / +1.1 %, nothing at 192 boards and nothing with three batches alive (the heads of one
-// batch already run under the towers of the others) -- while the tower launch that `roofline` times grows by the head's 20 us.
-// Not worth a second instantiation of the dominant kernel in the shipped library.
-template <int NS, bool HEAD>
+template <int NS>
 __global__ __launch_bounds__(Split<NS>::Threads)
-void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count, HeadConvLaunch head)
+void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 {
-    constexpr int kHeadLds = HEAD ? headc::head_conv_lds_bytes<1, 6>() : 0;
-    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes > kHeadLds ? Split<NS>::LdsBytes : kHeadLds];
+    __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
     int carry = 0;
     half8 af[2][Split<NS>::CT][2];                    // the filter fragments in registers, handed from layer to layer (DirectA)
     for (int i = 0; i < count; ++i) {
@@ -31,14 +22,10 @@ void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count, H
         else carry = conv_board_body<NS, 0, true, 0>(a, lds, blockIdx.x, 0, af, none, carry);
         carry |= kChained;
     }
-    if constexpr (HEAD) {
-        static_assert(Split<NS>::Threads == headc::kHeadThreads, "the head body runs on the tower's four waves");
-        // the last layer's stores are waited for by their waves (a layer ends that way); the barrier makes them the workgroup's
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        headc::head_conv_board_body<1, 6>(head, lds, blockIdx.x, 0);
-    }
 }
+// (Round 5 let this workgroup go on with both head convolutions of the board it had just finished -- one launch less per batch:
+// +0.1-0.4 % on resident passes, nothing with three batches alive, and the launch `roofline` times grew by the head's 20 us.  Not
+// shipped, and taken out of the source in round 6: DESIGN_HISTORY.md 14.8, profiles/r05_final/ab_head_in_tower.txt.)
 
 // The same walk with a board SPLIT over G = C / (32 * NS) workgroups (NS < C / 32): the batch is too small for a workgroup
 // per board to fill the chip.  Between two layers a workgroup needs the other channel blocks of its own board and nothing
@@ -113,35 +100,16 @@ bool tower_board_supported(int batch, int channels, bool crowded)
     return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || ((slices == 4 || slices == 8) && batch >= tower_min_batch()));
 }
 
-// The head convolution can ride in the tower launch where the tower is the wide split (256 channels: the head body's 256 threads)
-// and the head is the one-tile, whole-board form (S + 2 <= 16 output channels).
-bool tower_board_takes_head(int channels, int samples)
-{
-#ifdef DGNN_ABLATIONS
-    return channels == 256 && samples + 2 <= 16;
-#else
-    (void)channels; (void)samples;
-    return false;
-#endif
-}
-
-hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, const HeadConvLaunch* head)
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     if (!tower_board_supported(batch, channels, true)) return hipErrorInvalidValue;
-    if (head && !tower_board_takes_head(channels, head->samples)) return hipErrorInvalidValue;
     const dim3 grid(batch, 1);
-    const HeadConvLaunch none{};
     // A 256-channel tower walks with the wide work split (Split<16>: four waves, two 32-channel tiles each)
     switch (channels / 32) {
-        case 8:
-#ifdef DGNN_ABLATIONS
-            if (head) { hipLaunchKernelGGL((tower_board_kernel<16, true>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, *head); break; }
-#endif
-            hipLaunchKernelGGL((tower_board_kernel<16, false>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, none);
-            break;
-        case 4: hipLaunchKernelGGL((tower_board_kernel<4, false>), grid, dim3(kThreads), 0, stream, d_layers, count, none); break;
-        default: hipLaunchKernelGGL((tower_board_kernel<2, false>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, none); break;
+        case 8: hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count); break;
+        case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count); break;
     }
     return hipGetLastError();
 }
@@ -161,27 +129,14 @@ int tower_split_ns(int batch, int channels, int num_cus)
     return ns == slices ? 0 : ns;
 }
 
-// The pair split (Split<24>): a 256-channel board on two four-wave workgroups, both resident on one CU -- 2 x batch workgroups, all
-// of which must be resident: two per CU.  (The switch is the workspace's: DGNN_TOWER_PAIR, engine.cpp.)
-bool tower_pair_supported(int batch, int channels, int num_cus)
-{
-#ifdef DGNN_ABLATIONS     // measured and lost to the power cap: instantiated in the ablations build only
-    return channels == 256 && batch >= tower_min_batch() && batch <= num_cus;
-#else
-    (void)batch; (void)channels; (void)num_cus;
-    return false;
-#endif
-}
-
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
                               size_t done_words, unsigned* d_err, unsigned* base, unsigned* d_tickets, unsigned* ticket_base, hipStream_t stream,
                               bool inject_missing)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     const int slices = channels / 32;
-    if (ns == 24 && slices != 8) return hipErrorInvalidValue;
-    if (ns != 32 && ns != 24 && (ns < 1 || ns >= slices || slices % ns != 0)) return hipErrorInvalidValue;
-    const int groups = ns == 32 ? slices * 2 : ns == 24 ? 2 : slices / ns;          // workgroups per board (row split: channel blocks x 2 row halves)
+    if (ns != 32 && (ns < 1 || ns >= slices || slices % ns != 0)) return hipErrorInvalidValue;
+    const int groups = ns == 32 ? slices * 2 : slices / ns;          // workgroups per board (row split: channel blocks x 2 row halves)
     if ((size_t)batch * groups > done_words) return hipErrorInvalidValue;
     // The flags are never reset between launches: a launch publishes *base + 1 .. *base + count, the next one counts from
     // above that (whatever batch size or split it uses: every stale word is below its base).  Only a counter about to wrap
@@ -216,11 +171,6 @@ hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int ba
         (void)hipMemsetAsync(d_trace, 0, trace_words * 8, stream);
     }
     switch (ns) {
-#ifdef DGNN_ABLATIONS
-        case 24: hipLaunchKernelGGL((tower_split_kernel<24>), grid, dim3(Split<24>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_tickets, launch_tickets); break;
-#else
-        case 24: return hipErrorInvalidValue;
-#endif
         case 32: hipLaunchKernelGGL((tower_split_kernel<32>), grid, dim3(Split<32>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_tickets, launch_tickets); break;
         case 4: hipLaunchKernelGGL((tower_split_kernel<4>), grid, dim3(Split<4>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_tickets, launch_tickets); break;
         case 2: hipLaunchKernelGGL((tower_split_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, batch, groups, launch_base, d_done, d_err, d_trace, d_tickets, launch_tickets); break;

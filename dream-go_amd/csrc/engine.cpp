@@ -125,7 +125,6 @@ struct Workspace {
     bool pending = false;                   // a submit without its wait
     bool use_board = false;                 // padded slot-major layout + one-board-per-workgroup kernel (conv_board.hip)
     bool use_tower = false;                 // the residual tower as ONE launch where a workgroup owns a whole board (DGNN_TOWER)
-    bool use_pair = false;                  // 256 channels, 129+ boards: a board on TWO four-wave workgroups that share a CU (DGNN_TOWER_PAIR)
     ConvBoardLaunch* d_tower_layers = nullptr;   // 2 * blocks descriptors for tower_board_kernel, filled on first use
     unsigned long long* d_tower_timing = nullptr;   // measurement only (DGNN_TOWER_TIMING): per-layer s_memtime stamps of a whole-board tower
     int tower_timing_layers = 0;
@@ -303,7 +302,6 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
         // MI355X, 20x256 batch 256: 85.3 us per convolution against 91.3 with one launch per layer.  DGNN_TOWER=0: per layer.
         const char* tower = std::getenv("DGNN_TOWER");
         ws->use_tower = ws->use_board && !(tower && std::atoi(tower) == 0) && t.num_blocks > 0;
-        { const char* pair = ablation_env("DGNN_TOWER_PAIR"); ws->use_pair = pair && std::atoi(pair) != 0; }
         const char* up = ablation_env("DGNN_TOWER_UP");
         ws->up_in_tower = !(up && std::atoi(up) == 0);
         const char* split = std::getenv("DGNN_TOWER_SPLIT");
@@ -410,7 +408,6 @@ int tower_mode(const Workspace* ws)
     if (!(ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero)) return 0;
     const int channels = ws->net->topo.num_channels;
     const bool whole = tower_board_supported(ws->active, channels, ws->crowded);
-    if (whole && ws->use_pair && !ws->split_failed && tower_pair_supported(ws->active, channels, ws->dev->num_cus)) return 24;
     if (ws->crowded_per_layer && !whole && ws->split_pref == 1) return 0;
     if (ws->split_pref != 0 && !ws->split_failed && (!whole || ws->split_pref == 2)) {
         const int ns = tower_split_ns(ws->active, channels, ws->dev->num_cus);
@@ -423,10 +420,6 @@ bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
 
 // Whole-board towers for small batches on a crowded device (round 5); DGNN_CROWDED=0 (test / ablations build): the size alone decides (A/B).
 const bool kCrowdedTowers = [] { const char* e = test_env("DGNN_CROWDED"); return !(e && std::atoi(e) == 0); }();
-
-// The head convolution inside the whole-board tower launch (round 5: built, bit-identical, +0.1-0.4 % -- conv_board_tower.hip says why it is
-// not shipped): DGNN_HEAD_IN_TOWER=1 in the ablations build.
-const bool kHeadInTower = [] { const char* e = ablation_env("DGNN_HEAD_IN_TOWER"); return e && std::atoi(e) != 0; }();
 
 // Enqueues graph.rs:134-152 on the workspace's stream.  `tower_pair` (may be -1) selects the event pair that
 // brackets the residual convolutions.
@@ -495,7 +488,6 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
     };
 
     int cur = 0;
-    bool head_in_tower = false;
     const uint16_t* tower = nullptr;   // NHWC tower output for the heads
     auto stamp = [&](int stage) -> hipError_t { return ws->stage_on ? hipEventRecord(ws->stage_ev[stage], ws->stream) : hipSuccess; };
     // compact board records: the planes are built on the device (features.hip), straight into the up-layer's input on the board path
@@ -553,7 +545,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
             const int mode = tower_mode(ws);
             ws->dev->tower_passes[mode > 0 ? 2 : 1].fetch_add(1, std::memory_order_relaxed);
             if (mode > 0) {
-                const int groups = mode == 32 ? t.num_channels / 32 * 2 : mode == 24 ? 2 : t.num_channels / 32 / mode;
+                const int groups = mode == 32 ? t.num_channels / 32 * 2 : t.num_channels / 32 / mode;
                 SplitChain* chain = ws->dev->chain;
                 std::lock_guard<std::mutex> chained(chain->mutex);
                 if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
@@ -570,23 +562,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 DGNN_HIP(hipEventRecord(chain->done, ws->stream));
                 chain->recorded = true;
             } else {
-                // the head convolution rides in the tower launch where it can (the wide split, a one-tile head): its workgroup goes on with the
-                // board it has just finished
-                head_in_tower = kHeadInTower && t.head_w_board_offset != 0 && tower_board_takes_head(t.num_channels, t.num_samples) && !ws->d_tower_timing;
-                HeadConvLaunch hc;
-                if (head_in_tower) {
-                    int last = cur;
-                    for (int i = 0; i < t.num_blocks; ++i) last = (last + 2) % 3;
-                    hc.x = ws->d_act[last];
-                    hc.w = (const uint16_t*)(image + t.head_w_board_offset);
-                    hc.bias = (const uint16_t*)(image + t.head_b_offset);
-                    hc.policy_features = ws->d_policy_features;
-                    hc.value_features = ws->d_value_features;
-                    hc.batch = ws->active;
-                    hc.cin = t.num_channels;
-                    hc.samples = t.num_samples;
-                }
-                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream, head_in_tower ? &hc : nullptr));
+                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
                 if (ws->d_tower_timing) {
                     DGNN_HIP(hipStreamSynchronize(ws->stream));
                     const size_t words = (size_t)ws->tower_timing_layers * ws->batch * 8 * 4;
@@ -612,9 +588,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
         }
         if (tower_pair >= 0) DGNN_HIP(hipEventRecord(ws->tower_events[2 * tower_pair + 1], ws->stream));
         DGNN_HIP(stamp(3));
-        if (head_in_tower) {
-            // (done by the tower launch)
-        } else if (t.head_w_board_offset != 0) {
+        if (t.head_w_board_offset != 0) {
             HeadConvLaunch hc;                                                      // value_head.rs:76 + policy_head.rs:92
             hc.x = ws->d_act[cur];
             hc.w = (const uint16_t*)(image + t.head_w_board_offset);

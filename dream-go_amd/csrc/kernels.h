@@ -137,9 +137,7 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches
 // The residual tower as ONE launch, a workgroup per board walking all `count` layers (descriptors in HBM; conv_1 / conv_2 of
 // every block, relu, C -> C).  Only where a workgroup owns all channels of its board: conv_board_pick_ns(batch, C) == C / 32.
 bool tower_board_supported(int batch, int channels, bool crowded = false);
-struct HeadConvLaunch;
-bool tower_board_takes_head(int channels, int samples);
-hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, const HeadConvLaunch* head = nullptr);
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream);
 // The tower as one launch with a board SPLIT over C / (32 * ns) workgroups that hand their channel blocks to each other
 // (per-board flags in `d_done`: `done_words` >= batch * C / (32 * ns) words, zero when first used and never reset -- `*base` is
 // the launcher's running count they are compared against; `d_err`: one word, zero before the first launch, nonzero after a
@@ -148,7 +146,6 @@ hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int ba
 // kept to batch * C / (32 * ns) <= num_cus workgroups: it may run with fewer compute units than that -- conv_board_tower.hip -- but
 // should not need two rounds of them).
 int tower_split_ns(int batch, int channels, int num_cus);
-bool tower_pair_supported(int batch, int channels, int num_cus);
 hipError_t launch_tower_split(const ConvBoardLaunch* d_layers, int count, int batch, int channels, int ns, unsigned* d_done,
                               size_t done_words, unsigned* d_err, unsigned* base, unsigned* d_tickets, unsigned* ticket_base, hipStream_t stream,
                               bool inject_missing = false);

@@ -14,6 +14,10 @@ graft.package()   # registers dream-go_amd/ as `dream_go_amd`
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# tests/ablations/ exercises kernels that only the DGNN_ABLATIONS build of the library carries (csrc/ablations/): collected when that
+# library is the one loaded, otherwise not at all -- no skips in the default run
+collect_ignore = [] if "ablations" in os.environ.get("DGNN_LIBRARY", "") else ["ablations"]
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

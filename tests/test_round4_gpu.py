@@ -152,36 +152,6 @@ def test_logits_and_pre_tanh_in_ulps_and_against_exact_arithmetic(api_full, orac
     assert not problems, problems
 
 
-@pytest.mark.parametrize("blocks,batch", [(3, 256), (2, 200), (2, 129)])
-def test_pair_split_tower_equals_one_launch_per_layer(api, synth, blocks, batch, monkeypatch):
-    if b"ablations" not in api.lib.dgnn_version():
-        pytest.skip("the pair split lost to the power cap (DESIGN.md 13.4): only a library built with DGNN_ABLATIONS=1 instantiates it")
-    """Round 4, tower_split_kernel<24> (DGNN_TOWER_PAIR=1): a 256-channel board on TWO four-wave workgroups -- channels 0..127 and
-    128..255, 192 accumulators per wave, both resident on one CU -- that hand their halves to each other inside the launch like the
-    other splits.  Same per-layer code, same contraction order: bit-identical to one launch per layer and to the whole-board tower,
-    pass after pass."""
-    text = synth.to_json(synth.make_tensors(blocks, 256, seed=421))
-    monkeypatch.setenv("DGNN_TOWER", "0")
-    net = api.Network.from_json(text)
-    reference = []
-    with net.get_workspace(batch) as ws:
-        assert ws.conv_kernel() == "conv3x3_board_kernel"
-        for i in range(3):
-            reference.append(api.forward(ws, synth.make_features(batch, seed=430 + i)).unwrap())
-    net.destroy()
-    monkeypatch.setenv("DGNN_TOWER", "1")
-    monkeypatch.setenv("DGNN_TOWER_PAIR", "1")
-    net = api.Network.from_json(text)
-    with net.get_workspace(batch) as ws:
-        assert ws.conv_kernel() == "tower_split_kernel"
-        for rep in range(3):
-            for i in range(3):
-                value, policy = api.forward(ws, synth.make_features(batch, seed=430 + i)).unwrap()
-                assert np.array_equal(value.view(np.uint16), reference[i][0].view(np.uint16)), (rep, i)
-                assert np.array_equal(policy.view(np.uint16), reference[i][1].view(np.uint16)), (rep, i)
-    net.destroy()
-
-
 def test_coalescing_on_the_device_answers_with_the_evaluation_of_some_symmetry(api_full, synth):
     """dgnn_pool_set_coalescing on the real engine: sixteen threads ask for six positions in random symmetries at once.  Whatever the
     timing made of it -- evaluated on its own, or answered by following a request for the same position that was in flight -- every
