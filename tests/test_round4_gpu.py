@@ -212,7 +212,7 @@ def test_coalescing_on_the_device_answers_with_the_evaluation_of_some_symmetry(a
 def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_bits(api, synth, channels):
     """Round 5: a submission that finds other submissions on the device and brings the boards in flight to 176 or more runs the tower
     with a workgroup per board whatever its size (alone it would be split over several workgroups per board) -- at up to 128 channels,
-    where a compute unit holds two boards' workgroups (at 256 the pool is better off with the split launch: engine.cpp,
+    where a compute unit holds two boards' workgroups (at 256 channels such a submission runs one launch per layer instead: engine.cpp,
     note_submission_begins).  Every work split sums in the same order, so the answers are those of the same batches evaluated one at
     a time -- bit for bit, whichever tower each submission got."""
     import ctypes
@@ -235,16 +235,18 @@ def test_small_batches_on_a_crowded_device_get_whole_board_towers_and_the_same_b
             assert api.lib.dgnn_forward_wait(ws.handle, v.ctypes.data_as(u16p), p.ctypes.data_as(u16p)) == 0
             assert np.array_equal(v, alone[k][0]) and np.array_equal(p, alone[k][1]), (rounds, k)
     after = net.tower_stats()
-    whole, split = after["whole_board"] - before["whole_board"], after["split"] - before["split"]
-    print(f"{channels} channels, 3 x {batch} boards alive, 4 rounds: {whole} whole-board towers, {split} split towers")
-    assert whole + split == 12 and after["per_layer"] == before["per_layer"] and after["split_gave_up"] == 0
+    whole, split, per_layer = (after[k] - before[k] for k in ("whole_board", "split", "per_layer"))
+    print(f"{channels} channels, 3 x {batch} boards alive, 4 rounds: {whole} whole-board towers, {split} split towers, {per_layer} passes with one launch per layer")
+    assert whole + split + per_layer == 12 and after["split_gave_up"] == 0
     if channels <= 128:
         # which tower a submission got IS the feature (the test would have passed with the rule dead): the first submission of
         # a round finds the device empty (split), the third finds 192 boards there and brings them to 288 >= 176 (a workgroup per board);
         # the second depends on whether the first is still counted
-        assert whole >= 4 and split >= 4, (whole, split)
+        assert whole >= 4 and split >= 4 and per_layer == 0, (whole, split, per_layer)
     else:
-        assert whole == 0 and split == 12         # at 256 channels the rule is off: stays split (engine.cpp: note_submission_begins)
+        # at 256 channels a compute unit holds ONE board's workgroup: no whole-board towers for small batches; the first submission of a
+        # round is a split tower, one that finds 129+ boards of the others in flight runs one launch per layer (round 6)
+        assert whole == 0 and split >= 4 and per_layer >= 1, (whole, split, per_layer)
     for ws in spaces:
         ws.release()
     net.destroy()
