@@ -56,10 +56,12 @@ constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 
 
 // The ORDER of tower launches on a physical device, where it matters (process-global per device; two networks on one GPU -- a match
 // between two nets -- go through the same chain):
-//   * split launches are chained (each waits for the event behind the previous one).  A split launch runs with whatever compute units
-//     it is given (its workgroups draw tickets, conv_board_tower.hip), provided that more than 8 * (workgroups per board - 1) of them
-//     come its way in the end -- up to 120: two split launches side by side could each hold CUs with workgroups that wait for
-//     siblings the other one keeps from starting.  One at a time, that cannot happen.
+//   * split launches may run SIDE BY SIDE as long as the workgroups that can be waiting for a sibling -- at most 8 * (workgroups per
+//     board - 1) per launch, one unfinished board per ticket queue (conv_board_tower.hip) -- add up to no more than half the compute
+//     units (kSplitWaitersBudget): the other half is always free for the siblings they wait for, so every launch makes progress.  A
+//     launch that would take the sum past that waits for the launches in front of it (events; rounds 2-5 chained EVERY split launch
+//     behind the previous one, which left the 64 CUs that a 96-board launch does not use idle with two more such launches queued).
+//     A board on 16 workgroups (120 possible waiters) still runs alone; boards on 2 or 4 (8 / 24) overlap.
 //   * whole-board towers are NOT ordered against split launches.  Round 6 built that (a split launch behind every whole-board tower
 //     enqueued before it, whole-board towers behind the split launch in front of them) on the theory that a split launch taking half
 //     of the CUs a 256-board tower has just released turns the next tower's one round of the chip into two, and measured nothing:
@@ -69,8 +71,10 @@ constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 
 // the net, resolve_split_failure.)
 struct SplitChain {
     std::mutex mutex;
-    hipEvent_t done = nullptr;              // behind the most recent split launch
-    bool recorded = false;
+    struct Launch { hipEvent_t done; int waiters; bool live; };
+    Launch recent[4] = {};                  // the most recent split launches (ring, `next` is the oldest): the event behind each, and how many
+    int next = 0;                           // of its workgroups can be waiting for a sibling at any one time
+    hipEvent_t done = nullptr;              // (recent[0].done: what get_device_state checks)
 };
 
 struct Workspace {
@@ -118,6 +122,7 @@ struct Workspace {
     bool crowded = false;                   // the submission being enqueued shares the device with enough boards of other submissions
                                             // that a workgroup per board is the better tower at any size (tower_mode, note_submission_begins)
     int counted_in_flight = 0;              // boards of this workspace's submission counted in DeviceState::boards_in_flight
+    int counted_whole = 0;                  // ... and in DeviceState::whole_in_flight
     bool outputs_on_host = false;           // the most recent pass wrote value / policy into the pinned host buffers, not into d_value / d_policy
     bool host_io = false;                   // the submission being enqueued reads its records from / writes its outputs to the PINNED HOST buffers
                                             // themselves (zero copy: no H2D / D2H blit kernels around the compute, see kZeroCopy)
@@ -162,6 +167,7 @@ struct DeviceState {
     bool image_valid = false;               // d_image holds net->image (false between a reserve and the copy that fills it)
     struct SplitChain* chain = nullptr;     // the device's chain of split-tower launches (process-global, see split_chain)
     std::atomic<int> boards_in_flight{0};   // boards of submissions between their submit and their wait, all workspaces of this device
+    std::atomic<int> whole_in_flight{0};    // ... of those, the boards of submissions whose tower is one launch with a workgroup per board
     // passes enqueued on this device by the form their residual tower took, and the split towers that gave up (dgnn_network_tower_stats):
     // [0] one launch per layer, [1] a workgroup per board, [2] split tower, [3] give-ups
     std::atomic<unsigned long long> tower_passes[4] = {};
@@ -204,7 +210,9 @@ SplitChain* split_chain(int device)
     SplitChain*& chain = table[device];
     if (!chain) {
         chain = new SplitChain();
-        if (hipEventCreateWithFlags(&chain->done, hipEventDisableTiming) != hipSuccess) chain->done = nullptr;
+        for (SplitChain::Launch& l : chain->recent)
+            if (hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) l.done = nullptr;
+        chain->done = chain->recent[0].done && chain->recent[1].done && chain->recent[2].done && chain->recent[3].done ? chain->recent[0].done : nullptr;
     }
     return chain;
 }
@@ -418,6 +426,14 @@ int tower_mode(const Workspace* ws)
 
 bool tower_selected(const Workspace* ws) { return tower_mode(ws) != 0; }
 
+// Workgroups of split launches that may be waiting for a sibling at the same time (SplitChain): half the compute units; DGNN_SPLIT_BESIDE=0
+// (test / ablations build): every split launch behind the previous one, as in rounds 2-5 (A/B).
+int kSplitWaitersBudget(int num_cus)
+{
+    static const bool beside = [] { const char* e = test_env("DGNN_SPLIT_BESIDE"); return !(e && std::atoi(e) == 0); }();
+    return beside ? num_cus / 2 : 0;
+}
+
 // Whole-board towers for small batches on a crowded device (round 5); DGNN_CROWDED=0 (test / ablations build): the size alone decides (A/B).
 const bool kCrowdedTowers = [] { const char* e = test_env("DGNN_CROWDED"); return !(e && std::atoi(e) == 0); }();
 
@@ -548,8 +564,22 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 const int groups = mode == 32 ? t.num_channels / 32 * 2 : t.num_channels / 32 / mode;
                 SplitChain* chain = ws->dev->chain;
                 std::lock_guard<std::mutex> chained(chain->mutex);
-                if (chain->recorded) DGNN_HIP(hipStreamWaitEvent(ws->stream, chain->done, 0));
-                (void)groups;
+                // newest to oldest: launches this one may run beside while the possible waiters stay within the budget; from the first
+                // one that does not fit on, it waits (for that one and everything older)
+                const int waiters = 8 * (groups - 1);
+                int beside = waiters;
+                bool wait_rest = false;
+                for (int k = 1; k <= 4; ++k) {
+                    SplitChain::Launch& l = chain->recent[(chain->next + 4 - k) & 3];
+                    if (!l.live) continue;
+                    if (!wait_rest && hipEventQuery(l.done) == hipSuccess) { l.live = false; continue; }
+                    if (!wait_rest && beside + l.waiters <= kSplitWaitersBudget(ws->dev->num_cus)) { beside += l.waiters; continue; }
+                    wait_rest = true;
+                    DGNN_HIP(hipStreamWaitEvent(ws->stream, l.done, 0));
+                }
+                SplitChain::Launch& mine = chain->recent[chain->next];       // the oldest slot: waited for above if it was still live and did not fit...
+                if (mine.live && !wait_rest) DGNN_HIP(hipStreamWaitEvent(ws->stream, mine.done, 0));   // ... or now: its event is about to be re-recorded
+                chain->next = (chain->next + 1) & 3;
                 bool missing = false;
                 if (ws->inject_giveup != 0 && !ws->injected) {  // fault injection (tests)
                     ws->injected = true;
@@ -559,8 +589,9 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 DGNN_HIP(launch_tower_split(ws->d_tower_layers, layer_count, ws->active, t.num_channels, mode, ws->d_split_sync,
                                             (size_t)ws->batch * kSplitWordsPerBoard, ws->d_split_err, &ws->split_base, ws->d_split_tickets,
                                             &ws->split_ticket_base, ws->stream, missing));
-                DGNN_HIP(hipEventRecord(chain->done, ws->stream));
-                chain->recorded = true;
+                DGNN_HIP(hipEventRecord(mine.done, ws->stream));
+                mine.waiters = waiters;
+                mine.live = true;
             } else {
                 DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
                 if (ws->d_tower_timing) {
@@ -698,7 +729,7 @@ void nap_ns(long long ns)
 // (profiles/r05_final/crowded_in_the_pool_*.txt).
 //
 // At MORE than 128 channels (round 6): a batch too small for a workgroup per board that finds at least a whole-board tower's worth of
-// boards (129) of other submissions on the device runs ONE LAUNCH PER LAYER, not a split tower.  Alone on the device the split tower
+// boards (129) of other submissions' WHOLE-BOARD towers on the device runs ONE LAUNCH PER LAYER, not a split tower.  Alone on the device the split tower
 // is the fast form (latency: 25-30 % ahead of 41 launches); beside whole-board towers its workgroups wait for siblings
 // that wait for compute units (they hold theirs meanwhile), while the workgroups of a per-layer launch wait for nothing and take CUs
 // as the towers release them.  Measured in the pool, 20x256, 48 games in flight (13 % of the device batches below 129 boards; same
@@ -711,12 +742,16 @@ void note_submission_begins(Workspace* ws)       // in front of enqueue_forward:
 {
     const int others = ws->dev->boards_in_flight.load(std::memory_order_relaxed);
     ws->crowded = kCrowdedTowers && ws->net->topo.num_channels <= 128 && others > 0 && others + ws->active >= ws->dev->num_cus * 11 / 16;
-    ws->crowded_per_layer = kCrowdedPerLayer && ws->net->topo.num_channels > 128 && others >= ws->dev->num_cus / 2 + 1;
+    // (the boards of WHOLE-BOARD towers: small submissions among themselves are split launches that share the chip -- SplitChain)
+    ws->crowded_per_layer = kCrowdedPerLayer && ws->net->topo.num_channels > 128 &&
+                            ws->dev->whole_in_flight.load(std::memory_order_relaxed) >= ws->dev->num_cus / 2 + 1;
 }
 void note_submission_in_flight(Workspace* ws)    // with `pending = true`
 {
     ws->counted_in_flight = ws->active;
     ws->dev->boards_in_flight.fetch_add(ws->active, std::memory_order_relaxed);
+    ws->counted_whole = tower_mode(ws) < 0 ? ws->active : 0;
+    if (ws->counted_whole > 0) ws->dev->whole_in_flight.fetch_add(ws->counted_whole, std::memory_order_relaxed);
 }
 struct SubmissionBegins {                        // a submit that fails half way leaves no tower choice behind for the resident entry points
     Workspace* ws;
@@ -726,7 +761,8 @@ struct SubmissionBegins {                        // a submit that fails half way
 void note_submission_ends(Workspace* ws)
 {
     if (ws->counted_in_flight > 0) ws->dev->boards_in_flight.fetch_sub(ws->counted_in_flight, std::memory_order_relaxed);
-    ws->counted_in_flight = 0;
+    if (ws->counted_whole > 0) ws->dev->whole_in_flight.fetch_sub(ws->counted_whole, std::memory_order_relaxed);
+    ws->counted_in_flight = ws->counted_whole = 0;
     ws->crowded = ws->crowded_per_layer = false;
 }
 

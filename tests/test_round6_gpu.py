@@ -36,8 +36,11 @@ def test_a_split_tower_behind_whole_board_towers_of_the_same_process_never_gives
     (behind two of them: three batches alive, the pool's default) a submission of 16-96 boards runs as a split tower
     (DGNN_TOWER_SPLIT=2 when its workspace is built: a split tower wherever one is possible -- by default such a submission runs per
     layer in this crowd, the test below).  200 rounds:
-    zero give-ups, tower_split_kernel to the end, every answer bit-equal to the batch evaluated alone, and a round costs no more than
-    its parts evaluated one after the other -- nobody sat out a time-out."""
+    zero give-ups, tower_split_kernel to the end, every answer bit-equal to the batch evaluated alone, and no round anywhere near the
+    flag waits' 50 ms -- nobody sat out a time-out.  (A round may cost MORE than its parts one after the other: behind TWO towers the
+    split launch and the second tower compete for the compute units the first releases, and a tower that gets only some of them
+    needs a second round of the chip -- 9.3 against 7.9 ms in this process, 7.4 in tools/r06_order_ab.py's, depending on which hardware
+    queues the three streams land on.  That is why this is not what ships beside whole-board towers: the test below.)"""
     blocks, channels, big = 20, 256, 256
     net = api.Network.from_json(synth.to_json(synth.make_tensors(blocks, channels, seed=6100)))
     f_big = [np.ascontiguousarray(synth.make_features(big, seed=6101 + k)).view(np.uint16).reshape(-1) for k in range(towers_in_front)]
@@ -85,7 +88,7 @@ def test_a_split_tower_behind_whole_board_towers_of_the_same_process_never_gives
     assert after["split"] - before["split"] == rounds and after["whole_board"] - before["whole_board"] == rounds * towers_in_front
     assert after["per_layer"] == before["per_layer"]
     assert ws_small.conv_kernel() == "tower_split_kernel"
-    assert seconds / rounds < 1.10 * one_after_the_other and worst < 0.025, (seconds / rounds, one_after_the_other, worst)
+    assert seconds / rounds < 1.35 * one_after_the_other and worst < 0.025, (seconds / rounds, one_after_the_other, worst)
     for w in ws_big + [ws_small]:
         w.release()
     net.destroy()
