@@ -61,7 +61,11 @@ constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 
 //     units (kSplitWaitersBudget): the other half is always free for the siblings they wait for, so every launch makes progress.  A
 //     launch that would take the sum past that waits for the launches in front of it (events; rounds 2-5 chained EVERY split launch
 //     behind the previous one, which left the 64 CUs that a 96-board launch does not use idle with two more such launches queued).
-//     A board on 16 workgroups (120 possible waiters) still runs alone; boards on 2 or 4 (8 / 24) overlap.
+//     A board on 16 workgroups (120 possible waiters) still runs alone; boards on 2 or 4 (8 / 24) overlap -- but only with a launch
+//     that leaves compute units idle (fewer workgroups than CUs): beside one that fills the chip a second launch only interleaves
+//     with it.  Same box, three submissions alive, PCIe-inclusive (tools/r06_sweep_small.py, profiles/r06/sweep_small_*.jsonl;
+//     chained -> side by side): 48 boards 63.0 -> 69.8 k, 80: 63.1 -> 79.1 k, 96: 72.8 -> 79.7 k, 112: 76.0 -> 78.5 k evals/s; 64 and 128
+//     boards (256 workgroups a launch) 72.8 -> 71.6 k and 80.0 -> 78.7 k when overlapped all the same, hence the condition.
 //   * whole-board towers are NOT ordered against split launches.  Round 6 built that (a split launch behind every whole-board tower
 //     enqueued before it, whole-board towers behind the split launch in front of them) on the theory that a split launch taking half
 //     of the CUs a 256-board tower has just released turns the next tower's one round of the chip into two, and measured nothing:
@@ -71,7 +75,7 @@ constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 
 // the net, resolve_split_failure.)
 struct SplitChain {
     std::mutex mutex;
-    struct Launch { hipEvent_t done; int waiters; bool live; };
+    struct Launch { hipEvent_t done; int waiters; int workgroups; bool live; };
     Launch recent[4] = {};                  // the most recent split launches (ring, `next` is the oldest): the event behind each, and how many
     int next = 0;                           // of its workgroups can be waiting for a sibling at any one time
     hipEvent_t done = nullptr;              // (recent[0].done: what get_device_state checks)
@@ -573,7 +577,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                     SplitChain::Launch& l = chain->recent[(chain->next + 4 - k) & 3];
                     if (!l.live) continue;
                     if (!wait_rest && hipEventQuery(l.done) == hipSuccess) { l.live = false; continue; }
-                    if (!wait_rest && beside + l.waiters <= kSplitWaitersBudget(ws->dev->num_cus)) { beside += l.waiters; continue; }
+                    if (!wait_rest && l.workgroups < ws->dev->num_cus && beside + l.waiters <= kSplitWaitersBudget(ws->dev->num_cus)) { beside += l.waiters; continue; }
                     wait_rest = true;
                     DGNN_HIP(hipStreamWaitEvent(ws->stream, l.done, 0));
                 }
@@ -591,6 +595,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                                             &ws->split_ticket_base, ws->stream, missing));
                 DGNN_HIP(hipEventRecord(mine.done, ws->stream));
                 mine.waiters = waiters;
+                mine.workgroups = ws->active * groups;
                 mine.live = true;
             } else {
                 DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
