@@ -9,6 +9,8 @@
 // was handed (hipSetDevice is per-thread).
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -121,6 +123,7 @@ struct Workspace {
     uint16_t* h_value = nullptr;
     uint16_t* h_policy = nullptr;
 
+    int small_others = 0;                   // boards of OTHER submissions in flight on the device that are not whole-board towers (split launches this one may run beside)
     bool crowded_per_layer = false;         // ... at more than 128 channels: a batch too small for a workgroup per board runs one launch per layer while
                                             // whole-board towers of other submissions hold the device (note_submission_begins)
     bool crowded = false;                   // the submission being enqueued shares the device with enough boards of other submissions
@@ -415,6 +418,7 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
 // Two forms: a workgroup per board (tower_board_kernel), or -- batches too small for that to fill the chip -- a board split
 // over 2 / 4 / 8 workgroups that hand their channel blocks to each other inside the launch (tower_split_kernel).
 // Returns 0 = one launch per layer, -1 = a workgroup per board, n > 0 = split tower with n slices per workgroup.
+extern const bool kSplitSizedForTheCrowd;
 int tower_mode(const Workspace* ws)
 {
     if (!(ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero)) return 0;
@@ -422,6 +426,15 @@ int tower_mode(const Workspace* ws)
     const bool whole = tower_board_supported(ws->active, channels, ws->crowded);
     if (ws->crowded_per_layer && !whole && ws->split_pref == 1) return 0;
     if (ws->split_pref != 0 && !ws->split_failed && (!whole || ws->split_pref == 2)) {
+        // The split is sized for the boards that will SHARE the chip, not for this submission alone: tower_split_ns spreads a lone
+        // batch over as many workgroups as fill the chip (64 boards of 256 channels: four per board, the fabric-bound two-slice split);
+        // beside other split launches (SplitChain) fewer, larger workgroups per board do the same work with fewer bytes, and the
+        // launches together fill the chip (round 6; capped at half the CUs in boards: the sizing of a 128-board batch).
+        if (kSplitSizedForTheCrowd && ws->small_others > 0) {
+            const int crowd = std::min(ws->active + ws->small_others, std::max(ws->active, ws->dev->num_cus / 2));
+            const int ns = tower_split_ns(crowd, channels, ws->dev->num_cus);
+            if (ns > 0 && ns != 32) return ns;
+        }
         const int ns = tower_split_ns(ws->active, channels, ws->dev->num_cus);
         if (ns > 0) return ns;
     }
@@ -437,6 +450,9 @@ int kSplitWaitersBudget(int num_cus)
     static const bool beside = [] { const char* e = test_env("DGNN_SPLIT_BESIDE"); return !(e && std::atoi(e) == 0); }();
     return beside ? num_cus / 2 : 0;
 }
+
+// Split towers sized for the boards that share the chip (tower_mode); DGNN_SPLIT_CROWD=0 (test / ablations build): for the submission alone (A/B).
+const bool kSplitSizedForTheCrowd = [] { const char* e = test_env("DGNN_SPLIT_CROWD"); return !(e && std::atoi(e) == 0); }();
 
 // Whole-board towers for small batches on a crowded device (round 5); DGNN_CROWDED=0 (test / ablations build): the size alone decides (A/B).
 const bool kCrowdedTowers = [] { const char* e = test_env("DGNN_CROWDED"); return !(e && std::atoi(e) == 0); }();
@@ -747,6 +763,7 @@ void note_submission_begins(Workspace* ws)       // in front of enqueue_forward:
 {
     const int others = ws->dev->boards_in_flight.load(std::memory_order_relaxed);
     ws->crowded = kCrowdedTowers && ws->net->topo.num_channels <= 128 && others > 0 && others + ws->active >= ws->dev->num_cus * 11 / 16;
+    ws->small_others = std::max(0, others - ws->dev->whole_in_flight.load(std::memory_order_relaxed));
     // (the boards of WHOLE-BOARD towers: small submissions among themselves are split launches that share the chip -- SplitChain)
     ws->crowded_per_layer = kCrowdedPerLayer && ws->net->topo.num_channels > 128 &&
                             ws->dev->whole_in_flight.load(std::memory_order_relaxed) >= ws->dev->num_cus / 2 + 1;
@@ -761,7 +778,7 @@ void note_submission_in_flight(Workspace* ws)    // with `pending = true`
 struct SubmissionBegins {                        // a submit that fails half way leaves no tower choice behind for the resident entry points
     Workspace* ws;
     explicit SubmissionBegins(Workspace* w) : ws(w) { note_submission_begins(w); }
-    ~SubmissionBegins() { if (!ws->pending) ws->crowded = ws->crowded_per_layer = false; }
+    ~SubmissionBegins() { if (!ws->pending) { ws->crowded = ws->crowded_per_layer = false; ws->small_others = 0; } }
 };
 void note_submission_ends(Workspace* ws)
 {
@@ -769,6 +786,7 @@ void note_submission_ends(Workspace* ws)
     if (ws->counted_whole > 0) ws->dev->whole_in_flight.fetch_sub(ws->counted_whole, std::memory_order_relaxed);
     ws->counted_in_flight = ws->counted_whole = 0;
     ws->crowded = ws->crowded_per_layer = false;
+    ws->small_others = 0;
 }
 
 int mark_submission(Workspace* ws)      // behind the last copy of a submission

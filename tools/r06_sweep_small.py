@@ -25,7 +25,7 @@ def child():
     for n in [int(v) for v in os.environ.get("SWEEP_SIZES", "32,48,64,80,96,112,128").split(",")]:
         records = np.concatenate([board.record(1, i % 8) for i in range(n)])
         spaces = [net.get_workspace(n) for _ in range(3)]
-        row = {"beside": os.environ.get("DGNN_SPLIT_BESIDE", "1"), "net": f"{blocks}x{channels}", "boards": n, "kernel": spaces[0].conv_kernel()}
+        row = {"beside": os.environ.get("DGNN_SPLIT_BESIDE", "1"), "crowd": os.environ.get("DGNN_SPLIT_CROWD", "1"), "net": f"{blocks}x{channels}", "boards": n, "kernel": spaces[0].conv_kernel()}
         for alive in (1, 2, 3):
             api.forward_pipelined_timed_n(spaces[:alive], "records", records, n, 50)
             row[f"alive_{alive}"] = round(api.forward_pipelined_timed_n(spaces[:alive], "records", records, n, 600))
@@ -40,5 +40,6 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for beside in ("1", "0", "1", "0"):
-            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, DGNN_SPLIT_BESIDE=beside), check=True)
+        variants = [v.split(":") for v in os.environ.get("SWEEP_VARIANTS", "1:1,0:1,1:1,0:1").split(",")]      # beside:crowd
+        for beside, crowd in variants:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, DGNN_SPLIT_BESIDE=beside, DGNN_SPLIT_CROWD=crowd), check=True)
