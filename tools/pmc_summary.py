@@ -35,7 +35,7 @@ def main():
 
     lines = [f"# rocprofv3 PMC passes (`tools/profile.sh`), mean per dispatch\n"]
     totals = collections.defaultdict(list)
-    for pass_name in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    for pass_name in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_tcp", "pmc_tcc", "pmc_wait"):
         data = counters(os.path.join(src, pass_name))
         for kernel in sorted(data, key=lambda k: -sum(len(v) for v in data[k].values())):
             lines.append(f"\n## {pass_name}: `{kernel}`\n\n| counter | dispatches | mean |\n|---|---|---|")
@@ -56,7 +56,10 @@ def main():
             "batch": int(os.environ.get("BENCH_BATCH", "256")), "channels": int(os.environ.get("BENCH_CHANNELS", "256")),
         }
         for extra in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY",
-                      "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"):
+                      "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum",
+                      "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum",
+                      "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+                      "SQ_INSTS_VMEM_WR", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM"):
             if extra in mean:
                 traffic[extra] = mean[extra]
         with open(os.path.join(dst, "traffic.json"), "w") as f:
