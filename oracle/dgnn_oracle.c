@@ -255,6 +255,16 @@ static int dgo_dense_f64(const uint16_t* x, int batch, int num_in, const uint16_
     return DGO_OK;
 }
 
+/* The fp32 convolution (what every parity test and bench.py's cpu_baseline run).  Round 6: register-tiled -- 5 positions of a board
+ * row x 16 output channels per micro-kernel (ten AVX2 accumulators), on a ZERO-PADDED copy of the input, so that a filter row
+ * fetched from the cache serves five positions instead of one (the round 1-5 form streamed the unit's 590 KB of filter through
+ * the L2 for every position: 36 evaluations per second on 16 cores where torch's oneDNN does 175).  THE ARITHMETIC OF AN OUTPUT IS
+ * UNCHANGED: k runs tap-major then channel, one fused multiply-add per product, in order, starting from +0 -- a tap that falls off
+ * the board now adds fma(0, w, acc) = acc (exact for finite w; acc is never -0: it starts at +0 and +0 + (-0) = +0) where the old
+ * loop skipped it.  tests/test_oracle_kat.py (the reference's vectors, bit for bit) and the committed fixtures hold that. */
+#include <immintrin.h>
+#define DGO_CO_TILE 16
+#define DGO_POS_TILE 5
 int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
                 const uint16_t* w, const uint16_t* bias, int cout,
                 float alpha1, float alpha2, const uint16_t* z, int relu,
@@ -263,70 +273,92 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
     if (batch < 0 || size <= 0 || cin <= 0 || cout <= 0) return DGO_BAD_ARGUMENT;
     if (alpha2 != 0.0f && z == NULL) return DGO_BAD_ARGUMENT;
 
-    const size_t num_pos = (size_t)batch * size * size;
-    const int cout_pad = (cout + DGO_CO_BLOCK - 1) / DGO_CO_BLOCK * DGO_CO_BLOCK;
+    const int cout_pad = (cout + DGO_CO_TILE - 1) / DGO_CO_TILE * DGO_CO_TILE;
+    const int tiles_x = (size + DGO_POS_TILE - 1) / DGO_POS_TILE;
+    const int pw = tiles_x * DGO_POS_TILE + 2;          /* padded row: x = -1 .. tiles_x * 5 */
+    const int ph = size + 2;
+    const size_t plane = (size_t)ph * pw * cin;
 
-    float* xf = (float*)malloc(sizeof(float) * (num_pos * cin + 1));
-    /* weights re-laid as [tap][cin][cout_pad] so that the inner loop runs over cout */
+    float* xp = (float*)calloc((size_t)batch * plane + 8, sizeof(float));
+    /* weights re-laid as [cout tile][tap][cin][16]: the rows a micro-kernel walks are CONTIGUOUS (a [tap][cin][cout_pad] order puts them
+     * 1 KB apart at 256 channels -- four cache sets for the whole filter: every row then comes from the L3) */
     float* wf = (float*)calloc((size_t)9 * cin * cout_pad, sizeof(float));
     float* bf = (float*)calloc((size_t)cout_pad, sizeof(float));
-    if (!xf || !wf || !bf) { free(xf); free(wf); free(bf); return DGO_OUT_OF_MEMORY; }
+    if (!xp || !wf || !bf) { free(xp); free(wf); free(bf); return DGO_OUT_OF_MEMORY; }
 
-    dgo_f16_to_f32_array(x, xf, num_pos * cin);
+#pragma omp parallel for schedule(static)
+    for (long row = 0; row < (long)batch * size; ++row) {
+        const int b = (int)(row / size), yy = (int)(row % size);
+        const uint16_t* src = x + ((size_t)b * size + yy) * size * cin;
+        float* dst = xp + (size_t)b * plane + ((size_t)(yy + 1) * pw + 1) * cin;
+        for (size_t i = 0; i < (size_t)size * cin; ++i) dst[i] = dgo_f16_to_f32(src[i]);
+    }
 #pragma omp parallel for schedule(static)
     for (int co = 0; co < cout; ++co) {
         bf[co] = dgo_f16_to_f32(bias[co]);
         for (int tap = 0; tap < 9; ++tap)
             for (int ci = 0; ci < cin; ++ci)
-                wf[((size_t)tap * cin + ci) * cout_pad + co] =
+                wf[(((size_t)(co / DGO_CO_TILE) * 9 + tap) * cin + ci) * DGO_CO_TILE + co % DGO_CO_TILE] =
                     dgo_f16_to_f32(w[((size_t)co * 9 + tap) * cin + ci]);
     }
 
-    /* Work units = (board, block of output channels): the 9 * cin * DGO_CO_BLOCK weights of a unit stay in the core's
-     * cache while it walks the 361 positions of its board.  The arithmetic of an output is untouched by the loop order:
-     * k runs tap-major then channel, one fp32 fma per product, in order. */
-    const long num_blocks = (cout + DGO_CO_BLOCK - 1) / DGO_CO_BLOCK;
-    const long num_units = (long)batch * num_blocks;
+    /* Work units = (board, PAIR of 16-channel tiles), the two tiles one after the other: the 9 * cin * 16 weights of a tile (147 KB at
+     * cin = 256) stay in the core's cache while it walks the board, and a unit owns whole 64-byte lines of y (32 fp16 per position:
+     * with one tile per unit two threads wrote the two halves of every line -- eight threads ran slower than one). */
+    const long num_tiles = cout_pad / DGO_CO_TILE;
+    const long num_pairs = (num_tiles + 1) / 2;
+    const long num_units = (long)batch * num_pairs * 2;
 
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 2)
     for (long unit = 0; unit < num_units; ++unit) {
-        const int b = (int)(unit / num_blocks);
-        const int co0 = (int)(unit % num_blocks) * DGO_CO_BLOCK;
-        const int co_end = (co0 + DGO_CO_BLOCK < cout) ? DGO_CO_BLOCK : cout - co0;
+        const int b = (int)(unit / (num_pairs * 2));
+        const long tile = unit % (num_pairs * 2);
+        if (tile >= num_tiles) continue;
+        const int co0 = (int)tile * DGO_CO_TILE;
+        const int co_end = (co0 + DGO_CO_TILE < cout) ? DGO_CO_TILE : cout - co0;
+        const float* xb = xp + (size_t)b * plane;
 
         for (int yy = 0; yy < size; ++yy) {
-            for (int xx = 0; xx < size; ++xx) {
-                const size_t out_pos = ((size_t)b * size + yy) * size + xx;
-                float acc[DGO_CO_BLOCK];
-                for (int j = 0; j < DGO_CO_BLOCK; ++j) acc[j] = 0.0f;
+            for (int xt = 0; xt < tiles_x; ++xt) {
+                const int x0 = xt * DGO_POS_TILE;
+                __m256 acc[DGO_POS_TILE][2];
+                for (int p = 0; p < DGO_POS_TILE; ++p) { acc[p][0] = _mm256_setzero_ps(); acc[p][1] = _mm256_setzero_ps(); }
 
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int sy = yy + tap / 3 - 1;
-                    const int sx = xx + tap % 3 - 1;
-                    if (sy < 0 || sy >= size || sx < 0 || sx >= size) continue;
-
-                    const float* xin = xf + (((size_t)b * size + sy) * size + sx) * cin;
-                    const float* wt = wf + (size_t)tap * cin * cout_pad + co0;
-
+                    /* padded coordinates: (yy + dy + 1, x0 + p + dx + 1) */
+                    const float* xin = xb + ((size_t)(yy + tap / 3) * pw + (x0 + tap % 3)) * cin;
+                    const float* wt = wf + ((size_t)(co0 / DGO_CO_TILE) * 9 + tap) * cin * DGO_CO_TILE;
                     for (int ci = 0; ci < cin; ++ci) {
-                        const float v = xin[ci];
-                        const float* wr = wt + (size_t)ci * cout_pad;
-                        for (int j = 0; j < DGO_CO_BLOCK; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+                        const __m256 w0 = _mm256_loadu_ps(wt + (size_t)ci * DGO_CO_TILE);
+                        const __m256 w1 = _mm256_loadu_ps(wt + (size_t)ci * DGO_CO_TILE + 8);
+                        for (int p = 0; p < DGO_POS_TILE; ++p) {
+                            const __m256 v = _mm256_broadcast_ss(xin + (size_t)p * cin + ci);
+                            acc[p][0] = _mm256_fmadd_ps(v, w0, acc[p][0]);       /* fmaf(v, w, acc) per lane */
+                            acc[p][1] = _mm256_fmadd_ps(v, w1, acc[p][1]);
+                        }
                     }
                 }
 
-                for (int j = 0; j < co_end; ++j) {
-                    const int co = co0 + j;
-                    float t = fmaf(alpha1, acc[j], bf[co]);
-                    if (alpha2 != 0.0f) t = fmaf(alpha2, dgo_f16_to_f32(z[out_pos * cout + co]), t);
-                    if (relu && !(t > 0.0f)) t = 0.0f;
-                    y[out_pos * cout + co] = dgo_f32_to_f16(t);
+                for (int p = 0; p < DGO_POS_TILE; ++p) {
+                    const int xx = x0 + p;
+                    if (xx >= size) break;
+                    float a[DGO_CO_TILE];
+                    _mm256_storeu_ps(a, acc[p][0]);
+                    _mm256_storeu_ps(a + 8, acc[p][1]);
+                    const size_t out_pos = ((size_t)b * size + yy) * size + xx;
+                    for (int j = 0; j < co_end; ++j) {
+                        const int co = co0 + j;
+                        float t = fmaf(alpha1, a[j], bf[co]);
+                        if (alpha2 != 0.0f) t = fmaf(alpha2, dgo_f16_to_f32(z[out_pos * cout + co]), t);
+                        if (relu && !(t > 0.0f)) t = 0.0f;
+                        y[out_pos * cout + co] = dgo_f32_to_f16(t);
+                    }
                 }
             }
         }
     }
 
-    free(xf); free(wf); free(bf);
+    free(xp); free(wf); free(bf);
     return DGO_OK;
 }
 
