@@ -16,12 +16,21 @@ collective ("weak" scaling); the only collective is one RCCL broadcast of the pa
 issued by libdgnn_hip.so itself (dgnn_broadcast_weights): every rank but 0 starts from DIFFERENT weights of the
 same architecture, so checksum agreement afterwards proves that RCCL moved the image.
 
-Beside the engine number the line carries a bounded, MEASURED self-play leg (`selfplay`): real Go boards, the
-search, the leaf pool and the engine together, with the evaluations per move, cache-hit ratio and mean device batch
-it actually saw (BASELINE.json's metric is games/hour + evals/s; SURVEY.md 8d "reports the measured ratio"), the rollouts per
-second and the CPU cores the process kept busy.  The process pins itself to as many neighbouring CPUs as its cgroup quota
-pays for before any thread exists (replicas.pin_to_compact_cpus; DGNN_PIN_CPUS=0 switches it off); the
-CPU baseline runs unpinned.
+Beside the engine number the line carries MEASURED self-play legs -- real Go boards, the search, the leaf pool and the engine
+together (BASELINE.json's metric is games/hour + evals/s; SURVEY.md 8d "reports the measured ratio"):
+  whole_games          the steady state of WHOLE games on this run's own clock: --whole-games games in flight with replacement,
+                       --num-rollout 800, a ramp and a timed window (dgnn_selfplay_window); headline moves per second, games per hour
+                       as counted (with the count's sigma) and from the moves; `tower_passes`: the device passes by tower form
+  selfplay_midgame     stones 61..66 of 256 games (+ the same under the reference's batching rule, `selfplay_midgame_reference_rule`)
+  policy_play          --num-rollout 1 WITHOUT --ex-it (1 024 games in flight): 8 evaluations per move
+  policy_play_ex_it    BASELINE.json configs[4] AS WRITTEN: --ex-it --num-rollout 1 with --num-ex-it-rollout 1600 (the reference's default)
+  selfplay             (only with --selfplay-opening-leg 1) the first stones of games started together: a host-bound corner
+and, PCIe-inclusive, `value_reference_contract` (fp16 planes in host memory in, host buffers out, two workspaces alive: the
+contract of dg_nn::forward, graph.rs:130-156), `value_pcie_inclusive` (board records / packed planes / three alive) and
+`reference_style` (the `dream_go --bench` walk).  `cpu_baseline` is the FASTER of two CPU statements of the reference's semantics
+(the OpenMP C port that is also the parity checker; torch-CPU on the trainer's graph), the other one beside it.  The process pins
+itself to as many neighbouring CPUs as its cgroup quota pays for before any thread exists (replicas.pin_to_compact_cpus;
+DGNN_PIN_CPUS=0 switches it off); the CPU baseline runs unpinned.
 
 `--dry` runs the same control flow without a GPU (gloo, the deterministic CPU predictor behind the leaf pool): it
 exists so that the N > 1 path is covered by the CPU tests; its numbers mean nothing and the line says "dry": true.
@@ -79,6 +88,9 @@ def parse_args(argv=None):
                     help="> 0 (default 300): while a batch occupies the device a PARTIAL batch waits until this many microseconds before that batch "
                          "is expected to finish and leaves with what has queued up meanwhile (dgnn_pool_set_back_to_back; a full batch goes at "
                          "once); 0: the reference's rule, whatever is queued the moment a slot is free")
+    ap.add_argument("--selfplay-snap", default="", metavar="LO,HI",
+                    help="with --selfplay-back-to-back: a partial batch of LO < n < HI boards is cut to its LO oldest (dgnn_pool_set_back_to_back's snapping; "
+                         "an A/B switch: off in every default)")
     ap.add_argument("--selfplay-host-threads", type=int, default=4,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
@@ -327,7 +339,8 @@ def selfplay_pool(job, api, net, args, coalesce=None, back_to_back=None, batches
         pool.set_coalescing(True)
     lead = args.selfplay_back_to_back if back_to_back is None else back_to_back
     if lead > 0:
-        pool.set_back_to_back(lead)
+        snap = [int(v) for v in args.selfplay_snap.split(",")] if getattr(args, "selfplay_snap", "") else [0, 0]
+        pool.set_back_to_back(lead, snap[0], snap[1])
     return pool, {"coalesce": coalesce, "back_to_back": lead, "boards": boards, "alive": alive, "workers": workers}
 
 

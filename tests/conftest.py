@@ -43,7 +43,9 @@ def api():
 def api_full(api):
     """The same bindings over the TEST build of the library (lib/libdgnn_hip_test.so: the shipped library's kernel objects, the host
     sources with the entry points of include/dgnn_test.h exported as well).  Tests that pin single layers, the tree's / board's
-    accessors or fault paths take this fixture; everything that only needs the product surface takes `api`."""
+    accessors or fault paths take this fixture; everything that only needs the product surface takes `api`.
+    (Both libraries may be live in this process and each chains its own split launches per device -- ADVICE r05.  Harmless since
+    round 6: a split launch makes progress with whatever compute units it is given, conv_board_tower.hip.)"""
     return api.load_full()
 
 

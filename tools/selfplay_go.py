@@ -68,7 +68,7 @@ def main():
                                   "--whole-games-ramp", str(ramp), "--whole-games-seconds", str(seconds), "--selfplay-rollouts", str(args.rollouts),
                                   "--selfplay-leaves", str(args.leaves), "--selfplay-batches", str(args.max_batches), "--selfplay-workers", str(args.workers),
                                   "--selfplay-coalesce", str(args.coalesce), "--selfplay-back-to-back", str(args.back_to_back),
-                                  "--selfplay-host-threads", str(args.host_threads), "--selfplay-planes", args.planes])
+                                  "--selfplay-host-threads", str(args.host_threads), "--selfplay-planes", args.planes] + (["--selfplay-snap", args.snap] if args.snap else []))
         job = bench.Job(bargs)
         job.start(False)
         net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
