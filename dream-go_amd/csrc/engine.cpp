@@ -65,14 +65,14 @@ constexpr int kSplitWordsPerBoard = 16;   // split-tower flags per board: up to 
 //     behind the previous one, which left the 64 CUs that a 96-board launch does not use idle with two more such launches queued).
 //     A board on 16 workgroups (120 possible waiters) still runs alone; boards on 2 or 4 (8 / 24) overlap -- but only with a launch
 //     that leaves compute units idle (fewer workgroups than CUs): beside one that fills the chip a second launch only interleaves
-//     with it.  Same box, three submissions alive, PCIe-inclusive (tools/r06_sweep_small.py, profiles/r06/sweep_small_*.jsonl;
+//     with it.  Same box, three submissions alive, PCIe-inclusive (tools/r06_sweep_small.py, profiles/r06_final/sweep_small_*.jsonl;
 //     chained -> side by side): 48 boards 63.0 -> 69.8 k, 80: 63.1 -> 79.1 k, 96: 72.8 -> 79.7 k, 112: 76.0 -> 78.5 k evals/s; 64 and 128
 //     boards (256 workgroups a launch) 72.8 -> 71.6 k and 80.0 -> 78.7 k when overlapped all the same, hence the condition.
 //   * whole-board towers are NOT ordered against split launches.  Round 6 built that (a split launch behind every whole-board tower
 //     enqueued before it, whole-board towers behind the split launch in front of them) on the theory that a split launch taking half
 //     of the CUs a 256-board tower has just released turns the next tower's one round of the chip into two, and measured nothing:
 //     two 256-board towers and a 64-board split launch 7.42 against 7.38 ms per round, the pool with 48 games in flight 79.6-79.7 k
-//     against 80.5-80.7 k boards/s WITHOUT the ordering (profiles/r06/order_ab.jsonl, few_games_in_the_pool_split_alive.txt).  Taken out.
+//     against 80.5-80.7 k boards/s WITHOUT the ordering (profiles/r06_final/order_ab.jsonl, few_games_in_the_pool_split_alive.txt).  Taken out.
 // (Another PROCESS's launches are out of reach; they end, which is all the ticket argument needs -- and the flag waits' 50 ms limit is
 // the net, resolve_split_failure.)
 struct SplitChain {
@@ -754,7 +754,7 @@ void nap_ns(long long ns)
 // is the fast form (latency: 25-30 % ahead of 41 launches); beside whole-board towers its workgroups wait for siblings
 // that wait for compute units (they hold theirs meanwhile), while the workgroups of a per-layer launch wait for nothing and take CUs
 // as the towers release them.  Measured in the pool, 20x256, 48 games in flight (13 % of the device batches below 129 boards; same
-// box, interleaved, two runs each; profiles/r06/few_games_in_the_pool_split_alive.txt): split towers 79.6-79.7 k boards/s (80.5-80.7 k
+// box, interleaved, two runs each; profiles/r06_final/few_games_in_the_pool_split_alive.txt): split towers 79.6-79.7 k boards/s (80.5-80.7 k
 // without the ordering that round 6 tried), per layer 82.0-82.2 k.  (Round 5's pool ran per layer too -- by accident: its split towers
 // gave up behind the first whole-board tower, VERDICT r05 weak #2.  Now nothing gives up, and the form is chosen.)  DGNN_TOWER_SPLIT=2
 // keeps the split tower wherever one is possible (tests of the split tower in a crowd; A/B).

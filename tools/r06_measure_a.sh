@@ -4,7 +4,7 @@
 #                at least a whole-board tower's worth of other boards
 #   split        split towers also in a crowd (test build, DGNN_CROWDED_PER_LAYER=0) -- the first half of round 6
 #   split0       no split towers at all: batches below 129 boards always run one launch per layer -- what round 5's pool ran after its give-ups
-# (the first run of this script, profiles/r06/few_games_in_the_pool_split_alive.txt, had "shipped" = split towers ordered against
+# (the first run of this script, profiles/r06_final/few_games_in_the_pool_split_alive.txt, had "shipped" = split towers ordered against
 # whole-board towers and "order0" = split towers unordered: before the per-layer rule existed)
 out=gpurun_out/r06_measure_a
 mkdir -p $out

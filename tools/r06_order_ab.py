@@ -64,5 +64,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for order in ("1", "0", "1", "0"):      # (DGNN_TOWER_ORDER was taken out of the library after this script had run: profiles/r06/order_ab.jsonl)
+        for order in ("1", "0", "1", "0"):      # (DGNN_TOWER_ORDER was taken out of the library after this script had run: profiles/r06_final/order_ab.jsonl)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, DGNN_TOWER_ORDER=order), check=True)
