@@ -474,7 +474,7 @@ def whole_games_leg(job, api, replicas, net, args):
     # 96 games STARTED TOGETHER, whose searches share 40 % of their leaves -- not comparable, kept to say so.
     if not job.dry:
         for key, name, note in (
-                ("steady_state_profile", os.path.join("r05_final", "selfplay_steady_96g_600s.json"),
+                ("steady_state_profile", os.path.join("r06_final", "selfplay_steady_96g_600s.json"),
                  "the same leg over a 600 s window (tools/selfplay_go.py --games 96 --steady 20,600); a builder-run file beside the measurement, not the measurement"),
                 ("started_together_r04", os.path.join("r04_final", "selfplay_full_games_96g_l16_h4_sparse_b2b300.json"),
                  "96 games started together from the empty board and played to their end, no replacement (round 4): correlated games, 40 % of their "
