@@ -88,9 +88,12 @@ def parse_args(argv=None):
                     help="> 0 (default 300): while a batch occupies the device a PARTIAL batch waits until this many microseconds before that batch "
                          "is expected to finish and leaves with what has queued up meanwhile (dgnn_pool_set_back_to_back; a full batch goes at "
                          "once); 0: the reference's rule, whatever is queued the moment a slot is free")
-    ap.add_argument("--selfplay-snap", default="", metavar="LO,HI",
-                    help="with --selfplay-back-to-back: a partial batch of LO < n < HI boards is cut to its LO oldest (dgnn_pool_set_back_to_back's snapping; "
-                         "an A/B switch: off in every default)")
+    ap.add_argument("--selfplay-snap", default="auto", metavar="LO,HI",
+                    help="with --selfplay-back-to-back: a partial batch of LO < n < HI boards is cut to its LO oldest (dgnn_pool_set_back_to_back's snapping). "
+                         "Default \"auto\" = half the batch size, 7/8 of it (128,224): such a batch runs as a split tower of 1.6 ms instead of a whole-board "
+                         "tower of 3 ms that leaves a part of the chip idle.  With the split towers of round 6, same box: 24 games in flight 70.2 -> "
+                         "74.9 k boards/s, 32 games 74.6 -> 75.7 k, 48 and 96 games unchanged (profiles/r06_final/batch_cap_with_few_games.txt, "
+                         "snap_with_many_games.txt; round 4 measured a loss: its split towers were chained and sized alone).  \"\" or \"0,0\": off")
     ap.add_argument("--selfplay-host-threads", type=int, default=4,
                     help="host threads PER GPU the games of the self-play leg run on as fibers (0 = one OS thread per game, the reference's model)")
     ap.add_argument("--selfplay-planes", choices=["device", "host"], default="device",
@@ -339,14 +342,21 @@ def selfplay_pool(job, api, net, args, coalesce=None, back_to_back=None, batches
         pool.set_coalescing(True)
     lead = args.selfplay_back_to_back if back_to_back is None else back_to_back
     if lead > 0:
-        snap = [int(v) for v in args.selfplay_snap.split(",")] if getattr(args, "selfplay_snap", "") else [0, 0]
+        text = getattr(args, "selfplay_snap", "")
+        snap = [args.batch // 2, args.batch * 7 // 8] if text == "auto" else [int(v) for v in text.split(",")] if text else [0, 0]
+        if args.batch < 64 or snap[0] <= 0:
+            snap = [0, 0]
         pool.set_back_to_back(lead, snap[0], snap[1])
-    return pool, {"coalesce": coalesce, "back_to_back": lead, "boards": boards, "alive": alive, "workers": workers}
+        rule_snap = snap
+    else:
+        rule_snap = [0, 0]
+    return pool, {"coalesce": coalesce, "back_to_back": lead, "boards": boards, "alive": alive, "workers": workers, "snap": rule_snap}
 
 
 def pool_rule_text(args, rule):
     return (f"{rule['alive']} device batches alive, {rule['workers']} pool workers" +
-            (f", partial batches back to back (lead {rule['back_to_back']} us)" if rule["back_to_back"] > 0 else ", a free slot takes what is queued (the reference's rule)") +
+            (f", partial batches back to back (lead {rule['back_to_back']} us" + (f", {rule['snap'][0]} < n < {rule['snap'][1]} boards cut to {rule['snap'][0]}" if rule.get("snap", [0, 0])[0] > 0 else "") + ")"
+             if rule["back_to_back"] > 0 else ", a free slot takes what is queued (the reference's rule)") +
             (", positions in flight coalesced" if rule["coalesce"] else ", no coalescing (the reference: every miss is evaluated)"))
 
 

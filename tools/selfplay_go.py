@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--min-fill", type=int, default=0, metavar="BOARDS", help="> 0: a free batch slot waits for this many boards while another batch keeps the device busy (dgnn_pool_set_min_fill)")
     ap.add_argument("--min-fill-wait-us", type=int, default=1000)
     ap.add_argument("--back-to-back", type=int, default=300, metavar="LEAD_US", help="> 0 (default 300): a partial batch waits until this long before the batch on the device is expected to finish (dgnn_pool_set_back_to_back)")
-    ap.add_argument("--snap", default="", metavar="LO,HI", help="with --back-to-back: a batch of LO < n < HI boards is cut to its LO oldest, e.g. 128,208")
+    ap.add_argument("--snap", default="auto", metavar="LO,HI", help="with --back-to-back: a batch of LO < n < HI boards is cut to its LO oldest; \"auto\" (default) = half and 7/8 of --max-batch; \"\" = off")
     ap.add_argument("--coalesce", type=int, default=1, help="1: requests for a position in flight follow it (dgnn_pool_set_coalescing; only with a shared table); 0: off")
     ap.add_argument("--max-batches", type=int, default=3, help="device batches the pool keeps alive: 3 (default since round 5, DESIGN.md 14.2), 2 (the reference's rule), or 0 = adaptive (a rule that lost; test build)")
     ap.add_argument("--workers", type=int, default=0, help="pool worker threads per device; 0 (default) = one more than batches alive: a free worker takes the next batch while another is still handing its answers to the games (DESIGN.md 14.2: +2.5 %%)")
@@ -55,9 +55,9 @@ def main():
                          "way into a game played out by policy play, RAMP untimed seconds, then a window of SECONDS (bench.py's whole_games leg: "
                          "dgnn_selfplay_window); prints that leg's JSON")
     args = ap.parse_args()
-    lost_rules = args.extra_batch_queue > 0 or args.min_fill > 0 or args.max_batches == 0 or bool(args.snap)
+    lost_rules = args.extra_batch_queue > 0 or args.min_fill > 0 or args.max_batches == 0
     if lost_rules and not hasattr(api.lib, "dgnn_pool_set_min_fill"):
-        raise SystemExit("--extra-batch-queue / --min-fill / --max-batches 0 / --snap are batching rules that were measured and lost (DESIGN.md 13.5, 13.10): "
+        raise SystemExit("--extra-batch-queue / --min-fill / --max-batches 0 are batching rules that were measured and lost (DESIGN.md 13.5, 13.10): "
                          "their entry points are exported by the test build only -- DGNN_LIBRARY=dream-go_amd/lib/libdgnn_hip_test.so")
     if args.steady:
         # the same leg bench.py runs, with this tool's own settings, on one GPU
@@ -68,7 +68,7 @@ def main():
                                   "--whole-games-ramp", str(ramp), "--whole-games-seconds", str(seconds), "--selfplay-rollouts", str(args.rollouts),
                                   "--selfplay-leaves", str(args.leaves), "--selfplay-batches", str(args.max_batches), "--selfplay-workers", str(args.workers),
                                   "--selfplay-coalesce", str(args.coalesce), "--selfplay-back-to-back", str(args.back_to_back),
-                                  "--selfplay-host-threads", str(args.host_threads), "--selfplay-planes", args.planes] + (["--selfplay-snap", args.snap] if args.snap else []))
+                                  "--selfplay-host-threads", str(args.host_threads), "--selfplay-planes", args.planes, "--selfplay-snap", args.snap])
         job = bench.Job(bargs)
         job.start(False)
         net = api.Network.from_json(synth.to_json(synth.make_tensors(args.blocks, args.channels, seed=1)))
@@ -108,7 +108,9 @@ def main():
         pool.set_extra_batch_queue(2, 3, args.extra_batch_queue)
     if args.min_fill > 0:
         pool.set_min_fill(args.min_fill, args.min_fill_wait_us)
-    snap = [int(v) for v in args.snap.split(",")] if args.snap else [0, 0]
+    snap = [args.max_batch // 2, args.max_batch * 7 // 8] if args.snap == "auto" else [int(v) for v in args.snap.split(",")] if args.snap else [0, 0]
+    if args.max_batch < 64:
+        snap = [0, 0]
     if args.back_to_back > 0 or snap[0] > 0:
         pool.set_back_to_back(args.back_to_back, snap[0], snap[1])
     adaptive = args.max_batches == 0 and pool.takes_boards and args.extra_batch_queue == 0
