@@ -1,5 +1,7 @@
 #!/bin/sh
 # Round 6: the whole-board tower's workgroups started in phases (DGNN_TOWER_STAGGER="phases,us per phase", test build) against in lockstep.
+# RESULT (profiles/r06_final/stagger_ab.txt): every variant costs exactly its own start delay and gains nothing; the switch and the
+# kernel's prologue for it were taken out again (git log: "Whole-board tower: optional start in phases" and its revert).  Kept as the record.
 out=gpurun_out/r06_stagger
 mkdir -p $out
 for rep in 1 2; do
