@@ -7,21 +7,9 @@ namespace {
 
 template <int NS>
 __global__ __launch_bounds__(Split<NS>::Threads)
-void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count, unsigned stagger_phases, unsigned stagger_ticks)
+void tower_board_kernel(const ConvBoardLaunch* __restrict__ layers, int count)
 {
     __shared__ __attribute__((aligned(16))) char lds[Split<NS>::LdsBytes];
-    // STAGGER (round 6): all workgroups of a launch start together and do identical work, so they stay in lockstep for all 41 layers: every
-    // layer ends with 256 workgroups storing their 196 KB at the same moment -- 50 MB, more than the L2s hold -- and then 256 K loops
-    // pulling filter and activations at the same moment.  Phase p of `stagger_phases` (consecutive workgroups of an XCD) starts
-    // p * stagger_ticks of the 100 MHz clock late, once: the offsets persist, and one phase's epilogue falls into the other phases' K loops.
-    if (stagger_phases > 1) {
-        const unsigned phase = (blockIdx.x >> 3) % stagger_phases;
-        if (phase != 0 && threadIdx.x == 0) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)phase * stagger_ticks) __builtin_amdgcn_s_sleep(32);
-        }
-        __syncthreads();
-    }
     int carry = 0;
     half8 af[2][Split<NS>::CT][2];                    // the filter fragments in registers, handed from layer to layer (DirectA)
     for (int i = 0; i < count; ++i) {
@@ -112,17 +100,16 @@ bool tower_board_supported(int batch, int channels, bool crowded)
     return conv_board_supported(channels, channels) && channels >= 64 && (slices == 2 || ((slices == 4 || slices == 8) && batch >= tower_min_batch()));
 }
 
-hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, unsigned stagger_phases,
-                              unsigned stagger_ticks)
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream)
 {
     if (batch <= 0 || count <= 0) return hipSuccess;
     if (!tower_board_supported(batch, channels, true)) return hipErrorInvalidValue;
     const dim3 grid(batch, 1);
     // A 256-channel tower walks with the wide work split (Split<16>: four waves, two 32-channel tiles each)
     switch (channels / 32) {
-        case 8: hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count, stagger_phases, stagger_ticks); break;
-        case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count, stagger_phases, stagger_ticks); break;
-        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count, stagger_phases, stagger_ticks); break;
+        case 8: hipLaunchKernelGGL((tower_board_kernel<16>), grid, dim3(Split<16>::Threads), 0, stream, d_layers, count); break;
+        case 4: hipLaunchKernelGGL((tower_board_kernel<4>), grid, dim3(kThreads), 0, stream, d_layers, count); break;
+        default: hipLaunchKernelGGL((tower_board_kernel<2>), grid, dim3(Split<2>::Threads), 0, stream, d_layers, count); break;
     }
     return hipGetLastError();
 }

@@ -419,7 +419,6 @@ int create_workspace(Network* net, DeviceState* dev, int batch, Workspace** out)
 // over 2 / 4 / 8 workgroups that hand their channel blocks to each other inside the launch (tower_split_kernel).
 // Returns 0 = one launch per layer, -1 = a workgroup per board, n > 0 = split tower with n slices per workgroup.
 extern const bool kSplitSizedForTheCrowd;
-constexpr unsigned kDefaultStaggerPhases = 0, kDefaultStaggerUs = 0;      // (off until measured)
 int tower_mode(const Workspace* ws)
 {
     if (!(ws->use_board && ws->use_tower && ws->net->topo.gates_nonzero)) return 0;
@@ -454,19 +453,6 @@ int kSplitWaitersBudget(int num_cus)
 
 // Split towers sized for the boards that share the chip (tower_mode); DGNN_SPLIT_CROWD=0 (test / ablations build): for the submission alone (A/B).
 const bool kSplitSizedForTheCrowd = [] { const char* e = test_env("DGNN_SPLIT_CROWD"); return !(e && std::atoi(e) == 0); }();
-
-// The whole-board tower's workgroups started in phases (conv_board_tower.hip: STAGGER).  DGNN_TOWER_STAGGER="phases,microseconds per phase"
-// (test / ablations build; "0" = off).
-struct TowerStagger { unsigned phases, ticks; };
-const TowerStagger kTowerStagger = [] {
-    TowerStagger s{kDefaultStaggerPhases, kDefaultStaggerUs * 100u};
-    if (const char* e = test_env("DGNN_TOWER_STAGGER")) {
-        unsigned phases = 0, us = 0;
-        if (std::sscanf(e, "%u,%u", &phases, &us) >= 1) s = TowerStagger{phases, us * 100u};
-    }
-    if (s.phases < 2 || s.ticks == 0) s = TowerStagger{0, 0};
-    return s;
-}();
 
 // Whole-board towers for small batches on a crowded device (round 5); DGNN_CROWDED=0 (test / ablations build): the size alone decides (A/B).
 const bool kCrowdedTowers = [] { const char* e = test_env("DGNN_CROWDED"); return !(e && std::atoi(e) == 0); }();
@@ -628,8 +614,7 @@ int enqueue_forward(Workspace* ws, int tower_pair, int input_form = kInputFeatur
                 mine.workgroups = ws->active * groups;
                 mine.live = true;
             } else {
-                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream, kTowerStagger.phases,
-                                            ws->active >= ws->dev->num_cus / 2 ? kTowerStagger.ticks : 0));
+                DGNN_HIP(launch_tower_board(ws->d_tower_layers, layer_count, ws->active, t.num_channels, ws->stream));
                 if (ws->d_tower_timing) {
                     DGNN_HIP(hipStreamSynchronize(ws->stream));
                     const size_t words = (size_t)ws->tower_timing_layers * ws->batch * 8 * 4;

@@ -137,8 +137,7 @@ hipError_t launch_conv3x3_board(const ConvBoardLaunch& args, const BoardSwitches
 // The residual tower as ONE launch, a workgroup per board walking all `count` layers (descriptors in HBM; conv_1 / conv_2 of
 // every block, relu, C -> C).  Only where a workgroup owns all channels of its board: conv_board_pick_ns(batch, C) == C / 32.
 bool tower_board_supported(int batch, int channels, bool crowded = false);
-hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream, unsigned stagger_phases = 0,
-                              unsigned stagger_ticks = 0);
+hipError_t launch_tower_board(const ConvBoardLaunch* d_layers, int count, int batch, int channels, hipStream_t stream);
 // The tower as one launch with a board SPLIT over C / (32 * ns) workgroups that hand their channel blocks to each other
 // (per-board flags in `d_done`: `done_words` >= batch * C / (32 * ns) words, zero when first used and never reset -- `*base` is
 // the launcher's running count they are compared against; `d_err`: one word, zero before the first launch, nonzero after a
