@@ -255,16 +255,61 @@ static int dgo_dense_f64(const uint16_t* x, int batch, int num_in, const uint16_
     return DGO_OK;
 }
 
-/* The fp32 convolution (what every parity test and bench.py's cpu_baseline run).  Round 6: register-tiled -- 5 positions of a board
- * row x 16 output channels per micro-kernel (ten AVX2 accumulators), on a ZERO-PADDED copy of the input, so that a filter row
- * fetched from the cache serves five positions instead of one (the round 1-5 form streamed the unit's 590 KB of filter through
- * the L2 for every position: 36 evaluations per second on 16 cores where torch's oneDNN does 175).  THE ARITHMETIC OF AN OUTPUT IS
- * UNCHANGED: k runs tap-major then channel, one fused multiply-add per product, in order, starting from +0 -- a tap that falls off
- * the board now adds fma(0, w, acc) = acc (exact for finite w; acc is never -0: it starts at +0 and +0 + (-0) = +0) where the old
- * loop skipped it.  tests/test_oracle_kat.py (the reference's vectors, bit for bit) and the committed fixtures hold that. */
+/* The fp32 convolution as PLAIN loops: the readable statement (the form rounds 1-5 ran).  For every output: k runs tap-major then
+ * channel, off-board taps are skipped, one fused multiply-add per product, in order, starting from +0; then
+ * fp16(act(alpha1 * acc + bias [+ alpha2 * z])).  dgo_conv3x3 below is the same arithmetic made fast;
+ * tests/test_oracle_kat.py::test_fast_convolution_is_the_plain_one holds the two bit for bit against each other. */
+int dgo_conv3x3_plain(const uint16_t* x, int batch, int size, int cin,
+                      const uint16_t* w, const uint16_t* bias, int cout,
+                      float alpha1, float alpha2, const uint16_t* z, int relu,
+                      uint16_t* y)
+{
+    if (batch < 0 || size <= 0 || cin <= 0 || cout <= 0) return DGO_BAD_ARGUMENT;
+    if (alpha2 != 0.0f && z == NULL) return DGO_BAD_ARGUMENT;
+#pragma omp parallel for schedule(static)
+    for (long pos = 0; pos < (long)batch * size * size; ++pos) {
+        const int b = (int)(pos / (size * size)), yy = (int)(pos / size % size), xx = (int)(pos % size);
+        for (int co = 0; co < cout; ++co) {
+            float acc = 0.0f;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+                if (sy < 0 || sy >= size || sx < 0 || sx >= size) continue;
+                const uint16_t* xin = x + (((size_t)b * size + sy) * size + sx) * cin;
+                const uint16_t* wr = w + ((size_t)co * 9 + tap) * cin;
+                for (int ci = 0; ci < cin; ++ci) acc = fmaf(dgo_f16_to_f32(xin[ci]), dgo_f16_to_f32(wr[ci]), acc);
+            }
+            float t = fmaf(alpha1, acc, dgo_f16_to_f32(bias[co]));
+            if (alpha2 != 0.0f) t = fmaf(alpha2, dgo_f16_to_f32(z[(size_t)pos * cout + co]), t);
+            if (relu && !(t > 0.0f)) t = 0.0f;
+            y[(size_t)pos * cout + co] = dgo_f32_to_f16(t);
+        }
+    }
+    return DGO_OK;
+}
+
+/* The fp32 convolution (what every parity test and bench.py's cpu_baseline run), fast.  Round 6: register-tiled -- 5 positions of a
+ * board row x 16 output channels per micro-kernel (ten AVX2 accumulators), on a ZERO-PADDED copy of the input, the filter rows of
+ * a 16-channel tile contiguous, hardware fp16 conversions (F16C: exact half -> float; float -> half to nearest even, the rounding
+ * of dgo_f32_to_f16), a scratch buffer per calling thread instead of 121 MB of fresh pages per layer.  THE ARITHMETIC OF AN OUTPUT
+ * IS UNCHANGED: k runs tap-major then channel, one fused multiply-add per product, in order, starting from +0 -- a tap that falls
+ * off the board adds fma(0, w, acc) = acc (exact for finite w; acc is never -0: it starts at +0 and +0 + (-0) = +0) where the
+ * plain loop skips it.  (The round 1-5 form streamed a unit's 590 KB of filter through the L2 for every position, rows 1 KB apart
+ * in four cache sets: 36 evaluations per second on 16 cores.) */
 #include <immintrin.h>
 #define DGO_CO_TILE 16
 #define DGO_POS_TILE 5
+
+static void dgo_f16_to_f32_run(const uint16_t* src, float* dst, size_t n)
+{
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) _mm256_storeu_ps(dst + i, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(src + i))));
+    for (; i < n; ++i) dst[i] = dgo_f16_to_f32(src[i]);
+}
+
+static _Thread_local float* dgo_scratch = NULL;          /* the padded input of the calling thread's convolutions (grow-only) */
+static _Thread_local size_t dgo_scratch_floats = 0;
+static _Thread_local long dgo_scratch_layout[3] = {0, 0, 0};   /* (batch, size, cin) it was last zero-bordered for */
+
 int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
                 const uint16_t* w, const uint16_t* bias, int cout,
                 float alpha1, float alpha2, const uint16_t* z, int relu,
@@ -278,20 +323,31 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
     const int pw = tiles_x * DGO_POS_TILE + 2;          /* padded row: x = -1 .. tiles_x * 5 */
     const int ph = size + 2;
     const size_t plane = (size_t)ph * pw * cin;
+    const size_t need = (size_t)batch * plane + 8;
 
-    float* xp = (float*)calloc((size_t)batch * plane + 8, sizeof(float));
+    /* the border must be zero; the interior is rewritten by every call: a buffer that last served the same layout keeps its border */
+    if (need > dgo_scratch_floats) {
+        free(dgo_scratch);
+        dgo_scratch = (float*)calloc(need, sizeof(float));
+        dgo_scratch_floats = dgo_scratch ? need : 0;
+        if (!dgo_scratch) return DGO_OUT_OF_MEMORY;
+    } else if (dgo_scratch_layout[0] != batch || dgo_scratch_layout[1] != size || dgo_scratch_layout[2] != cin) {
+        float* const base = dgo_scratch;
+#pragma omp parallel for schedule(static)
+        for (long b = 0; b < batch; ++b) memset(base + (size_t)b * plane, 0, plane * sizeof(float));
+    }
+    dgo_scratch_layout[0] = batch; dgo_scratch_layout[1] = size; dgo_scratch_layout[2] = cin;
+    float* const xp = dgo_scratch;
     /* weights re-laid as [cout tile][tap][cin][16]: the rows a micro-kernel walks are CONTIGUOUS (a [tap][cin][cout_pad] order puts them
      * 1 KB apart at 256 channels -- four cache sets for the whole filter: every row then comes from the L3) */
     float* wf = (float*)calloc((size_t)9 * cin * cout_pad, sizeof(float));
     float* bf = (float*)calloc((size_t)cout_pad, sizeof(float));
-    if (!xp || !wf || !bf) { free(xp); free(wf); free(bf); return DGO_OUT_OF_MEMORY; }
+    if (!wf || !bf) { free(wf); free(bf); return DGO_OUT_OF_MEMORY; }
 
 #pragma omp parallel for schedule(static)
     for (long row = 0; row < (long)batch * size; ++row) {
         const int b = (int)(row / size), yy = (int)(row % size);
-        const uint16_t* src = x + ((size_t)b * size + yy) * size * cin;
-        float* dst = xp + (size_t)b * plane + ((size_t)(yy + 1) * pw + 1) * cin;
-        for (size_t i = 0; i < (size_t)size * cin; ++i) dst[i] = dgo_f16_to_f32(src[i]);
+        dgo_f16_to_f32_run(x + ((size_t)b * size + yy) * size * cin, xp + (size_t)b * plane + ((size_t)(yy + 1) * pw + 1) * cin, (size_t)size * cin);
     }
 #pragma omp parallel for schedule(static)
     for (int co = 0; co < cout; ++co) {
@@ -308,6 +364,7 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
     const long num_tiles = cout_pad / DGO_CO_TILE;
     const long num_pairs = (num_tiles + 1) / 2;
     const long num_units = (long)batch * num_pairs * 2;
+    const __m256 va1 = _mm256_set1_ps(alpha1), va2 = _mm256_set1_ps(alpha2), zero = _mm256_setzero_ps();
 
 #pragma omp parallel for schedule(dynamic, 2)
     for (long unit = 0; unit < num_units; ++unit) {
@@ -317,6 +374,7 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
         const int co0 = (int)tile * DGO_CO_TILE;
         const int co_end = (co0 + DGO_CO_TILE < cout) ? DGO_CO_TILE : cout - co0;
         const float* xb = xp + (size_t)b * plane;
+        const __m256 b0 = _mm256_loadu_ps(bf + co0), b1 = _mm256_loadu_ps(bf + co0 + 8);
 
         for (int yy = 0; yy < size; ++yy) {
             for (int xt = 0; xt < tiles_x; ++xt) {
@@ -342,10 +400,27 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
                 for (int p = 0; p < DGO_POS_TILE; ++p) {
                     const int xx = x0 + p;
                     if (xx >= size) break;
+                    const size_t out_pos = ((size_t)b * size + yy) * size + xx;
+                    if (co_end == DGO_CO_TILE) {
+                        /* t = fmaf(alpha1, acc, bias); [t = fmaf(alpha2, z, t);] relu: t > 0 ? t : +0 (a NaN gives 0, as !(t > 0) does); fp16 nearest even */
+                        __m256 t0 = _mm256_fmadd_ps(va1, acc[p][0], b0), t1 = _mm256_fmadd_ps(va1, acc[p][1], b1);
+                        if (alpha2 != 0.0f) {
+                            const uint16_t* zr = z + out_pos * cout + co0;
+                            t0 = _mm256_fmadd_ps(va2, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)zr)), t0);
+                            t1 = _mm256_fmadd_ps(va2, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(zr + 8))), t1);
+                        }
+                        if (relu) {
+                            t0 = _mm256_and_ps(t0, _mm256_cmp_ps(t0, zero, _CMP_GT_OQ));
+                            t1 = _mm256_and_ps(t1, _mm256_cmp_ps(t1, zero, _CMP_GT_OQ));
+                        }
+                        uint16_t* yr = y + out_pos * cout + co0;
+                        _mm_storeu_si128((__m128i*)yr, _mm256_cvtps_ph(t0, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+                        _mm_storeu_si128((__m128i*)(yr + 8), _mm256_cvtps_ph(t1, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+                        continue;
+                    }
                     float a[DGO_CO_TILE];
                     _mm256_storeu_ps(a, acc[p][0]);
                     _mm256_storeu_ps(a + 8, acc[p][1]);
-                    const size_t out_pos = ((size_t)b * size + yy) * size + xx;
                     for (int j = 0; j < co_end; ++j) {
                         const int co = co0 + j;
                         float t = fmaf(alpha1, a[j], bf[co]);
@@ -358,7 +433,7 @@ int dgo_conv3x3(const uint16_t* x, int batch, int size, int cin,
         }
     }
 
-    free(xp); free(wf); free(bf);
+    free(wf); free(bf);
     return DGO_OK;
 }
 

@@ -183,6 +183,8 @@ def lib():
         L.dgo_conv3x3.argtypes = [u16p, ctypes.c_int, ctypes.c_int, ctypes.c_int, u16p, u16p, ctypes.c_int,
                                   ctypes.c_float, ctypes.c_float, u16p, ctypes.c_int, u16p]
         L.dgo_conv3x3.restype = ctypes.c_int
+        L.dgo_conv3x3_plain.argtypes = L.dgo_conv3x3.argtypes
+        L.dgo_conv3x3_plain.restype = ctypes.c_int
         L.dgo_dense.argtypes = [u16p, ctypes.c_int, ctypes.c_int, u16p, u16p, ctypes.c_int,
                                 ctypes.c_float, ctypes.c_int, u16p]
         L.dgo_dense.restype = ctypes.c_int
@@ -238,13 +240,15 @@ def f16(values):
     return np.asarray(values, dtype=np.float32).astype(np.float16).view(np.uint16)
 
 
-def conv3x3(x, batch, size, cin, w, bias, cout, alpha1=1.0, alpha2=0.0, z=None, relu=True):
+def conv3x3(x, batch, size, cin, w, bias, cout, alpha1=1.0, alpha2=0.0, z=None, relu=True, plain=False):
+    """plain=True: the readable loops (dgo_conv3x3_plain) instead of the register-tiled form -- the same bits, tested."""
     x, xp = _u16(x); w, wp = _u16(w); bias, bp = _u16(bias)
     zp = None
     if z is not None:
         z, zp = _u16(z)
     y = np.empty(batch * size * size * cout, dtype=np.uint16)
-    status = lib().dgo_conv3x3(xp, batch, size, cin, wp, bp, cout, alpha1, alpha2, zp, int(relu),
+    fn = lib().dgo_conv3x3_plain if plain else lib().dgo_conv3x3
+    status = fn(xp, batch, size, cin, wp, bp, cout, alpha1, alpha2, zp, int(relu),
                                y.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)))
     assert status == 0, status
     return y

@@ -153,3 +153,34 @@ def test_c_restatement_matches_numpy_statement(oracle, synth):
     assert np.abs(f16_to_f32(p_c) - f16_to_f32(p_n)).max() <= 1e-3
     sums = f16_to_f32(p_c).reshape(batch, 362).sum(axis=1)
     assert np.all(np.abs(sums - 1) < 5e-3)
+
+
+def test_fast_convolution_is_the_plain_one(oracle):
+    """oracle/dgnn_oracle.c states the convolution twice: as plain loops (dgo_conv3x3_plain: what one reads against conv2d.rs:171-220
+    and convolution_bias_activation.rs:21-41) and register-tiled with hardware fp16 conversions on a zero-padded copy (dgo_conv3x3:
+    what every parity test and the CPU baseline run).  Bit for bit the same on everything that distinguishes them: every fp16 value
+    as an input (subnormals, -0, the largest finite ones), board edges, channel counts that are not multiples of 16 or 8, outputs
+    that overflow to infinity or round into the subnormals, with and without the skip input and ReLU, two calls of different shapes
+    in a row (the padded scratch buffer is reused), boards of 3 x 3 and 19 x 19."""
+    rng = np.random.default_rng(606)
+    finite = np.array([h for h in range(65536) if (h >> 10) & 31 != 31], dtype=np.uint16)        # every finite half
+    cases = [(2, 19, 32, 48, 0.5, True), (1, 3, 8, 2, None, True), (3, 19, 16, 8, 0.25, False), (1, 19, 64, 40, None, False),
+             (2, 5, 24, 17, 0.75, True), (1, 19, 256, 32, 0.5, True)]
+    for batch, size, cin, cout, alpha, relu in cases + cases[:2]:
+        n = batch * size * size * cin
+        x = rng.choice(finite, size=n).astype(np.uint16)
+        x[rng.random(n) < 0.5] = 0                                                                   # post-ReLU sparsity, and taps on real zeros
+        scale = rng.choice([1e-3, 0.05, 1.0, 30.0])
+        w = (rng.normal(0, scale, (cout, 3, 3, cin))).astype(np.float16).view(np.uint16)
+        w.reshape(-1)[: min(200, w.size)] = rng.choice(finite, size=min(200, w.size))                # a sprinkle of extreme weights
+        b = rng.choice(finite, size=cout).astype(np.uint16)
+        z = rng.choice(finite, size=batch * size * size * cout).astype(np.uint16) if alpha is not None else None
+        a1, a2 = (alpha, 1.0 - alpha) if alpha is not None else (1.0, 0.0)
+        fast = oracle.conv3x3(x, batch, size, cin, w, b, cout, alpha1=a1, alpha2=a2, z=z, relu=relu)
+        plain = oracle.conv3x3(x, batch, size, cin, w, b, cout, alpha1=a1, alpha2=a2, z=z, relu=relu, plain=True)
+        same = fast == plain
+        # (a NaN is a NaN in both -- infinity minus infinity among the extreme operands -- whatever its payload)
+        nan = lambda v: ((v >> 10) & 31 == 31) & (v & 1023 != 0)
+        assert np.all(same | (nan(fast) & nan(plain))), (batch, size, cin, cout, int(np.count_nonzero(~same)))
+        assert np.count_nonzero((fast >> 10) & 31 == 31) < fast.size                                   # not everything overflowed
+
