@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r4d
+# NOTE (round 6): the switch this script toggles (pair split / head-in-tower / arrival handshake) has been removed from the sources; the script is kept as the record of how the files it names under profiles/ were produced.
 timeout 300 python -m pytest tests/test_round4_gpu.py -q -m gpu -k pair_split --timeout 120 > gpurun_out/r4d/pair_test.log 2>&1; echo "pair test rc $?"; tail -3 gpurun_out/r4d/pair_test.log
 for rep in 1 2; do
   for pair in 0 1; do

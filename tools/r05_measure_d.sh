@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): the switch this script toggles (pair split / head-in-tower / arrival handshake) has been removed from the sources; the script is kept as the record of how the files it names under profiles/ were produced.
 # Round 5, fourth GPU call: the arrival handshake (failure-path tests, its price at 9x128 batch 32) and zero-copy I/O (A/B), then the suite.
 out=gpurun_out/r05d
 mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 6): the switch this script toggles (pair split / head-in-tower / arrival handshake) has been removed from the sources; the script is kept as the record of how the files it names under profiles/ were produced.
 # Round 5, seventh GPU call: the head convolution inside the tower launch -- the suite, then A/B on one box (test build: DGNN_HEAD_IN_TOWER).
 out=gpurun_out/r05g
 mkdir -p $out
