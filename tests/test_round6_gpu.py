@@ -194,3 +194,26 @@ def test_expert_iteration_at_nine_by_128_on_the_engine(api, synth):
           f"({plain['evals'] / moves:.1f} without ex-it), mean device batch {(after['boards'] - before['boards']) / max(after['batches'] - before['batches'], 1):.1f}; towers {stats}")
     assert per_move > plain["evals"] / moves + 0.5 * searches * 100 / moves         # the searches' leaves went through the engine
     assert stats["split_gave_up"] == 0
+
+
+def test_workspace_download_returns_the_last_pass_whichever_entry_point_ran_it(api, synth):
+    """with zero copy a dgnn_forward* call writes value and policy into the pinned host buffers only; dgnn_workspace_download
+    ("the outputs of the most recent pass") used to hand out what an EARLIER resident pass had left in HBM."""
+    net = api.Network.from_json(synth.to_json(synth.make_tensors(2, 64, seed=6500)))
+    first, second = synth.make_features(4, seed=6501), synth.make_features(4, seed=6502)
+    with net.get_workspace(4) as ws:
+        ws.upload(first)
+        ws.forward_resident()
+        ws.sync()
+        resident = ws.download()
+        a = (resident.value.view(np.uint16).copy(), resident.policy.view(np.uint16).copy())
+        out = api.forward(ws, second)                                  # zero copy: outputs land in the pinned block
+        b = (out.value.view(np.uint16).copy(), out.policy.view(np.uint16).copy())
+        assert not np.array_equal(a[1], b[1])
+        got = ws.download()
+        assert np.array_equal(got.value.view(np.uint16), b[0]) and np.array_equal(got.policy.view(np.uint16), b[1])
+        ws.forward_resident()                                          # resident again (the planes of `second` are what is in HBM now)
+        ws.sync()
+        again = ws.download()
+        assert np.array_equal(again.value.view(np.uint16), b[0]) and np.array_equal(again.policy.view(np.uint16), b[1])
+    net.destroy()
